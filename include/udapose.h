@@ -1,0 +1,150 @@
+/* udapose.h - C ABI of libudapose_hip.so: the MI355X (gfx950) kernels behind the mean-teacher UDA pose-estimation
+ * hot path of VisionLearningGroup/UDA_PoseEstimation.
+ *
+ * The reference has no FFI layer: its hot path is reached through Python modules (lib.models.pose_resnet*,
+ * lib.models.loss, lib.models.Style_net, lib.keypoint_detection, utils).  Each entry point below names the reference
+ * interface (file:line under the reference tree) whose device work it replaces; the Python shells in
+ * uda_poseestimation_amd/ bind them with ctypes.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every pointer is a DEVICE pointer unless its name starts with
+ * h_ (host) or the comment says "host array"; `stream` is a hipStream_t passed as void*; return 0 on success,
+ * negative UDAPOSE_ERR_* otherwise; no allocation and no synchronisation inside a call after the first call for a
+ * given convolution geometry (the first call uploads a small tap table); re-entrant across streams.
+ * Activations are NHWC bf16 unless stated; heat-maps are NCHW fp32.
+ */
+#ifndef UDAPOSE_H
+#define UDAPOSE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UDAPOSE_OK 0
+#define UDAPOSE_ERR_ARG (-1)
+#define UDAPOSE_ERR_LAUNCH (-2)
+#define UDAPOSE_ERR_UNSUPPORTED (-3)
+
+int udapose_version(void);
+
+/* ---------------------------------------------------------------- convolution family
+ * Replaces torch.nn.Conv2d / ConvTranspose2d as used by torchvision Bottleneck (lib/models/resnet.py:8-10,25-40),
+ * Upsampling (lib/models/pose_resnet.py:33-43), the head (pose_resnet.py:74) and the VGG encoder / decoder
+ * (lib/models/Style_net.py:32-118). */
+typedef struct {
+    int N, Hi, Wi, Ci;   /* input NHWC (Ci multiple of 32, or exactly 8 for 3-channel images padded to 8) */
+    int Co, KH, KW, stride, pad;
+    int transposed;      /* 1: ConvTranspose2d(k, stride, pad), output_padding 0 */
+    int reflect;         /* 1: ReflectionPad2d(pad) instead of zero padding */
+    int upsample;        /* 1: input is read through nn.Upsample(scale_factor=2, mode='nearest') */
+} udapose_conv_desc;
+
+#define UDAPOSE_EPI_RELU 1
+#define UDAPOSE_EPI_OUT_F32 2
+void udapose_conv_out_hw(const udapose_conv_desc* d, int* Ho, int* Wo);
+int udapose_conv_stat_rows(const udapose_conv_desc* d);
+/* y[N,Ho,Wo,Co] = conv(x, w_fwd) (+bias[Co]) (+res) (ReLU); stats (optional): [stat_rows][2][Co] fp32 partial
+ * (sum, sum of squares) of the fp32 result before bias/res - the BatchNorm batch statistics.  w_fwd: bf16 [Co][KH*KWp][Ci]. */
+int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, const void* w_fwd, void* y, const void* res,
+                       const float* bias, float* stats, int epilogue_flags);
+/* dx[N,Hi,Wi,Ci] = conv^T(dy, w_bwd) (+res);  w_bwd: bf16 [Ci][KH*KW][Co] */
+int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res);
+/* dw fp32 [Co][KH*KWp][Ci] (transposed: [Ci][KH*KW][Co]) = (accumulate ? dw : 0) + sum_pixels dy * x */
+int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate);
+/* weight packing from fp32: cast (n % 8 == 0); per-tap transpose [A][T][B] -> [B][T][A]; strided gather with zero padding */
+int udapose_cast_f32_bf16(void* stream, const float* src, void* dst, size_t n);
+int udapose_transpose_cast(void* stream, const float* src, void* dst, int A, int T, int B);
+int udapose_pack_strided(void* stream, const float* src, void* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh,
+                         long skw, long sb);
+
+/* ---------------------------------------------------------------- layout conversion at the NCHW fp32 boundary */
+int udapose_nchw_f32_to_nhwc_bf16(void* stream, const float* src, void* dst, int N, int C, int HW, int Cpad);
+/* optional per-channel clamp lo/hi[C] = the "recover" clamp of train_human.py:32-33,276,351,356 */
+int udapose_nhwc_to_nchw_f32(void* stream, const void* src, int src_is_f32, float* dst, int N, int C, int HW, int Cstride,
+                             const float* lo, const float* hi);
+
+/* ---------------------------------------------------------------- BatchNorm2d, training mode (torch.nn.BatchNorm2d in
+ * .train(): 107 layers of the pose net, train_human.py:320-321) */
+int udapose_bn_finalize(void* stream, const float* stats, int stat_rows, int C, double count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                        float* scale, float* shift, float* save_mean, float* save_invstd);
+int udapose_bn_eval_coeff(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, float* scale, float* shift);
+int udapose_bn_apply(void* stream, const void* y, const void* res, void* z, size_t numel, int C, const float* scale, const float* shift,
+                     int relu);
+int udapose_bn_bwd_rows(size_t npix);
+/* dz -> dy (+ masked g); slab: [bn_bwd_rows][2][C] fp32 scratch, coef: [3][C] fp32 scratch */
+int udapose_bn_bwd(void* stream, const void* dz, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
+                   const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* slab, float* coef,
+                   float* dgamma, float* dbeta, float beta_acc);
+
+/* ---------------------------------------------------------------- pooling (ResNet stem maxpool 3x3 s2 p1, resnet.py:30;
+ * VGG MaxPool2d(2,2,ceil_mode=True), Style_net.py:72) */
+int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C);
+int udapose_maxpool3x3s2_bwd(void* stream, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C);
+int udapose_maxpool2x2_ceil(void* stream, const void* x, void* y, int N, int H, int W, int C);
+
+/* ---------------------------------------------------------------- whole pose network (lib/models/pose_resnet.py:59-126:
+ * PoseResNet.forward = head(upsampling(backbone(x)))), parameters by index in .parameters() order (host arrays of
+ * device pointers), buffers in .buffers() order.  4-D weights are fp32 in channels_last physical layout. */
+typedef void* udapose_net_t;
+int udapose_net_create(const int layers[4], int num_keypoints, int N, int H, int W, udapose_net_t* out);
+void udapose_net_destroy(udapose_net_t net);
+int udapose_net_num_params(udapose_net_t net);
+int udapose_net_num_buffers(udapose_net_t net);
+long long udapose_net_param_numel(udapose_net_t net, int i);
+size_t udapose_net_wpack_bytes(udapose_net_t net);
+size_t udapose_net_act_bytes(udapose_net_t net);
+size_t udapose_net_ws_bytes(udapose_net_t net);
+void udapose_net_out_shape(udapose_net_t net, int shape[4]);
+int udapose_net_pack_weights(udapose_net_t net, void* stream, const void* const* h_params, void* wpack, int with_bwd);
+int udapose_net_forward(udapose_net_t net, void* stream, const float* x_nchw, const void* const* h_params, void* const* h_buffers,
+                        const void* wpack, void* act, void* ws, float* out_nchw, int training, float momentum);
+int udapose_net_backward(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
+                         void* act, void* ws, void* const* h_grads, float beta);
+
+/* ---------------------------------------------------------------- heat-map losses and decode (fp32 NCHW rows [R=B*K][HW]) */
+/* JointsMSELoss (lib/models/loss.py:39-49): rows[r] = 0.5*w[r]*mean_hw((p-g)^2); mean_out = mean_r rows (reduction='mean') */
+int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out);
+/* d pred = gscale[0] * w[r] * (p-g) / (R*HW) */
+int udapose_joints_mse_bwd(void* stream, const float* pred, const float* gt, const float* w, const float* gscale, int R, int HW,
+                           float* dpred);
+/* ConsLoss (lib/models/loss.py:124-132): mean_out = sum(mask*(s-t)^2)/(R*HW) */
+int udapose_cons_loss_fwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, int R, int HW, float* rows,
+                          float* mean_out);
+int udapose_cons_loss_bwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const float* gscale, int R,
+                          int HW, float* dstu);
+/* get_max_preds(_torch) (lib/keypoint_detection.py:9-37, utils.py:54-75) and rectify (utils.py:77-109): any output may
+ * be NULL.  patch: [(2*rad+1)^2] fp32 Gaussian table built by the caller exactly as utils.py:93-98 does. */
+int udapose_heatmap_argmax(void* stream, const float* hm, int R, int H, int W, float* maxvals, int* flat_idx, float* preds_xy,
+                           float* rectified, const float* patch, int rad);
+/* confidence mask (train_human.py:427-430): thr = k-th smallest of act[n]; mask[i] = (tea_mask[i]*act_local[i]) > thr */
+int udapose_kth_mask(void* stream, const float* act, const float* tea_mask, int n, int k, float* thr_out, unsigned char* mask,
+                     const float* act_local, int n_local);
+/* PCK (lib/keypoint_detection.py:40-94) from decoded coordinates [B,K,2]; acc[K], avg_cnt[2] = (avg_acc, cnt) */
+int udapose_pck(void* stream, const float* pred_xy, const float* gt_xy, int B, int K, float norm_x, float norm_y, float thr, float* acc,
+                float* avg_cnt);
+
+/* ---------------------------------------------------------------- optimizer sweeps over many tensors (device tables) */
+int udapose_multi_chunk(void);
+/* OldWeightEMA.step (utils.py:21-25): t = fl(fl(t*alpha) + fl(s*one_minus_alpha)), bit-exact two-rounding form */
+int udapose_ema_multi(void* stream, const long long* tgt_ptrs, const long long* src_ptrs, const long long* sizes, const int* blk_tensor,
+                      const long long* blk_off, int nblocks, float alpha, float one_minus_alpha);
+/* torch.optim.Adam.step (train_human.py:139,286) */
+int udapose_adam_multi(void* stream, const long long* p, const long long* g, const long long* m, const long long* v,
+                       const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int step, float grad_scale);
+/* torch.optim.SGD(momentum, nesterov) (train_human.py:137) */
+int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes,
+                      const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float momentum, float weight_decay,
+                      int nesterov, int first_step, float grad_scale);
+
+/* ---------------------------------------------------------------- AdaIN (lib/models/Style_net.py:4-29,167-168), NHWC bf16
+ * out = alpha*adain(content, style) + (1-alpha)*content; stats_out (optional) [N][C][4] = (mean_c, std_c, mean_s, std_s) */
+int udapose_adain(void* stream, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps,
+                  float alpha, float* stats_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

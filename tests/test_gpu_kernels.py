@@ -1,0 +1,228 @@
+"""GPU parity tests of each kernel family, through the C ABI, against the torch-CPU fp32 oracle of the same op evaluated on
+the SAME bf16-rounded inputs (so the only differences are accumulation order and the final bf16 rounding of outputs).
+Tolerances: bf16 outputs -> |err| <= 1.2e-2 * max|ref| (bf16 has 8 bits of mantissa: 3.9e-3 relative per rounding);
+fp32 outputs -> 1e-4 relative to max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from uda_poseestimation_amd import _hip
+    _hip.lib()
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def nhwc(x):      # NCHW fp32 cpu -> NHWC bf16 cuda
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def nchw(y):      # NHWC cuda -> NCHW fp32 cpu
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, tol):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+CONV_CASES = [
+    # name, N, H, W, Ci, Co, K, stride, pad
+    ("1x1_64_256", 2, 16, 16, 64, 256, 1, 1, 0),
+    ("1x1_s2", 2, 16, 16, 256, 512, 1, 2, 0),
+    ("3x3_s1", 2, 16, 16, 64, 64, 3, 1, 1),
+    ("3x3_s2", 2, 16, 16, 128, 128, 3, 2, 1),
+    ("3x3_ragged", 3, 12, 12, 64, 128, 3, 1, 1),
+    ("3x3_odd", 1, 9, 7, 32, 64, 3, 2, 1),
+    ("1x1_big", 4, 32, 32, 256, 1024, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(dev, case):
+    from uda_poseestimation_amd import ops
+    _, N, H, W, Ci, Co, K, s, p = case
+    g = torch.Generator().manual_seed(1)
+    x = bf(torch.randn(N, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5)
+    d = ops.conv_desc(N, H, W, Ci, Co, K, s, p)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=s, padding=p)
+    y, stats = ops.conv2d_fwd(nhwc(x), ops.pack_weight(w.cuda(), d, "fwd"), d, want_stats=True)
+    close(nchw(y), ref.detach(), 1.2e-2)
+    # fused BN statistics: column sums of the fp32 result
+    ssum = stats.double().sum(0).cpu()
+    np.testing.assert_allclose(ssum[0].numpy(), ref.detach().double().sum((0, 2, 3)).numpy(), rtol=2e-3, atol=2e-3 * ref.abs().sum().item() / Co)
+    np.testing.assert_allclose(ssum[1].numpy(), (ref.detach().double() ** 2).sum((0, 2, 3)).numpy(), rtol=2e-3)
+    dy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(dy)
+    if Ci % 32 == 0:
+        dx = ops.conv2d_bwd_data(nhwc(dy), ops.pack_weight(w.cuda(), d, "bwd"), d)
+        close(nchw(dx), xr.grad, 1.2e-2)
+    dw = ops.conv2d_bwd_weight(nhwc(dy), nhwc(x), d)          # [Co][T][Ci] fp32
+    close(dw.cpu().reshape(Co, K, K, Ci).permute(0, 3, 1, 2), wr.grad, 2e-3)
+    dw2 = ops.conv2d_bwd_weight(nhwc(dy), nhwc(x), d, dw=dw.clone())   # accumulate path
+    close(dw2.cpu(), 2 * dw.cpu(), 1e-4)
+
+
+def test_conv_epilogue_res_bias_relu_f32(dev):
+    from uda_poseestimation_amd import ops
+    g = torch.Generator().manual_seed(2)
+    N, H, W, Ci = 2, 8, 8, 256
+    for Co in (16, 18, 21):      # heads: human / animal / hand key-point counts
+        x = bf(torch.randn(N, Ci, H, W, generator=g))
+        w = bf(torch.randn(Co, Ci, 1, 1, generator=g) * 0.05)
+        b = torch.randn(Co, generator=g)
+        d = ops.conv_desc(N, H, W, Ci, Co, 1)
+        y = ops.conv2d_fwd(nhwc(x), ops.pack_weight(w.cuda(), d), d, bias=b.cuda(), out_f32=True)
+        close(nchw(y), F.conv2d(x, w, b), 1e-4)
+    Co = 64
+    x = bf(torch.randn(N, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 1, 1, generator=g) * 0.05)
+    r = bf(torch.randn(N, Co, H, W, generator=g))
+    d = ops.conv_desc(N, H, W, Ci, Co, 1)
+    y = ops.conv2d_fwd(nhwc(x), ops.pack_weight(w.cuda(), d), d, res=nhwc(r), relu=True)
+    close(nchw(y), F.relu(F.conv2d(x, w) + r), 1.2e-2)
+
+
+def test_stem_conv7x7(dev):
+    from uda_poseestimation_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 2, 64, 64
+    x = bf(torch.randn(N, 3, H, W, generator=g))
+    w = bf(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    d = ops.conv_desc(N, H, W, 8, 64, 7, 2, 3)
+    x8 = ops.to_nhwc_bf16(x.cuda(), 8)
+    assert x8.shape == (N, H, W, 8) and float(x8[..., 3:].abs().max()) == 0.0
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(x, wr, stride=2, padding=3)
+    y = ops.conv2d_fwd(x8, ops.pack_weight(w.cuda(), d), d)
+    close(nchw(y), ref.detach(), 1.2e-2)
+    dy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(dy)
+    dw = ops.conv2d_bwd_weight(nhwc(dy), x8, d).cpu().reshape(64, 7, 8, 8)[:, :, :7, :3].permute(0, 3, 1, 2)
+    close(dw, wr.grad, 2e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 2048, 256), (2, 16, 16, 256, 256), (1, 5, 6, 64, 32)], ids=["up1", "up2", "odd"])
+def test_deconv4x4s2(dev, shape):
+    from uda_poseestimation_amd import ops
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(4)
+    x = bf(torch.randn(N, Ci, H, W, generator=g))
+    w = bf(torch.randn(Ci, Co, 4, 4, generator=g) / (Ci * 4) ** 0.5)
+    d = ops.conv_desc(N, H, W, Ci, Co, 4, 2, 1, transposed=True)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, stride=2, padding=1)
+    y, stats = ops.conv2d_fwd(nhwc(x), ops.pack_weight(w.cuda(), d, "fwd"), d, want_stats=True)
+    assert tuple(y.shape) == (N, 2 * H, 2 * W, Co)
+    close(nchw(y), ref.detach(), 1.2e-2)
+    np.testing.assert_allclose(stats.double().sum(0)[1].cpu().numpy(), (ref.detach().double() ** 2).sum((0, 2, 3)).numpy(), rtol=2e-3)
+    dy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(dy)
+    dx = ops.conv2d_bwd_data(nhwc(dy), ops.pack_weight(w.cuda(), d, "bwd"), d)
+    close(nchw(dx), xr.grad, 1.2e-2)
+    dw = ops.conv2d_bwd_weight(nhwc(dy), nhwc(x), d)           # [Ci][16][Co]
+    close(dw.cpu().reshape(Ci, 4, 4, Co).permute(0, 3, 1, 2), wr.grad, 2e-3)
+
+
+def test_reflect_and_upsample_conv(dev):
+    from uda_poseestimation_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Ci, Co = 2, 10, 12, 64, 64
+    x = bf(torch.randn(N, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / 24)
+    b = torch.randn(Co, generator=g)
+    d = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1, reflect=True)
+    y = ops.conv2d_fwd(nhwc(x), ops.pack_weight(w.cuda(), d), d, bias=b.cuda(), relu=True)
+    close(nchw(y), F.relu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)), 1.2e-2)
+    d2 = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1, reflect=True, upsample=True)
+    y2 = ops.conv2d_fwd(nhwc(x), ops.pack_weight(w.cuda(), d2), d2, bias=b.cuda())
+    xu = F.interpolate(x, scale_factor=2, mode="nearest")
+    close(nchw(y2), F.conv2d(F.pad(xu, (1, 1, 1, 1), mode="reflect"), w, b), 1.2e-2)
+    # 3-channel image input (first VGG 3x3 conv): Ci padded to 8
+    x3 = bf(torch.randn(N, 3, H, W, generator=g))
+    w3 = bf(torch.randn(64, 3, 3, 3, generator=g) / 5)
+    d3 = ops.conv_desc(N, H, W, 8, 64, 3, 1, 1, reflect=True)
+    y3 = ops.conv2d_fwd(ops.to_nhwc_bf16(x3.cuda(), 8), ops.pack_weight(w3.cuda(), d3), d3)
+    close(nchw(y3), F.conv2d(F.pad(x3, (1, 1, 1, 1), mode="reflect"), w3), 1.2e-2)
+
+
+def test_batchnorm_train_fwd_bwd(dev):
+    from uda_poseestimation_amd import ops
+    g = torch.Generator().manual_seed(6)
+    N, H, W, Ci, C_ = 4, 16, 16, 64, 128
+    x = bf(torch.randn(N, Ci, H, W, generator=g))
+    w = bf(torch.randn(C_, Ci, 1, 1, generator=g) * 0.2)
+    res = bf(torch.randn(N, C_, H, W, generator=g))
+    gamma = torch.rand(C_, generator=g) + 0.5
+    beta = torch.randn(C_, generator=g) * 0.1
+    d = ops.conv_desc(N, H, W, Ci, C_, 1)
+    y, stats = ops.conv2d_fwd(nhwc(x), ops.pack_weight(w.cuda(), d), d, want_stats=True)
+    rm, rv = torch.zeros(C_).cuda(), torch.ones(C_).cuda()
+    nbt = torch.zeros((), dtype=torch.int64).cuda()
+    z, mean, invstd = ops.bn_train_fwd(y, stats, gamma.cuda(), beta.cuda(), rm, rv, nbt, res=nhwc(res), relu=True)
+    # oracle on the stored bf16 conv output
+    yc = nchw(y).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C_)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    bn.train()
+    zr = F.relu(bn(yc) + res)
+    close(nchw(z), zr.detach(), 1.5e-2)
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=2e-2)
+    assert int(nbt) == 1
+    dz = bf(torch.randn(zr.shape, generator=g))
+    # the ReLU mask is taken from the DEVICE output z (pre-activations within rounding of 0 may differ in sign
+    # between the two evaluation orders; the gradient definition is the same)
+    gm = dz * (nchw(z) > 0)
+    (bn(yc) + res).backward(gm)
+    dy, dgamma, dbeta, gmask = ops.bn_bwd(nhwc(dz), z, y, gamma.cuda(), mean, invstd, relu=True, want_g=True)
+    close(nchw(dy), yc.grad, 3e-2)
+    close(dgamma.cpu(), bn.weight.grad, 2e-2)
+    close(dbeta.cpu(), bn.bias.grad, 2e-2)
+    close(nchw(gmask), gm, 1.2e-2)
+    assert ((nchw(z) > 0) != (zr.detach() > 0)).float().mean().item() < 1e-3
+
+
+def test_maxpool(dev):
+    from uda_poseestimation_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = F.relu(bf(torch.randn(2, 64, 18, 20, generator=g)))        # many exact ties at 0 (post-ReLU)
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    y, idx = ops.maxpool3x3s2_fwd(nhwc(x))
+    assert torch.equal(nchw(y), ref.detach())
+    dy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(dy)
+    dx = ops.maxpool3x3s2_bwd(nhwc(dy), idx, 18, 20)
+    close(nchw(dx), xr.grad, 1.2e-2)
+    x2 = bf(torch.randn(2, 64, 9, 11, generator=g))
+    assert torch.equal(nchw(ops.maxpool2x2_ceil(nhwc(x2))), F.max_pool2d(x2, 2, 2, 0, ceil_mode=True))
+
+
+def test_adain_matches_oracle(dev, golden_dir):
+    import os
+    from oracle import style_ref
+    from uda_poseestimation_amd import ops
+    z = np.load(os.path.join(golden_dir, "style.npz"))
+    c, s = bf(torch.from_numpy(z["c"])), bf(torch.from_numpy(z["s"]))
+    out, st = ops.adain(nhwc(c), nhwc(s), alpha=0.6, want_stats=True)
+    ref = 0.6 * style_ref.adain_ref(c, s) + 0.4 * c
+    close(nchw(out), ref, 1.2e-2)
+    m, sd = style_ref.calc_mean_std_ref(c)
+    np.testing.assert_allclose(st[..., 0].cpu().numpy(), m.reshape(2, 512).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(st[..., 1].cpu().numpy(), sd.reshape(2, 512).numpy(), rtol=1e-4)

@@ -1,0 +1,110 @@
+"""ctypes binding of libudapose_hip.so (C ABI declared in include/udapose.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the library is missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libudapose_hip.so")
+_lib = None
+
+vp, ci, cf, cd, sz, ll, cl = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_longlong, C.c_long
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("N", "Hi", "Wi", "Ci", "Co", "KH", "KW", "stride", "pad", "transposed", "reflect", "upsample")]
+
+
+_SIGS = {
+    "udapose_version": (ci, []),
+    "udapose_conv_out_hw": (None, [vp, vp, vp]),
+    "udapose_conv_stat_rows": (ci, [vp]),
+    "udapose_conv2d_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci]),
+    "udapose_conv2d_bwd_data": (ci, [vp, vp, vp, vp, vp, vp]),
+    "udapose_conv2d_bwd_weight": (ci, [vp, vp, vp, vp, vp, ci]),
+    "udapose_cast_f32_bf16": (ci, [vp, vp, vp, sz]),
+    "udapose_transpose_cast": (ci, [vp, vp, vp, ci, ci, ci]),
+    "udapose_pack_strided": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, cl, cl, cl, cl]),
+    "udapose_nchw_f32_to_nhwc_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_nhwc_to_nchw_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
+    "udapose_bn_finalize": (ci, [vp, vp, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp]),
+    "udapose_bn_eval_coeff": (ci, [vp, ci, vp, vp, vp, vp, cf, vp, vp]),
+    "udapose_bn_apply": (ci, [vp, vp, vp, vp, sz, ci, vp, vp, ci]),
+    "udapose_bn_bwd_rows": (ci, [sz]),
+    "udapose_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, sz, ci, vp, vp, vp, ci, vp, vp, vp, vp, cf]),
+    "udapose_maxpool3x3s2_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_maxpool3x3s2_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_maxpool2x2_ceil": (ci, [vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_net_create": (ci, [vp, ci, ci, ci, ci, vp]),
+    "udapose_net_destroy": (None, [vp]),
+    "udapose_net_num_params": (ci, [vp]),
+    "udapose_net_num_buffers": (ci, [vp]),
+    "udapose_net_param_numel": (ll, [vp, ci]),
+    "udapose_net_wpack_bytes": (sz, [vp]),
+    "udapose_net_act_bytes": (sz, [vp]),
+    "udapose_net_ws_bytes": (sz, [vp]),
+    "udapose_net_out_shape": (None, [vp, vp]),
+    "udapose_net_pack_weights": (ci, [vp, vp, vp, vp, ci]),
+    "udapose_net_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf]),
+    "udapose_net_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf]),
+    "udapose_joints_mse_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),
+    "udapose_joints_mse_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
+    "udapose_cons_loss_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),
+    "udapose_cons_loss_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
+    "udapose_heatmap_argmax": (ci, [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci]),
+    "udapose_kth_mask": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci]),
+    "udapose_pck": (ci, [vp, vp, vp, ci, ci, cf, cf, cf, vp, vp]),
+    "udapose_multi_chunk": (ci, []),
+    "udapose_ema_multi": (ci, [vp, vp, vp, vp, vp, vp, ci, cf, cf]),
+    "udapose_adam_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, cf]),
+    "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf]),
+    "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
+}
+EXPORTS = tuple(_SIGS.keys())
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (raises loudly if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `make -C uda_poseestimation_amd/csrc` (or __graft_entry__.build()). "
+                "uda_poseestimation_amd has no CPU / eager fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        raise RuntimeError(f"libudapose_hip call failed ({what}): error {code}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("uda_poseestimation_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback; "
+                               "the CPU restatement lives in oracle/ and is test-only)")

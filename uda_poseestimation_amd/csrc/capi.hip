@@ -1,0 +1,176 @@
+// extern "C" surface of libudapose_hip.so (declared in include/udapose.h).
+#include "conv_plan.h"
+#include "../../include/udapose.h"
+
+int pw_nchw_f32_to_nhwc_bf16(hipStream_t, const float*, bf16_t*, int, int, int, int);
+int pw_nhwc_to_nchw_f32(hipStream_t, const void*, int, float*, int, int, int, int, const float*, const float*);
+int pw_cast_f32_bf16(hipStream_t, const float*, bf16_t*, size_t);
+int pw_transpose_cast(hipStream_t, const float*, bf16_t*, int, int, int);
+int pw_pack_strided(hipStream_t, const float*, bf16_t*, int, int, int, int, int, int, long, long, long, long);
+int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
+                   float*, float*);
+int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
+int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
+int pw_bn_bwd_rows(size_t);
+int pw_bn_bwd(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
+              float*, float*, float*, float*, float);
+int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
+int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
+int pw_maxpool2x2_ceil(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int);
+int hm_sqdiff_rows(hipStream_t, const float*, const float*, const float*, const unsigned char*, int, int, float, float*, float*);
+int hm_sqdiff_bwd(hipStream_t, const float*, const float*, const float*, const unsigned char*, const float*, float, int, int, float*);
+int hm_argmax_rectify(hipStream_t, const float*, int, int, int, float*, int*, float*, float*, const float*, int);
+int hm_kth_mask(hipStream_t, const float*, const float*, int, int, float*, unsigned char*, const float*, int);
+int hm_pck(hipStream_t, const float*, const float*, int, int, float, float, float, float*, float*);
+int opt_chunk();
+int opt_ema(hipStream_t, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float);
+int opt_adam(hipStream_t, const long long*, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int,
+             float, float, float, float, float, int, float);
+int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float, float,
+            int, int, float);
+int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, float, float, float*);
+void* net_create(const int layers[4], int K, int N, int H, int W);
+void net_destroy(void*);
+int net_num_params(void*);
+int net_num_buffers(void*);
+long long net_param_numel(void*, int);
+size_t net_wpack_bytes(void*);
+size_t net_act_bytes(void*);
+size_t net_ws_bytes(void*);
+void net_out_shape(void*, int*);
+int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
+int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
+int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float);
+
+static ConvGeom to_geom(const udapose_conv_desc* d) {
+    return ConvGeom{d->N, d->Hi, d->Wi, d->Ci, d->Co, d->KH, d->KW, d->stride, d->pad, d->transposed, d->reflect, d->upsample};
+}
+#define S(x) ((hipStream_t)(x))
+#define B16(x) ((bf16_t*)(x))
+#define CB16(x) ((const bf16_t*)(x))
+
+extern "C" {
+
+int udapose_version(void) { return 100; }
+
+void udapose_conv_out_hw(const udapose_conv_desc* d, int* Ho, int* Wo) { ConvGeom g = to_geom(d); *Ho = g.Ho(); *Wo = g.Wo(); }
+int udapose_conv_stat_rows(const udapose_conv_desc* d) { return conv_stat_rows(to_geom(d)); }
+int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, const void* w_fwd, void* y, const void* res, const float* bias,
+                       float* stats, int flags) {
+    if (!d || !x || !w_fwd || !y) return UDAPOSE_ERR_ARG;
+    ConvEpilogue e;
+    e.res = CB16(res); e.bias = bias; e.stats = stats; e.relu = (flags & UDAPOSE_EPI_RELU) != 0; e.out_f32 = (flags & UDAPOSE_EPI_OUT_F32) != 0;
+    return conv_fprop(S(stream), to_geom(d), CB16(x), CB16(w_fwd), y, e);
+}
+int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res) {
+    if (!d || !dy || !w_bwd || !dx) return UDAPOSE_ERR_ARG;
+    return conv_dgrad(S(stream), to_geom(d), CB16(dy), CB16(w_bwd), B16(dx), CB16(res));
+}
+int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate) {
+    if (!d || !dy || !x || !dw) return UDAPOSE_ERR_ARG;
+    return conv_wgrad(S(stream), to_geom(d), CB16(dy), CB16(x), dw, accumulate, -1);
+}
+int udapose_cast_f32_bf16(void* stream, const float* src, void* dst, size_t n) { return pw_cast_f32_bf16(S(stream), src, B16(dst), n); }
+int udapose_transpose_cast(void* stream, const float* src, void* dst, int A, int T, int B) { return pw_transpose_cast(S(stream), src, B16(dst), A, T, B); }
+int udapose_pack_strided(void* stream, const float* src, void* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
+    return pw_pack_strided(S(stream), src, B16(dst), A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
+}
+int udapose_nchw_f32_to_nhwc_bf16(void* stream, const float* src, void* dst, int N, int C, int HW, int Cpad) {
+    return pw_nchw_f32_to_nhwc_bf16(S(stream), src, B16(dst), N, C, HW, Cpad);
+}
+int udapose_nhwc_to_nchw_f32(void* stream, const void* src, int src_is_f32, float* dst, int N, int C, int HW, int Cs, const float* lo, const float* hi) {
+    return pw_nhwc_to_nchw_f32(S(stream), src, src_is_f32, dst, N, C, HW, Cs, lo, hi);
+}
+int udapose_bn_finalize(void* stream, const float* stats, int rows, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
+                        long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
+    return pw_bn_finalize(S(stream), stats, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift, save_mean, save_invstd);
+}
+int udapose_bn_eval_coeff(void* stream, int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
+                          float* shift) {
+    return pw_bn_eval_coeff(S(stream), C, gamma, beta, rm, rv, eps, scale, shift);
+}
+int udapose_bn_apply(void* stream, const void* y, const void* res, void* z, size_t numel, int C, const float* scale, const float* shift, int relu) {
+    return pw_bn_apply(S(stream), CB16(y), CB16(res), B16(z), numel, C, scale, shift, relu);
+}
+int udapose_bn_bwd_rows(size_t npix) { return pw_bn_bwd_rows(npix); }
+int udapose_bn_bwd(void* stream, const void* dz, const void* z, const void* y, void* dy, void* gout, size_t npix, int C, const float* gamma,
+                   const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta, float beta_acc) {
+    return pw_bn_bwd(S(stream), CB16(dz), CB16(z), CB16(y), B16(dy), B16(gout), npix, C, gamma, mean, invstd, relu, slab, coef, dgamma, dbeta, beta_acc);
+}
+int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C) {
+    return pw_maxpool3x3s2_fwd(S(stream), CB16(x), B16(y), idx, N, H, W, C);
+}
+int udapose_maxpool3x3s2_bwd(void* stream, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C) {
+    return pw_maxpool3x3s2_bwd(S(stream), CB16(dy), idx, B16(dx), N, H, W, C);
+}
+int udapose_maxpool2x2_ceil(void* stream, const void* x, void* y, int N, int H, int W, int C) {
+    return pw_maxpool2x2_ceil(S(stream), CB16(x), B16(y), N, H, W, C);
+}
+
+int udapose_net_create(const int layers[4], int K, int N, int H, int W, udapose_net_t* out) {
+    if (!out) return UDAPOSE_ERR_ARG;
+    *out = net_create(layers, K, N, H, W);
+    return *out ? UDAPOSE_OK : UDAPOSE_ERR_ARG;
+}
+void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
+int udapose_net_num_params(udapose_net_t n) { return net_num_params(n); }
+int udapose_net_num_buffers(udapose_net_t n) { return net_num_buffers(n); }
+long long udapose_net_param_numel(udapose_net_t n, int i) { return net_param_numel(n, i); }
+size_t udapose_net_wpack_bytes(udapose_net_t n) { return net_wpack_bytes(n); }
+size_t udapose_net_act_bytes(udapose_net_t n) { return net_act_bytes(n); }
+size_t udapose_net_ws_bytes(udapose_net_t n) { return net_ws_bytes(n); }
+void udapose_net_out_shape(udapose_net_t n, int shape[4]) { net_out_shape(n, shape); }
+int udapose_net_pack_weights(udapose_net_t n, void* stream, const void* const* params, void* wpack, int with_bwd) {
+    return net_pack_weights(n, S(stream), params, wpack, with_bwd);
+}
+int udapose_net_forward(udapose_net_t n, void* stream, const float* x, const void* const* params, void* const* buffers, const void* wpack, void* act,
+                        void* ws, float* out, int training, float momentum) {
+    return net_forward(n, S(stream), x, params, buffers, wpack, act, ws, out, training, momentum);
+}
+int udapose_net_backward(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act, void* ws,
+                         void* const* grads, float beta) {
+    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta);
+}
+
+int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out) {
+    return hm_sqdiff_rows(S(stream), pred, gt, w, nullptr, R, HW, 0.5f, rows, mean_out);
+}
+int udapose_joints_mse_bwd(void* stream, const float* pred, const float* gt, const float* w, const float* gscale, int R, int HW, float* dpred) {
+    return hm_sqdiff_bwd(S(stream), pred, gt, w, nullptr, gscale, (float)(1.0 / ((double)R * HW)), R, HW, dpred);
+}
+int udapose_cons_loss_fwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, int R, int HW, float* rows, float* mean_out) {
+    return hm_sqdiff_rows(S(stream), stu, tea, nullptr, mask, R, HW, 1.0f, rows, mean_out);
+}
+int udapose_cons_loss_bwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const float* gscale, int R, int HW, float* dstu) {
+    return hm_sqdiff_bwd(S(stream), stu, tea, nullptr, mask, gscale, (float)(2.0 / ((double)R * HW)), R, HW, dstu);
+}
+int udapose_heatmap_argmax(void* stream, const float* hm, int R, int H, int W, float* maxvals, int* flat_idx, float* preds, float* rect,
+                           const float* patch, int rad) {
+    if (rect && !patch) return UDAPOSE_ERR_ARG;
+    return hm_argmax_rectify(S(stream), hm, R, H, W, maxvals, flat_idx, preds, rect, patch, rad);
+}
+int udapose_kth_mask(void* stream, const float* act, const float* tm, int n, int k, float* thr_out, unsigned char* mask, const float* act_local,
+                     int n_local) {
+    return hm_kth_mask(S(stream), act, tm, n, k, thr_out, mask, act_local, n_local);
+}
+int udapose_pck(void* stream, const float* pred, const float* gt, int B, int K, float nx, float ny, float thr, float* acc, float* avg_cnt) {
+    return hm_pck(S(stream), pred, gt, B, K, nx, ny, thr, acc, avg_cnt);
+}
+int udapose_multi_chunk(void) { return opt_chunk(); }
+int udapose_ema_multi(void* stream, const long long* t, const long long* s, const long long* sizes, const int* bt, const long long* bo, int nb,
+                      float alpha, float oma) {
+    return opt_ema(S(stream), t, s, sizes, bt, bo, nb, alpha, oma);
+}
+int udapose_adam_multi(void* stream, const long long* p, const long long* g, const long long* m, const long long* v, const long long* sizes,
+                       const int* bt, const long long* bo, int nb, float lr, float b1, float b2, float eps, float wd, int step, float gscale) {
+    return opt_adam(S(stream), p, g, m, v, sizes, bt, bo, nb, lr, b1, b2, eps, wd, step, gscale);
+}
+int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes, const int* bt,
+                      const long long* bo, int nb, float lr, float mom, float wd, int nesterov, int first, float gscale) {
+    return opt_sgd(S(stream), p, g, buf, sizes, bt, bo, nb, lr, mom, wd, nesterov, first, gscale);
+}
+int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha, float* stats_out) {
+    return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, stats_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Host-side description of one convolution and the tap plans (fprop / dgrad / wgrad) the igemm kernels execute.
+#pragma once
+#include <vector>
+#include "igemm.h"
+
+struct ConvGeom {
+    int N, Hi, Wi, Ci;      // logical input (for transposed: the small side)
+    int Co, KH, KW, stride, pad;
+    int transposed;         // 1 = ConvTranspose2d(k, stride, pad, output_padding = 0)
+    int reflect;            // reflection padding (style net)
+    int upsample;           // nearest x2 upsample folded into the loader (style decoder); Hi/Wi are the PHYSICAL dims
+    int Ho() const { return transposed ? (Hi - 1) * stride - 2 * pad + KH : (((Hi << upsample) + 2 * pad - KH) / stride + 1); }
+    int Wo() const { return transposed ? (Wi - 1) * stride - 2 * pad + KW : (((Wi << upsample) + 2 * pad - KW) / stride + 1); }
+    bool smallc() const { return Ci == 8; }
+    int KWp() const { return smallc() ? ((KW + 3) & ~3) : KW; }   // taps padded so that 4 taps fill a 32-wide K step
+    int wtaps() const { return KH * KWp(); }
+};
+
+struct TapPlan {
+    std::vector<IgTap> taps;
+    int nclass = 1;
+    IgClass cls[4];
+    const IgTap* d_taps = nullptr;   // device copy (owned by the plan cache)
+};
+
+// direction 0: fprop (also the plan wgrad walks), 1: dgrad
+const TapPlan* get_tap_plan(const ConvGeom& g, int direction);
+
+int igemm_pick_tile(int M, int Co, int nclass);
+int igemm_stat_rows(int M, int Co, int nclass, int tile);
+int igemm_launch(IgParams& p, int tile, hipStream_t stream);
+int wgrad_pick_tile(int Rdim, int Cdim, int smallc);
+int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream);
+
+struct ConvEpilogue {
+    const bf16_t* res = nullptr;
+    const float* bias = nullptr;
+    float* stats = nullptr;
+    int relu = 0;
+    int out_f32 = 0;
+};
+// y = conv(x, w_fwd[Co][wtaps][Ci])
+int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e);
+// dx = conv^T(dy, w_bwd[Ci][wtaps][Co]) (+ res)
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, bf16_t* dx, const bf16_t* res);
+// dw (fp32, [Co][wtaps][Ci]; transposed: [Ci][wtaps][Co]) (+)= ...;  rows_valid < 0 -> all rows
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid);
+int conv_stat_rows(const ConvGeom& g);

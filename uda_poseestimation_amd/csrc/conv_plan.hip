@@ -1,0 +1,135 @@
+// Tap-plan construction (which input pixel and weight slab every filter tap of every sub-pixel class touches) and the
+// three convolution entry points built on the igemm / wgrad kernels.
+#include <map>
+#include <mutex>
+#include <tuple>
+#include "conv_plan.h"
+
+namespace {
+
+std::mutex g_mu;
+std::map<std::tuple<int, int, int, int, int, int, int>, TapPlan*> g_plans;
+
+// classes of a stride-s transposed mapping: output/in-grad pixel o = s*i + a receives tap k iff k == (a+p) mod s,
+// from source pixel i + (a+p-k)/s.
+void build_subpixel(TapPlan& tp, int KH, int KW, int KWp, int s, int p) {
+    tp.nclass = s * s;
+    for (int a = 0; a < s; ++a)
+        for (int b = 0; b < s; ++b) {
+            IgClass& c = tp.cls[a * s + b];
+            c.tap_off = (int)tp.taps.size();
+            c.oa = a;
+            c.ob = b;
+            for (int kh = 0; kh < KH; ++kh) {
+                if (((a + p - kh) % s + s) % s) continue;
+                for (int kw = 0; kw < KW; ++kw) {
+                    if (((b + p - kw) % s + s) % s) continue;
+                    tp.taps.push_back(IgTap{(a + p - kh) / s, (b + p - kw) / s, kh * KWp + kw, a * s + b});
+                }
+            }
+            c.ntaps = (int)tp.taps.size() - c.tap_off;
+        }
+}
+void build_direct(TapPlan& tp, int KH, int KW, int KWp, int p) {
+    tp.nclass = 1;
+    tp.cls[0] = IgClass{0, KH * KWp, 0, 0};
+    for (int kh = 0; kh < KH; ++kh)
+        for (int kw = 0; kw < KWp; ++kw) tp.taps.push_back(IgTap{kh - p, kw - p, kh * KWp + kw, 0});
+}
+
+}  // namespace
+
+const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
+    const auto key = std::make_tuple(g.KH, g.KW, g.stride, g.pad, g.transposed, g.KWp(), direction);
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    TapPlan* tp = new TapPlan();
+    const int KWp = g.KWp();
+    const bool sub = (direction == 0) ? (g.transposed != 0) : (g.transposed == 0 && g.stride > 1);
+    if (g.stride > 2 && sub) { delete tp; return nullptr; }
+    if (sub) {
+        build_subpixel(*tp, g.KH, g.KW, KWp, g.stride, g.pad);
+    } else if (direction == 0 || g.transposed) {
+        build_direct(*tp, g.KH, g.KW, KWp, g.pad);          // fprop of a conv, or dgrad of a transposed conv
+    } else {
+        tp->nclass = 1;                                      // dgrad of a stride-1 conv: mirrored offsets
+        tp->cls[0] = IgClass{0, g.KH * g.KW, 0, 0};
+        for (int kh = 0; kh < g.KH; ++kh)
+            for (int kw = 0; kw < g.KW; ++kw) tp->taps.push_back(IgTap{g.pad - kh, g.pad - kw, kh * KWp + kw, 0});
+    }
+    IgTap* d = nullptr;
+    const size_t bytes = (tp->taps.size() + 4) * sizeof(IgTap);
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) { delete tp; return nullptr; }
+    std::vector<IgTap> padded(tp->taps);
+    for (int i = 0; i < 4; ++i) padded.push_back(IgTap{1 << 20, 1 << 20, 0, 0});
+    if (hipMemcpy(d, padded.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { delete tp; return nullptr; }
+    tp->d_taps = d;
+    g_plans[key] = tp;
+    return tp;
+}
+
+int conv_stat_rows(const ConvGeom& g) {
+    const int nclass = g.transposed ? g.stride * g.stride : 1;
+    const int M = g.transposed ? g.N * g.Hi * g.Wi : g.N * g.Ho() * g.Wo();
+    return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass));
+}
+
+int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e) {
+    const TapPlan* tp = get_tap_plan(g, 0);
+    if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
+    if (g.transposed && (g.reflect || g.upsample)) return UDAPOSE_ERR_UNSUPPORTED;
+    IgParams p{};
+    p.x = x; p.w = w_fwd; p.y = y; p.res = e.res; p.bias = e.bias; p.stats = e.stats; p.taps = tp->d_taps;
+    p.N = g.N; p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci;
+    p.Ho = g.Ho(); p.Wo = g.Wo(); p.Co = g.Co;
+    if (g.transposed) { p.Hg = g.Hi; p.Wg = g.Wi; p.s = 1; p.os = g.stride; }
+    else { p.Hg = p.Ho; p.Wg = p.Wo; p.s = g.stride; p.os = 1; }
+    p.M = g.N * p.Hg * p.Wg;
+    p.wtaps = g.wtaps();
+    p.flags = (g.reflect ? IG_FLAG_REFLECT : 0) | (g.upsample ? IG_FLAG_UPSAMPLE : 0) | (e.relu ? IG_FLAG_RELU : 0) |
+              (e.out_f32 ? IG_FLAG_OUT_F32 : 0) | (g.smallc() ? IG_FLAG_SMALLC : 0);
+    p.nclass = tp->nclass;
+    for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
+    return igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+}
+
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, bf16_t* dx, const bf16_t* res) {
+    if (g.reflect || g.upsample || g.smallc()) return UDAPOSE_ERR_UNSUPPORTED;
+    const TapPlan* tp = get_tap_plan(g, 1);
+    if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
+    IgParams p{};
+    p.x = dy; p.w = w_bwd; p.y = dx; p.res = res; p.taps = tp->d_taps;
+    p.N = g.N; p.Hi = g.Ho(); p.Wi = g.Wo(); p.Ci = g.Co;     // igemm "input" is dy
+    p.Ho = g.Hi; p.Wo = g.Wi; p.Co = g.Ci;                     // igemm "output" is dx
+    if (g.transposed) { p.Hg = g.Hi; p.Wg = g.Wi; p.s = g.stride; p.os = 1; }
+    else if (g.stride > 1) { p.Hg = (g.Hi + g.stride - 1) / g.stride; p.Wg = (g.Wi + g.stride - 1) / g.stride; p.s = 1; p.os = g.stride; }
+    else { p.Hg = g.Hi; p.Wg = g.Wi; p.s = 1; p.os = 1; }
+    p.M = g.N * p.Hg * p.Wg;
+    p.wtaps = g.wtaps();
+    p.flags = 0;
+    p.nclass = tp->nclass;
+    for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
+    return igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+}
+
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid) {
+    if (g.reflect || g.upsample) return UDAPOSE_ERR_UNSUPPORTED;
+    const TapPlan* tp = get_tap_plan(g, 0);
+    if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
+    WgParams p{};
+    p.dy = dy; p.x = x; p.dw = dw; p.taps = tp->d_taps;
+    p.N = g.N; p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci;
+    p.Ho = g.Ho(); p.Wo = g.Wo(); p.Co = g.Co;
+    if (g.transposed) { p.Hg = g.Hi; p.Wg = g.Wi; p.s = 1; p.os = g.stride; }
+    else { p.Hg = p.Ho; p.Wg = p.Wo; p.s = g.stride; p.os = 1; }
+    p.M = g.N * p.Hg * p.Wg;
+    p.wtaps = g.wtaps();
+    p.flags = (g.smallc() ? IG_FLAG_SMALLC : 0) | (g.transposed ? WG_FLAG_SWAP : 0);
+    p.nclass = tp->nclass;
+    for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
+    p.total_taps = (int)tp->taps.size();
+    const int Rdim = g.transposed ? g.Ci : g.Co, Cdim = g.transposed ? g.Co : g.Ci;
+    p.rows_valid = rows_valid < 0 ? Rdim : rows_valid;
+    return wgrad_launch(p, wgrad_pick_tile(Rdim, Cdim, g.smallc()), accumulate, s);
+}

@@ -1,0 +1,60 @@
+// Parameter block shared by the implicit-GEMM convolution kernels (fprop, dgrad, sub-pixel deconv) and wgrad.
+#pragma once
+#include "common.h"
+
+// One filter tap of one output class: input offset (dy,dx) relative to (i*s, j*s) and the weight slab index.
+struct IgTap { int dy, dx, widx, cls; };   // cls: owning output class (used by wgrad)
+// An output class (sub-pixel phase): rows m=(n,i,j) over an Hg x Wg grid write output pixel (i*os+oa, j*os+ob).
+struct IgClass { int tap_off, ntaps, oa, ob; };
+
+#define IG_FLAG_REFLECT 1     // reflection padding instead of zero padding
+#define IG_FLAG_UPSAMPLE 2    // input is read through a nearest x2 upsample (logical dims = 2x physical)
+#define IG_FLAG_RELU 4
+#define IG_FLAG_OUT_F32 8     // y is fp32 NHWC instead of bf16 NHWC
+#define IG_FLAG_SMALLC 16     // Ci == 8: one 32-wide K step covers 4 taps (stem / first VGG conv)
+
+struct IgParams {
+    const bf16_t* x;        // NHWC bf16 [N, Hi, Wi, Ci]
+    const bf16_t* w;        // [Co][wtaps][Ci] bf16 (K-contiguous per output channel)
+    void* y;                // NHWC [N, Ho, Wo, Co] bf16 (or fp32)
+    const bf16_t* res;      // optional residual, same shape as y (bf16), added before ReLU
+    const float* bias;      // optional [Co]
+    float* stats;           // optional per-channel partial sums: [stat_rows][2][Co] fp32 (sum, sumsq of fp32 acc)
+    const IgTap* taps;      // device tap table
+    int N, Hi, Wi, Ci;
+    int Ho, Wo, Co;
+    int Hg, Wg;             // row grid per class
+    int s, os;              // input stride multiplier, output stride multiplier
+    int M;                  // N*Hg*Wg rows per class
+    int wtaps;              // taps per output channel in w (row length = wtaps*Ci)
+    int flags;
+    int nclass;
+    IgClass cls[4];
+    FastDiv div_hw, div_w;  // m / (Hg*Wg), rem / Wg
+    int m_tiles, n_tiles;
+};
+
+// wgrad: dW[r][tap][c] (fp32) (+)= sum_m P[pixP][r] * Q[pixQ][c]
+struct WgParams {
+    const bf16_t* dy;       // NHWC [N, Ho, Wo, Co]   (gradient of the conv output)
+    const bf16_t* x;        // NHWC [N, Hi, Wi, Ci]   (conv input)
+    float* dw;              // fp32, layout [R][wtaps][C] where (R,C) = (Co,Ci) or, with swap, (Ci,Co)
+    const IgTap* taps;
+    int N, Hi, Wi, Ci;
+    int Ho, Wo, Co;
+    int Hg, Wg;
+    int s, os;
+    int M;
+    int wtaps;
+    int flags;              // IG_FLAG_SMALLC ; WG_FLAG_SWAP ; WG_FLAG_ACCUM
+    int nclass;
+    IgClass cls[4];
+    FastDiv div_hw, div_w;
+    int ksplit;             // number of M splits (grid.z)
+    int msteps_per_split;   // 32-row steps per split
+    int r_tiles, c_tiles;
+    int total_taps;
+    int rows_valid;         // dW rows actually stored (<= R; head: Co is padded to 32 in dy)
+};
+#define WG_FLAG_SWAP 32       // rows of dW come from x (deconv weight layout [Ci][tap][Co])
+#define WG_FLAG_ATOMIC 64     // accumulate into dw with fp32 atomics (ksplit>1 or beta=1)

@@ -1,0 +1,386 @@
+// PoseResNet executor: the whole forward / backward of the reference's pose network
+// (lib/models/pose_resnet.py:59-91 over the torchvision ResNet-v1.5 trunk, lib/models/resnet.py:25-40) as one C++ plan
+// that enqueues hand-written gfx950 kernels on a HIP stream.  No allocation, no synchronisation, no host round trip
+// inside forward/backward (graph-capturable after one warm-up call that fills the tap-plan cache).
+//
+// Data layout in HBM: activations NHWC bf16 (pre-BN conv output y and post-BN/ReLU z both kept for backward), weights
+// bf16 packed [Co][taps][Ci] (fprop) and [Ci][taps][Co] (dgrad) from the fp32 channels_last master copies, BN statistics
+// fp32.  Parameters are addressed by index in torch `.parameters()` order, buffers in `.buffers()` order.
+#include <string>
+#include <vector>
+#include "conv_plan.h"
+
+int pw_nchw_f32_to_nhwc_bf16(hipStream_t, const float*, bf16_t*, int, int, int, int);
+int pw_nhwc_to_nchw_f32(hipStream_t, const void*, int, float*, int, int, int, int, const float*, const float*);
+int pw_cast_f32_bf16(hipStream_t, const float*, bf16_t*, size_t);
+int pw_transpose_cast(hipStream_t, const float*, bf16_t*, int, int, int);
+int pw_pack_strided(hipStream_t, const float*, bf16_t*, int, int, int, int, int, int, long, long, long, long);
+int pw_unpack_strided(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long, float);
+int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
+                   float*, float*);
+int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
+int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
+int pw_bn_bwd_rows(size_t);
+int pw_bn_bwd(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
+              float*, float*, float*, float*, float);
+int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
+int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
+int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+#define CK(expr) do { int _e = (expr); if (_e != UDAPOSE_OK) return _e; } while (0)
+
+struct ConvL {
+    ConvGeom g;
+    int w_idx = -1;         // parameter index of the weight
+    int bias_idx = -1;
+    size_t wf_off = 0, wb_off = 0;   // bf16 packs inside wpack (bytes)
+    size_t in_off = 0;      // activation arena offset of the input (bytes)
+    size_t y_off = 0;       // pre-BN output
+};
+struct BnL {
+    int C = 0;
+    int g_idx = -1, b_idx = -1;             // parameter indices
+    int rm_idx = -1, rv_idx = -1, nbt_idx = -1;   // buffer indices
+    size_t save_off = 0;    // fp32 [2][C] saved mean / invstd in the arena
+    size_t z_off = 0;       // post-BN(-ReLU) output
+    size_t npix = 0;
+};
+struct Block {
+    ConvL c1, c2, c3, cd;
+    BnL b1, b2, b3, bd;
+    bool has_ds = false;
+    size_t in_off = 0, zd_off = 0;
+    size_t npix_in = 0;
+};
+
+struct Net {
+    int layers[4], K, N, H, W;
+    int n_params = 0, n_buffers = 0;
+    std::vector<long long> param_numel;
+    // stem
+    ConvL stem; BnL stem_bn;
+    size_t x8_off = 0, pool_off = 0, poolidx_off = 0;
+    int Hs = 0, Ws = 0, Hp = 0, Wp = 0;
+    std::vector<Block> blocks;
+    ConvL up[3]; BnL up_bn[3];
+    ConvL head;
+    size_t head_out_off = 0;          // fp32 NHWC [N,Ho,Wo,K]
+    int fc_w_idx = -1, fc_b_idx = -1;
+    size_t act_bytes = 0, wpack_bytes = 0, ws_bytes = 0;
+    // workspace carve (bytes)
+    size_t ws_slab = 0, ws_coef = 0, ws_gbuf[6] = {0, 0, 0, 0, 0, 0}, ws_dyhead = 0, ws_dwtmp = 0, ws_headbwd = 0;
+    size_t gbuf_bytes = 0;
+    int Hout = 0, Wout = 0;
+};
+
+size_t act_alloc(Net& n, size_t bytes) { size_t o = n.act_bytes; n.act_bytes = align_up(o + bytes); return o; }
+size_t wp_alloc(Net& n, size_t bytes) { size_t o = n.wpack_bytes; n.wpack_bytes = align_up(o + bytes); return o; }
+
+void add_conv(Net& n, ConvL& c, int Hi, int Wi, int Ci, int Co, int K, int stride, int pad, int transposed, size_t in_off, bool need_bwd_pack) {
+    c.g = ConvGeom{n.N, Hi, Wi, Ci, Co, K, K, stride, pad, transposed, 0, 0};
+    c.w_idx = n.n_params++;
+    n.param_numel.push_back((long long)Co * (Ci == 8 ? 3 : Ci) * K * K);
+    c.in_off = in_off;
+    const size_t welems = (size_t)Co * c.g.wtaps() * Ci;
+    c.wf_off = wp_alloc(n, welems * 2);
+    if (need_bwd_pack) c.wb_off = wp_alloc(n, welems * 2);
+    c.y_off = act_alloc(n, (size_t)n.N * c.g.Ho() * c.g.Wo() * Co * 2);
+}
+void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true) {
+    b.C = C;
+    b.g_idx = n.n_params++; n.param_numel.push_back(C);
+    b.b_idx = n.n_params++; n.param_numel.push_back(C);
+    b.rm_idx = n.n_buffers++; b.rv_idx = n.n_buffers++; b.nbt_idx = n.n_buffers++;
+    b.save_off = act_alloc(n, (size_t)2 * C * 4);
+    b.npix = npix;
+    if (alloc_z) b.z_off = act_alloc(n, npix * C * 2);
+}
+
+Net* build(const int layers[4], int K, int N, int H, int W) {
+    Net* np = new Net();
+    Net& n = *np;
+    for (int i = 0; i < 4; ++i) n.layers[i] = layers[i];
+    n.K = K; n.N = N; n.H = H; n.W = W;
+    n.x8_off = act_alloc(n, (size_t)N * H * W * 8 * 2);
+    // stem: conv 7x7 s2 p3 (3 -> padded 8 input channels), bn, relu, maxpool 3x3 s2 p1
+    add_conv(n, n.stem, H, W, 8, 64, 7, 2, 3, 0, n.x8_off, false);
+    n.Hs = n.stem.g.Ho(); n.Ws = n.stem.g.Wo();
+    add_bn(n, n.stem_bn, 64, (size_t)N * n.Hs * n.Ws);
+    n.Hp = (n.Hs + 2 - 3) / 2 + 1; n.Wp = (n.Ws + 2 - 3) / 2 + 1;
+    n.pool_off = act_alloc(n, (size_t)N * n.Hp * n.Wp * 64 * 2);
+    n.poolidx_off = act_alloc(n, (size_t)N * n.Hp * n.Wp * 64);
+    size_t cur = n.pool_off;
+    int Hc = n.Hp, Wc = n.Wp, Cc = 64;
+    const int planes[4] = {64, 128, 256, 512};
+    for (int L = 0; L < 4; ++L)
+        for (int bi = 0; bi < layers[L]; ++bi) {
+            n.blocks.emplace_back();
+            Block& b = n.blocks.back();
+            const int P = planes[L], stride = (bi == 0 && L > 0) ? 2 : 1;
+            b.in_off = cur;
+            b.npix_in = (size_t)N * Hc * Wc;
+            b.has_ds = (bi == 0);
+            // parameter order follows torchvision Bottleneck: conv1,bn1,conv2,bn2,conv3,bn3,(downsample.0, downsample.1)
+            add_conv(n, b.c1, Hc, Wc, Cc, P, 1, 1, 0, 0, cur, true);
+            add_bn(n, b.b1, P, (size_t)N * Hc * Wc);
+            add_conv(n, b.c2, Hc, Wc, P, P, 3, stride, 1, 0, b.b1.z_off, true);
+            const int Ho = b.c2.g.Ho(), Wo = b.c2.g.Wo();
+            add_bn(n, b.b2, P, (size_t)N * Ho * Wo);
+            add_conv(n, b.c3, Ho, Wo, P, P * 4, 1, 1, 0, 0, b.b2.z_off, true);
+            add_bn(n, b.b3, P * 4, (size_t)N * Ho * Wo);
+            if (b.has_ds) {
+                add_conv(n, b.cd, Hc, Wc, Cc, P * 4, 1, stride, 0, 0, cur, true);
+                add_bn(n, b.bd, P * 4, (size_t)N * Ho * Wo);
+                b.zd_off = b.bd.z_off;
+            }
+            cur = b.b3.z_off; Hc = Ho; Wc = Wo; Cc = P * 4;
+        }
+    n.fc_w_idx = n.n_params++; n.param_numel.push_back(1000LL * 2048);
+    n.fc_b_idx = n.n_params++; n.param_numel.push_back(1000);
+    for (int i = 0; i < 3; ++i) {
+        add_conv(n, n.up[i], Hc, Wc, Cc, 256, 4, 2, 1, 1, cur, true);
+        Hc = n.up[i].g.Ho(); Wc = n.up[i].g.Wo(); Cc = 256;
+        add_bn(n, n.up_bn[i], 256, (size_t)N * Hc * Wc);
+        cur = n.up_bn[i].z_off;
+    }
+    // head: 1x1 conv with bias -> fp32
+    n.head.g = ConvGeom{N, Hc, Wc, 256, K, 1, 1, 1, 0, 0, 0, 0};
+    n.head.w_idx = n.n_params++; n.param_numel.push_back((long long)K * 256);
+    n.head.bias_idx = n.n_params++; n.param_numel.push_back(K);
+    n.head.in_off = cur;
+    n.head.wf_off = wp_alloc(n, (size_t)K * 256 * 2);
+    n.head.wb_off = wp_alloc(n, (size_t)256 * 32 * 2);      // [256][1][32] zero-padded for dgrad
+    n.head_out_off = act_alloc(n, (size_t)N * Hc * Wc * K * 4);
+    n.Hout = Hc; n.Wout = Wc;
+
+    // transient workspace: BN stat slabs, coefficient vectors, gradient ping-pong buffers
+    size_t max_slab = 0, max_act = 0;
+    auto upd = [&](const ConvL& c) {
+        const size_t rows = (size_t)conv_stat_rows(c.g);
+        max_slab = std::max(max_slab, rows * 2 * c.g.Co * 4);
+        max_act = std::max(max_act, (size_t)n.N * c.g.Ho() * c.g.Wo() * c.g.Co * 2);
+        max_act = std::max(max_act, (size_t)n.N * c.g.Hi * c.g.Wi * c.g.Ci * 2);
+    };
+    upd(n.stem);
+    for (auto& b : n.blocks) { upd(b.c1); upd(b.c2); upd(b.c3); if (b.has_ds) upd(b.cd); }
+    for (int i = 0; i < 3; ++i) upd(n.up[i]);
+    max_slab = std::max(max_slab, (size_t)1024 * 2 * 2048 * 4);   // bn backward partials: <=1024 rows x 2 x C
+    size_t o = 0;
+    n.ws_slab = o; o = align_up(o + max_slab);
+    n.ws_coef = o; o = align_up(o + (size_t)3 * 2048 * 4 + 2 * 2048 * 4);
+    n.gbuf_bytes = align_up(max_act);
+    for (int i = 0; i < 6; ++i) { n.ws_gbuf[i] = o; o += n.gbuf_bytes; }
+    n.ws_dyhead = o; o = align_up(o + (size_t)N * Hc * Wc * 32 * 2);
+    n.ws_dwtmp = o; o = align_up(o + std::max((size_t)64 * 56 * 8 * 4, (size_t)32 * 256 * 4));
+    n.ws_bytes = o;
+    return np;
+}
+
+struct Pool {
+    char* base; size_t off[6]; bool used[6] = {false, false, false, false, false, false};
+    bf16_t* get() { for (int i = 0; i < 6; ++i) if (!used[i]) { used[i] = true; return (bf16_t*)(base + off[i]); } return nullptr; }
+    void put(const void* p) { for (int i = 0; i < 6; ++i) if ((char*)p == base + off[i]) used[i] = false; }
+};
+
+int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* params, char* wpack, bool with_bwd) {
+    const float* w = (const float*)params[c.w_idx];
+    const ConvGeom& g = c.g;
+    bf16_t* wf = (bf16_t*)(wpack + c.wf_off);
+    bf16_t* wb = (bf16_t*)(wpack + c.wb_off);
+    const int T = g.KH * g.KW;
+    if (g.smallc()) {
+        // master: [Co][KH][KW][3] (channels_last of [Co,3,KH,KW]) -> [Co][KH][KWp][8]
+        return pw_pack_strided(s, w, wf, g.Co, g.KH, g.KWp(), g.KW, 8, 3, (long)g.KH * g.KW * 3, (long)g.KW * 3, 3, 1);
+    }
+    if (!g.transposed) {
+        // master physical [Co][T][Ci]: fprop pack is a cast, dgrad pack [Ci][T][Co] a per-tap transpose
+        CK(pw_cast_f32_bf16(s, w, wf, (size_t)g.Co * T * g.Ci));
+        if (with_bwd) CK(pw_transpose_cast(s, w, wb, g.Co, T, g.Ci));
+    } else {
+        // ConvTranspose2d master physical [Ci][T][Co] (channels_last of [Ci,Co,KH,KW]): dgrad pack is the cast
+        CK(pw_transpose_cast(s, w, wf, g.Ci, T, g.Co));
+        if (with_bwd) CK(pw_cast_f32_bf16(s, w, wb, (size_t)g.Ci * T * g.Co));
+    }
+    return UDAPOSE_OK;
+}
+
+int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, void* const* buffers, const char* wpack,
+                char* act, char* ws, int training, float momentum, const bf16_t* res, int relu) {
+    ConvEpilogue e;
+    float* slab = (float*)(ws + n.ws_slab);
+    float* scale = (float*)(ws + n.ws_coef);
+    float* shift = scale + 2048;
+    float* save = (float*)(act + b.save_off);
+    e.stats = training ? slab : nullptr;
+    CK(conv_fprop(s, c.g, (const bf16_t*)(act + c.in_off), (const bf16_t*)(wpack + c.wf_off), act + c.y_off, e));
+    const float* gamma = (const float*)params[b.g_idx];
+    const float* beta = (const float*)params[b.b_idx];
+    if (training)
+        CK(pw_bn_finalize(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, (float*)buffers[b.rm_idx], (float*)buffers[b.rv_idx],
+                          (long long*)buffers[b.nbt_idx], momentum, 1e-5f, scale, shift, save, save + b.C));
+    else
+        CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
+    return pw_bn_apply(s, (const bf16_t*)(act + c.y_off), res, (bf16_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
+}
+
+}  // namespace
+
+// ============================================================================ public (C++) entry points
+void* net_create(const int layers[4], int K, int N, int H, int W) {
+    if (K < 1 || K > 32 || N < 1 || H % 32 || W % 32) return nullptr;
+    return build(layers, K, N, H, W);
+}
+void net_destroy(void* h) { delete (Net*)h; }
+int net_num_params(void* h) { return ((Net*)h)->n_params; }
+int net_num_buffers(void* h) { return ((Net*)h)->n_buffers; }
+long long net_param_numel(void* h, int i) { return ((Net*)h)->param_numel[i]; }
+size_t net_wpack_bytes(void* h) { return ((Net*)h)->wpack_bytes; }
+size_t net_act_bytes(void* h) { return ((Net*)h)->act_bytes; }
+size_t net_ws_bytes(void* h) { return ((Net*)h)->ws_bytes; }
+void net_out_shape(void* h, int* shp) { Net& n = *(Net*)h; shp[0] = n.N; shp[1] = n.K; shp[2] = n.Hout; shp[3] = n.Wout; }
+
+int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wpack_, int with_bwd) {
+    Net& n = *(Net*)h;
+    char* wpack = (char*)wpack_;
+    CK(pack_conv(s, n, n.stem, params, wpack, false));
+    for (auto& b : n.blocks) {
+        CK(pack_conv(s, n, b.c1, params, wpack, with_bwd));
+        CK(pack_conv(s, n, b.c2, params, wpack, with_bwd));
+        CK(pack_conv(s, n, b.c3, params, wpack, with_bwd));
+        if (b.has_ds) CK(pack_conv(s, n, b.cd, params, wpack, with_bwd));
+    }
+    for (int i = 0; i < 3; ++i) CK(pack_conv(s, n, n.up[i], params, wpack, with_bwd));
+    const float* hw = (const float*)params[n.head.w_idx];
+    CK(pw_cast_f32_bf16(s, hw, (bf16_t*)(wpack + n.head.wf_off), (size_t)n.K * 256));
+    if (with_bwd)   // [256][1][32]: wb[ci][k] = w[k][ci], zero for k >= K
+        CK(pw_pack_strided(s, hw, (bf16_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 32, n.K, 1, 0, 0, 256));
+    return UDAPOSE_OK;
+}
+
+int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* params, void* const* buffers, const void* wpack_, void* act_, void* ws_,
+                float* out_nchw, int training, float momentum) {
+    Net& n = *(Net*)h;
+    const char* wpack = (const char*)wpack_;
+    char* act = (char*)act_;
+    char* ws = (char*)ws_;
+    CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (bf16_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
+    CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
+    CK(pw_maxpool3x3s2_fwd(s, (const bf16_t*)(act + n.stem_bn.z_off), (bf16_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N, n.Hs,
+                           n.Ws, 64));
+    for (auto& b : n.blocks) {
+        CK(conv_bn_fwd(s, n, b.c1, b.b1, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
+        CK(conv_bn_fwd(s, n, b.c2, b.b2, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
+        const bf16_t* res = (const bf16_t*)(act + b.in_off);
+        if (b.has_ds) {
+            CK(conv_bn_fwd(s, n, b.cd, b.bd, params, buffers, wpack, act, ws, training, momentum, nullptr, 0));
+            res = (const bf16_t*)(act + b.zd_off);
+        }
+        CK(conv_bn_fwd(s, n, b.c3, b.b3, params, buffers, wpack, act, ws, training, momentum, res, 1));
+    }
+    for (int i = 0; i < 3; ++i) CK(conv_bn_fwd(s, n, n.up[i], n.up_bn[i], params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
+    ConvEpilogue e;
+    e.bias = (const float*)params[n.head.bias_idx];
+    e.out_f32 = 1;
+    CK(conv_fprop(s, n.head.g, (const bf16_t*)(act + n.head.in_off), (const bf16_t*)(wpack + n.head.wf_off), act + n.head_out_off, e));
+    return pw_nhwc_to_nchw_f32(s, act + n.head_out_off, 1, out_nchw, n.N, n.K, n.Hout * n.Wout, n.K, nullptr, nullptr);
+}
+
+namespace {
+// backward of conv+bn(+relu): dz (grad wrt z) -> parameter grads, returns dx of the conv input in a pool buffer
+int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, const char* wpack, char* act, char* ws,
+                void* const* grads, float beta, Pool& pool, const bf16_t* dz, bf16_t* gout, int relu, const bf16_t* dx_res, bf16_t** dx_out,
+                bool need_dx) {
+    float* slab = (float*)(ws + n.ws_slab);
+    float* coef = (float*)(ws + n.ws_coef) + 4096;
+    const float* save = (const float*)(act + b.save_off);
+    bf16_t* dy = pool.get();
+    if (!dy) return UDAPOSE_ERR_ARG;
+    CK(pw_bn_bwd(s, dz, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx], save,
+                 save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta));
+    const bf16_t* xin = (const bf16_t*)(act + c.in_off);
+    if (c.g.smallc()) {
+        float* tmp = (float*)(ws + n.ws_dwtmp);
+        CK(conv_wgrad(s, c.g, dy, xin, tmp, 0, -1));
+        CK(pw_unpack_strided(s, tmp, (float*)grads[c.w_idx], c.g.Co, c.g.KH, c.g.KWp(), c.g.KW, 8, 3, (long)c.g.KH * c.g.KW * 3, (long)c.g.KW * 3, 3, 1,
+                             beta));
+    } else {
+        CK(conv_wgrad(s, c.g, dy, xin, (float*)grads[c.w_idx], beta != 0.f, -1));
+    }
+    if (need_dx) {
+        bf16_t* dx = pool.get();
+        if (!dx) return UDAPOSE_ERR_ARG;
+        CK(conv_dgrad(s, c.g, dy, (const bf16_t*)(wpack + c.wb_off), dx, dx_res));
+        *dx_out = dx;
+    }
+    pool.put(dy);
+    return UDAPOSE_OK;
+}
+}  // namespace
+
+// grads[i] (fp32, same physical layout as params[i]) = beta*grads[i] + d loss / d params[i]; beta in {0,1}
+int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack_, void* act_, void* ws_,
+                 void* const* grads, float beta) {
+    Net& n = *(Net*)h;
+    const char* wpack = (const char*)wpack_;
+    char* act = (char*)act_;
+    char* ws = (char*)ws_;
+    Pool pool;
+    pool.base = ws;
+    for (int i = 0; i < 6; ++i) pool.off[i] = n.ws_gbuf[i];
+    const int HWo = n.Hout * n.Wout;
+    // head
+    bf16_t* dyh = (bf16_t*)(ws + n.ws_dyhead);
+    CK(pw_nchw_f32_to_nhwc_bf16(s, dout_nchw, dyh, n.N, n.K, HWo, 32));
+    CK(pw_plane_sum(s, dout_nchw, (float*)grads[n.head.bias_idx], n.N, n.K, HWo, beta));
+    ConvGeom hg = n.head.g;
+    hg.Co = 32;   // dy is channel-padded to 32
+    float* tmp = (float*)(ws + n.ws_dwtmp);
+    CK(conv_wgrad(s, hg, dyh, (const bf16_t*)(act + n.head.in_off), tmp, 0, n.K));
+    CK(pw_unpack_strided(s, tmp, (float*)grads[n.head.w_idx], n.K, 1, 1, 1, 256, 256, 256, 0, 0, 1, beta));
+    bf16_t* dz = pool.get();
+    CK(conv_dgrad(s, hg, dyh, (const bf16_t*)(wpack + n.head.wb_off), dz, nullptr));
+    // deconv stack
+    for (int i = 2; i >= 0; --i) {
+        bf16_t* dx = nullptr;
+        CK(conv_bn_bwd(s, n, n.up[i], n.up_bn[i], params, wpack, act, ws, grads, beta, pool, dz, nullptr, 1, nullptr, &dx, true));
+        pool.put(dz);
+        dz = dx;
+    }
+    // bottlenecks, last to first
+    for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
+        Block& b = n.blocks[bi];
+        // bn3 (+ReLU of the block output): g = masked dz is written in place and feeds the skip branch
+        bf16_t *dz2 = nullptr, *dz1 = nullptr, *dxd = nullptr, *dxin = nullptr;
+        CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, dz, 1, nullptr, &dz2, true));
+        CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, nullptr, 1, nullptr, &dz1, true));
+        pool.put(dz2);
+        const bool first = (bi == 0);
+        const bf16_t* skip = dz;
+        if (b.has_ds) {
+            CK(conv_bn_bwd(s, n, b.cd, b.bd, params, wpack, act, ws, grads, beta, pool, dz, nullptr, 0, nullptr, &dxd, true));
+            skip = dxd;
+        }
+        CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, nullptr, 1, skip, &dxin, true));
+        pool.put(dz1);
+        if (dxd) pool.put(dxd);
+        pool.put(dz);
+        dz = dxin;
+        (void)first;
+    }
+    // stem: maxpool -> bn/relu -> conv (no input gradient)
+    bf16_t* dzs = pool.get();
+    CK(pw_maxpool3x3s2_bwd(s, dz, (const unsigned char*)(act + n.poolidx_off), dzs, n.N, n.Hs, n.Ws, 64));
+    pool.put(dz);
+    bf16_t* none = nullptr;
+    CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, nullptr, 1, nullptr, &none, false));
+    pool.put(dzs);
+    // backbone.fc is not part of the forward: zero gradient when overwriting
+    if (beta == 0.f) {
+        if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemsetAsync(grads[n.fc_b_idx], 0, (size_t)1000 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    }
+    return UDAPOSE_OK;
+}

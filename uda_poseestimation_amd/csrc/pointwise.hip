@@ -1,0 +1,465 @@
+// Memory-bound kernels of the pose network for gfx950: layout conversion, weight packing, training-mode BatchNorm
+// (finalize / apply / backward), 3x3 s2 and 2x2 ceil max-pooling.  All activation tensors are NHWC bf16 and every
+// thread moves 16 bytes (8 channels) per access.  These kernels are HBM-roofline bound (8 TB/s peak).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int nblk(size_t n, int per = TPB) { return (int)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------ layout conversion
+// src NCHW fp32 [N,C,HW] -> dst NHWC bf16 [N,HW,Cp] (channels >= C zero-filled); one thread per (pixel, 8-channel group)
+__global__ void nchw_f32_to_nhwc_bf16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int HW, int Cp) {
+    const int G = Cp >> 3;
+    const size_t total = (size_t)N * HW * G;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const size_t pix = i % ((size_t)N * HW);      // pixel fastest: coalesced plane reads
+        const int g = (int)(i / ((size_t)N * HW));
+        const size_t n = pix / HW, hw = pix % HW;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = g * 8 + e;
+            o[e] = (bf16_t)(c < C ? src[(n * C + c) * HW + hw] : 0.f);
+        }
+        *(bf16x8*)(dst + pix * Cp + g * 8) = o;
+    }
+}
+
+// src NHWC (fp32 or bf16) [N,HW,Cs] -> dst NCHW fp32 [N,C,HW], optional per-channel clamp (style-net output)
+template <typename T>
+__global__ void nhwc_to_nchw_f32_k(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int Cs,
+                                   const float* __restrict__ lo, const float* __restrict__ hi) {
+    const size_t total = (size_t)N * HW;
+    for (size_t pix = (size_t)blockIdx.x * TPB + threadIdx.x; pix < total; pix += (size_t)gridDim.x * TPB) {
+        const size_t n = pix / HW, hw = pix % HW;
+        for (int c = 0; c < C; ++c) {
+            float v = (float)src[pix * Cs + c];
+            if (lo) v = fmaxf(fminf(v, hi[c]), lo[c]);
+            dst[(n * C + c) * HW + hw] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight packing (fp32 master -> bf16 GEMM layouts)
+__global__ void cast_f32_bf16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+        const f32x4 a = *(const f32x4*)(src + i * 8), b = *(const f32x4*)(src + i * 8 + 4);
+        bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+        *(bf16x8*)(dst + i * 8) = o;
+    }
+}
+// src [A][T][B] fp32 -> dst [B][T][A] bf16 (32x32 LDS-tiled transpose per tap); grid = (B/32, A/32, T)
+__global__ void transpose_cast_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int A, int T, int B) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, b0 = blockIdx.x * 32, a0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, b = b0 + tx;
+        tile[r][tx] = (a < A && b < B) ? src[((size_t)a * T + t) * B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int b = b0 + r, a = a0 + tx;
+        if (a < A && b < B) dst[((size_t)b * T + t) * A + a] = (bf16_t)tile[tx][r];
+    }
+}
+// generic strided gather with zero padding: dst[a][kh][kwp][bp] bf16 <- src[a*sa + kh*skh + kw*skw + b*sb] (kw<KW, b<B)
+__global__ void pack_strided_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int A, int KH, int KWp, int KW, int Bp, int B,
+                               long sa, long skh, long skw, long sb) {
+    const size_t total = (size_t)A * KH * KWp * Bp;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int b = (int)(i % Bp);
+        size_t r = i / Bp;
+        const int kw = (int)(r % KWp); r /= KWp;
+        const int kh = (int)(r % KH);
+        const int a = (int)(r / KH);
+        float v = 0.f;
+        if (kw < KW && b < B) v = src[a * sa + kh * skh + kw * skw + b * sb];
+        dst[i] = (bf16_t)v;
+    }
+}
+// inverse of pack_strided for gradients: dst[a*sa + kh*skh + kw*skw + b*sb] (beta*dst +) = src[a][kh][kwp][bp] (fp32)
+__global__ void unpack_strided_k(const float* __restrict__ src, float* __restrict__ dst, int A, int KH, int KWp, int KW, int Bp, int B,
+                                 long sa, long skh, long skw, long sb, float beta) {
+    const size_t total = (size_t)A * KH * KW * B;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int b = (int)(i % B);
+        size_t r = i / B;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH);
+        const int a = (int)(r / KH);
+        const float v = src[(((size_t)a * KH + kh) * KWp + kw) * Bp + b];
+        float* d = dst + (a * sa + kh * skh + kw * skw + b * sb);
+        *d = (beta != 0.f ? beta * *d : 0.f) + v;
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm (training mode)
+// Finalize: reduce the conv epilogue's partial sums [rows][2][C] in fp64, produce scale/shift and saved mean/invstd,
+// update running stats (momentum, unbiased variance) exactly like torch.nn.BatchNorm2d in train().
+__global__ void bn_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                              long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ scale,
+                              float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s1 += (double)slab[(size_t)r * 2 * C + c];
+        s2 += (double)slab[(size_t)r * 2 * C + C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+// eval mode: scale/shift from running statistics
+__global__ void bn_eval_coeff_k(int C, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                const float* __restrict__ rv, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// z = [relu]( y*scale[c] + shift[c] [+ res] ), NHWC bf16, 8 channels per thread
+__global__ void bn_apply_k(const bf16_t* __restrict__ y, const bf16_t* __restrict__ res, bf16_t* __restrict__ z, size_t n8, int C,
+                           const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+    const int G = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+        const int c0 = (int)(i % G) * 8;
+        const bf16x8 v = *(const bf16x8*)(y + i * 8);
+        const f32x4 sa = *(const f32x4*)(scale + c0), sb = *(const f32x4*)(scale + c0 + 4);
+        const f32x4 ha = *(const f32x4*)(shift + c0), hb = *(const f32x4*)(shift + c0 + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e] * (e < 4 ? sa[e] : sb[e - 4]) + (e < 4 ? ha[e] : hb[e - 4]);
+        if (res) {
+            const bf16x8 r = *(const bf16x8*)(res + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += (float)r[e];
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)((relu && o[e] < 0.f) ? 0.f : o[e]);
+        *(bf16x8*)(z + i * 8) = ov;
+    }
+}
+
+// Backward reduce: per-channel sum(g) and sum(g*xhat), g = dz * (z>0) when relu.  Partial slab [blocks][2][C].
+// Requires C/8 to be a power of two <= 256 (thread's channel group is loop-invariant).
+__global__ void bn_bwd_reduce_k(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+                                size_t npix, int C, const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                float* __restrict__ slab, int pix_per_block) {
+    __shared__ float red[TPB][17];
+    const int G = C >> 3;
+    const int g = threadIdx.x % G, prow = threadIdx.x / G, pstep = TPB / G;
+    const int c0 = g * 8;
+    float mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; s1[e] = 0.f; s2[e] = 0.f; }
+    const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+    size_t p1 = p0 + pix_per_block;
+    if (p1 > npix) p1 = npix;
+    for (size_t p = p0 + prow; p < p1; p += pstep) {
+        const size_t off = p * C + c0;
+        const bf16x8 d = *(const bf16x8*)(dz + off);
+        const bf16x8 yy = *(const bf16x8*)(y + off);
+        bf16x8 zz;
+        if (relu) zz = *(const bf16x8*)(z + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gv = (float)d[e];
+            if (relu && !((float)zz[e] > 0.f)) gv = 0.f;
+            s1[e] += gv;
+            s2[e] += gv * (((float)yy[e] - mu[e]) * is[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float a[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = 0.f;
+        for (int k = 0; k < pstep; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] += red[threadIdx.x + k * G][e];
+        float* sp = slab + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sp[c0 + e] = a[e]; sp[C + c0 + e] = a[8 + e]; }
+    }
+}
+// Finalize backward: dgamma, dbeta (beta_acc*old + new) and the apply coefficients ca = gamma*invstd, cb = sum(g)/M,
+// cc = sum(g*xhat)/M.
+__global__ void bn_bwd_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
+                                  const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                  float beta_acc, float* __restrict__ coef) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s1 += (double)slab[(size_t)r * 2 * C + c];
+        s2 += (double)slab[(size_t)r * 2 * C + C + c];
+    }
+    if (dgamma) {
+        dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
+        dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
+    }
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(s1 / count);
+    coef[2 * C + c] = (float)(s2 / count);
+}
+// dy = ca*(g - cb - xhat*cc); optionally also write g (masked dz) for the skip branch
+__global__ void bn_bwd_apply_k(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+                               bf16_t* __restrict__ dy, bf16_t* __restrict__ gout, size_t n8, int C, const float* __restrict__ mean,
+                               const float* __restrict__ invstd, const float* __restrict__ coef, int relu) {
+    const int G = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+        const int c0 = (int)(i % G) * 8;
+        const bf16x8 d = *(const bf16x8*)(dz + i * 8);
+        const bf16x8 yy = *(const bf16x8*)(y + i * 8);
+        bf16x8 zz;
+        if (relu) zz = *(const bf16x8*)(z + i * 8);
+        bf16x8 o, go;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float gv = (float)d[e];
+            if (relu && !((float)zz[e] > 0.f)) gv = 0.f;
+            const float xh = ((float)yy[e] - mean[c]) * invstd[c];
+            o[e] = (bf16_t)(coef[c] * (gv - coef[C + c] - xh * coef[2 * C + c]));
+            go[e] = (bf16_t)gv;
+        }
+        *(bf16x8*)(dy + i * 8) = o;
+        if (gout) *(bf16x8*)(gout + i * 8) = go;
+    }
+}
+
+// ------------------------------------------------------------------ max pooling (NHWC bf16)
+// 3x3 stride 2 pad 1 (ResNet stem).  Saves the winning tap (0..8, first max in (kh,kw) scan order like ATen) per element.
+__global__ void maxpool3x3s2_fwd_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
+                                   int W, int C, int Ho, int Wo) {
+    const int G = C >> 3;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int g = (int)(i % G);
+        size_t r = i / G;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float best[8];
+        unsigned char bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int h = ho * 2 - 1 + kh, w = wo * 2 - 1 + kw;
+                if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                    const bf16x8 v = *(const bf16x8*)(x + (((size_t)n * H + h) * W + w) * C + g * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        if (first || f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(kh * 3 + kw); }
+                    }
+                    first = false;
+                }
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
+        *(bf16x8*)(y + i * 8) = o;
+        if (idx) {
+            unsigned long long pk = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk |= (unsigned long long)bi[e] << (8 * e);
+            *(unsigned long long*)(idx + i * 8) = pk;
+        }
+    }
+}
+// gather-style backward (no atomics): each input pixel checks the <=4 windows that contain it
+__global__ void maxpool3x3s2_bwd_k(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ idx, bf16_t* __restrict__ dx, int N,
+                                   int H, int W, int C, int Ho, int Wo) {
+    const int G = C >> 3;
+    const size_t total = (size_t)N * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int g = (int)(i % G);
+        size_t r = i / G;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const int ho0 = h >> 1, wo0 = w >> 1;     // windows with ho in {ho0, ho0+1 if h odd}: 2ho-1 <= h <= 2ho+1
+        for (int ho = ho0; ho <= ((h + 1) >> 1); ++ho)
+            for (int wo = wo0; wo <= ((w + 1) >> 1); ++wo) {
+                if (ho >= Ho || wo >= Wo) continue;
+                const int kh = h - (ho * 2 - 1), kw = w - (wo * 2 - 1);
+                if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8;
+                const unsigned long long pk = *(const unsigned long long*)(idx + o);
+                const bf16x8 d = *(const bf16x8*)(dy + o);
+                const unsigned tap = (unsigned)(kh * 3 + kw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (((pk >> (8 * e)) & 0xFF) == tap) acc[e] += (float)d[e];
+            }
+        bf16x8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)acc[e];
+        *(bf16x8*)(dx + i * 8) = o8;
+    }
+}
+// 2x2 stride 2 ceil-mode (VGG encoder, inference only)
+__global__ void maxpool2x2_ceil_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+    const int G = C >> 3;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int g = (int)(i % G);
+        size_t r = i / G;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+        for (int kh = 0; kh < 2; ++kh)
+            for (int kw = 0; kw < 2; ++kw) {
+                const int h = ho * 2 + kh, w = wo * 2 + kw;
+                if (h < H && w < W) {
+                    const bf16x8 v = *(const bf16x8*)(x + (((size_t)n * H + h) * W + w) * C + g * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], (float)v[e]);
+                }
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
+        *(bf16x8*)(y + i * 8) = o;
+    }
+}
+
+// per-plane sums of an NCHW fp32 tensor over (n, hw): out[c] (beta*old +) = sum  (head bias gradient)
+__global__ void plane_sum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW, float beta) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n)
+        for (int i = threadIdx.x; i < HW; i += TPB) s += (double)x[((size_t)n * C + c) * HW + i];
+    __shared__ double red[TPB / 64];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < TPB / 64; ++i) t += red[i];
+        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)t;
+    }
+}
+
+inline int grid_for(size_t items) {
+    size_t b = (items + TPB - 1) / TPB;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host launchers (internal C++ API; C-ABI wrappers in capi.hip)
+int pw_nchw_f32_to_nhwc_bf16(hipStream_t s, const float* src, bf16_t* dst, int N, int C, int HW, int Cp) {
+    if (Cp % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_k, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, dst, N, C, HW, Cp);
+    return udapose_check_launch();
+}
+int pw_nhwc_to_nchw_f32(hipStream_t s, const void* src, int src_is_f32, float* dst, int N, int C, int HW, int Cs, const float* lo, const float* hi) {
+    if (src_is_f32)
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_k<float>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const float*)src, dst, N, C, HW, Cs, lo, hi);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_k<bf16_t>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const bf16_t*)src, dst, N, C, HW, Cs, lo, hi);
+    return udapose_check_launch();
+}
+int pw_cast_f32_bf16(hipStream_t s, const float* src, bf16_t* dst, size_t n) {
+    if (n % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(cast_f32_bf16_k, dim3(grid_for(n / 8)), dim3(TPB), 0, s, src, dst, n / 8);
+    return udapose_check_launch();
+}
+int pw_transpose_cast(hipStream_t s, const float* src, bf16_t* dst, int A, int T, int B) {
+    hipLaunchKernelGGL(transpose_cast_k, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
+    return udapose_check_launch();
+}
+int pw_pack_strided(hipStream_t s, const float* src, bf16_t* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
+    hipLaunchKernelGGL(pack_strided_k, dim3(grid_for((size_t)A * KH * KWp * Bp)), dim3(TPB), 0, s, src, dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
+    return udapose_check_launch();
+}
+int pw_unpack_strided(hipStream_t s, const float* src, float* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb, float beta) {
+    hipLaunchKernelGGL(unpack_strided_k, dim3(grid_for((size_t)A * KH * KW * B)), dim3(TPB), 0, s, src, dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb, beta);
+    return udapose_check_launch();
+}
+int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
+                   long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
+    hipLaunchKernelGGL(bn_finalize_k, dim3(nblk(C)), dim3(TPB), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
+                       save_mean, save_invstd);
+    return udapose_check_launch();
+}
+int pw_bn_eval_coeff(hipStream_t s, int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift) {
+    hipLaunchKernelGGL(bn_eval_coeff_k, dim3(nblk(C)), dim3(TPB), 0, s, C, gamma, beta, rm, rv, eps, scale, shift);
+    return udapose_check_launch();
+}
+int pw_bn_apply(hipStream_t s, const bf16_t* y, const bf16_t* res, bf16_t* z, size_t n, int C, const float* scale, const float* shift, int relu) {
+    if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(bn_apply_k, dim3(grid_for(n / 8)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    return udapose_check_launch();
+}
+int pw_bn_bwd_rows(size_t npix) {
+    size_t b = (npix + 511) / 512;
+    if (b > 1024) b = 1024;
+    return (int)(b < 1 ? 1 : b);
+}
+int pw_bn_bwd(hipStream_t s, const bf16_t* dz, const bf16_t* z, const bf16_t* y, bf16_t* dy, bf16_t* gout, size_t npix, int C, const float* gamma,
+              const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta, float beta_acc) {
+    const int G = C / 8;
+    if (C % 8 || G > 256 || (G & (G - 1))) return UDAPOSE_ERR_UNSUPPORTED;
+    const int rows = pw_bn_bwd_rows(npix);
+    const int ppb = (int)((npix + rows - 1) / rows);
+    hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(rows), dim3(TPB), 0, s, dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(nblk(C)), dim3(TPB), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(grid_for(npix * G)), dim3(TPB), 0, s, dz, z, y, dy, gout, npix * G, C, mean, invstd, coef, relu);
+    return udapose_check_launch();
+}
+int pw_maxpool3x3s2_fwd(hipStream_t s, const bf16_t* x, bf16_t* y, unsigned char* idx, int N, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_k, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_maxpool3x3s2_bwd(hipStream_t s, const bf16_t* dy, const unsigned char* idx, bf16_t* dx, int N, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_k, dim3(grid_for((size_t)N * H * W * (C / 8))), dim3(TPB), 0, s, dy, idx, dx, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_maxpool2x2_ceil(hipStream_t s, const bf16_t* x, bf16_t* y, int N, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(maxpool2x2_ceil_k, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_plane_sum(hipStream_t s, const float* x, float* out, int N, int C, int HW, float beta) {
+    hipLaunchKernelGGL(plane_sum_k, dim3(C), dim3(TPB), 0, s, x, out, N, C, HW, beta);
+    return udapose_check_launch();
+}

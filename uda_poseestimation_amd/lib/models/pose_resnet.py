@@ -1,0 +1,257 @@
+"""Simple-Baseline pose network (API mirror of the reference's lib/models/pose_resnet.py:11-126) on the MI355X executor.
+
+`PoseResNet.forward` = head(upsampling(backbone(x))) exactly as pose_resnet.py:80-84, but the whole chain (107 convs /
+BNs, ReLUs, max-pool, 3 deconvs, head) is enqueued by ONE call into libudapose_hip.so (csrc/net.hip); backward is one
+call as well.  Sub-modules are the usual torch.nn containers, so `state_dict()` keys, `.parameters()` order, `.cuda()`,
+`.train()/.eval()`, optimizers, GradScaler and OldWeightEMA behave as with the reference.  There is no CPU path.
+"""
+import ctypes as C
+import weakref
+
+import torch
+import torch.nn as nn
+
+from ... import _hip
+from ..._hip import check, lib, ptr
+from .resnet import _resnet
+from .resnet import Bottleneck as Bottleneck_default
+
+__all__ = ['pose_resnet101', 'pose_resnet50']
+
+
+class Upsampling(nn.Sequential):
+    """3-layer deconvolution of Simple Baseline (pose_resnet.py:11-56); containers only, executed by the net executor."""
+
+    def __init__(self, in_channel=2048, hidden_dims=(256, 256, 256), kernel_sizes=(4, 4, 4), bias=False):
+        assert len(hidden_dims) == len(kernel_sizes), 'ERROR: len(hidden_dims) is different len(kernel_sizes)'
+        layers = []
+        for hidden_dim, kernel_size in zip(hidden_dims, kernel_sizes):
+            if kernel_size == 4:
+                padding, output_padding = 1, 0
+            elif kernel_size == 3:
+                padding, output_padding = 1, 1
+            elif kernel_size == 2:
+                padding, output_padding = 0, 0
+            else:
+                raise NotImplementedError("kernel_size is {}".format(kernel_size))
+            layers.append(nn.ConvTranspose2d(in_channel, hidden_dim, kernel_size, stride=2, padding=padding,
+                                             output_padding=output_padding, bias=bias))
+            layers.append(nn.BatchNorm2d(hidden_dim))
+            layers.append(nn.ReLU(inplace=True))
+            in_channel = hidden_dim
+        super().__init__(*layers)
+        for m in self.modules():
+            if isinstance(m, nn.ConvTranspose2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if bias:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._cfg = (tuple(hidden_dims), tuple(kernel_sizes), bool(bias))
+
+
+class _NetHandle:
+    """One executor plan (fixed N,H,W) plus its device work areas."""
+
+    def __init__(self, layers, K, N, H, W, device):
+        h = C.c_void_p()
+        arr = (C.c_int * 4)(*layers)
+        check(lib().udapose_net_create(arr, K, N, H, W, C.byref(h)), "net_create")
+        self.h = h
+        self.n_params = lib().udapose_net_num_params(h)
+        self.n_buffers = lib().udapose_net_num_buffers(h)
+        self.numel = [lib().udapose_net_param_numel(h, i) for i in range(self.n_params)]
+        self.act_bytes = lib().udapose_net_act_bytes(h)
+        shp = (C.c_int * 4)()
+        lib().udapose_net_out_shape(h, shp)
+        self.out_shape = tuple(shp)
+        self.ws = torch.empty(lib().udapose_net_ws_bytes(h), dtype=torch.uint8, device=device)
+        self.wpack = torch.empty(lib().udapose_net_wpack_bytes(h), dtype=torch.uint8, device=device)
+        self.wpack_version = None
+        self.act_nograd = None
+        self._fin = weakref.finalize(self, lib().udapose_net_destroy, h)
+
+
+class _PoseNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        out, act, hd = net._run_forward(x, save=need_grad)
+        ctx.net, ctx.act, ctx.hd = net, act, hd
+        ctx.nparams = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net = ctx.net
+        net._run_backward(dout, ctx.act, ctx.hd)
+        ctx.act = None
+        # parameter gradients are accumulated straight into p.grad (views of the module's flat gradient buffer)
+        return (None, None) + (None,) * ctx.nparams
+
+
+class PoseResNet(nn.Module):
+    """Simple Baseline for key-point detection (pose_resnet.py:59-91) on the MI355X executor."""
+
+    def __init__(self, backbone, upsampling, feature_dim, num_keypoints, finetune=False):
+        super().__init__()
+        self.backbone = backbone
+        self.upsampling = upsampling
+        self.head = nn.Conv2d(in_channels=feature_dim, out_channels=num_keypoints, kernel_size=1, stride=1, padding=0)
+        self.finetune = finetune
+        for m in self.head.modules():
+            nn.init.normal_(m.weight, std=0.001)
+            nn.init.constant_(m.bias, 0)
+        if getattr(upsampling, "_cfg", None) != ((256, 256, 256), (4, 4, 4), False) or feature_dim != 256:
+            raise NotImplementedError("the MI355X executor implements the reference configuration: 3 x deconv(256, k=4), no bias")
+        self.num_keypoints = num_keypoints
+        self.bn_momentum = 0.1
+        self._handles = {}
+        self._ptr_cache = None
+        self._flat_grad = None
+        self._to_channels_last()
+
+    # ------------------------------------------------------------------ layout / pointer bookkeeping
+    def _to_channels_last(self):
+        for p in self.parameters():
+            if p.dim() == 4 and not p.data.is_contiguous(memory_format=torch.channels_last):
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+            elif p.dim() == 4 and p.data.stride(1) != 1:
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._to_channels_last()
+        self._ptr_cache = None
+        self._flat_grad = None
+        self._handles = {}
+        return r
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # accept checkpoints saved from DataParallel wrappers ('module.' prefix, train_human.py:229-230)
+        if any(k.startswith("module.") for k in state_dict):
+            state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _pointers(self):
+        params = list(self.parameters())
+        bufs = list(self.buffers())
+        key = (params[0].data_ptr(), params[-1].data_ptr(), bufs[0].data_ptr(), len(params))
+        if self._ptr_cache is None or self._ptr_cache[0] != key:
+            for p in params:
+                if p.dtype != torch.float32:
+                    raise RuntimeError("PoseResNet master parameters must be fp32 (bf16 compute copies are made by the executor)")
+                if p.dim() == 4 and p.stride(1) != 1 and p.shape[1] != 1:
+                    self._to_channels_last()
+                    return self._pointers()
+            pa = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+            ba = (C.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+            self._ptr_cache = (key, pa, ba, params)
+        return self._ptr_cache[1], self._ptr_cache[2], self._ptr_cache[3]
+
+    def _grad_views(self, params):
+        """p.grad tensors are views (same strides as p) of one flat fp32 buffer: one all-reduce / one Adam sweep."""
+        if self._flat_grad is None or self._flat_grad.device != params[0].device:
+            total = sum(p.numel() for p in params)
+            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+            views, off = [], 0
+            for p in params:
+                views.append(self._flat_grad[off:off + p.numel()].as_strided(p.shape, p.stride()))
+                off += p.numel()
+            self._grad_view_list = views
+        return self._grad_view_list
+
+    def _handle(self, x):
+        N, Cc, H, W = x.shape
+        if Cc != 3:
+            raise ValueError("PoseResNet expects [N,3,H,W] input")
+        key = (N, H, W, x.device.index)
+        hd = self._handles.get(key)
+        if hd is None:
+            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device)
+            params = list(self.parameters())
+            assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
+            for i, p in enumerate(params):
+                assert p.numel() == hd.numel[i], f"parameter {i} size mismatch: {p.numel()} vs {hd.numel[i]}"
+            self._handles[key] = hd
+        return hd
+
+    # ------------------------------------------------------------------ executor calls
+    def _run_forward(self, x, save):
+        _hip.require_cuda(x)
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        hd = self._handle(x)
+        pa, ba, params = self._pointers()
+        s = _hip.stream()
+        version = sum(p._version for p in params)
+        need_bwd_pack = save
+        if hd.wpack_version != (version, need_bwd_pack) and hd.wpack_version != (version, True):
+            check(lib().udapose_net_pack_weights(hd.h, s, pa, ptr(hd.wpack), int(need_bwd_pack)), "net_pack_weights")
+            hd.wpack_version = (version, need_bwd_pack)
+        if save:
+            act = torch.empty(hd.act_bytes, dtype=torch.uint8, device=x.device)
+        else:
+            if hd.act_nograd is None:
+                hd.act_nograd = torch.empty(hd.act_bytes, dtype=torch.uint8, device=x.device)
+            act = hd.act_nograd
+        out = torch.empty(hd.out_shape, dtype=torch.float32, device=x.device)
+        check(lib().udapose_net_forward(hd.h, s, ptr(x), pa, ba, ptr(hd.wpack), ptr(act), ptr(hd.ws), ptr(out), int(self.training),
+                                        float(self.bn_momentum)), "net_forward")
+        return out, (act if save else None), hd
+
+    def _run_backward(self, dout, act, hd):
+        pa, ba, params = self._pointers()
+        views = self._grad_views(params)
+        if params[0].grad is None:
+            beta = 0.0
+        elif params[0].grad.data_ptr() == views[0].data_ptr():
+            beta = 1.0
+        else:   # foreign gradient tensors: adopt their values, then accumulate
+            for p, v in zip(params, views):
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                else:
+                    v.zero_()
+            beta = 1.0
+        ga = getattr(self, "_grad_ptrs", None)
+        if ga is None or ga[0] != views[0].data_ptr():
+            ga = (views[0].data_ptr(), (C.c_void_p * len(views))(*[v.data_ptr() for v in views]))
+            self._grad_ptrs = ga
+        dout = dout.contiguous().float()
+        check(lib().udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(hd.ws), ga[1], beta), "net_backward")
+        for p, v in zip(params, views):
+            if p.requires_grad:
+                p.grad = v
+
+    def forward(self, x):
+        params = list(self.parameters())
+        return _PoseNetFn.apply(x, self, *params)
+
+    def get_parameters(self, lr=1.):
+        return [
+            {'params': self.backbone.parameters(), 'lr': 0.1 * lr if self.finetune else lr},
+            {'params': self.upsampling.parameters(), 'lr': lr},
+            {'params': self.head.parameters(), 'lr': lr},
+        ]
+
+
+def _pose_resnet(arch, num_keypoints, block, layers, pretrained_backbone, deconv_with_bias, finetune=False, progress=True, **kwargs):
+    backbone = _resnet(arch, block, layers, pretrained_backbone, progress, **kwargs)
+    upsampling = Upsampling(backbone.out_features, bias=deconv_with_bias)
+    model = PoseResNet(backbone, upsampling, 256, num_keypoints, finetune)
+    return model
+
+
+def pose_resnet101(num_keypoints, pretrained_backbone=True, deconv_with_bias=False, finetune=False, progress=True, **kwargs):
+    """Simple Baseline with a ResNet-101 backbone (pose_resnet.py:102-112)."""
+    return _pose_resnet('resnet101', num_keypoints, Bottleneck_default, [3, 4, 23, 3], pretrained_backbone, deconv_with_bias, finetune,
+                        progress, **kwargs)
+
+
+def pose_resnet50(num_keypoints, pretrained_backbone=True, deconv_with_bias=False, finetune=False, progress=True, **kwargs):
+    """Simple Baseline with a ResNet-50 backbone (pose_resnet.py:116-126)."""
+    return _pose_resnet('resnet50', num_keypoints, Bottleneck_default, [3, 4, 6, 3], pretrained_backbone, deconv_with_bias, finetune,
+                        progress, **kwargs)

@@ -1,0 +1,160 @@
+"""Thin tensor-level wrappers over the C ABI (one function per kernel family).
+
+Tensors are torch CUDA tensors used only as device memory; all arithmetic happens in libudapose_hip.so.
+Activations: NHWC bf16 contiguous ([N,H,W,C]); weights packed bf16 [Co][taps][Ci]; heat-maps NCHW fp32.
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+from ._hip import ConvDesc, check, lib, ptr, require_cuda, stream
+
+EPI_RELU, EPI_OUT_F32 = 1, 2
+
+
+def conv_desc(N, Hi, Wi, Ci, Co, K, stride=1, pad=0, transposed=False, reflect=False, upsample=False):
+    return ConvDesc(N, Hi, Wi, Ci, Co, K, K, stride, pad, int(transposed), int(reflect), int(upsample))
+
+
+def conv_out_hw(d):
+    ho, wo = C.c_int(), C.c_int()
+    lib().udapose_conv_out_hw(C.byref(d), C.byref(ho), C.byref(wo))
+    return ho.value, wo.value
+
+
+def kwp(d):
+    return (d.KW + 3) // 4 * 4 if d.Ci == 8 else d.KW
+
+
+def pack_weight(w, d, direction="fwd"):
+    """fp32 torch-layout weight ([Co,Ci,KH,KW]; transposed: [Ci,Co,KH,KW]) -> packed bf16 for fprop or dgrad."""
+    require_cuda(w)
+    T = d.KH * d.KW
+    wc = w.detach().float().contiguous(memory_format=torch.channels_last)   # physical [A][KH][KW][B]
+    flat = wc.permute(0, 2, 3, 1)                                           # logical [A,KH,KW,B], contiguous
+    A, B = flat.shape[0], flat.shape[3]
+    if d.Ci == 8:
+        assert direction == "fwd" and not d.transposed
+        out = torch.empty(d.Co, d.KH, kwp(d), 8, dtype=torch.bfloat16, device=w.device)
+        check(lib().udapose_pack_strided(stream(), ptr(flat), ptr(out), d.Co, d.KH, kwp(d), d.KW, 8, B, d.KH * d.KW * B, d.KW * B, B, 1), "pack")
+        return out
+    direct = (direction == "fwd") != bool(d.transposed)
+    if direct:
+        out = torch.empty(A, T, B, dtype=torch.bfloat16, device=w.device)
+        check(lib().udapose_cast_f32_bf16(stream(), ptr(flat), ptr(out), flat.numel()), "cast")
+    else:
+        out = torch.empty(B, T, A, dtype=torch.bfloat16, device=w.device)
+        check(lib().udapose_transpose_cast(stream(), ptr(flat), ptr(out), A, T, B), "transpose_cast")
+    return out
+
+
+def conv2d_fwd(x, w_fwd, d, res=None, bias=None, relu=False, out_f32=False, want_stats=False):
+    require_cuda(x, w_fwd)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (d.N, d.Hi, d.Wi, d.Ci)
+    ho, wo = conv_out_hw(d)
+    y = torch.empty(d.N, ho, wo, d.Co, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    stats = None
+    if want_stats:
+        rows = lib().udapose_conv_stat_rows(C.byref(d))
+        stats = torch.empty(rows, 2, d.Co, dtype=torch.float32, device=x.device)
+    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    check(lib().udapose_conv2d_fwd(stream(), C.byref(d), ptr(x), ptr(w_fwd), ptr(y), ptr(res), ptr(bias), ptr(stats), flags), "conv2d_fwd")
+    return (y, stats) if want_stats else y
+
+
+def conv2d_bwd_data(dy, w_bwd, d, res=None):
+    require_cuda(dy, w_bwd)
+    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.bfloat16, device=dy.device)
+    check(lib().udapose_conv2d_bwd_data(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res)), "conv2d_bwd_data")
+    return dx
+
+
+def conv2d_bwd_weight(dy, x, d, dw=None):
+    require_cuda(dy, x)
+    T = d.KH * kwp(d)
+    shape = (d.Ci, T, d.Co) if d.transposed else (d.Co, T, d.Ci)
+    acc = dw is not None
+    if dw is None:
+        dw = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(lib().udapose_conv2d_bwd_weight(stream(), C.byref(d), ptr(dy), ptr(x), ptr(dw), int(acc)), "conv2d_bwd_weight")
+    return dw
+
+
+def to_nhwc_bf16(x_nchw, cpad=None):
+    require_cuda(x_nchw)
+    N, Cc, H, W = x_nchw.shape
+    cpad = cpad or (Cc + 7) // 8 * 8
+    out = torch.empty(N, H, W, cpad, dtype=torch.bfloat16, device=x_nchw.device)
+    check(lib().udapose_nchw_f32_to_nhwc_bf16(stream(), ptr(x_nchw.float().contiguous()), ptr(out), N, Cc, H * W, cpad), "to_nhwc")
+    return out
+
+
+def to_nchw_f32(x_nhwc, channels=None, lo=None, hi=None):
+    require_cuda(x_nhwc)
+    N, H, W, Cs = x_nhwc.shape
+    Cc = channels or Cs
+    out = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x_nhwc.device)
+    check(lib().udapose_nhwc_to_nchw_f32(stream(), ptr(x_nhwc), int(x_nhwc.dtype == torch.float32), ptr(out), N, Cc, H * W, Cs, ptr(lo), ptr(hi)),
+          "to_nchw")
+    return out
+
+
+def bn_train_fwd(y, stats, gamma, beta, running_mean, running_var, nbt, momentum=0.1, eps=1e-5, res=None, relu=True):
+    C_ = y.shape[-1]
+    dev = y.device
+    scale, shift, mean, invstd = (torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4))
+    count = float(y.numel() // C_)
+    check(lib().udapose_bn_finalize(stream(), ptr(stats), stats.shape[0], C_, count, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                    ptr(nbt), momentum, eps, ptr(scale), ptr(shift), ptr(mean), ptr(invstd)), "bn_finalize")
+    z = torch.empty_like(y)
+    check(lib().udapose_bn_apply(stream(), ptr(y), ptr(res), ptr(z), y.numel(), C_, ptr(scale), ptr(shift), int(relu)), "bn_apply")
+    return z, mean, invstd
+
+
+def bn_bwd(dz, z, y, gamma, mean, invstd, relu=True, want_g=False):
+    C_ = y.shape[-1]
+    npix = y.numel() // C_
+    dev = y.device
+    rows = lib().udapose_bn_bwd_rows(npix)
+    slab = torch.empty(rows, 2, C_, dtype=torch.float32, device=dev)
+    coef = torch.empty(3, C_, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C_, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C_, dtype=torch.float32, device=dev)
+    dy = torch.empty_like(y)
+    g = torch.empty_like(y) if want_g else None
+    check(lib().udapose_bn_bwd(stream(), ptr(dz), ptr(z), ptr(y), ptr(dy), ptr(g), npix, C_, ptr(gamma), ptr(mean), ptr(invstd), int(relu),
+                               ptr(slab), ptr(coef), ptr(dgamma), ptr(dbeta), 0.0), "bn_bwd")
+    return dy, dgamma, dbeta, g
+
+
+def maxpool3x3s2_fwd(x):
+    N, H, W, C_ = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(N, Ho, Wo, C_, dtype=torch.bfloat16, device=x.device)
+    idx = torch.empty(N, Ho, Wo, C_, dtype=torch.uint8, device=x.device)
+    check(lib().udapose_maxpool3x3s2_fwd(stream(), ptr(x), ptr(y), ptr(idx), N, H, W, C_), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool3x3s2_bwd(dy, idx, H, W):
+    N, _, _, C_ = dy.shape
+    dx = torch.empty(N, H, W, C_, dtype=torch.bfloat16, device=dy.device)
+    check(lib().udapose_maxpool3x3s2_bwd(stream(), ptr(dy), ptr(idx), ptr(dx), N, H, W, C_), "maxpool_bwd")
+    return dx
+
+
+def maxpool2x2_ceil(x):
+    N, H, W, C_ = x.shape
+    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C_, dtype=torch.bfloat16, device=x.device)
+    check(lib().udapose_maxpool2x2_ceil(stream(), ptr(x), ptr(y), N, H, W, C_), "maxpool2x2")
+    return y
+
+
+def adain(content, style, alpha=1.0, eps=1e-5, want_stats=False):
+    N, H, W, C_ = content.shape
+    out = torch.empty_like(content)
+    st = torch.empty(N, C_, 4, dtype=torch.float32, device=content.device) if want_stats else None
+    check(lib().udapose_adain(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps, float(alpha), ptr(st)),
+          "adain")
+    return (out, st) if want_stats else out
