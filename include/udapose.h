@@ -47,8 +47,10 @@ int udapose_conv_stat_rows(const udapose_conv_desc* d);
  * (sum, sum of squares) of the fp32 result before bias/res - the BatchNorm batch statistics.  w_fwd: bf16 [Co][KH*KWp][Ci]. */
 int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, const void* w_fwd, void* y, const void* res,
                        const float* bias, float* stats, int epilogue_flags);
-/* dx[N,Hi,Wi,Ci] = conv^T(dy, w_bwd) (+res);  w_bwd: bf16 [Ci][KH*KW][Co] */
-int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res);
+/* dx[N,Hi,Wi,Ci] = conv^T(dy, w_bwd) (+res);  w_bwd: bf16 [Ci][KH*KW][Co]; out_f32: dx stored as fp32 (gradients that
+ * feed a BatchNorm backward close to the loss, where the BN projection cancels most of the gradient) */
+int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res,
+                            int out_f32);
 /* dw fp32 [Co][KH*KWp][Ci] (transposed: [Ci][KH*KW][Co]) = (accumulate ? dw : 0) + sum_pixels dy * x */
 int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate);
 /* weight packing from fp32: cast (n % 8 == 0); per-tap transpose [A][T][B] -> [B][T][A]; strided gather with zero padding */
@@ -73,8 +75,8 @@ int udapose_bn_eval_coeff(void* stream, int C, const float* gamma, const float* 
 int udapose_bn_apply(void* stream, const void* y, const void* res, void* z, size_t numel, int C, const float* scale, const float* shift,
                      int relu);
 int udapose_bn_bwd_rows(size_t npix);
-/* dz -> dy (+ masked g); slab: [bn_bwd_rows][2][C] fp32 scratch, coef: [3][C] fp32 scratch */
-int udapose_bn_bwd(void* stream, const void* dz, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
+/* dz (bf16, or fp32 when dz_is_f32) -> dy (+ masked g); slab: [bn_bwd_rows][2][C] fp32 scratch, coef: [3][C] fp32 scratch */
+int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
                    const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* slab, float* coef,
                    float* dgamma, float* dbeta, float beta_acc);
 

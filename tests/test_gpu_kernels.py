@@ -46,6 +46,7 @@ CONV_CASES = [
     ("3x3_ragged", 3, 12, 12, 64, 128, 3, 1, 1),
     ("3x3_odd", 1, 9, 7, 32, 64, 3, 2, 1),
     ("1x1_big", 4, 32, 32, 256, 1024, 1, 1, 0),
+    ("1x1_head32", 2, 16, 16, 256, 32, 1, 1, 0),
 ]
 
 
@@ -191,9 +192,9 @@ def test_batchnorm_train_fwd_bwd(dev):
     gm = dz * (nchw(z) > 0)
     (bn(yc) + res).backward(gm)
     dy, dgamma, dbeta, gmask = ops.bn_bwd(nhwc(dz), z, y, gamma.cuda(), mean, invstd, relu=True, want_g=True)
-    close(nchw(dy), yc.grad, 3e-2)
-    close(dgamma.cpu(), bn.weight.grad, 2e-2)
-    close(dbeta.cpu(), bn.bias.grad, 2e-2)
+    close(nchw(dy), yc.grad, 1.2e-2)
+    close(dgamma.cpu(), bn.weight.grad, 5e-3)
+    close(dbeta.cpu(), bn.bias.grad, 5e-3)
     close(nchw(gmask), gm, 1.2e-2)
     assert ((nchw(z) > 0) != (zr.detach() > 0)).float().mean().item() < 1e-3
 

@@ -12,7 +12,7 @@ int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, co
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
 int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
-int pw_bn_bwd(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
+int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
               float*, float*, float*, float*, float);
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
@@ -62,9 +62,9 @@ int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, 
     e.res = CB16(res); e.bias = bias; e.stats = stats; e.relu = (flags & UDAPOSE_EPI_RELU) != 0; e.out_f32 = (flags & UDAPOSE_EPI_OUT_F32) != 0;
     return conv_fprop(S(stream), to_geom(d), CB16(x), CB16(w_fwd), y, e);
 }
-int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res) {
+int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res, int out_f32) {
     if (!d || !dy || !w_bwd || !dx) return UDAPOSE_ERR_ARG;
-    return conv_dgrad(S(stream), to_geom(d), CB16(dy), CB16(w_bwd), B16(dx), CB16(res));
+    return conv_dgrad(S(stream), to_geom(d), CB16(dy), CB16(w_bwd), dx, CB16(res), out_f32);
 }
 int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate) {
     if (!d || !dy || !x || !dw) return UDAPOSE_ERR_ARG;
@@ -93,9 +93,11 @@ int udapose_bn_apply(void* stream, const void* y, const void* res, void* z, size
     return pw_bn_apply(S(stream), CB16(y), CB16(res), B16(z), numel, C, scale, shift, relu);
 }
 int udapose_bn_bwd_rows(size_t npix) { return pw_bn_bwd_rows(npix); }
-int udapose_bn_bwd(void* stream, const void* dz, const void* z, const void* y, void* dy, void* gout, size_t npix, int C, const float* gamma,
-                   const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta, float beta_acc) {
-    return pw_bn_bwd(S(stream), CB16(dz), CB16(z), CB16(y), B16(dy), B16(gout), npix, C, gamma, mean, invstd, relu, slab, coef, dgamma, dbeta, beta_acc);
+int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
+                   const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
+                   float beta_acc) {
+    return pw_bn_bwd(S(stream), dz, dz_is_f32, CB16(z), CB16(y), B16(dy), B16(gout), npix, C, gamma, mean, invstd, relu, slab, coef, dgamma, dbeta,
+                     beta_acc);
 }
 int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C) {
     return pw_maxpool3x3s2_fwd(S(stream), CB16(x), B16(y), idx, N, H, W, C);

@@ -42,7 +42,7 @@ struct ConvEpilogue {
 // y = conv(x, w_fwd[Co][wtaps][Ci])
 int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e);
 // dx = conv^T(dy, w_bwd[Ci][wtaps][Co]) (+ res)
-int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, bf16_t* dx, const bf16_t* res);
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32);
 // dw (fp32, [Co][wtaps][Ci]; transposed: [Ci][wtaps][Co]) (+)= ...;  rows_valid < 0 -> all rows
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid);
 int conv_stat_rows(const ConvGeom& g);

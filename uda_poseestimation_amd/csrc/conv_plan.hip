@@ -94,7 +94,7 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* 
     return igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
 }
 
-int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, bf16_t* dx, const bf16_t* res) {
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32) {
     if (g.reflect || g.upsample || g.smallc()) return UDAPOSE_ERR_UNSUPPORTED;
     const TapPlan* tp = get_tap_plan(g, 1);
     if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
@@ -107,7 +107,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     else { p.Hg = g.Hi; p.Wg = g.Wi; p.s = 1; p.os = 1; }
     p.M = g.N * p.Hg * p.Wg;
     p.wtaps = g.wtaps();
-    p.flags = 0;
+    p.flags = out_f32 ? IG_FLAG_OUT_F32 : 0;
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     return igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);

@@ -160,9 +160,24 @@ __global__ void bn_apply_k(const bf16_t* __restrict__ y, const bf16_t* __restric
     }
 }
 
+// 8 consecutive gradient values as fp32 (the gradient entering a BN backward may be kept in fp32 near the loss, where
+// g - mean(g) - xhat*mean(g*xhat) cancels most of g and bf16 rounding of g would dominate the result)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+}
+
 // Backward reduce: per-channel sum(g) and sum(g*xhat), g = dz * (z>0) when relu.  Partial slab [blocks][2][C].
 // Requires C/8 to be a power of two <= 256 (thread's channel group is loop-invariant).
-__global__ void bn_bwd_reduce_k(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+template <typename DZ>
+__global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
                                 size_t npix, int C, const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                 float* __restrict__ slab, int pix_per_block) {
     __shared__ float red[TPB][17];
@@ -177,13 +192,14 @@ __global__ void bn_bwd_reduce_k(const bf16_t* __restrict__ dz, const bf16_t* __r
     if (p1 > npix) p1 = npix;
     for (size_t p = p0 + prow; p < p1; p += pstep) {
         const size_t off = p * C + c0;
-        const bf16x8 d = *(const bf16x8*)(dz + off);
+        float d[8];
+        load8<DZ>(dz + off, d);
         const bf16x8 yy = *(const bf16x8*)(y + off);
         bf16x8 zz;
         if (relu) zz = *(const bf16x8*)(z + off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float gv = (float)d[e];
+            float gv = d[e];
             if (relu && !((float)zz[e] > 0.f)) gv = 0.f;
             s1[e] += gv;
             s2[e] += gv * (((float)yy[e] - mu[e]) * is[e]);
@@ -225,13 +241,15 @@ __global__ void bn_bwd_finalize_k(const float* __restrict__ slab, int rows, int 
     coef[2 * C + c] = (float)(s2 / count);
 }
 // dy = ca*(g - cb - xhat*cc); optionally also write g (masked dz) for the skip branch
-__global__ void bn_bwd_apply_k(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+template <typename DZ>
+__global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
                                bf16_t* __restrict__ dy, bf16_t* __restrict__ gout, size_t n8, int C, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ coef, int relu) {
     const int G = C >> 3;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
         const int c0 = (int)(i % G) * 8;
-        const bf16x8 d = *(const bf16x8*)(dz + i * 8);
+        float d[8];
+        load8<DZ>(dz + i * 8, d);
         const bf16x8 yy = *(const bf16x8*)(y + i * 8);
         bf16x8 zz;
         if (relu) zz = *(const bf16x8*)(z + i * 8);
@@ -239,7 +257,7 @@ __global__ void bn_bwd_apply_k(const bf16_t* __restrict__ dz, const bf16_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
-            float gv = (float)d[e];
+            float gv = d[e];
             if (relu && !((float)zz[e] > 0.f)) gv = 0.f;
             const float xh = ((float)yy[e] - mean[c]) * invstd[c];
             o[e] = (bf16_t)(coef[c] * (gv - coef[C + c] - xh * coef[2 * C + c]));
@@ -433,15 +451,24 @@ int pw_bn_bwd_rows(size_t npix) {
     if (b > 1024) b = 1024;
     return (int)(b < 1 ? 1 : b);
 }
-int pw_bn_bwd(hipStream_t s, const bf16_t* dz, const bf16_t* z, const bf16_t* y, bf16_t* dy, bf16_t* gout, size_t npix, int C, const float* gamma,
-              const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta, float beta_acc) {
+int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, const bf16_t* y, bf16_t* dy, bf16_t* gout, size_t npix, int C,
+              const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
+              float beta_acc) {
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1))) return UDAPOSE_ERR_UNSUPPORTED;
     const int rows = pw_bn_bwd_rows(npix);
     const int ppb = (int)((npix + rows - 1) / rows);
-    hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(rows), dim3(TPB), 0, s, dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
+    if (dz_is_f32)
+        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(TPB), 0, s, (const float*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(nblk(C)), dim3(TPB), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(grid_for(npix * G)), dim3(TPB), 0, s, dz, z, y, dy, gout, npix * G, C, mean, invstd, coef, relu);
+    if (dz_is_f32)
+        hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)dz, z, y, dy, gout, npix * G, C, mean, invstd,
+                           coef, relu);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, dy, gout, npix * G, C, mean,
+                           invstd, coef, relu);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_fwd(hipStream_t s, const bf16_t* x, bf16_t* y, unsigned char* idx, int N, int H, int W, int C) {

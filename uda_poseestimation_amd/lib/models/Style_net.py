@@ -1,0 +1,237 @@
+"""AdaIN style-transfer network (API mirror of the reference's lib/models/Style_net.py:4-177) on MI355X kernels.
+
+`vgg` and `decoder` are module-level nn.Sequential singletons with the reference's exact child indices, so the
+training script's `Style_net.decoder.load_state_dict(...)`, `Style_net.vgg.load_state_dict(...)`,
+`nn.Sequential(*list(vgg.children())[:31])` and `Style_net.Net(vgg, decoder)` (train_human.py:120-131) work unchanged.
+The children are parameter containers: `Net.forward` walks them and issues one fused kernel per
+[ReflectionPad2d -> Conv2d -> ReLU] group (reflection, nearest x2 upsample, bias and ReLU live inside the conv
+kernel), the ceil-mode max-pools, and the AdaIN kernel.  Activations are NHWC bf16 with fp32 accumulation.
+
+Only the inference path the training loop consumes is implemented: `forward(...)[2]` (= g_t).  The reference also
+re-encodes g_t to compute a content and a Gram style loss that the loop discards (train_human.py:350 takes [2]);
+those two values are returned as zeros unless `compute_losses=True` is requested, which is not supported on device.
+"""
+import torch
+import torch.nn as nn
+
+from ... import _hip, ops
+from ..._hip import check, lib, ptr
+
+
+def _nchw_feat(feat):
+    assert feat.dim() == 4
+    _hip.require_cuda(feat)
+    return feat.detach().float().contiguous()
+
+
+def calc_mean_std(feat, eps=1e-5):
+    """Per-(n,c) mean and sqrt(unbiased var + eps) over H*W (Style_net.py:4-12), from the AdaIN kernel's statistics."""
+    size = feat.size()
+    assert (len(size) == 4)
+    N, C = size[:2]
+    x = ops.to_nhwc_bf16(_nchw_feat(feat), (C + 63) // 64 * 64)
+    _, st = ops.adain(x, x, alpha=0.0, eps=eps, want_stats=True)
+    return st[:, :C, 0].reshape(N, C, 1, 1).to(feat.dtype), st[:, :C, 1].reshape(N, C, 1, 1).to(feat.dtype)
+
+
+def adain(content_feat, style_feat):
+    """(content - mean_c) / std_c * std_s + mean_s (Style_net.py:21-29); NCHW in/out at the API boundary."""
+    assert (content_feat.size()[:2] == style_feat.size()[:2])
+    N, C, H, W = content_feat.shape
+    Cp = (C + 63) // 64 * 64
+    out = ops.adain(ops.to_nhwc_bf16(_nchw_feat(content_feat), Cp), ops.to_nhwc_bf16(_nchw_feat(style_feat), Cp), alpha=1.0)
+    return ops.to_nchw_f32(out, C).to(content_feat.dtype)
+
+
+decoder = nn.Sequential(
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(512, 256, (3, 3)),
+    nn.ReLU(),
+    nn.Upsample(scale_factor=2, mode='nearest'),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(256, 256, (3, 3)),
+    nn.ReLU(),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(256, 256, (3, 3)),
+    nn.ReLU(),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(256, 256, (3, 3)),
+    nn.ReLU(),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(256, 128, (3, 3)),
+    nn.ReLU(),
+    nn.Upsample(scale_factor=2, mode='nearest'),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(128, 128, (3, 3)),
+    nn.ReLU(),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(128, 64, (3, 3)),
+    nn.ReLU(),
+    nn.Upsample(scale_factor=2, mode='nearest'),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(64, 64, (3, 3)),
+    nn.ReLU(),
+    nn.ReflectionPad2d((1, 1, 1, 1)),
+    nn.Conv2d(64, 3, (3, 3)),
+)
+
+
+def _vgg_layers():
+    cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512]
+    mods = [nn.Conv2d(3, 3, (1, 1))]
+    cin = 3
+    for v in cfg:
+        if v == 'M':
+            mods.append(nn.MaxPool2d((2, 2), (2, 2), (0, 0), ceil_mode=True))
+        else:
+            mods += [nn.ReflectionPad2d((1, 1, 1, 1)), nn.Conv2d(cin, v, (3, 3)), nn.ReLU()]
+            cin = v
+    return mods
+
+
+vgg = nn.Sequential(*_vgg_layers())
+
+
+class _Step:
+    __slots__ = ("kind", "conv", "pre1x1", "relu", "upsample")
+
+    def __init__(self, kind, conv=None, pre1x1=None, relu=False, upsample=False):
+        self.kind, self.conv, self.pre1x1, self.relu, self.upsample = kind, conv, pre1x1, relu, upsample
+
+
+def _compile(children):
+    """Group a child list into fused device steps."""
+    steps, i, pend_up, pend_1x1 = [], 0, False, None
+    ch = list(children)
+    while i < len(ch):
+        m = ch[i]
+        if isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1):
+            pend_1x1 = m          # 3->3 colour transform: folded into the next 3x3 conv (reflection pad commutes with it)
+            i += 1
+        elif isinstance(m, nn.Upsample):
+            pend_up = True
+            i += 1
+        elif isinstance(m, nn.ReflectionPad2d):
+            conv = ch[i + 1]
+            assert isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3), "expected ReflectionPad2d -> Conv2d(3x3)"
+            relu = i + 2 < len(ch) and isinstance(ch[i + 2], nn.ReLU)
+            steps.append(_Step("conv", conv, pend_1x1, relu, pend_up))
+            pend_up, pend_1x1 = False, None
+            i += 3 if relu else 2
+        elif isinstance(m, nn.MaxPool2d):
+            steps.append(_Step("pool"))
+            i += 1
+        else:
+            raise NotImplementedError(f"unsupported style-net child {type(m).__name__}")
+    assert pend_1x1 is None and not pend_up
+    return steps
+
+
+class _SeqRunner:
+    """Runs a compiled step list on NHWC bf16 tensors; packed weights are cached until a parameter changes."""
+
+    def __init__(self, children):
+        self.steps = _compile(children)
+        self._packs = {}
+
+    def _packed(self, st, d):
+        conv = st.conv
+        ver = (conv.weight._version, conv.bias._version, conv.weight.data_ptr(),
+               None if st.pre1x1 is None else (st.pre1x1.weight._version, st.pre1x1.bias._version))
+        hit = self._packs.get(id(conv))
+        if hit is None or hit[0] != ver:
+            w, b = conv.weight.detach().float(), conv.bias.detach().float()
+            if st.pre1x1 is not None:
+                w1 = st.pre1x1.weight.detach().float().reshape(st.pre1x1.out_channels, st.pre1x1.in_channels)
+                b1 = st.pre1x1.bias.detach().float()
+                b = b + torch.einsum("omhw,m->o", w, b1)
+                w = torch.einsum("omhw,mc->ochw", w, w1)
+            hit = (ver, ops.pack_weight(w.contiguous(), d, "fwd"), b.contiguous())
+            self._packs[id(conv)] = hit
+        return hit[1], hit[2]
+
+    def run(self, x, taps=None, final_f32=False):
+        """x NHWC bf16.  `taps`: step indices after which to record the activation (encode_with_intermediate)."""
+        outs = []
+        for si, st in enumerate(self.steps):
+            if st.kind == "pool":
+                x = ops.maxpool2x2_ceil(x)
+            else:
+                N, H, W, Cin = x.shape
+                d = ops.conv_desc(N, H, W, Cin, st.conv.out_channels, 3, 1, 1, reflect=True, upsample=st.upsample)
+                w, b = self._packed(st, d)
+                last = si == len(self.steps) - 1
+                x = ops.conv2d_fwd(x, w, d, bias=b, relu=st.relu, out_f32=(final_f32 and last))
+            if taps is not None and si in taps:
+                outs.append(x)
+        return (x, outs) if taps is not None else x
+
+
+class Net(nn.Module):
+    def __init__(self, encoder, decoder):
+        super(Net, self).__init__()
+        enc_layers = list(encoder.children())
+        self.enc_1 = nn.Sequential(*enc_layers[:4])  # input -> relu1_1
+        self.enc_2 = nn.Sequential(*enc_layers[4:11])  # relu1_1 -> relu2_1
+        self.enc_3 = nn.Sequential(*enc_layers[11:18])  # relu2_1 -> relu3_1
+        self.enc_4 = nn.Sequential(*enc_layers[18:31])  # relu3_1 -> relu4_1
+        self.decoder = decoder
+        self.mse_loss = nn.MSELoss()
+        for name in ['enc_1', 'enc_2', 'enc_3', 'enc_4']:
+            for param in getattr(self, name).parameters():
+                param.requires_grad = False
+        self._enc = _SeqRunner(enc_layers[:31])
+        self._dec = _SeqRunner(list(decoder.children()))
+        # step indices that end enc_1..enc_4 (relu1_1, relu2_1, relu3_1, relu4_1)
+        self._enc_taps = self._stage_ends([len(list(getattr(self, f"enc_{i}").children())) for i in range(1, 5)], enc_layers[:31])
+
+    @staticmethod
+    def _stage_ends(stage_child_counts, children):
+        ends, acc, steps_seen, i = [], 0, 0, 0
+        bounds = []
+        for c in stage_child_counts:
+            acc += c
+            bounds.append(acc)
+        ch = list(children)
+        si = -1
+        out = []
+        for b in bounds:
+            while i < b:
+                m = ch[i]
+                if isinstance(m, nn.ReflectionPad2d):
+                    relu = i + 2 < len(ch) and isinstance(ch[i + 2], nn.ReLU)
+                    si += 1
+                    i += 3 if relu else 2
+                elif isinstance(m, nn.MaxPool2d):
+                    si += 1
+                    i += 1
+                else:
+                    i += 1
+            out.append(si)
+        return out
+
+    def _image_in(self, img):
+        _hip.require_cuda(img)
+        return ops.to_nhwc_bf16(img.detach().float().contiguous(), 8)
+
+    def encode_with_intermediate(self, input):
+        """relu1_1, relu2_1, relu3_1, relu4_1 as NCHW fp32 tensors (Style_net.py:136-142)."""
+        _, feats = self._enc.run(self._image_in(input), taps=set(self._enc_taps))
+        return [ops.to_nchw_f32(f) for f in feats]
+
+    def encode(self, input):
+        return ops.to_nchw_f32(self._enc.run(self._image_in(input)))
+
+    def forward(self, content, style, alpha=1.0, clamp=None):
+        """-> (loss_c, loss_s, g_t).  `clamp=(lo[3], hi[3])` fuses the loop's recover clamp (train_human.py:351) into the
+        output conversion."""
+        assert 0 <= alpha <= 1
+        with torch.no_grad():
+            sf = self._enc.run(self._image_in(style))
+            cf = self._enc.run(self._image_in(content))
+            t = ops.adain(cf, sf, alpha=float(alpha))              # alpha-blend fused (Style_net.py:167-168)
+            g = self._dec.run(t, final_f32=True)                    # [N,H,W,3] fp32
+            lo, hi = (None, None) if clamp is None else (clamp[0].float().contiguous(), clamp[1].float().contiguous())
+            g_t = ops.to_nchw_f32(g, 3, lo, hi)
+        zero = torch.zeros((), device=g_t.device)
+        return zero, zero.clone(), g_t

@@ -75,8 +75,8 @@ class _NetHandle:
 
 class _PoseNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, net, *params):
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, x, net, need_grad, *params):
+        # (grad mode is always off inside Function.forward: the caller decides whether backward state is kept)
         out, act, hd = net._run_forward(x, save=need_grad)
         ctx.net, ctx.act, ctx.hd = net, act, hd
         ctx.nparams = len(params)
@@ -85,10 +85,12 @@ class _PoseNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         net = ctx.net
+        if ctx.act is None:
+            raise RuntimeError("PoseResNet backward without saved activations (forward ran without grad, or backward ran twice)")
         net._run_backward(dout, ctx.act, ctx.hd)
         ctx.act = None
         # parameter gradients are accumulated straight into p.grad (views of the module's flat gradient buffer)
-        return (None, None) + (None,) * ctx.nparams
+        return (None, None, None) + (None,) * ctx.nparams
 
 
 class PoseResNet(nn.Module):
@@ -228,7 +230,8 @@ class PoseResNet(nn.Module):
 
     def forward(self, x):
         params = list(self.parameters())
-        return _PoseNetFn.apply(x, self, *params)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _PoseNetFn.apply(x, self, need_grad, *params)
 
     def get_parameters(self, lr=1.):
         return [

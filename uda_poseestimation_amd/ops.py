@@ -63,10 +63,10 @@ def conv2d_fwd(x, w_fwd, d, res=None, bias=None, relu=False, out_f32=False, want
     return (y, stats) if want_stats else y
 
 
-def conv2d_bwd_data(dy, w_bwd, d, res=None):
+def conv2d_bwd_data(dy, w_bwd, d, res=None, out_f32=False):
     require_cuda(dy, w_bwd)
-    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.bfloat16, device=dy.device)
-    check(lib().udapose_conv2d_bwd_data(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res)), "conv2d_bwd_data")
+    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dy.device)
+    check(lib().udapose_conv2d_bwd_data(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res), int(out_f32)), "conv2d_bwd_data")
     return dx
 
 
@@ -123,7 +123,8 @@ def bn_bwd(dz, z, y, gamma, mean, invstd, relu=True, want_g=False):
     dbeta = torch.empty(C_, dtype=torch.float32, device=dev)
     dy = torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
-    check(lib().udapose_bn_bwd(stream(), ptr(dz), ptr(z), ptr(y), ptr(dy), ptr(g), npix, C_, ptr(gamma), ptr(mean), ptr(invstd), int(relu),
+    check(lib().udapose_bn_bwd(stream(), ptr(dz), int(dz.dtype == torch.float32), ptr(z), ptr(y), ptr(dy), ptr(g), npix, C_, ptr(gamma), ptr(mean),
+                               ptr(invstd), int(relu),
                                ptr(slab), ptr(coef), ptr(dgamma), ptr(dbeta), 0.0), "bn_bwd")
     return dy, dgamma, dbeta, g
 
