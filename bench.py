@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Benchmark of the mean-teacher UDA pose-estimation hot path on MI355X (BASELINE.json metric).
+
+One STEP = one pass of the reference training step (train_human.py:326-444, k=1) over one synthetic batch:
+student forward+backward on x_s and on x_t_stu (N images each), teacher forward on x_t_tea (N images), heat-map
+re-warps, JointsMSE + masked consistency loss (rectify, k-th value mask), Adam, EMA teacher update - PoseResNet-101,
+K=16, 256x256, N=32 per GPU, bf16 compute / fp32 master weights (BASELINE.json configs[1]).  img/s counts N per step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 10 --warmup 3
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  "roofline":     MFMA roofline of the dominant kernel family (implicit-GEMM fprop/dgrad), from HIP events recorded on the
+                  launch stream around every convolution launch of the LAST timed step;
+  "cpu_baseline": the CPU oracle's (oracle/step_ref.py, plain torch fp32) throughput on this host, bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FWD_GFLOP_PER_IMAGE = 24.165       # PoseResNet-101, K=16, 256x256 forward
+
+
+def cpu_baseline(n, arch_layers, seconds_budget=25.0):
+    """CPU oracle step (kind 'port'): PoseResNet-101 mean-teacher step on `n` images, fp32, all host cores."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_ref
+    from uda_poseestimation_amd import synthetic
+    torch.manual_seed(0)
+    stu, tea = PoseResNetRef(arch_layers, 16), PoseResNetRef(arch_layers, 16)
+    tea.load_state_dict(stu.state_dict())
+    opt = torch.optim.Adam(stu.parameters(), lr=1e-4)
+    b = synthetic.mean_teacher_batch(n, seed=0)
+    times = []
+    t_start = time.time()
+    for it in range(3):
+        t0 = time.time()
+        train_step_ref(stu, tea, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"], b["aug_param_tea"])
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": n / best, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"PoseResNet-101 mean-teacher step (student fwd+bwd on 2x{n}, teacher fwd on {n}, losses, Adam, EMA) fp32 "
+                      f"oracle/step_ref.py, {len(times)} iteration(s), best of the non-first: {best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per domain (BASELINE: 32)")
+    ap.add_argument("--arch", default="pose_resnet101")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback); the CPU oracle lives in oracle/ and is only the baseline leg")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from uda_poseestimation_amd import _hip, synthetic
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    import uda_poseestimation_amd.lib.models as models
+    lib = _hip.lib()
+
+    N, K = args.batch, 16
+    torch.manual_seed(0)
+    student = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
+    teacher = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
+    trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=2)
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, seed=rank)          # a different shard per rank (weak scaling)
+    g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+    def step():
+        return trainer.train_step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prof = (ctypes.c_double * 9)()
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            lib.udapose_prof_begin()          # HIP events around every conv launch of the last timed step
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _hip.check(lib.udapose_prof_end(prof), "prof_end")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out["loss_all"])
+    assert loss == loss, "loss is NaN"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * N * args.steps / elapsed
+        fl, ms_f, fp_f = prof[0], prof[1], prof[2]
+        dl, ms_d, fp_d = prof[3], prof[4], prof[5]
+        wl, ms_w, fp_w = prof[6], prof[7], prof[8]
+        ig_l, ig_ms, ig_fl = fl + dl, ms_f + ms_d, fp_f + fp_d
+        achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        layers = {"pose_resnet101": [3, 4, 23, 3], "pose_resnet50": [3, 4, 6, 3]}[args.arch]
+        res = {
+            "metric": "images/sec (student+teacher step) 256x256 b=32", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.arch} K=16 mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
+                                   f"Adam, EMA), 256x256, b={N}/GPU, no AdaIN (BASELINE.json configs[1])",
+                       "global_batch": world * N, "parallelism": f"dp{world}"},
+            "loss": loss,
+            "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if args.arch == "pose_resnet101" else None,
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fprop+dgrad, bf16 MFMA 16x16x32)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": int(ig_l), "avg_launch_us": round(ig_ms * 1e3 / max(ig_l, 1), 2),
+                         "flops_per_launch_avg": ig_fl / max(ig_l, 1), "kernel_ms_per_step": round(ig_ms, 3),
+                         "wgrad": {"launches_per_step": int(wl), "kernel_ms_per_step": round(ms_w, 3),
+                                   "achieved": round(fp_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else None}},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_images, layers)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,6 +146,18 @@ int udapose_sgd_multi(void* stream, const long long* p, const long long* g, cons
 int udapose_adain(void* stream, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps,
                   float alpha, float* stats_out);
 
+/* ---------------------------------------------------------------- batched nearest inverse-affine re-warp
+ * (torchvision.transforms.functional.affine x3 per sample, train_human.py:366-368,388-390,412,421-423): NCHW fp32;
+ * theta [N][nstage][6] = the inverse affine matrices in application order; backward != 0: src = d(out), dst = d(in). */
+int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage,
+                           int backward);
+
+/* ---------------------------------------------------------------- per-launch timing of the MFMA kernels (bench.py roofline)
+ * HIP events are recorded on the launch stream around every convolution launch between begin and end.
+ * h_out9 (host): for kind in (fprop, dgrad, wgrad): launches, total milliseconds, total algorithmic FLOPs. */
+void udapose_prof_begin(void);
+int udapose_prof_end(double* h_out9);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,9 @@ int opt_adam(hipStream_t, const long long*, const long long*, const long long*, 
 int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float, float,
             int, int, float);
 int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, float, float, float*);
+int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
+void prof_begin();
+int prof_end(double*);
 void* net_create(const int layers[4], int K, int N, int H, int W);
 void net_destroy(void*);
 int net_num_params(void*);
@@ -174,5 +177,12 @@ int udapose_sgd_multi(void* stream, const long long* p, const long long* g, cons
 int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha, float* stats_out) {
     return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, stats_out);
 }
+
+int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage, int backward) {
+    return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);
+}
+
+void udapose_prof_begin(void) { prof_begin(); }
+int udapose_prof_end(double* h_out9) { return prof_end(h_out9); }
 
 }  // extern "C"

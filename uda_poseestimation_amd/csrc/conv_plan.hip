@@ -5,6 +5,16 @@
 #include <tuple>
 #include "conv_plan.h"
 
+int prof_before(hipStream_t s, int kind, double flops);
+void prof_after(hipStream_t s, int token);
+
+static double alg_flops(const ConvGeom& g) {
+    // algorithmic FLOPs of the convolution (true channel count: 8-channel inputs are 3-channel images padded)
+    const double ci = g.Ci == 8 ? 3.0 : (double)g.Ci;
+    const double opix = g.transposed ? (double)g.N * g.Hi * g.Wi : (double)g.N * g.Ho() * g.Wo();
+    return 2.0 * opix * g.Co * ci * g.KH * g.KW;
+}
+
 namespace {
 
 std::mutex g_mu;
@@ -91,7 +101,10 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* 
               (e.out_f32 ? IG_FLAG_OUT_F32 : 0) | (g.smallc() ? IG_FLAG_SMALLC : 0);
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
-    return igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+    const int tok = prof_before(s, 0, alg_flops(g));
+    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+    prof_after(s, tok);
+    return rc;
 }
 
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32) {
@@ -110,7 +123,10 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     p.flags = out_f32 ? IG_FLAG_OUT_F32 : 0;
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
-    return igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+    const int tok = prof_before(s, 1, alg_flops(g));
+    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+    prof_after(s, tok);
+    return rc;
 }
 
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid) {
@@ -131,5 +147,8 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     p.total_taps = (int)tp->taps.size();
     const int Rdim = g.transposed ? g.Ci : g.Co, Cdim = g.transposed ? g.Co : g.Ci;
     p.rows_valid = rows_valid < 0 ? Rdim : rows_valid;
-    return wgrad_launch(p, wgrad_pick_tile(Rdim, Cdim, g.smallc()), accumulate, s);
+    const int tok = prof_before(s, 2, alg_flops(g));
+    const int rc = wgrad_launch(p, wgrad_pick_tile(Rdim, Cdim, g.smallc()), accumulate, s);
+    prof_after(s, tok);
+    return rc;
 }

@@ -1,0 +1,127 @@
+"""Mean-teacher training step of the reference (train_human.py:244-302 `pretrain`, :305-458 `train`) on the MI355X path.
+
+The reference keeps this logic inside its train scripts; this harness reproduces the order of operations so that
+bench.py, smoke() and the tests can drive the hot path the way `train_human.py` does:
+
+    zero_grad -> [style s2t / t2s] -> teacher forward (no grad, train-mode BN) -> re-warp teacher heat-maps
+    -> [occlusion] -> student(x_s), student(x_t_stu) (two separate forwards) -> re-warp student heat-maps
+    -> JointsMSE(source) -> activations / rectify / k-th value mask -> ConsLoss -> backward
+    -> (data parallel: one all-reduce of the flat gradient buffer over RCCL) -> Adam -> EMA -> PCK
+
+Data parallelism: one process per GPU, the batch is sharded per image, every rank holds full
+student / teacher replicas; the only collectives are the gradient all-reduce (student only) and a tiny all-gather of
+the per-key-point confidences so that the mask threshold stays the GLOBAL-batch k-th value.  BN statistics stay per
+rank, as with the reference's nn.DataParallel.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import optim as fused_optim
+from . import utils as mt
+from . import warp
+from .lib import keypoint_detection as kd
+from .lib.models.loss import ConsLoss, JointsMSELoss
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradSync:
+    """All-reduce (mean) of the student's flat fp32 gradient buffer: ONE collective per step over RCCL/xGMI.
+    (The PoseResNet executor writes every parameter gradient into views of a single buffer.)"""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self):
+        if not _dist_on():
+            return
+        flat = getattr(self.model, "_flat_grad", None)
+        if flat is None:
+            raise RuntimeError("GradSync: model has no flat gradient buffer yet (run backward first)")
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / dist.get_world_size())
+
+
+def gather_activates(act):
+    """All ranks' [N_local, K] confidences -> flat global vector (for the global-batch k-th value, train_human.py:429)."""
+    if not _dist_on():
+        return None
+    bufs = [torch.empty_like(act) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, act.contiguous())
+    return torch.cat([b.reshape(-1) for b in bufs])
+
+
+class MeanTeacherTrainer:
+    def __init__(self, student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=2, image_size=256,
+                 heatmap_size=64, use_sgd=False, style_net=None, recover=None, s2t_freq=0.5, t2s_freq=0.5, s2t_alpha=(0.0, 1.0),
+                 t2s_alpha=(0.0, 1.0), rng=None):
+        self.student, self.teacher = student, teacher
+        self.criterion, self.con_criterion = JointsMSELoss(), ConsLoss()
+        if use_sgd:
+            self.stu_optimizer = fused_optim.FusedSGD(student.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, nesterov=True)
+        else:
+            self.stu_optimizer = fused_optim.FusedAdam(student.parameters(), lr=lr)
+        self.tea_optimizer = mt.OldWeightEMA(teacher, student, alpha=teacher_alpha)   # ctor copies student -> teacher
+        self.sync = GradSync(student)
+        self.lambda_c, self.mask_ratio, self.sigma = lambda_c, mask_ratio, sigma
+        self.ratio = image_size / heatmap_size
+        self.style_net, self.recover = style_net, recover
+        self.s2t_freq, self.t2s_freq, self.s2t_alpha, self.t2s_alpha = s2t_freq, t2s_freq, s2t_alpha, t2s_alpha
+        self.rng = rng if rng is not None else np.random   # the reference draws from the global np.random
+
+    # ------------------------------------------------------------------ train_human.py:262-302
+    def pretrain_step(self, x_s, label_s, weight_s, x_t=None):
+        self.student.train()
+        self.stu_optimizer.zero_grad()
+        if self.style_net is not None and self.s2t_freq > self.rng.rand():
+            a = self.rng.uniform(*self.s2t_alpha)
+            x_s = self.style_net(x_s, x_t, a, clamp=self.recover)[2]
+        y_s = self.student(x_s)
+        loss = self.criterion(y_s, label_s, weight_s)
+        loss.backward()
+        self.sync()
+        self.stu_optimizer.step()
+        return {"loss_all": loss.detach(), "loss_s": loss.detach(), "y_s": y_s.detach()}
+
+    # ------------------------------------------------------------------ train_human.py:326-444
+    def train_step(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, aug_param_stu, aug_params_tea, with_accuracy=False):
+        student, teacher = self.student, self.teacher
+        student.train()
+        teacher.train()                     # the teacher's BN uses batch statistics too (train_human.py:321)
+        self.stu_optimizer.zero_grad()
+        if not isinstance(x_t_teas, (list, tuple)):
+            x_t_teas, aug_params_tea = [x_t_teas], [aug_params_tea]
+        x_s_ori, x_t_teas_ori = x_s, list(x_t_teas)
+        with torch.no_grad():
+            if self.style_net is not None and self.s2t_freq > self.rng.rand():
+                a = self.rng.uniform(*self.s2t_alpha)
+                x_s = self.style_net(x_s, x_t_teas_ori[0], a, clamp=self.recover)[2]
+            if self.style_net is not None and self.t2s_freq > self.rng.rand():
+                a = self.rng.uniform(*self.t2s_alpha)
+                x_t_teas = [self.style_net(x_t, x_s_ori, a, clamp=self.recover)[2] for x_t in x_t_teas]
+            y_t_teas = [teacher(x_t) for x_t in x_t_teas]
+            recons = [warp.recon_heatmaps(y, ap, self.ratio) for y, ap in zip(y_t_teas, aug_params_tea)]
+            y_t_tea_recon = recons[0] if len(recons) == 1 else torch.stack(recons).mean(0)
+        y_s = student(x_s)
+        y_t_stu = student(x_t_stu)          # separate forwards: separate BN statistics per domain
+        y_t_stu_recon = warp.recon_heatmaps(y_t_stu, aug_param_stu, self.ratio)
+        loss_s = self.criterion(y_s, label_s, weight_s)
+        with torch.no_grad():
+            # activations BEFORE rectify; threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats)
+            activates = mt.heatmap_activations(y_t_tea_recon)
+            tea_mask, _, _ = mt.confidence_mask(y_t_tea_recon, self.mask_ratio, None, gather_activates(activates), activates)
+            y_t_tea_rect = mt.rectify(y_t_tea_recon, sigma=self.sigma)
+        loss_c = self.con_criterion(y_t_stu_recon, y_t_tea_rect, tea_mask=tea_mask)
+        loss_all = loss_s + self.lambda_c * loss_c
+        loss_all.backward()
+        self.sync()
+        self.stu_optimizer.step()
+        self.tea_optimizer.step()           # EMA after the optimizer step (train_human.py:437-438)
+        out = {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": y_s.detach()}
+        if with_accuracy:
+            _, avg_acc, cnt, _ = kd.accuracy(y_s.detach(), label_s)
+            out["acc_s"], out["cnt_s"] = avg_acc, cnt
+        return out

@@ -1,0 +1,78 @@
+"""Synthetic batches with the shapes and statistics of the reference's data contract: used by
+bench.py, smoke() and the tests because no dataset is available offline.  Host-side numpy only.
+
+Label heat-maps follow lib/datasets/util.py:12-70 (`generate_target`): centre int(kp/stride + 0.5), un-normalised
+(6*sigma+1)^2 Gaussian clipped at the borders, weight 0 when the centre falls outside.
+"""
+import numpy as np
+import torch
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], np.float32)
+
+
+def gaussian_labels(keypoints, visible, heatmap_size, sigma, image_size):
+    """keypoints [K,2] px, visible [K,1] -> (target [K,H,W] f32, weight [K,1] f32)."""
+    K = keypoints.shape[0]
+    Wd, Hd = heatmap_size
+    target = np.zeros((K, Hd, Wd), np.float32)
+    weight = np.ones((K, 1), np.float32)
+    weight[:, 0] = visible[:, 0]
+    rad = sigma * 3
+    size = 2 * rad + 1
+    ax = np.arange(0, size, 1, np.float32)
+    c0 = size // 2
+    g = np.exp(-((ax[None, :] - c0) ** 2 + (ax[:, None] - c0) ** 2) / (2 * sigma ** 2))
+    stride = np.array(image_size) / np.array(heatmap_size)
+    for j in range(K):
+        mx = int(keypoints[j][0] / stride[0] + 0.5)
+        my = int(keypoints[j][1] / stride[1] + 0.5)
+        if mx >= Wd or my >= Hd or mx < 0 or my < 0:
+            weight[j] = 0
+            continue
+        ulx, uly, brx, bry = int(mx - rad), int(my - rad), int(mx + rad + 1), int(my + rad + 1)
+        if weight[j] > 0.5:
+            target[j][max(0, uly):min(bry, Hd), max(0, ulx):min(brx, Wd)] = \
+                g[max(0, -uly):min(bry, Hd) - uly, max(0, -ulx):min(brx, Wd) - ulx]
+    return target, weight
+
+
+def images(n, size, seed, normalise="imagenet"):
+    """N(0,1) noise clipped to the range a normalised [0,1] image can take."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, size, size, generator=g)
+    if normalise == "imagenet":
+        lo = torch.tensor((0 - IMAGENET_MEAN) / IMAGENET_STD).view(1, 3, 1, 1)
+        hi = torch.tensor((1 - IMAGENET_MEAN) / IMAGENET_STD).view(1, 3, 1, 1)
+    else:   # animal pipeline: mean subtraction only (train_animal.py:34-35)
+        m = torch.tensor([0.3999, 0.3909, 0.3871]).view(1, 3, 1, 1)
+        lo, hi = -m, 1 - m
+    return torch.maximum(torch.minimum(x, hi), lo)
+
+
+def aug_params(n, rs, max_angle=60.0, max_shear=30.0, max_trans=12.8, scale=(0.6, 1.3)):
+    """Collated inverse-augmentation tuple as produced by lib/transforms/keypoint_detection.py:139,396-412."""
+    angle = torch.tensor(-rs.uniform(-max_angle, max_angle, n), dtype=torch.float64)
+    tx = torch.tensor(-np.round(rs.uniform(-max_trans, max_trans, n)).astype(np.int64))
+    ty = torch.tensor(-np.round(rs.uniform(-max_trans, max_trans, n)).astype(np.int64))
+    sx = torch.tensor(-rs.uniform(-max_shear, max_shear, n), dtype=torch.float64)
+    sy = torch.zeros(n, dtype=torch.float64)
+    sc = torch.tensor(1.0 / rs.uniform(scale[0], scale[1], n), dtype=torch.float64)
+    return [angle, [tx, ty], [sx, sy], sc]
+
+
+def mean_teacher_batch(n, num_keypoints=16, image_size=256, heatmap_size=64, sigma=2, seed=0, normalise="imagenet"):
+    """One (source, target) batch pair with the fields the loop consumes (train_human.py:329-340)."""
+    rs = np.random.RandomState(seed)
+    kp = rs.uniform(0, image_size, size=(n, num_keypoints, 2)).astype(np.float32)
+    vis = np.ones((num_keypoints, 1), np.float32)
+    lab = [gaussian_labels(kp[i], vis, (heatmap_size, heatmap_size), sigma, (image_size, image_size)) for i in range(n)]
+    return {
+        "x_s": images(n, image_size, seed, normalise),
+        "label_s": torch.from_numpy(np.stack([l[0] for l in lab])),
+        "weight_s": torch.from_numpy(np.stack([l[1] for l in lab])),
+        "x_t_stu": images(n, image_size, seed + 1, normalise),
+        "x_t_tea": images(n, image_size, seed + 2, normalise),
+        "aug_param_stu": aug_params(n, rs),
+        "aug_param_tea": aug_params(n, rs),
+    }

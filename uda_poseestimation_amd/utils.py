@@ -113,19 +113,26 @@ def rectify(hm, sigma):  # b, c, h, w -> b, c, h, w
     return out.to(hm.dtype)
 
 
-def confidence_mask(recon, mask_ratio, tea_mask=None, gathered_activates=None):
-    """train_human.py:427-430 without the host round trip: activates = amax_{hw}(recon); thr = k-th smallest with
-    k = int(mask_ratio * numel); mask = (tea_mask * activates) > thr.  `gathered_activates` (all ranks' activates,
-    flattened) makes thr the GLOBAL-batch statistic under data parallelism.  Returns (mask bool [B,K], activates [B,K], thr)."""
+def heatmap_activations(recon):
+    """activates = amax over (h,w) per (b,k)  (train_human.py:427), one sweep."""
     _hip.require_cuda(recon)
     src = recon.detach().float().contiguous()
     B, K, H, W = src.shape
     act = torch.empty(B, K, dtype=torch.float32, device=src.device)
     check(lib().udapose_heatmap_argmax(_hip.stream(), ptr(src), B * K, H, W, ptr(act), None, None, None, None, 0), "amax")
+    return act
+
+
+def confidence_mask(recon, mask_ratio, tea_mask=None, gathered_activates=None, activates=None):
+    """train_human.py:427-430 without the host round trip: activates = amax_{hw}(recon); thr = k-th smallest with
+    k = int(mask_ratio * numel); mask = (tea_mask * activates) > thr.  `gathered_activates` (all ranks' activates,
+    flattened) makes thr the GLOBAL-batch statistic under data parallelism.  Returns (mask bool [B,K], activates [B,K], thr)."""
+    act = heatmap_activations(recon) if activates is None else activates
+    B, K = act.shape
     pool = act.reshape(-1) if gathered_activates is None else gathered_activates.detach().float().reshape(-1).contiguous()
     k = int(mask_ratio * pool.numel())
-    mask = torch.empty(B, K, dtype=torch.uint8, device=src.device)
-    thr = torch.empty((), dtype=torch.float32, device=src.device)
+    mask = torch.empty(B, K, dtype=torch.uint8, device=act.device)
+    thr = torch.empty((), dtype=torch.float32, device=act.device)
     tm = None if tea_mask is None else tea_mask.detach().float().contiguous()
     check(lib().udapose_kth_mask(_hip.stream(), ptr(pool), ptr(tm), pool.numel(), k, ptr(thr), ptr(mask), ptr(act), B * K), "kth_mask")
     return mask.bool(), act, thr

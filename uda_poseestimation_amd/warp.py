@@ -1,0 +1,95 @@
+"""Batched heat-map / image re-warp on the device.
+
+Stands in for the per-sample `tF.affine` triplets of the training loop (train_human.py:361-372, 385-391, 412, 418-423):
+translate by (tx/ratio, ty/ratio); rotate by `angle` and scale; shear by (sx, sy) - three sequential nearest-neighbour
+resamplings, evaluated by ONE kernel as a chain of index maps (results identical to the sequential form).  The inverse
+affine matrices are built on the host in double precision exactly like torchvision's `_get_inverse_affine_matrix`
+(torchvision itself is not a dependency); parameters arrive as the collated `aug_param` structure of
+lib/transforms/keypoint_detection.py:139: [angle[N], [tx[N], ty[N]], [sx[N], sy[N]], scale[N]].
+"""
+import math
+
+import torch
+
+from . import _hip
+from ._hip import check, lib, ptr
+
+
+def inverse_affine_matrix(angle, translate, scale, shear):
+    """torchvision.transforms.functional._get_inverse_affine_matrix with center=(0,0) (tensor inputs)."""
+    rot = math.radians(angle)
+    sx, sy = math.radians(shear[0]), math.radians(shear[1])
+    tx, ty = translate
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    m = [d / scale, -b / scale, 0.0, -c / scale, a / scale, 0.0]
+    m[2] += m[0] * (-tx) + m[1] * (-ty)
+    m[5] += m[3] * (-tx) + m[4] * (-ty)
+    return m
+
+
+def _as_list(v, n):
+    if torch.is_tensor(v):
+        return [float(x) for x in v.tolist()]
+    if isinstance(v, (list, tuple)):
+        return [float(x) for x in v]
+    return [float(v)] * n
+
+
+def recon_thetas(aug_param, n, ratio=1.0, device=None):
+    """[N,3,6] fp32 matrices of the loop's translate -> rotate+scale -> shear chain for a collated aug_param."""
+    angle, (tx, ty), (sx, sy), scale = aug_param
+    angle, tx, ty, sx, sy, scale = (_as_list(v, n) for v in (angle, tx, ty, sx, sy, scale))
+    th = torch.empty(n, 3, 6, dtype=torch.float32)
+    for i in range(n):
+        th[i, 0] = torch.tensor(inverse_affine_matrix(0.0, [tx[i] / ratio, ty[i] / ratio], 1.0, [0.0, 0.0]))
+        th[i, 1] = torch.tensor(inverse_affine_matrix(angle[i], [0.0, 0.0], scale[i], [0.0, 0.0]))
+        th[i, 2] = torch.tensor(inverse_affine_matrix(0.0, [0.0, 0.0], 1.0, [sx[i], sy[i]]))
+    return th.to(device) if device is not None else th
+
+
+def single_thetas(angle, translate, scale, shear, n, device=None):
+    """[N,1,6]: one warp per sample (the occlusion path's warp-back, train_human.py:412)."""
+    angle, scale = _as_list(angle, n), _as_list(scale, n)
+    tx, ty = _as_list(translate[0], n), _as_list(translate[1], n)
+    sx, sy = _as_list(shear[0], n), _as_list(shear[1], n)
+    th = torch.empty(n, 1, 6, dtype=torch.float32)
+    for i in range(n):
+        th[i, 0] = torch.tensor(inverse_affine_matrix(angle[i], [tx[i], ty[i]], scale[i], [sx[i], sy[i]]))
+    return th.to(device) if device is not None else th
+
+
+class _WarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, theta):
+        _hip.require_cuda(x, theta)
+        xin = x.detach().float().contiguous()
+        N, C, H, W = xin.shape
+        th = theta.detach().float().contiguous()
+        assert th.shape[0] == N and th.shape[2] == 6
+        out = torch.empty_like(xin)
+        check(lib().udapose_affine_nearest(_hip.stream(), ptr(xin), ptr(out), ptr(th), N, C, H, W, th.shape[1], 0), "affine_nearest")
+        ctx.save_for_backward(th)
+        ctx.in_dtype = x.dtype
+        return out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (th,) = ctx.saved_tensors
+        gin = g.detach().float().contiguous()
+        N, C, H, W = gin.shape
+        dx = torch.empty_like(gin)
+        check(lib().udapose_affine_nearest(_hip.stream(), ptr(gin), ptr(dx), ptr(th), N, C, H, W, th.shape[1], 1), "affine_nearest_bwd")
+        return dx.to(ctx.in_dtype), None
+
+
+def warp_chain(x, theta):
+    """x [N,C,H,W]; theta [N,S,6] inverse affine matrices applied in order 0..S-1 (nearest, zero fill); differentiable."""
+    return _WarpFn.apply(x, theta)
+
+
+def recon_heatmaps(y, aug_param, ratio):
+    """The loop's heat-map re-warp (train_human.py:361-372 / 418-423) for the whole batch."""
+    return warp_chain(y, recon_thetas(aug_param, y.shape[0], ratio, y.device))
