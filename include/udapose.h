@@ -155,6 +155,8 @@ int udapose_affine_nearest(void* stream, const float* src, float* dst, const flo
 /* ---------------------------------------------------------------- per-launch timing of the MFMA kernels (bench.py roofline)
  * HIP events are recorded on the launch stream around every convolution launch between begin and end.
  * h_out9 (host): for kind in (fprop, dgrad, wgrad): launches, total milliseconds, total algorithmic FLOPs. */
+/* tuning hook: force tile configuration ids / split count (-1 = heuristic); not for production use */
+void udapose_debug_set_tiles(int igemm_tile, int wgrad_tile, int wgrad_ksplit);
 void udapose_prof_begin(void);
 int udapose_prof_end(double* h_out9);
 

@@ -30,6 +30,7 @@ int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, c
             int, int, float);
 int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, float, float, float*);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
+extern int g_igemm_tile_override, g_wgrad_tile_override, g_wgrad_ksplit_override;
 void prof_begin();
 int prof_end(double*);
 void* net_create(const int layers[4], int K, int N, int H, int W);
@@ -182,6 +183,9 @@ int udapose_affine_nearest(void* stream, const float* src, float* dst, const flo
     return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);
 }
 
+void udapose_debug_set_tiles(int igemm_tile, int wgrad_tile, int wgrad_ksplit) {
+    g_igemm_tile_override = igemm_tile; g_wgrad_tile_override = wgrad_tile; g_wgrad_ksplit_override = wgrad_ksplit;
+}
 void udapose_prof_begin(void) { prof_begin(); }
 int udapose_prof_end(double* h_out9) { return prof_end(h_out9); }
 

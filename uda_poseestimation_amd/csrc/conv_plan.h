@@ -12,7 +12,7 @@ struct ConvGeom {
     int Ho() const { return transposed ? (Hi - 1) * stride - 2 * pad + KH : (((Hi << upsample) + 2 * pad - KH) / stride + 1); }
     int Wo() const { return transposed ? (Wi - 1) * stride - 2 * pad + KW : (((Wi << upsample) + 2 * pad - KW) / stride + 1); }
     bool smallc() const { return Ci == 8; }
-    int KWp() const { return smallc() ? ((KW + 3) & ~3) : KW; }   // taps padded so that 4 taps fill a 32-wide K step
+    int KWp() const { return smallc() ? ((KW + 7) & ~7) : KW; }   // taps padded so that 8 taps fill a 64-wide K step
     int wtaps() const { return KH * KWp(); }
 };
 
@@ -26,7 +26,7 @@ struct TapPlan {
 // direction 0: fprop (also the plan wgrad walks), 1: dgrad
 const TapPlan* get_tap_plan(const ConvGeom& g, int direction);
 
-int igemm_pick_tile(int M, int Co, int nclass);
+int igemm_pick_tile(int M, int Co, int nclass, int K);
 int igemm_stat_rows(int M, int Co, int nclass, int tile);
 int igemm_launch(IgParams& p, int tile, hipStream_t stream);
 int wgrad_pick_tile(int Rdim, int Cdim, int smallc);

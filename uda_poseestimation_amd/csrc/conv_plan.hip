@@ -82,7 +82,9 @@ const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
 int conv_stat_rows(const ConvGeom& g) {
     const int nclass = g.transposed ? g.stride * g.stride : 1;
     const int M = g.transposed ? g.N * g.Hi * g.Wi : g.N * g.Ho() * g.Wo();
-    return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass));
+    const TapPlan* tp = get_tap_plan(g, 0);
+    const int K = (tp ? tp->cls[0].ntaps : g.KH * g.KW) * g.Ci;     // same K as conv_fprop passes
+    return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass, K));
 }
 
 int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e) {
@@ -102,7 +104,7 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* 
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     const int tok = prof_before(s, 0, alg_flops(g));
-    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci), s);
     prof_after(s, tok);
     return rc;
 }
@@ -124,7 +126,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     const int tok = prof_before(s, 1, alg_flops(g));
-    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass), s);
+    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci), s);
     prof_after(s, tok);
     return rc;
 }

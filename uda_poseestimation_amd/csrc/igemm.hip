@@ -19,26 +19,53 @@
 
 namespace {
 
-__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+// 16 bytes of zeros: the source of every padded / out-of-range lane of the LDS-DMA loads
+__device__ u32x4 g_zero16[2];
 
-template <int BM, int BN, int WM, int WN>
+// XOR swizzle of the 16-byte chunk index inside a 128-byte LDS row: makes the ds_read_b128 fragment reads (lane l ->
+// row l&15, chunk l>>4) conflict-free (2 rows per 256-byte bank row; derivation in DESIGN.md)
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int BM, int BN, int WM, int WN, int NS>
 struct IgCfg {
+    static constexpr int BK = 64;                          // K elements per stage (128-byte LDS rows)
+    static constexpr int BNL = BN < 64 ? 64 : BN;          // B rows held in LDS (every wave issues the same number of DMAs)
     static constexpr int TM = BM / WM, TN = BN / WN;
     static constexpr int MT = TM / 16, NT = TN / 16;
-    static constexpr int A_LD = BM / 64 > 0 ? BM / 64 : 1;
-    static constexpr int B_LD = BN / 64 > 0 ? BN / 64 : 1;
-    static constexpr int ER = TM < 32 ? TM : 32;          // epilogue rows per pass
-    static constexpr int ELD = TN + 4;                    // fp32 row stride of the staging tile
-    static constexpr int TAP_BYTES = 1024;                // 64 taps
-    static constexpr int STAGE_BYTES = 2 * (BM + BN) * 64;
+    static constexpr int A_PW = BM / 32, B_PW = BNL / 32;  // LDS-DMA instructions per wave per stage (8 rows x 128 B each)
+    static constexpr int ER = TM < 32 ? TM : 32;           // epilogue rows per pass
+    static constexpr int ELD = TN + 4;                     // fp32 row stride of the staging tile
+    static constexpr int TAP_BYTES = 1024;                 // 64 taps
+    static constexpr int STAGE1 = (BM + BNL) * 128;
+    static constexpr int STAGE_BYTES = NS * STAGE1;
     static constexpr int EPI_BYTES = 4 * ER * ELD * 4;
     static constexpr int LDS_BYTES = TAP_BYTES + (STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES);
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 24, "vmcnt range");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+// Main loop: NS-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers), counted vmcnt waits and
+// ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
+// stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
-    using C = IgCfg<BM, BN, WM, WN>;
-    constexpr int TM = C::TM, TN = C::TN, MT = C::MT, NT = C::NT, A_LD = C::A_LD, B_LD = C::B_LD;
+    using C = IgCfg<BM, BN, WM, WN, NS>;
+    constexpr int TM = C::TM, TN = C::TN, MT = C::MT, NT = C::NT, A_PW = C::A_PW, B_PW = C::B_PW, BNL = C::BNL;
+    constexpr int LPS = A_PW + B_PW;    // DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     IgTap* taps_l = (IgTap*)smem;
     char* stage = smem + C::TAP_BYTES;
@@ -55,15 +82,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 
     if (tid < cls.ntaps && tid < 64) taps_l[tid] = p.taps[cls.tap_off + tid];
 
-    // ---- per-thread loader state (rows are fixed for the whole K loop)
-    const int chunk = tid & 3;
-    int a_hi0[A_LD], a_wi0[A_LD], a_nb[A_LD];
-    bool a_ok[A_LD];
+    // ---- per-lane loader state: DMA instruction i of this wave fills LDS rows (i*4+wid)*8 .. +8, lane -> (row, chunk)
+    const int lrow = lane >> 3, pchunk = lane & 7;
+    int a_hi0[A_PW], a_wi0[A_PW], a_nb[A_PW], a_lc[A_PW];
+    bool a_ok[A_PW];
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-        const int r = (tid >> 2) + 64 * i;
+    for (int i = 0; i < A_PW; ++i) {
+        const int r = (i * 4 + wid) * 8 + lrow;
         const int m = m0 + r;
-        a_ok[i] = (r < BM) && (m < p.M);
+        a_ok[i] = m < p.M;
+        a_lc[i] = pchunk ^ swz(r);                     // logical chunk this lane fetches (swizzle on the SOURCE side)
         const uint32_t mm = a_ok[i] ? (uint32_t)m : 0u;
         const uint32_t n = fdiv(mm, p.div_hw);
         const uint32_t rem = mm - n * (uint32_t)(p.Hg * p.Wg);
@@ -73,28 +101,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         a_wi0[i] = (int)jj * p.s;
         a_nb[i] = (int)n * p.Hi * p.Wi;
     }
-    bool b_ok[B_LD];
-    size_t b_row[B_LD];
+    bool b_ok[B_PW];
+    int b_lc[B_PW];
+    size_t b_row[B_PW];
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) {
-        const int r = (tid >> 2) + 64 * i;
+    for (int i = 0; i < B_PW; ++i) {
+        const int r = (i * 4 + wid) * 8 + lrow;
         const int co = n0 + r;
         b_ok[i] = (r < BN) && (co < p.Co);
+        b_lc[i] = pchunk ^ swz(r);
         b_row[i] = (size_t)(b_ok[i] ? co : 0) * (size_t)(p.wtaps * p.Ci);
     }
 
-    const int nsteps = smallc ? (cls.ntaps >> 2) : (cls.ntaps * p.Ci) >> 5;
-    u32x4 ra[A_LD], rb[B_LD];
-    int tap_cur = 0, c0_cur = 0;   // uniform K cursor (non-SMALLC)
+    const int nsteps = smallc ? (cls.ntaps >> 3) : (cls.ntaps * p.Ci) >> 6;
+    int tap_cur = 0, c0_cur = 0;   // uniform K cursor
+    const char* zsrc = (const char*)g_zero16;
 
     __syncthreads();   // tap table visible
 
-    auto issue_loads = [&]() {
-        const int tap = smallc ? (tap_cur + chunk) : tap_cur;
-        const IgTap t = taps_l[tap];
-        const int coff = smallc ? 0 : c0_cur + chunk * 8;
+    auto issue_stage = [&](int buf) {
+        char* A = stage + buf * C::STAGE1;
+        char* B = A + BM * 128;
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
+        for (int i = 0; i < A_PW; ++i) {
+            const IgTap t = taps_l[smallc ? tap_cur + a_lc[i] : tap_cur];
+            const int coff = smallc ? 0 : c0_cur + a_lc[i] * 8;
             int hi = a_hi0[i] + t.dy, wi = a_wi0[i] + t.dx;
             if (reflect) {
                 hi = hi < 0 ? -hi : (hi >= Hl ? 2 * Hl - 2 - hi : hi);
@@ -102,32 +133,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
             }
             const bool ok = a_ok[i] && (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
             hi >>= up; wi >>= up;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *(const u32x4*)(p.x + ((size_t)(a_nb[i] + hi * p.Wi + wi) * p.Ci + coff));
-            ra[i] = v;
+            const char* src = ok ? (const char*)(p.x + ((size_t)(a_nb[i] + hi * p.Wi + wi) * p.Ci + coff)) : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(A + (i * 4 + wid) * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (b_ok[i]) v = *(const u32x4*)(p.w + (b_row[i] + (size_t)t.widx * p.Ci + coff));
-            rb[i] = v;
+        for (int i = 0; i < B_PW; ++i) {
+            const IgTap t = taps_l[smallc ? tap_cur + b_lc[i] : tap_cur];
+            const int coff = smallc ? 0 : c0_cur + b_lc[i] * 8;
+            const char* src = b_ok[i] ? (const char*)(p.w + (b_row[i] + (size_t)t.widx * p.Ci + coff)) : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
         }
-        if (smallc) tap_cur += 4;
-        else { c0_cur += 32; if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; } }
-    };
-    auto store_lds = [&](int buf) {
-        char* A = stage + buf * (BM + BN) * 64;
-        char* B = A + BM * 64;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int r = (tid >> 2) + 64 * i;
-            if (r < BM) *(u32x4*)(A + r * 64 + ((chunk ^ swz(r)) << 4)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int r = (tid >> 2) + 64 * i;
-            if (r < BN) *(u32x4*)(B + r * 64 + ((chunk ^ swz(r)) << 4)) = rb[i];
-        }
+        if (smallc) tap_cur += 8;
+        else { c0_cur += 64; if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; } }
     };
 
     f32x4 acc[MT][NT];
@@ -136,37 +155,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nsteps > 0) {
-        issue_loads();
-        store_lds(0);
+    // prologue: NS-1 stages in flight (empty stages are still issued from the zero page so that the counts stay exact)
+    int issued = 0;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) {
+        if (st < nsteps) { issue_stage(st); ++issued; }
     }
-    __syncthreads();
 
     const int frow = lane & 15, fchunk = lane >> 4;
     for (int st = 0; st < nsteps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nsteps) issue_loads();
-        const char* A = stage + buf * (BM + BN) * 64;
-        const char* B = A + BM * 64;
-        bf16x8 af[MT], bfr[NT];
+        const int buf = st % NS;
+        // stage st must have landed: at most (issued - st - 1) younger stages may still be in flight
+        if (issued - st - 1 >= NS - 2) wait_vmcnt<LPS*(NS - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                  // every wave's share of stage st is in LDS; buffer (st-1)%NS is free
+        if (issued < nsteps) { issue_stage(issued % NS); ++issued; }
+        const char* A = stage + buf * C::STAGE1;
+        const char* B = A + BM * 128;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int r = wm * TM + i * 16 + frow;
-            af[i] = *(const bf16x8*)(A + r * 64 + ((fchunk ^ swz(r)) << 4));
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * TM + i * 16 + frow;
+                af[i] = *(const bf16x8*)(A + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * TN + j * 16 + frow;
+                bfr[j] = *(const bf16x8*)(B + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int r = wn * TN + j * 16 + frow;
-            bfr[j] = *(const bf16x8*)(B + r * 64 + ((fchunk ^ swz(r)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        if (st + 1 < nsteps) store_lds(buf ^ 1);
-        __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // all LDS reads of the ring are done before the epilogue reuses it
 
     // ---- epilogue: accumulators -> LDS (per-wave region) -> 8-channel vectors -> global
     constexpr int ER = C::ER, ELD = C::ELD, LPR = TN / 8 /*lanes per row*/, RPP = 64 / LPR /*rows per pass*/;
@@ -263,56 +290,63 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 int launch_cfg(IgParams& p, hipStream_t stream) {
-    using C = IgCfg<BM, BN, WM, WN>;
+    using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Co + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NS>), grid, dim3(256), C::LDS_BYTES, stream, p);
     return udapose_check_launch();
 }
 
 }  // namespace
 
-// Tile selection: fill the 256 CUs first, then prefer the larger tile.
-int igemm_pick_tile(int M, int Co, int nclass) {
-    if (Co <= 32) return 3;                       // 128x32 (head / 3-channel outputs)
-    if (Co <= 64) return 1;                       // 128x64
-    const long t128 = (long)((M + 127) / 128) * ((Co + 127) / 128) * nclass;
-    if (t128 >= 512) return 0;                    // 128x128
-    return 2;                                     // 64x64
+int g_igemm_tile_override = -1;   // debug/tuning hook (udapose_debug_set_tiles)
+
+// Tile selection (measured on MI355X over every PoseResNet-101 layer shape at N=32, tools/tune_conv.py): take the
+// largest tile that still yields >= 512 workgroups (2 per CU); 64x64 tiles use the 4-deep ring when K is long.
+// ids: 0 = 128x128 NS3, 1 = 128x64 NS3, 2 = 64x64 NS4, 3 = 128x32 NS3, 4 = 128x128 NS2, 5 = 64x64 NS2, 6 = 128x64 NS2
+int igemm_pick_tile(int M, int Co, int nclass, int K) {
+    if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
+    if (Co <= 32) return 3;
+    auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((Co + bn - 1) / bn) * nclass; };
+    if (Co > 64 && blocks(128, 128) >= 512) return 4;
+    if (blocks(128, 64) >= 512) return 6;
+    return K >= 1024 ? 2 : 5;
 }
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     switch (tile) {
-        case 0: return nclass * ((M + 127) / 128) * 2;
-        case 1: return nclass * ((M + 127) / 128) * 2;
-        case 2: return nclass * ((M + 63) / 64) * 2;
-        default: return nclass * ((M + 127) / 128) * 4;
+        case 2: case 5: return nclass * ((M + 63) / 64) * 2;
+        case 3: return nclass * ((M + 127) / 128) * 4;
+        default: return nclass * ((M + 127) / 128) * 2;
     }
 }
 
 int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
-    if (p.Ci % 8 != 0 || (!(p.flags & IG_FLAG_SMALLC) && p.Ci % 32 != 0)) return UDAPOSE_ERR_ARG;
+    if (p.Ci % 8 != 0 || (!(p.flags & IG_FLAG_SMALLC) && p.Ci % 64 != 0)) return UDAPOSE_ERR_ARG;
     if ((p.flags & IG_FLAG_SMALLC) && p.Ci != 8) return UDAPOSE_ERR_ARG;
     if (!(p.flags & IG_FLAG_OUT_F32) && (p.Co % 8) != 0) return UDAPOSE_ERR_ARG;
     for (int c = 0; c < p.nclass; ++c) {
         if (p.cls[c].ntaps > 64 || p.cls[c].ntaps < 0) return UDAPOSE_ERR_ARG;
-        if ((p.flags & IG_FLAG_SMALLC) && (p.cls[c].ntaps & 3)) return UDAPOSE_ERR_ARG;
+        if ((p.flags & IG_FLAG_SMALLC) && (p.cls[c].ntaps & 7)) return UDAPOSE_ERR_ARG;
     }
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     switch (tile) {
-        case 0: return launch_cfg<128, 128, 2, 2>(p, stream);
-        case 1: return launch_cfg<128, 64, 2, 2>(p, stream);
-        case 2: return launch_cfg<64, 64, 2, 2>(p, stream);
-        case 3: return launch_cfg<128, 32, 4, 1>(p, stream);
+        case 0: return launch_cfg<128, 128, 2, 2, 3>(p, stream);
+        case 1: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
+        case 2: return launch_cfg<64, 64, 2, 2, 4>(p, stream);
+        case 3: return launch_cfg<128, 32, 4, 1, 3>(p, stream);
+        case 4: return launch_cfg<128, 128, 2, 2, 2>(p, stream);
+        case 5: return launch_cfg<64, 64, 2, 2, 2>(p, stream);
+        case 6: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
         default: return UDAPOSE_ERR_ARG;
     }
 }

@@ -159,7 +159,7 @@ Net* build(const int layers[4], int K, int N, int H, int W) {
     n.head.bias_idx = n.n_params++; n.param_numel.push_back(K);
     n.head.in_off = cur;
     n.head.wf_off = wp_alloc(n, (size_t)K * 256 * 2);
-    n.head.wb_off = wp_alloc(n, (size_t)256 * 32 * 2);      // [256][1][32] zero-padded for dgrad
+    n.head.wb_off = wp_alloc(n, (size_t)256 * 64 * 2);      // [256][1][64] zero-padded for dgrad
     n.head_out_off = act_alloc(n, (size_t)N * Hc * Wc * K * 4);
     n.Hout = Hc; n.Wout = Wc;
 
@@ -180,8 +180,8 @@ Net* build(const int layers[4], int K, int N, int H, int W) {
     n.ws_coef = o; o = align_up(o + (size_t)3 * 2048 * 4 + 2 * 2048 * 4);
     n.gbuf_bytes = align_up(2 * max_act);   // x2: the deconv-stage gradients are fp32
     for (int i = 0; i < 6; ++i) { n.ws_gbuf[i] = o; o += n.gbuf_bytes; }
-    n.ws_dyhead = o; o = align_up(o + (size_t)N * Hc * Wc * 32 * 2);
-    n.ws_dwtmp = o; o = align_up(o + std::max((size_t)64 * 56 * 8 * 4, (size_t)32 * 256 * 4));
+    n.ws_dyhead = o; o = align_up(o + (size_t)N * Hc * Wc * 64 * 2);
+    n.ws_dwtmp = o; o = align_up(o + std::max((size_t)64 * 56 * 8 * 4, (size_t)64 * 256 * 4));
     n.ws_bytes = o;
     return np;
 }
@@ -237,7 +237,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
 
 // ============================================================================ public (C++) entry points
 void* net_create(const int layers[4], int K, int N, int H, int W) {
-    if (K < 1 || K > 32 || N < 1 || H % 32 || W % 32) return nullptr;
+    if (K < 1 || K > 64 || N < 1 || H % 32 || W % 32) return nullptr;
     return build(layers, K, N, H, W);
 }
 void net_destroy(void* h) { delete (Net*)h; }
@@ -262,8 +262,8 @@ int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wp
     for (int i = 0; i < 3; ++i) CK(pack_conv(s, n, n.up[i], params, wpack, with_bwd));
     const float* hw = (const float*)params[n.head.w_idx];
     CK(pw_cast_f32_bf16(s, hw, (bf16_t*)(wpack + n.head.wf_off), (size_t)n.K * 256));
-    if (with_bwd)   // [256][1][32]: wb[ci][k] = w[k][ci], zero for k >= K
-        CK(pw_pack_strided(s, hw, (bf16_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 32, n.K, 1, 0, 0, 256));
+    if (with_bwd)   // [256][1][64]: wb[ci][k] = w[k][ci], zero for k >= K
+        CK(pw_pack_strided(s, hw, (bf16_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
     return UDAPOSE_OK;
 }
 
@@ -340,10 +340,10 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     const int HWo = n.Hout * n.Wout;
     // head
     bf16_t* dyh = (bf16_t*)(ws + n.ws_dyhead);
-    CK(pw_nchw_f32_to_nhwc_bf16(s, dout_nchw, dyh, n.N, n.K, HWo, 32));
+    CK(pw_nchw_f32_to_nhwc_bf16(s, dout_nchw, dyh, n.N, n.K, HWo, 64));
     CK(pw_plane_sum(s, dout_nchw, (float*)grads[n.head.bias_idx], n.N, n.K, HWo, beta));
     ConvGeom hg = n.head.g;
-    hg.Co = 32;   // dy is channel-padded to 32
+    hg.Co = 64;   // dy is channel-padded to 64 (one 64-wide K step)
     float* tmp = (float*)(ws + n.ws_dwtmp);
     CK(conv_wgrad(s, hg, dyh, (const bf16_t*)(act + n.head.in_off), tmp, 0, n.K));
     CK(pw_unpack_strided(s, tmp, (float*)grads[n.head.w_idx], n.K, 1, 1, 1, 256, 256, 256, 0, 0, 1, beta));

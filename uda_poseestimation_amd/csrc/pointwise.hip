@@ -97,20 +97,38 @@ __global__ void unpack_strided_k(const float* __restrict__ src, float* __restric
 }
 
 // ------------------------------------------------------------------ BatchNorm (training mode)
-// Finalize: reduce the conv epilogue's partial sums [rows][2][C] in fp64, produce scale/shift and saved mean/invstd,
-// update running stats (momentum, unbiased variance) exactly like torch.nn.BatchNorm2d in train().
-__global__ void bn_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
+// Column sums of a partial-sum slab [rows][2][C]: block = 32 channels x 32 row lanes (1024 threads), 128-byte coalesced
+// row segments, fp64 accumulation, LDS tree over the row lanes.  Result for channel c0+cl in (s1, s2) of lanes rl == 0.
+constexpr int FIN_T = 1024;
+__device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int rows, int C, int c, bool cvalid, double& s1, double& s2,
+                                            double (*red)[32][2]) {
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    double a = 0.0, b = 0.0;
+    if (cvalid)
+        for (int r = rl; r < rows; r += 32) {
+            a += (double)slab[(size_t)r * 2 * C + c];
+            b += (double)slab[(size_t)r * 2 * C + C + c];
+        }
+    red[rl][cl][0] = a; red[rl][cl][1] = b;
+    __syncthreads();
+    for (int st = 16; st > 0; st >>= 1) {
+        if (rl < st) { red[rl][cl][0] += red[rl + st][cl][0]; red[rl][cl][1] += red[rl + st][cl][1]; }
+        __syncthreads();
+    }
+    s1 = red[0][cl][0]; s2 = red[0][cl][1];
+}
+// Finalize: reduce the conv epilogue's partial sums in fp64, produce scale/shift and saved mean/invstd, update running
+// stats (momentum, unbiased variance) exactly like torch.nn.BatchNorm2d in train().
+__global__ __launch_bounds__(FIN_T) void bn_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                               long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ scale,
                               float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    const int c = blockIdx.x * TPB + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s1 += (double)slab[(size_t)r * 2 * C + c];
-        s2 += (double)slab[(size_t)r * 2 * C + C + c];
-    }
+    __shared__ double red[32][32][2];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    double s1, s2;
+    slab_colsum(slab, rows, C, c, c < C, s1, s2, red);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -222,16 +240,14 @@ __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restr
 }
 // Finalize backward: dgamma, dbeta (beta_acc*old + new) and the apply coefficients ca = gamma*invstd, cb = sum(g)/M,
 // cc = sum(g*xhat)/M.
-__global__ void bn_bwd_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
                                   const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float beta_acc, float* __restrict__ coef) {
-    const int c = blockIdx.x * TPB + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s1 += (double)slab[(size_t)r * 2 * C + c];
-        s2 += (double)slab[(size_t)r * 2 * C + C + c];
-    }
+    __shared__ double red[32][32][2];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double s1, s2;
+    slab_colsum(slab, rows, C, c, c < C, s1, s2, red);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
     if (dgamma) {
         dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
         dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
@@ -433,7 +449,7 @@ int pw_unpack_strided(hipStream_t s, const float* src, float* dst, int A, int KH
 }
 int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
                    long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
-    hipLaunchKernelGGL(bn_finalize_k, dim3(nblk(C)), dim3(TPB), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
+    hipLaunchKernelGGL(bn_finalize_k, dim3((C + 31) / 32), dim3(FIN_T), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
                        save_mean, save_invstd);
     return udapose_check_launch();
 }
@@ -447,22 +463,24 @@ int pw_bn_apply(hipStream_t s, const bf16_t* y, const bf16_t* res, bf16_t* z, si
     return udapose_check_launch();
 }
 int pw_bn_bwd_rows(size_t npix) {
-    size_t b = (npix + 511) / 512;
-    if (b > 1024) b = 1024;
-    return (int)(b < 1 ? 1 : b);
+    // upper bound used to size the scratch slab; the launch picks rows = min(1024, ceil(npix / pixels-per-iteration))
+    return (int)(npix < 1024 ? (npix < 1 ? 1 : npix) : 1024);
 }
 int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, const bf16_t* y, bf16_t* dy, bf16_t* gout, size_t npix, int C,
               const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
               float beta_acc) {
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1))) return UDAPOSE_ERR_UNSUPPORTED;
-    const int rows = pw_bn_bwd_rows(npix);
+    const int pstep = TPB / G;                                  // pixels a block covers per iteration
+    size_t want = (npix + pstep - 1) / pstep;
+    if (want > 1024) want = 1024;
+    const int rows = (int)(want < 1 ? 1 : want);
     const int ppb = (int)((npix + rows - 1) / rows);
     if (dz_is_f32)
         hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(TPB), 0, s, (const float*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(nblk(C)), dim3(TPB), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
     if (dz_is_f32)
         hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)dz, z, y, dy, gout, npix * G, C, mean, invstd,
                            coef, relu);

@@ -210,28 +210,37 @@ int launch_wg(WgParams& p, hipStream_t stream) {
 
 }  // namespace
 
+int g_wgrad_tile_override = -1, g_wgrad_ksplit_override = -1;   // debug/tuning hooks
+
 // tile ids: 0 = 128x128, 1 = 64x64, 2 = 64x32 (Ci==8 stem), 3 = 32x128 (narrow-row: head)
 int wgrad_pick_tile(int Rdim, int Cdim, int smallc) {
     if (smallc) return 2;
+    if (g_wgrad_tile_override >= 0 && Rdim > 32) return g_wgrad_tile_override;
     if (Rdim <= 32) return 3;
-    if (Rdim >= 128 && Cdim >= 128) return 0;
-    return 1;
+    return 1;    // refined in wgrad_launch once the tap count is known (128x128 only for large weight tensors)
 }
 
 int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
     const bool smallc = (p.flags & IG_FLAG_SMALLC) != 0;
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
     if (p.Co % 8 != 0 || p.Ci % 8 != 0) return UDAPOSE_ERR_ARG;
-    if (smallc && (p.Ci != 8 || swap || (p.total_taps & 3))) return UDAPOSE_ERR_ARG;
+    if (smallc && (p.Ci != 8 || swap || (p.total_taps & 7))) return UDAPOSE_ERR_ARG;
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
     static const int RT[4] = {128, 64, 64, 32}, CT[4] = {128, 64, 32, 128};
+    // measured (tools/tune_conv.py): 64x64 tiles win except for large weight tensors with a short pixel reduction
+    if (tile == 1 && g_wgrad_tile_override < 0 && Rdim >= 128 && Cdim >= 128 &&
+        (long)((Rdim + 127) / 128) * ((Cdim + 127) / 128) * p.total_taps >= 256)
+        tile = 0;
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
     const int ms_total = (p.M + 31) / 32;
+    // split the pixel reduction until ~1024 workgroups exist, keeping >= 4 steps per split; every extra split adds one
+    // fp32 atomic pass over the weight tensor (chip-wide atomic rate 1.3 TB/s)
     int ks = 1;
-    while (tiles * ks < 1024 && ms_total / (ks * 2) >= 8) ks *= 2;
+    while (tiles * ks < 1024 && ms_total / (ks * 2) >= 4) ks *= 2;
+    if (g_wgrad_ksplit_override > 0) { ks = g_wgrad_ksplit_override; while (ks > 1 && ms_total / ks < 1) ks /= 2; }
     p.ksplit = ks;
     p.msteps_per_split = (ms_total + ks - 1) / ks;
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;

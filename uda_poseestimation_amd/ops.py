@@ -24,7 +24,7 @@ def conv_out_hw(d):
 
 
 def kwp(d):
-    return (d.KW + 3) // 4 * 4 if d.Ci == 8 else d.KW
+    return (d.KW + 7) // 8 * 8 if d.Ci == 8 else d.KW
 
 
 def pack_weight(w, d, direction="fwd"):
