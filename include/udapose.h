@@ -132,10 +132,11 @@ int udapose_multi_chunk(void);
 /* OldWeightEMA.step (utils.py:21-25): t = fl(fl(t*alpha) + fl(s*one_minus_alpha)), bit-exact two-rounding form */
 int udapose_ema_multi(void* stream, const long long* tgt_ptrs, const long long* src_ptrs, const long long* sizes, const int* blk_tensor,
                       const long long* blk_off, int nblocks, float alpha, float one_minus_alpha);
-/* torch.optim.Adam.step (train_human.py:139,286) */
+/* torch.optim.Adam.step (train_human.py:139,286).  dev_state (optional, 4 floats, zero-initialised): device-resident step
+ * counter + bias corrections, advanced by the call itself (hipGraph-replay safe); if NULL, `step` is the host's step. */
 int udapose_adam_multi(void* stream, const long long* p, const long long* g, const long long* m, const long long* v,
                        const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, int step, float grad_scale);
+                       float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state);
 /* torch.optim.SGD(momentum, nesterov) (train_human.py:137) */
 int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes,
                       const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float momentum, float weight_decay,

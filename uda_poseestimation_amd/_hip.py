@@ -59,7 +59,7 @@ _SIGS = {
     "udapose_pck": (ci, [vp, vp, vp, ci, ci, cf, cf, cf, vp, vp]),
     "udapose_multi_chunk": (ci, []),
     "udapose_ema_multi": (ci, [vp, vp, vp, vp, vp, vp, ci, cf, cf]),
-    "udapose_adam_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, cf]),
+    "udapose_adam_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, cf, vp]),
     "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf]),
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_debug_set_tiles": (None, [ci, ci, ci]),

@@ -25,7 +25,7 @@ int hm_pck(hipStream_t, const float*, const float*, int, int, float, float, floa
 int opt_chunk();
 int opt_ema(hipStream_t, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float);
 int opt_adam(hipStream_t, const long long*, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int,
-             float, float, float, float, float, int, float);
+             float, float, float, float, float, int, float, float*);
 int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float, float,
             int, int, float);
 int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, float, float, float*);
@@ -168,8 +168,9 @@ int udapose_ema_multi(void* stream, const long long* t, const long long* s, cons
     return opt_ema(S(stream), t, s, sizes, bt, bo, nb, alpha, oma);
 }
 int udapose_adam_multi(void* stream, const long long* p, const long long* g, const long long* m, const long long* v, const long long* sizes,
-                       const int* bt, const long long* bo, int nb, float lr, float b1, float b2, float eps, float wd, int step, float gscale) {
-    return opt_adam(S(stream), p, g, m, v, sizes, bt, bo, nb, lr, b1, b2, eps, wd, step, gscale);
+                       const int* bt, const long long* bo, int nb, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
+                       float* dev_state) {
+    return opt_adam(S(stream), p, g, m, v, sizes, bt, bo, nb, lr, b1, b2, eps, wd, step, gscale, dev_state);
 }
 int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes, const int* bt,
                       const long long* bo, int nb, float lr, float mom, float wd, int nesterov, int first, float gscale) {

@@ -44,6 +44,15 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
     return (t + ((n - t) >> 1)) >> (f.shift - 1);
 }
 
+// XCD-aware work-group remap (MI355X: 8 XCDs, each with a private 4 MiB L2; work-groups are dealt round-robin, so b and
+// b+8 share an L2).  Returns a bijective permutation of the linear block id that gives every XCD one CONTIGUOUS range of
+// work ids, so that blocks which re-read the same operand panels hit the same L2 instead of each XCD streaming the whole
+// working set from the Infinity Cache.  Placement is a speed matter only; results never depend on it.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t total) {
+    const uint32_t q = total >> 3, r = total & 7u, xcd = bid & 7u, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
 }

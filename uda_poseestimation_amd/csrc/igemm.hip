@@ -72,8 +72,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const IgClass cls = p.cls[blockIdx.z];
-    const int n_tile = blockIdx.x % p.n_tiles, m_tile = blockIdx.x / p.n_tiles;
+    // XCD-aware order: each XCD owns a contiguous range of (class, m_tile) so its L2 holds a 1/8 slice of the activations
+    const uint32_t tiles = (uint32_t)p.m_tiles * p.n_tiles;
+    const uint32_t wid_lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, tiles * gridDim.z);
+    const int cls_id = (int)(wid_lin / tiles);
+    const uint32_t tile_id = wid_lin - cls_id * tiles;
+    const IgClass cls = p.cls[cls_id];
+    const int n_tile = tile_id % p.n_tiles, m_tile = tile_id / p.n_tiles;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const bool smallc = (p.flags & IG_FLAG_SMALLC) != 0;
     const bool reflect = (p.flags & IG_FLAG_REFLECT) != 0;
@@ -119,9 +124,54 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 
     __syncthreads();   // tap table visible
 
+    // Fast path (zero padding, no upsample, Ci >= 64): everything that depends on the row is hoisted out of the K loop.
+    // Per row: element offset of its (tap 0,0) pixel and a bit mask of the taps that fall inside the image; per K step
+    // only a wave-uniform offset is added.  (The K loop is otherwise issue-bound on address arithmetic: measured 8
+    // VALU + 7 SALU instructions per MFMA before this.)
+    const bool fast = !smallc && !reflect && !up;
+    long long a_base[A_PW];
+    unsigned long long a_mask[A_PW];
+    long long b_base[B_PW];
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            a_base[i] = ((long long)a_nb[i] + (long long)a_hi0[i] * p.Wi + a_wi0[i]) * p.Ci + a_lc[i] * 8;
+            unsigned long long mk = 0ull;
+            for (int t = 0; t < cls.ntaps; ++t) {
+                const IgTap tt = taps_l[t];
+                const int hi = a_hi0[i] + tt.dy, wi = a_wi0[i] + tt.dx;
+                if (a_ok[i] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) mk |= 1ull << t;
+            }
+            a_mask[i] = mk;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) b_base[i] = (long long)b_row[i] + b_lc[i] * 8;
+    }
+
     auto issue_stage = [&](int buf) {
         char* A = stage + buf * C::STAGE1;
         char* B = A + BM * 128;
+        if (fast) {
+            const IgTap t = taps_l[tap_cur];                                 // wave-uniform
+            const long long aoff = ((long long)t.dy * p.Wi + t.dx) * p.Ci + c0_cur;
+            const long long boff = (long long)t.widx * p.Ci + c0_cur;
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) {
+                const bool ok = (a_mask[i] >> tap_cur) & 1ull;
+                const char* src = ok ? (const char*)(p.x + (a_base[i] + aoff)) : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(A + (i * 4 + wid) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i) {
+                const char* src = b_ok[i] ? (const char*)(p.w + (b_base[i] + boff)) : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
+            }
+            c0_cur += 64;
+            if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
             const IgTap t = taps_l[smallc ? tap_cur + a_lc[i] : tap_cur];
@@ -282,7 +332,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
             }
         }
         if (lane < LPR && cbase < p.Co) {
-            const size_t srow = ((size_t)blockIdx.z * p.m_tiles + m_tile) * WM + wm;
+            const size_t srow = ((size_t)cls_id * p.m_tiles + m_tile) * WM + wm;
             float* sp = p.stats + srow * 2 * p.Co;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sp[cbase + e] = s1[e]; sp[p.Co + cbase + e] = s2[e]; }

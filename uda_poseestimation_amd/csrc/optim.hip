@@ -2,6 +2,16 @@
 // through a block -> (tensor, offset) table; 16-byte accesses; HBM-roofline bound (EMA 12 B/param, Adam 28 B/param).
 #include "common.h"
 
+// no FMA contraction in this file: the EMA must round p*alpha and src*(1-alpha) separately to be bit-identical with the
+// reference's two-step update (hipcc contracts a*b+c by default, and __fmul_rn/__fadd_rn do not prevent it)
+#pragma clang fp contract(off)
+// (belt and braces: the products are additionally pinned in registers by an empty asm, which no contraction can cross)
+__device__ __forceinline__ float ema1(float p, float s, float a, float b) {
+    float t1 = p * a, t2 = s * b;
+    asm volatile("" : "+v"(t1), "+v"(t2));
+    return t1 + t2;
+}
+
 namespace {
 constexpr int TPB = 256;
 constexpr int CHUNK = 4096;   // elements per block
@@ -30,20 +40,30 @@ __global__ void ema_k(MtTable t, float alpha, float one_minus_alpha) {
             f32x4 p = *(f32x4*)(tp + i);
             const f32x4 s = *(const f32x4*)(sp + i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) p[e] = __fadd_rn(__fmul_rn(p[e], alpha), __fmul_rn(s[e], one_minus_alpha));
+            for (int e = 0; e < 4; ++e) p[e] = ema1(p[e], s[e], alpha, one_minus_alpha);
             *(f32x4*)(tp + i) = p;
         }
         const long long tail = off + ((end - off) & ~3LL);
         for (long long i = tail + threadIdx.x; i < end; i += TPB)
-            tp[i] = __fadd_rn(__fmul_rn(tp[i], alpha), __fmul_rn(sp[i], one_minus_alpha));
+            tp[i] = ema1(tp[i], sp[i], alpha, one_minus_alpha);
     } else {
         for (long long i = off + threadIdx.x; i < end; i += TPB)
-            tp[i] = __fadd_rn(__fmul_rn(tp[i], alpha), __fmul_rn(sp[i], one_minus_alpha));
+            tp[i] = ema1(tp[i], sp[i], alpha, one_minus_alpha);
     }
 }
 
+// device-resident step counter (graph-replay safe): state = [step, 1-beta1^step, sqrt(1-beta2^step), -]
+__global__ void adam_tick_k(float* __restrict__ state, float beta1, float beta2) {
+    const double t = (double)state[0] + 1.0;
+    state[0] = (float)t;
+    state[1] = (float)(1.0 - pow((double)beta1, t));
+    state[2] = (float)sqrt(1.0 - pow((double)beta2, t));
+}
+
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0): operands a=param b=grad c=exp_avg d=exp_avg_sq
-__global__ void adam_k(MtTable t, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+__global__ void adam_k(MtTable t, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                       const float* __restrict__ dev_state) {
+    if (dev_state) { bc1 = dev_state[1]; bc2_sqrt = dev_state[2]; }
     const int ti = t.blk_tensor[blockIdx.x];
     const long long off = t.blk_off[blockIdx.x];
     float* p = (float*)t.a[ti];
@@ -67,6 +87,7 @@ __global__ void adam_k(MtTable t, float lr, float beta1, float beta2, float eps,
 
 // torch.optim.SGD(momentum, nesterov, weight_decay): a=param b=grad c=momentum buffer
 __global__ void sgd_k(MtTable t, float lr, float momentum, float wd, int nesterov, int first_step, float gscale) {
+    // (first_step: torch initialises the momentum buffer with the first gradient)
     const int ti = t.blk_tensor[blockIdx.x];
     const long long off = t.blk_off[blockIdx.x];
     float* p = (float*)t.a[ti];
@@ -95,12 +116,15 @@ int opt_ema(hipStream_t s, const long long* tgt, const long long* src, const lon
 }
 int opt_adam(hipStream_t s, const long long* p, const long long* g, const long long* m, const long long* v, const long long* sizes,
              const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float beta1, float beta2, float eps, float wd, int step,
-             float gscale) {
+             float gscale, float* dev_state) {
     MtTable t{p, g, m, v, sizes, blk_tensor, blk_off};
     if (nblocks <= 0) return UDAPOSE_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_k, dim3(nblocks), dim3(TPB), 0, s, t, lr, beta1, beta2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale);
+    // dev_state != NULL: the step counter and bias corrections live on the device (incremented here, so that a captured
+    // graph replays correctly); otherwise `step` is the host's 1-based step
+    double bc1 = 1.0, bc2 = 1.0;
+    if (dev_state) hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(1), 0, s, dev_state, beta1, beta2);
+    else { bc1 = 1.0 - pow((double)beta1, (double)step); bc2 = 1.0 - pow((double)beta2, (double)step); }
+    hipLaunchKernelGGL(adam_k, dim3(nblocks), dim3(TPB), 0, s, t, lr, beta1, beta2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, dev_state);
     return udapose_check_launch();
 }
 int opt_sgd(hipStream_t s, const long long* p, const long long* g, const long long* buf, const long long* sizes, const int* blk_tensor,

@@ -104,11 +104,21 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
                                             double (*red)[32][2]) {
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     double a = 0.0, b = 0.0;
-    if (cvalid)
-        for (int r = rl; r < rows; r += 32) {
+    if (cvalid) {
+        // 4 independent row loads in flight per thread (the loop is latency-bound otherwise)
+        int r = rl;
+        for (; r + 96 < rows; r += 128) {
+            const float* q = slab + (size_t)r * 2 * C + c;
+            const float a0 = q[0], b0 = q[C], a1 = q[(size_t)64 * C], b1 = q[(size_t)64 * C + C];
+            const float a2 = q[(size_t)128 * C], b2 = q[(size_t)128 * C + C], a3 = q[(size_t)192 * C], b3 = q[(size_t)192 * C + C];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; r < rows; r += 32) {
             a += (double)slab[(size_t)r * 2 * C + c];
             b += (double)slab[(size_t)r * 2 * C + C + c];
         }
+    }
     red[rl][cl][0] = a; red[rl][cl][1] = b;
     __syncthreads();
     for (int st = 16; st > 0; st >>= 1) {

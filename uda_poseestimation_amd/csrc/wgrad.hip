@@ -194,6 +194,210 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA version (tiles 128x128 and 64x64, Ci >= 64): NS-deep ring of [64 pixels][channels] stages filled by
+// global_load_lds_dwordx4 (no staging registers), counted vmcnt + one raw s_barrier per stage.  The DMA writes 1 KiB
+// contiguously, so rows cannot be padded: the 16-byte chunk index is XOR-swizzled on the SOURCE side instead
+// (chunk ^ ((row>>1)&3)<<1 for 128-byte rows, chunk ^ (row&7)<<1 for 256-byte rows), which makes the transposing reads
+// of one 32-lane half (8 pixel rows x 32 bytes) hit 16 distinct 16-byte bank slots.
+__device__ u32x4 g_wzero16[2];
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+template <int CH> __device__ __forceinline__ int wswz(int row) {   // CH = channels per LDS row (64 or 128)
+    return CH == 64 ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
+}
+
+template <int RT, int CT, int WR, int WC, int NS>
+struct WdCfg {
+    static constexpr int TR = RT / WR, TC = CT / WC;
+    static constexpr int MT = TR / 16, NT = TC / 16;
+    static constexpr int PROW = RT * 2, QROW = CT * 2;               // bytes per LDS row
+    static constexpr int P_BYTES = 64 * PROW, Q_BYTES = 64 * QROW;
+    static constexpr int P_PW = P_BYTES / 4096, Q_PW = Q_BYTES / 4096; // DMA instructions per wave per stage
+    static constexpr int STAGE1 = P_BYTES + Q_BYTES;
+    static constexpr int LDS_BYTES = NS * STAGE1;
+};
+
+template <int RT, int CT, int WR, int WC, int NS>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
+    using C = WdCfg<RT, CT, WR, WC, NS>;
+    constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
+    constexpr int LPS = P_PW + Q_PW;
+    constexpr int P_RPI = 1024 / C::PROW, Q_RPI = 1024 / C::QROW;    // rows per DMA instruction (8 or 4)
+    constexpr int P_CPR = C::PROW / 16, Q_CPR = C::QROW / 16;        // 16-byte chunks per row (8 or 16)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
+    // XCD-aware order: the split index (pixel range) is the slowest coordinate, so each XCD's L2 serves one pixel range
+    const uint32_t gxy = gridDim.x * gridDim.y;
+    const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
+    const uint32_t bz = lin / gxy, bxy = lin - bz * gxy;
+    const uint32_t by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
+    const int c_tile = bx % p.c_tiles, r_tile = bx / p.c_tiles;
+    const int r0 = r_tile * RT, c0 = c_tile * CT;
+    const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
+    const bool p_is_x = swap;
+    const IgTap tp = p.taps[by];
+    const IgClass cls = p.cls[tp.cls];
+    const int ms_total = (p.M + 63) >> 6;                            // 64-pixel stages
+    const int per = (ms_total + p.ksplit - 1) / p.ksplit;
+    const int ms0 = bz * per;
+    int ms1 = ms0 + per;
+    if (ms1 > ms_total) ms1 = ms_total;
+    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const char* zsrc = (const char*)g_wzero16;
+
+    // Address generation is the issue-slot hog of this loop (measured 24 VALU instructions per MFMA when every row was
+    // decomposed into (n,i,j) twice per stage), so: P and Q rows of a lane are the same pixels (RT == CT), operands
+    // whose pixel index is linear in m skip the decomposition entirely (dy of every plain conv; x of 1x1 stride-1 convs).
+    static_assert(RT == CT, "P and Q share their row mapping");
+    const bool dy_lin = p.os == 1 && cls.oa == 0 && cls.ob == 0 && p.Hg == p.Ho && p.Wg == p.Wo;
+    const bool x_lin = p.s == 1 && tp.dy == 0 && tp.dx == 0 && p.Hg == p.Hi && p.Wg == p.Wi;
+    const int lrow = lane / P_CPR, pch = lane % P_CPR;
+    auto issue_stage = [&](int st, int buf) {
+        const int mb = (ms0 + st) << 6;
+        char* P = smem + buf * C::STAGE1;
+        char* Q = P + C::P_BYTES;
+#pragma unroll
+        for (int i = 0; i < P_PW; ++i) {
+            const int row = (i * 4 + wid) * P_RPI + lrow;
+            const int lc = pch ^ wswz<RT>(row);
+            const int m = mb + row;
+            const bool mok = m < p.M;
+            const char* sx = zsrc;
+            const char* sd = zsrc;
+            if (mok) {
+                uint32_t n = 0, ii = 0, jj = 0;
+                if (!(dy_lin && x_lin)) {
+                    n = fdiv((uint32_t)m, p.div_hw);
+                    const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Hg * p.Wg);
+                    ii = fdiv(rem, p.div_w);
+                    jj = rem - ii * (uint32_t)p.Wg;
+                }
+                if (x_lin) sx = (const char*)(p.x + (size_t)m * p.Ci);
+                else {
+                    const int hi = (int)ii * p.s + tp.dy, wi = (int)jj * p.s + tp.dx;
+                    if ((unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi)
+                        sx = (const char*)(p.x + (((size_t)n * p.Hi + hi) * p.Wi + wi) * p.Ci);
+                }
+                if (dy_lin) sd = (const char*)(p.dy + (size_t)m * p.Co);
+                else {
+                    const uint32_t oh = ii * p.os + cls.oa, ow = jj * p.os + cls.ob;
+                    if (oh < (uint32_t)p.Ho && ow < (uint32_t)p.Wo) sd = (const char*)(p.dy + (((size_t)n * p.Ho + oh) * p.Wo + ow) * p.Co);
+                }
+            }
+            const char* sp = p_is_x ? sx : sd;
+            const char* sq = p_is_x ? sd : sx;
+            const int pc = r0 + lc * 8, qc = c0 + lc * 8;
+            sp = (sp != zsrc && pc < Rdim) ? sp + (size_t)pc * 2 : zsrc;
+            sq = (sq != zsrc && qc < Cdim) ? sq + (size_t)qc * 2 : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
+                                             (__attribute__((address_space(3))) void*)(Q + (i * 4 + wid) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int issued = 0;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nsteps) { issue_stage(st, st); ++issued; }
+
+    const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st % NS;
+        if (issued - st - 1 >= NS - 2) wg_wait_vmcnt<LPS*(NS - 2)>();
+        else wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (issued < nsteps) { issue_stage(issued, issued % NS); ++issued; }
+        const char* P = smem + buf * C::STAGE1;
+        const char* Q = P + C::P_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int col = wr * TR + i * 16 + 4 * pp;           // first of this lane's 4 columns
+                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 32 * kk + 16 * h + 4 * g + qq;
+                    const int off = row * C::PROW + ((((col >> 3) ^ wswz<RT>(row)) << 4) | ((col & 4) << 1));
+                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, P + off));
+                    if (h == 0) u.s.a = v; else u.s.b = v;
+                }
+                af[i] = u.v;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = wc * TC + j * 16 + 4 * pp;
+                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 32 * kk + 16 * h + 4 * g + qq;
+                    const int off = row * C::QROW + ((((col >> 3) ^ wswz<CT>(row)) << 4) | ((col & 4) << 1));
+                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, Q + off));
+                    if (h == 0) u.s.a = v; else u.s.b = v;
+                }
+                bfr[j] = u.v;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const bool atomic = (p.flags & WG_FLAG_ATOMIC) != 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = r0 + wr * TR + i * 16 + (lane >> 4) * 4 + r;
+                const int cc = c0 + wc * TC + j * 16 + (lane & 15);
+                if (rr >= Rdim || rr >= p.rows_valid || cc >= Cdim) continue;
+                const size_t off = ((size_t)rr * p.wtaps + tp.widx) * Cdim + cc;
+                const float v = acc[i][j][r];
+                if (atomic) atomicAdd(p.dw + off, v);
+                else p.dw[off] = v;
+            }
+}
+
+template <int RT, int CT, int WR, int WC, int NS>
+int launch_wd(WgParams& p, hipStream_t stream) {
+    using C = WdCfg<RT, CT, WR, WC, NS>;
+    const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
+    const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
+    p.r_tiles = (Rdim + RT - 1) / RT;
+    p.c_tiles = (Cdim + CT - 1) / CT;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<RT, CT, WR, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid(p.r_tiles * p.c_tiles, p.total_taps, p.ksplit);
+    hipLaunchKernelGGL((wgrad_dma_kernel<RT, CT, WR, WC, NS>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    return udapose_check_launch();
+}
+
 template <int RT, int CT, int WR, int WC>
 int launch_wg(WgParams& p, hipStream_t stream) {
     using C = WgCfg<RT, CT, WR, WC>;
@@ -235,7 +439,8 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
         tile = 0;
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
-    const int ms_total = (p.M + 31) / 32;
+    const bool dma = !smallc && (tile == 0 || tile == 1) && (p.Ci % 64 == 0) && (p.Co % 64 == 0);
+    const int ms_total = dma ? (p.M + 63) / 64 : (p.M + 31) / 32;
     // split the pixel reduction until ~1024 workgroups exist, keeping >= 4 steps per split; every extra split adds one
     // fp32 atomic pass over the weight tensor (chip-wide atomic rate 1.3 TB/s)
     int ks = 1;
@@ -248,6 +453,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
         const size_t n = (size_t)Rdim * p.wtaps * Cdim;
         if (hipMemsetAsync(p.dw, 0, n * sizeof(float), stream) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }
+    if (dma) return tile == 0 ? launch_wd<128, 128, 2, 2, 2>(p, stream) : launch_wd<64, 64, 2, 2, 4>(p, stream);
     switch (tile) {
         case 0: return launch_wg<128, 128, 2, 2>(p, stream);
         case 1: return launch_wg<64, 64, 2, 2>(p, stream);

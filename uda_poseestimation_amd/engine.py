@@ -88,12 +88,26 @@ class MeanTeacherTrainer:
 
     # ------------------------------------------------------------------ train_human.py:326-444
     def train_step(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, aug_param_stu, aug_params_tea, with_accuracy=False):
+        """Eager step from the loader's collated batch (aug_param tuples as produced by the reference's transforms)."""
+        if not isinstance(x_t_teas, (list, tuple)):
+            x_t_teas, aug_params_tea = [x_t_teas], [aug_params_tea]
+        n, dev = x_t_stu.shape[0], x_t_stu.device
+        theta_stu = warp.recon_thetas(aug_param_stu, n, self.ratio, dev)
+        thetas_tea = [warp.recon_thetas(ap, n, self.ratio, dev) for ap in aug_params_tea]
+        out = self._forward_backward(x_s, label_s, weight_s, x_t_stu, list(x_t_teas), theta_stu, thetas_tea)
+        self.sync()
+        self._update()
+        if with_accuracy:
+            _, avg_acc, cnt, _ = kd.accuracy(out["y_s"], label_s)
+            out["acc_s"], out["cnt_s"] = avg_acc, cnt
+        return out
+
+    def _forward_backward(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
+        """Device-only part up to the gradients (no host reads, no H2D copies: capturable in a hipGraph)."""
         student, teacher = self.student, self.teacher
         student.train()
         teacher.train()                     # the teacher's BN uses batch statistics too (train_human.py:321)
         self.stu_optimizer.zero_grad()
-        if not isinstance(x_t_teas, (list, tuple)):
-            x_t_teas, aug_params_tea = [x_t_teas], [aug_params_tea]
         x_s_ori, x_t_teas_ori = x_s, list(x_t_teas)
         with torch.no_grad():
             if self.style_net is not None and self.s2t_freq > self.rng.rand():
@@ -103,11 +117,11 @@ class MeanTeacherTrainer:
                 a = self.rng.uniform(*self.t2s_alpha)
                 x_t_teas = [self.style_net(x_t, x_s_ori, a, clamp=self.recover)[2] for x_t in x_t_teas]
             y_t_teas = [teacher(x_t) for x_t in x_t_teas]
-            recons = [warp.recon_heatmaps(y, ap, self.ratio) for y, ap in zip(y_t_teas, aug_params_tea)]
+            recons = [warp.warp_chain(y, th) for y, th in zip(y_t_teas, thetas_tea)]
             y_t_tea_recon = recons[0] if len(recons) == 1 else torch.stack(recons).mean(0)
         y_s = student(x_s)
         y_t_stu = student(x_t_stu)          # separate forwards: separate BN statistics per domain
-        y_t_stu_recon = warp.recon_heatmaps(y_t_stu, aug_param_stu, self.ratio)
+        y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
         loss_s = self.criterion(y_s, label_s, weight_s)
         with torch.no_grad():
             # activations BEFORE rectify; threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats)
@@ -117,11 +131,60 @@ class MeanTeacherTrainer:
         loss_c = self.con_criterion(y_t_stu_recon, y_t_tea_rect, tea_mask=tea_mask)
         loss_all = loss_s + self.lambda_c * loss_c
         loss_all.backward()
-        self.sync()
+        return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": y_s.detach()}
+
+    def _update(self):
         self.stu_optimizer.step()
         self.tea_optimizer.step()           # EMA after the optimizer step (train_human.py:437-438)
-        out = {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": y_s.detach()}
-        if with_accuracy:
-            _, avg_acc, cnt, _ = kd.accuracy(y_s.detach(), label_s)
-            out["acc_s"], out["cnt_s"] = avg_acc, cnt
-        return out
+
+
+class GraphedTrainStep:
+    """The mean-teacher step captured into two hipGraphs (forward/backward, then Adam+EMA) around the eager gradient
+    all-reduce: ~2500 kernel launches per step are replayed by two graph launches, which removes the host launch gaps.
+    Inputs are copied into static device tensors before each replay; the re-warp matrices are computed on the host from
+    the batch's aug_param tuples exactly as in the eager step.  Style transfer / occlusion draw host random numbers per
+    step and therefore stay on the eager path."""
+
+    def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2):
+        assert trainer.style_net is None, "the graphed step covers the style-free configuration"
+        self.t = trainer
+        dev = x_s.device
+        n = x_s.shape[0]
+        self.n = n
+        self.static = {"x_s": x_s.clone(), "label_s": label_s.clone(), "weight_s": weight_s.clone(), "x_t_stu": x_t_stu.clone(),
+                       "x_t_tea": x_t_tea.clone(),
+                       "theta_stu": warp.recon_thetas(aug_param_stu, n, trainer.ratio, dev),
+                       "theta_tea": warp.recon_thetas(aug_param_tea, n, trainer.ratio, dev)}
+        st = self.static
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):     # fills the tap-plan / table caches and reaches allocator steady state
+                trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
+                                          [st["theta_tea"]])
+                trainer.sync()
+                trainer._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_fb, self.g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.out = trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
+                                                 [st["theta_tea"]])
+        trainer.sync()
+        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
+            trainer._update()
+        torch.cuda.synchronize()
+
+    def step(self, x_s=None, label_s=None, weight_s=None, x_t_stu=None, x_t_tea=None, aug_param_stu=None, aug_param_tea=None):
+        st = self.static
+        for k, v in (("x_s", x_s), ("label_s", label_s), ("weight_s", weight_s), ("x_t_stu", x_t_stu), ("x_t_tea", x_t_tea)):
+            if v is not None and v.data_ptr() != st[k].data_ptr():
+                st[k].copy_(v, non_blocking=True)
+        if aug_param_stu is not None:
+            st["theta_stu"].copy_(warp.recon_thetas(aug_param_stu, self.n, self.t.ratio), non_blocking=True)
+        if aug_param_tea is not None:
+            st["theta_tea"].copy_(warp.recon_thetas(aug_param_tea, self.n, self.t.ratio), non_blocking=True)
+        self.g_fb.replay()
+        self.t.sync()
+        self.g_up.replay()
+        return self.out

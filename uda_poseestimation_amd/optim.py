@@ -47,9 +47,15 @@ class FusedAdam(_FusedBase):
             ps, t = got
             group["step"] += 1
             b1, b2 = group["betas"]
+            # the step counter / bias corrections live on the device so that a captured step replays correctly
+            ds = group.get("_dev_state")
+            if ds is None or ds.device != ps[0].device:
+                ds = torch.zeros(4, dtype=torch.float32, device=ps[0].device)
+                ds[0] = group["step"] - 1
+                group["_dev_state"] = ds
             check(lib().udapose_adam_multi(_hip.stream(), ptr(t.ptrs[0]), ptr(t.ptrs[1]), ptr(t.ptrs[2]), ptr(t.ptrs[3]), ptr(t.sizes), ptr(t.blk_t),
                                            ptr(t.blk_o), t.nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                           float(group["weight_decay"]), int(group["step"]), float(group["grad_scale"])), "adam_multi")
+                                           float(group["weight_decay"]), int(group["step"]), float(group["grad_scale"]), ptr(ds)), "adam_multi")
             _bump_versions(ps)
         return loss
 

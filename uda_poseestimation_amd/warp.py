@@ -38,16 +38,29 @@ def _as_list(v, n):
     return [float(v)] * n
 
 
+def _inv_mats(angle, tx, ty, scale, sx, sy):
+    """Vectorised (float64) inverse_affine_matrix for arrays of parameters -> [n, 6]."""
+    import numpy as np
+    rot, sx, sy = np.radians(angle), np.radians(sx), np.radians(sy)
+    a = np.cos(rot - sy) / np.cos(sy)
+    b = -np.cos(rot - sy) * np.tan(sx) / np.cos(sy) - np.sin(rot)
+    c = np.sin(rot - sy) / np.cos(sy)
+    d = -np.sin(rot - sy) * np.tan(sx) / np.cos(sy) + np.cos(rot)
+    m0, m1, m3, m4 = d / scale, -b / scale, -c / scale, a / scale
+    m2 = m0 * (-tx) + m1 * (-ty)
+    m5 = m3 * (-tx) + m4 * (-ty)
+    return np.stack([m0, m1, m2, m3, m4, m5], -1)
+
+
 def recon_thetas(aug_param, n, ratio=1.0, device=None):
     """[N,3,6] fp32 matrices of the loop's translate -> rotate+scale -> shear chain for a collated aug_param."""
+    import numpy as np
     angle, (tx, ty), (sx, sy), scale = aug_param
-    angle, tx, ty, sx, sy, scale = (_as_list(v, n) for v in (angle, tx, ty, sx, sy, scale))
-    th = torch.empty(n, 3, 6, dtype=torch.float32)
-    for i in range(n):
-        th[i, 0] = torch.tensor(inverse_affine_matrix(0.0, [tx[i] / ratio, ty[i] / ratio], 1.0, [0.0, 0.0]))
-        th[i, 1] = torch.tensor(inverse_affine_matrix(angle[i], [0.0, 0.0], scale[i], [0.0, 0.0]))
-        th[i, 2] = torch.tensor(inverse_affine_matrix(0.0, [0.0, 0.0], 1.0, [sx[i], sy[i]]))
-    return th.to(device) if device is not None else th
+    angle, tx, ty, sx, sy, scale = (np.asarray(_as_list(v, n), np.float64) for v in (angle, tx, ty, sx, sy, scale))
+    z, o = np.zeros(n), np.ones(n)
+    th = np.stack([_inv_mats(z, tx / ratio, ty / ratio, o, z, z), _inv_mats(angle, z, z, scale, z, z), _inv_mats(z, z, z, o, sx, sy)], 1)
+    t = torch.from_numpy(th.astype(np.float32))
+    return t.to(device) if device is not None else t
 
 
 def single_thetas(angle, translate, scale, shear, n, device=None):
