@@ -31,6 +31,19 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (/opt/skills/gu
 FWD_GFLOP_PER_IMAGE = 24.165       # PoseResNet-101, K=16, 256x256 forward
 
 
+def measured_traffic_per_igemm_launch():
+    """HBM bytes per igemm launch from the committed PMC passes (profiles/r1_pmc_hbm_traffic.txt: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this benchmark; FETCH_SIZE doubled per the gfx950 note)."""
+    try:
+        import ast
+        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.txt")).read().strip())
+        n, f = d["fetch"]["igemm"]
+        _, w = d["write"]["igemm"]
+        return (2.0 * f + w) * 1024.0 / n
+    except Exception:
+        return None
+
+
 def cpu_baseline(n, arch_layers, seconds_budget=25.0):
     """CPU oracle step (kind 'port'): PoseResNet-101 mean-teacher step on `n` images, fp32, all host cores."""
     from oracle.pose_resnet_ref import PoseResNetRef
@@ -155,7 +168,9 @@ def main():
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if args.arch == "pose_resnet101" else None,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fprop+dgrad, bf16 MFMA 16x16x32)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic_per_igemm_launch(),
+                         "traffic_note": "HBM bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                         "(profiles/r1_pmc_hbm_traffic.txt), not collected live",
                          "launches_per_step": int(ig_l), "avg_launch_us": round(ig_ms * 1e3 / max(ig_l, 1), 2),
                          "flops_per_launch_avg": ig_fl / max(ig_l, 1), "kernel_ms_per_step": round(ig_ms, 3),
                          "wgrad": {"launches_per_step": int(wl), "kernel_ms_per_step": round(ms_w, 3),
