@@ -41,6 +41,7 @@ typedef struct {
 
 #define UDAPOSE_EPI_RELU 1
 #define UDAPOSE_EPI_OUT_F32 2
+#define UDAPOSE_EPI_F32 4   /* x, w_fwd ([Co][taps][Ci] fp32), res and y are fp32: exact fp32 MFMA path (Ci multiple of 32 or 8) */
 void udapose_conv_out_hw(const udapose_conv_desc* d, int* Ho, int* Wo);
 int udapose_conv_stat_rows(const udapose_conv_desc* d);
 /* y[N,Ho,Wo,Co] = conv(x, w_fwd) (+bias[Co]) (+res) (ReLU); stats (optional): [stat_rows][2][Co] fp32 partial
@@ -90,7 +91,9 @@ int udapose_maxpool2x2_ceil(void* stream, const void* x, void* y, int N, int H, 
  * PoseResNet.forward = head(upsampling(backbone(x)))), parameters by index in .parameters() order (host arrays of
  * device pointers), buffers in .buffers() order.  4-D weights are fp32 in channels_last physical layout. */
 typedef void* udapose_net_t;
-int udapose_net_create(const int layers[4], int num_keypoints, int N, int H, int W, udapose_net_t* out);
+/* fp32 != 0: fp32 activations and exact fp32 MFMA, FORWARD ONLY (the reference runs the teacher and validate() in fp32,
+ * train_human.py:347-358,461-500); fp32 == 0: bf16 compute with fp32 accumulation, forward and backward. */
+int udapose_net_create(const int layers[4], int num_keypoints, int N, int H, int W, int fp32, udapose_net_t* out);
 void udapose_net_destroy(udapose_net_t net);
 int udapose_net_num_params(udapose_net_t net);
 int udapose_net_num_buffers(udapose_net_t net);

@@ -227,3 +227,24 @@ def test_adain_matches_oracle(dev, golden_dir):
     m, sd = style_ref.calc_mean_std_ref(c)
     np.testing.assert_allclose(st[..., 0].cpu().numpy(), m.reshape(2, 512).numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(st[..., 1].cpu().numpy(), sd.reshape(2, 512).numpy(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", [("1x1", 2, 16, 16, 64, 256, 1, 1, 0), ("3x3_s2", 2, 16, 16, 128, 128, 3, 2, 1), ("3x3_ragged", 3, 12, 12, 32, 64, 3, 1, 1)],
+                         ids=lambda c: c[0])
+def test_conv_fp32_exact_path(dev, case):
+    """Exact fp32 MFMA path (forward only): fp32 in / fp32 out, compared with torch fp32 at 2e-6 relative."""
+    from uda_poseestimation_amd import ops
+    _, N, H, W, Ci, Co, K, s, p = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    r = torch.randn(N, Co, (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1, generator=g)
+    d = ops.conv_desc(N, H, W, Ci, Co, K, s, p)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wg = w.permute(0, 2, 3, 1).contiguous().reshape(Co, K * K, Ci).cuda()
+    rg = r.permute(0, 2, 3, 1).contiguous().cuda()
+    y, stats = ops.conv2d_fwd(xg, wg, d, res=rg, relu=True, want_stats=True)
+    assert y.dtype == torch.float32
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    close(nchw(y), F.relu(ref + r), 2e-6)
+    np.testing.assert_allclose(stats.double().sum(0)[0].cpu().numpy(), ref.double().sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)

@@ -194,3 +194,38 @@ def test_full_size_heatmaps_within_1e3_and_argmax_identical():
             clear = (top2[:, 0] - top2[:, 1]) > 2 * err       # arg-max identity where the peak margin exceeds the error
             assert torch.equal(fr.argmax(1)[clear], fy.argmax(1)[clear])
             print("clear-peak rows:", int(clear.sum()), "/ 32")
+
+
+@pytest.mark.parametrize("arch", ["pose_resnet50", "pose_resnet101"])
+def test_fp32_mode_meets_the_1e3_heatmap_bar_and_identical_argmax(arch):
+    """north_star's bar, on the precision the reference itself uses for the teacher / validate(): exact fp32 MFMA forward
+    vs the fp32 CPU oracle, default (reference) initialisation, training-mode BN, full 256x256 input."""
+    import uda_poseestimation_amd.lib.models as models
+    from oracle import pose_resnet_ref
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    from oracle.keypoints_ref import get_max_preds_ref
+    torch.manual_seed(0)
+    ref = getattr(pose_resnet_ref, arch + "_ref")(16)
+    net = models.__dict__[arch](num_keypoints=16, pretrained_backbone=False)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda()
+    net.precision = "fp32"
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(1)).clamp(-2.1, 2.6)
+    ref.train(); net.train()
+    with torch.no_grad():
+        y_ref = ref(x)
+        y = net(x.cuda())
+    err = (y.cpu() - y_ref).abs().max().item()
+    print(f"{arch} fp32 mode: max|y|={y_ref.abs().max().item():.4f} max|device - oracle|={err:.3e}")
+    assert err < 1e-3
+    p_dev, _ = kd.get_max_preds(y)
+    p_ref, _ = get_max_preds_ref(y_ref.numpy())
+    top2 = y_ref.reshape(32, -1).topk(2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 4 * err).reshape(2, 16).numpy()
+    assert np.array_equal(p_dev.cpu().numpy()[clear], p_ref[clear]) and clear.mean() > 0.9
+    # running statistics updated exactly like torch
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-3, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        net(x.cuda())            # grad-enabled forward is refused in the forward-only precision

@@ -38,7 +38,7 @@ _SIGS = {
     "udapose_maxpool3x3s2_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
     "udapose_maxpool3x3s2_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
     "udapose_maxpool2x2_ceil": (ci, [vp, vp, vp, ci, ci, ci, ci]),
-    "udapose_net_create": (ci, [vp, ci, ci, ci, ci, vp]),
+    "udapose_net_create": (ci, [vp, ci, ci, ci, ci, ci, vp]),
     "udapose_net_destroy": (None, [vp]),
     "udapose_net_num_params": (ci, [vp]),
     "udapose_net_num_buffers": (ci, [vp]),

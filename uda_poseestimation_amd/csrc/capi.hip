@@ -33,7 +33,7 @@ int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int,
 extern int g_igemm_tile_override, g_wgrad_tile_override, g_wgrad_ksplit_override;
 void prof_begin();
 int prof_end(double*);
-void* net_create(const int layers[4], int K, int N, int H, int W);
+void* net_create(const int layers[4], int K, int N, int H, int W, int f32);
 void net_destroy(void*);
 int net_num_params(void*);
 int net_num_buffers(void*);
@@ -63,7 +63,7 @@ int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, 
                        float* stats, int flags) {
     if (!d || !x || !w_fwd || !y) return UDAPOSE_ERR_ARG;
     ConvEpilogue e;
-    e.res = CB16(res); e.bias = bias; e.stats = stats; e.relu = (flags & UDAPOSE_EPI_RELU) != 0; e.out_f32 = (flags & UDAPOSE_EPI_OUT_F32) != 0;
+    e.res = CB16(res); e.bias = bias; e.stats = stats; e.relu = (flags & UDAPOSE_EPI_RELU) != 0; e.out_f32 = (flags & UDAPOSE_EPI_OUT_F32) != 0; e.f32 = (flags & UDAPOSE_EPI_F32) != 0;
     return conv_fprop(S(stream), to_geom(d), CB16(x), CB16(w_fwd), y, e);
 }
 int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res, int out_f32) {
@@ -113,9 +113,9 @@ int udapose_maxpool2x2_ceil(void* stream, const void* x, void* y, int N, int H, 
     return pw_maxpool2x2_ceil(S(stream), CB16(x), B16(y), N, H, W, C);
 }
 
-int udapose_net_create(const int layers[4], int K, int N, int H, int W, udapose_net_t* out) {
+int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32, udapose_net_t* out) {
     if (!out) return UDAPOSE_ERR_ARG;
-    *out = net_create(layers, K, N, H, W);
+    *out = net_create(layers, K, N, H, W, fp32);
     return *out ? UDAPOSE_OK : UDAPOSE_ERR_ARG;
 }
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }

@@ -38,6 +38,7 @@ struct ConvEpilogue {
     float* stats = nullptr;
     int relu = 0;
     int out_f32 = 0;
+    int f32 = 0;            // x, w, res, y are fp32 (exact fp32 MFMA path; forward only)
 };
 // y = conv(x, w_fwd[Co][wtaps][Ci])
 int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e);

@@ -11,6 +11,7 @@ struct IgClass { int tap_off, ntaps, oa, ob; };
 #define IG_FLAG_UPSAMPLE 2    // input is read through a nearest x2 upsample (logical dims = 2x physical)
 #define IG_FLAG_RELU 4
 #define IG_FLAG_OUT_F32 8     // y is fp32 NHWC instead of bf16 NHWC
+#define IG_FLAG_F32 128      // x, w, res and y are fp32 (exact fp32 MFMA path, forward only)
 #define IG_FLAG_SMALLC 16     // Ci == 8: one 32-wide K step covers 4 taps (stem / first VGG conv)
 
 struct IgParams {

@@ -61,9 +61,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Main loop: NS-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers), counted vmcnt waits and
 // ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
 // stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
-template <int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
+    // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
+    // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int EPC = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+    constexpr int BKE = 128 / (int)sizeof(T);     // K elements per stage
+    constexpr int TPS = BKE / 8;                  // taps per stage on the Ci == 8 path
+    const T* px = (const T*)p.x;
+    const T* pw = (const T*)p.w;
     constexpr int TM = C::TM, TN = C::TN, MT = C::MT, NT = C::NT, A_PW = C::A_PW, B_PW = C::B_PW, BNL = C::BNL;
     constexpr int LPS = A_PW + B_PW;    // DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         b_row[i] = (size_t)(b_ok[i] ? co : 0) * (size_t)(p.wtaps * p.Ci);
     }
 
-    const int nsteps = smallc ? (cls.ntaps >> 3) : (cls.ntaps * p.Ci) >> 6;
+    const int nsteps = smallc ? cls.ntaps / TPS : (cls.ntaps * p.Ci) / BKE;
     int tap_cur = 0, c0_cur = 0;   // uniform K cursor
     const char* zsrc = (const char*)g_zero16;
 
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     if (fast) {
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
-            a_base[i] = ((long long)a_nb[i] + (long long)a_hi0[i] * p.Wi + a_wi0[i]) * p.Ci + a_lc[i] * 8;
+            a_base[i] = ((long long)a_nb[i] + (long long)a_hi0[i] * p.Wi + a_wi0[i]) * p.Ci + a_lc[i] * EPC;
             unsigned long long mk = 0ull;
             for (int t = 0; t < cls.ntaps; ++t) {
                 const IgTap tt = taps_l[t];
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
             a_mask[i] = mk;
         }
 #pragma unroll
-        for (int i = 0; i < B_PW; ++i) b_base[i] = (long long)b_row[i] + b_lc[i] * 8;
+        for (int i = 0; i < B_PW; ++i) b_base[i] = (long long)b_row[i] + b_lc[i] * EPC;
     }
 
     auto issue_stage = [&](int buf) {
@@ -158,24 +166,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 #pragma unroll
             for (int i = 0; i < A_PW; ++i) {
                 const bool ok = (a_mask[i] >> tap_cur) & 1ull;
-                const char* src = ok ? (const char*)(p.x + (a_base[i] + aoff)) : zsrc;
+                const char* src = ok ? (const char*)(px + (a_base[i] + aoff)) : zsrc;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(A + (i * 4 + wid) * 1024), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < B_PW; ++i) {
-                const char* src = b_ok[i] ? (const char*)(p.w + (b_base[i] + boff)) : zsrc;
+                const char* src = b_ok[i] ? (const char*)(pw + (b_base[i] + boff)) : zsrc;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
             }
-            c0_cur += 64;
+            c0_cur += BKE;
             if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; }
             return;
         }
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
-            const IgTap t = taps_l[smallc ? tap_cur + a_lc[i] : tap_cur];
-            const int coff = smallc ? 0 : c0_cur + a_lc[i] * 8;
+            const IgTap t = taps_l[smallc ? tap_cur + a_lc[i] * EPC / 8 : tap_cur];
+            const int coff = smallc ? (a_lc[i] * EPC) & 7 : c0_cur + a_lc[i] * EPC;
             int hi = a_hi0[i] + t.dy, wi = a_wi0[i] + t.dx;
             if (reflect) {
                 hi = hi < 0 ? -hi : (hi >= Hl ? 2 * Hl - 2 - hi : hi);
@@ -183,20 +191,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
             }
             const bool ok = a_ok[i] && (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
             hi >>= up; wi >>= up;
-            const char* src = ok ? (const char*)(p.x + ((size_t)(a_nb[i] + hi * p.Wi + wi) * p.Ci + coff)) : zsrc;
+            const char* src = ok ? (const char*)(px + ((size_t)(a_nb[i] + hi * p.Wi + wi) * p.Ci + coff)) : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(A + (i * 4 + wid) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_PW; ++i) {
-            const IgTap t = taps_l[smallc ? tap_cur + b_lc[i] : tap_cur];
-            const int coff = smallc ? 0 : c0_cur + b_lc[i] * 8;
-            const char* src = b_ok[i] ? (const char*)(p.w + (b_row[i] + (size_t)t.widx * p.Ci + coff)) : zsrc;
+            const IgTap t = taps_l[smallc ? tap_cur + b_lc[i] * EPC / 8 : tap_cur];
+            const int coff = smallc ? (b_lc[i] * EPC) & 7 : c0_cur + b_lc[i] * EPC;
+            const char* src = b_ok[i] ? (const char*)(pw + (b_row[i] + (size_t)t.widx * p.Ci + coff)) : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
         }
-        if (smallc) tap_cur += 8;
-        else { c0_cur += 64; if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; } }
+        if (smallc) tap_cur += TPS;
+        else { c0_cur += BKE; if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; } }
     };
 
     f32x4 acc[MT][NT];
@@ -222,24 +230,50 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         if (issued < nsteps) { issue_stage(issued % NS); ++issued; }
         const char* A = stage + buf * C::STAGE1;
         const char* B = A + BM * 128;
+        if constexpr (!F32) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[MT], bfr[NT];
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[MT], bfr[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int r = wm * TM + i * 16 + frow;
+                    af[i] = *(const bf16x8*)(A + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int r = wn * TN + j * 16 + frow;
+                    bfr[j] = *(const bf16x8*)(B + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // fp32: lane group q = lane>>4 owns k = 8q..8q+7 of the 32-deep stage (two 16-byte chunks of its row); sub-step
+            // e feeds element e of both operands to one exact 16x16x4 MFMA (the k <-> lane-group assignment is the same for
+            // A and B, so the sum over k is unchanged)
+            f32x4 al[MT][2], bl[NT][2];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int r = wm * TM + i * 16 + frow;
-                af[i] = *(const bf16x8*)(A + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) al[i][h] = *(const f32x4*)(A + r * 128 + (((2 * fchunk + h) ^ swz(r)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int r = wn * TN + j * 16 + frow;
-                bfr[j] = *(const bf16x8*)(B + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bl[j][h] = *(const f32x4*)(B + r * 128 + (((2 * fchunk + h) ^ swz(r)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int e = 0; e < 8; ++e)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[i][e >> 2][e & 3], bl[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     const int cg = lane % LPR, rsub = lane / LPR;
     const int cbase = n0 + wn * TN + cg * 8;
     const bool relu = (p.flags & IG_FLAG_RELU) != 0;
-    const bool outf32 = (p.flags & IG_FLAG_OUT_F32) != 0;
+    const bool outf32 = F32 || (p.flags & IG_FLAG_OUT_F32) != 0;
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -294,9 +328,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias[e];
                 if (p.res) {
-                    const bf16x8 rv = *(const bf16x8*)(p.res + off);
+                    if constexpr (F32) {
+                        const f32x4 r0 = *(const f32x4*)((const float*)p.res + off), r1 = *(const f32x4*)((const float*)p.res + off + 4);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                    } else {
+                        const bf16x8 rv = *(const bf16x8*)(p.res + off);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    }
                 }
                 if (relu) {
 #pragma unroll
@@ -340,19 +380,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
-int launch_cfg(IgParams& p, hipStream_t stream) {
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+int launch_cfg_t(IgParams& p, hipStream_t stream) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Co + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NS>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS>), grid, dim3(256), C::LDS_BYTES, stream, p);
     return udapose_check_launch();
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_cfg(IgParams& p, hipStream_t stream) {
+    return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS>(p, stream) : launch_cfg_t<bf16_t, BM, BN, WM, WN, NS>(p, stream);
 }
 
 }  // namespace
@@ -380,12 +425,13 @@ int igemm_stat_rows(int M, int Co, int nclass, int tile) {
 }
 
 int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
-    if (p.Ci % 8 != 0 || (!(p.flags & IG_FLAG_SMALLC) && p.Ci % 64 != 0)) return UDAPOSE_ERR_ARG;
+    const int bke = (p.flags & IG_FLAG_F32) ? 32 : 64;
+    if (p.Ci % 8 != 0 || (!(p.flags & IG_FLAG_SMALLC) && p.Ci % bke != 0)) return UDAPOSE_ERR_ARG;
     if ((p.flags & IG_FLAG_SMALLC) && p.Ci != 8) return UDAPOSE_ERR_ARG;
-    if (!(p.flags & IG_FLAG_OUT_F32) && (p.Co % 8) != 0) return UDAPOSE_ERR_ARG;
+    if (!(p.flags & (IG_FLAG_OUT_F32 | IG_FLAG_F32)) && (p.Co % 8) != 0) return UDAPOSE_ERR_ARG;
     for (int c = 0; c < p.nclass; ++c) {
         if (p.cls[c].ntaps > 64 || p.cls[c].ntaps < 0) return UDAPOSE_ERR_ARG;
-        if ((p.flags & IG_FLAG_SMALLC) && (p.cls[c].ntaps & 7)) return UDAPOSE_ERR_ARG;
+        if ((p.flags & IG_FLAG_SMALLC) && (p.cls[c].ntaps % (bke / 8))) return UDAPOSE_ERR_ARG;
     }
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);

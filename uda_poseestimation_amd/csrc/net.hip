@@ -28,6 +28,11 @@ int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
+int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
+int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
+int pw_pack_strided_f32(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long);
+int pw_bn_apply_f32(hipStream_t, const float*, const float*, float*, size_t, int, const float*, const float*, int);
+int pw_maxpool3x3s2_fwd_f32(hipStream_t, const float*, float*, unsigned char*, int, int, int, int);
 
 namespace {
 
@@ -65,6 +70,8 @@ struct Block {
 
 struct Net {
     int layers[4], K, N, H, W;
+    int f32 = 0;            // 1: fp32 storage + exact fp32 MFMA (forward only: the reference's teacher / validate() precision)
+    size_t es = 2;          // bytes per activation element
     int n_params = 0, n_buffers = 0;
     std::vector<long long> param_numel;
     // stem
@@ -92,9 +99,10 @@ void add_conv(Net& n, ConvL& c, int Hi, int Wi, int Ci, int Co, int K, int strid
     n.param_numel.push_back((long long)Co * (Ci == 8 ? 3 : Ci) * K * K);
     c.in_off = in_off;
     const size_t welems = (size_t)Co * c.g.wtaps() * Ci;
-    c.wf_off = wp_alloc(n, welems * 2);
-    if (need_bwd_pack) c.wb_off = wp_alloc(n, welems * 2);
-    c.y_off = act_alloc(n, (size_t)n.N * c.g.Ho() * c.g.Wo() * Co * 2);
+    // fp32 mode reads plain-conv weights straight from the fp32 master ([Co][taps][Ci] is its physical layout)
+    if (!n.f32 || c.g.smallc() || transposed) c.wf_off = wp_alloc(n, welems * n.es);
+    if (need_bwd_pack && !n.f32) c.wb_off = wp_alloc(n, welems * 2);
+    c.y_off = act_alloc(n, (size_t)n.N * c.g.Ho() * c.g.Wo() * Co * n.es);
 }
 void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true) {
     b.C = C;
@@ -103,21 +111,23 @@ void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true) {
     b.rm_idx = n.n_buffers++; b.rv_idx = n.n_buffers++; b.nbt_idx = n.n_buffers++;
     b.save_off = act_alloc(n, (size_t)2 * C * 4);
     b.npix = npix;
-    if (alloc_z) b.z_off = act_alloc(n, npix * C * 2);
+    if (alloc_z) b.z_off = act_alloc(n, npix * C * n.es);
 }
 
-Net* build(const int layers[4], int K, int N, int H, int W) {
+Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
     Net* np = new Net();
     Net& n = *np;
+    n.f32 = f32 ? 1 : 0;
+    n.es = f32 ? 4 : 2;
     for (int i = 0; i < 4; ++i) n.layers[i] = layers[i];
     n.K = K; n.N = N; n.H = H; n.W = W;
-    n.x8_off = act_alloc(n, (size_t)N * H * W * 8 * 2);
+    n.x8_off = act_alloc(n, (size_t)N * H * W * 8 * n.es);
     // stem: conv 7x7 s2 p3 (3 -> padded 8 input channels), bn, relu, maxpool 3x3 s2 p1
     add_conv(n, n.stem, H, W, 8, 64, 7, 2, 3, 0, n.x8_off, false);
     n.Hs = n.stem.g.Ho(); n.Ws = n.stem.g.Wo();
     add_bn(n, n.stem_bn, 64, (size_t)N * n.Hs * n.Ws);
     n.Hp = (n.Hs + 2 - 3) / 2 + 1; n.Wp = (n.Ws + 2 - 3) / 2 + 1;
-    n.pool_off = act_alloc(n, (size_t)N * n.Hp * n.Wp * 64 * 2);
+    n.pool_off = act_alloc(n, (size_t)N * n.Hp * n.Wp * 64 * n.es);
     n.poolidx_off = act_alloc(n, (size_t)N * n.Hp * n.Wp * 64);
     size_t cur = n.pool_off;
     int Hc = n.Hp, Wc = n.Wp, Cc = 64;
@@ -198,6 +208,12 @@ int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* pa
     bf16_t* wf = (bf16_t*)(wpack + c.wf_off);
     bf16_t* wb = (bf16_t*)(wpack + c.wb_off);
     const int T = g.KH * g.KW;
+    if (n.f32) {
+        if (g.smallc())
+            return pw_pack_strided_f32(s, w, (float*)(wpack + c.wf_off), g.Co, g.KH, g.KWp(), g.KW, 8, 3, (long)g.KH * g.KW * 3, (long)g.KW * 3, 3, 1);
+        if (g.transposed) return pw_transpose_f32(s, w, (float*)(wpack + c.wf_off), g.Ci, T, g.Co);
+        return UDAPOSE_OK;
+    }
     if (g.smallc()) {
         // master: [Co][KH][KW][3] (channels_last of [Co,3,KH,KW]) -> [Co][KH][KWp][8]
         return pw_pack_strided(s, w, wf, g.Co, g.KH, g.KWp(), g.KW, 8, 3, (long)g.KH * g.KW * 3, (long)g.KW * 3, 3, 1);
@@ -222,7 +238,9 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     float* shift = scale + 2048;
     float* save = (float*)(act + b.save_off);
     e.stats = training ? slab : nullptr;
-    CK(conv_fprop(s, c.g, (const bf16_t*)(act + c.in_off), (const bf16_t*)(wpack + c.wf_off), act + c.y_off, e));
+    e.f32 = n.f32;
+    const void* wptr = (n.f32 && !c.g.smallc() && !c.g.transposed) ? params[c.w_idx] : (const void*)(wpack + c.wf_off);
+    CK(conv_fprop(s, c.g, (const bf16_t*)(act + c.in_off), (const bf16_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
     if (training)
@@ -230,15 +248,17 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
                           (long long*)buffers[b.nbt_idx], momentum, 1e-5f, scale, shift, save, save + b.C));
     else
         CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
+    if (n.f32)
+        return pw_bn_apply_f32(s, (const float*)(act + c.y_off), (const float*)res, (float*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
     return pw_bn_apply(s, (const bf16_t*)(act + c.y_off), res, (bf16_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
 }
 
 }  // namespace
 
 // ============================================================================ public (C++) entry points
-void* net_create(const int layers[4], int K, int N, int H, int W) {
+void* net_create(const int layers[4], int K, int N, int H, int W, int f32) {
     if (K < 1 || K > 64 || N < 1 || H % 32 || W % 32) return nullptr;
-    return build(layers, K, N, H, W);
+    return build(layers, K, N, H, W, f32);
 }
 void net_destroy(void* h) { delete (Net*)h; }
 int net_num_params(void* h) { return ((Net*)h)->n_params; }
@@ -261,6 +281,7 @@ int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wp
     }
     for (int i = 0; i < 3; ++i) CK(pack_conv(s, n, n.up[i], params, wpack, with_bwd));
     const float* hw = (const float*)params[n.head.w_idx];
+    if (n.f32) return UDAPOSE_OK;      // the head reads its fp32 master directly
     CK(pw_cast_f32_bf16(s, hw, (bf16_t*)(wpack + n.head.wf_off), (size_t)n.K * 256));
     if (with_bwd)   // [256][1][64]: wb[ci][k] = w[k][ci], zero for k >= K
         CK(pw_pack_strided(s, hw, (bf16_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
@@ -273,10 +294,15 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
-    CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (bf16_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
+    if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
+    else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (bf16_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
-    CK(pw_maxpool3x3s2_fwd(s, (const bf16_t*)(act + n.stem_bn.z_off), (bf16_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N, n.Hs,
-                           n.Ws, 64));
+    if (n.f32)
+        CK(pw_maxpool3x3s2_fwd_f32(s, (const float*)(act + n.stem_bn.z_off), (float*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
+                                   n.Hs, n.Ws, 64));
+    else
+        CK(pw_maxpool3x3s2_fwd(s, (const bf16_t*)(act + n.stem_bn.z_off), (bf16_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
+                               n.Hs, n.Ws, 64));
     for (auto& b : n.blocks) {
         CK(conv_bn_fwd(s, n, b.c1, b.b1, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
         CK(conv_bn_fwd(s, n, b.c2, b.b2, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
@@ -291,7 +317,9 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     ConvEpilogue e;
     e.bias = (const float*)params[n.head.bias_idx];
     e.out_f32 = 1;
-    CK(conv_fprop(s, n.head.g, (const bf16_t*)(act + n.head.in_off), (const bf16_t*)(wpack + n.head.wf_off), act + n.head_out_off, e));
+    e.f32 = n.f32;
+    const void* hwp = n.f32 ? params[n.head.w_idx] : (const void*)(wpack + n.head.wf_off);
+    CK(conv_fprop(s, n.head.g, (const bf16_t*)(act + n.head.in_off), (const bf16_t*)hwp, act + n.head_out_off, e));
     return pw_nhwc_to_nchw_f32(s, act + n.head_out_off, 1, out_nchw, n.N, n.K, n.Hout * n.Wout, n.K, nullptr, nullptr);
 }
 
@@ -331,6 +359,7 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
 int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack_, void* act_, void* ws_,
                  void* const* grads, float beta) {
     Net& n = *(Net*)h;
+    if (n.f32) return UDAPOSE_ERR_UNSUPPORTED;   // fp32 mode is forward-only (teacher / validate precision)
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;

@@ -9,21 +9,46 @@ constexpr int TPB = 256;
 inline int nblk(size_t n, int per = TPB) { return (int)((n + per - 1) / per); }
 
 // ------------------------------------------------------------------ layout conversion
-// src NCHW fp32 [N,C,HW] -> dst NHWC bf16 [N,HW,Cp] (channels >= C zero-filled); one thread per (pixel, 8-channel group)
-__global__ void nchw_f32_to_nhwc_bf16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int HW, int Cp) {
+// 8 consecutive activation values <-> fp32 registers, for bf16 or fp32 storage
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *(bf16x8*)p = o;
+}
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+
+// src NCHW fp32 [N,C,HW] -> dst NHWC [N,HW,Cp] (channels >= C zero-filled); one thread per (pixel, 8-channel group)
+template <typename T>
+__global__ void nchw_f32_to_nhwc_k(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int HW, int Cp) {
     const int G = Cp >> 3;
     const size_t total = (size_t)N * HW * G;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
         const size_t pix = i % ((size_t)N * HW);      // pixel fastest: coalesced plane reads
         const int g = (int)(i / ((size_t)N * HW));
         const size_t n = pix / HW, hw = pix % HW;
-        bf16x8 o;
+        float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = g * 8 + e;
-            o[e] = (bf16_t)(c < C ? src[(n * C + c) * HW + hw] : 0.f);
+            o[e] = c < C ? src[(n * C + c) * HW + hw] : 0.f;
         }
-        *(bf16x8*)(dst + pix * Cp + g * 8) = o;
+        st8<T>(dst + pix * Cp + g * 8, o);
     }
 }
 
@@ -50,8 +75,9 @@ __global__ void cast_f32_bf16_k(const float* __restrict__ src, bf16_t* __restric
         *(bf16x8*)(dst + i * 8) = o;
     }
 }
-// src [A][T][B] fp32 -> dst [B][T][A] bf16 (32x32 LDS-tiled transpose per tap); grid = (B/32, A/32, T)
-__global__ void transpose_cast_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int A, int T, int B) {
+// src [A][T][B] fp32 -> dst [B][T][A] (bf16 or fp32) (32x32 LDS-tiled transpose per tap); grid = (B/32, A/32, T)
+template <typename D>
+__global__ void transpose_cast_k(const float* __restrict__ src, D* __restrict__ dst, int A, int T, int B) {
     __shared__ float tile[32][33];
     const int t = blockIdx.z, b0 = blockIdx.x * 32, a0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -62,11 +88,12 @@ __global__ void transpose_cast_k(const float* __restrict__ src, bf16_t* __restri
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int b = b0 + r, a = a0 + tx;
-        if (a < A && b < B) dst[((size_t)b * T + t) * A + a] = (bf16_t)tile[tx][r];
+        if (a < A && b < B) dst[((size_t)b * T + t) * A + a] = (D)tile[tx][r];
     }
 }
 // generic strided gather with zero padding: dst[a][kh][kwp][bp] bf16 <- src[a*sa + kh*skh + kw*skw + b*sb] (kw<KW, b<B)
-__global__ void pack_strided_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int A, int KH, int KWp, int KW, int Bp, int B,
+template <typename D>
+__global__ void pack_strided_k(const float* __restrict__ src, D* __restrict__ dst, int A, int KH, int KWp, int KW, int Bp, int B,
                                long sa, long skh, long skw, long sb) {
     const size_t total = (size_t)A * KH * KWp * Bp;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
@@ -77,7 +104,7 @@ __global__ void pack_strided_k(const float* __restrict__ src, bf16_t* __restrict
         const int a = (int)(r / KH);
         float v = 0.f;
         if (kw < KW && b < B) v = src[a * sa + kh * skh + kw * skw + b * sb];
-        dst[i] = (bf16_t)v;
+        dst[i] = (D)v;
     }
 }
 // inverse of pack_strided for gradients: dst[a*sa + kh*skh + kw*skw + b*sb] (beta*dst +) = src[a][kh][kwp][bp] (fp32)
@@ -164,27 +191,29 @@ __global__ void bn_eval_coeff_k(int C, const float* __restrict__ gamma, const fl
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-// z = [relu]( y*scale[c] + shift[c] [+ res] ), NHWC bf16, 8 channels per thread
-__global__ void bn_apply_k(const bf16_t* __restrict__ y, const bf16_t* __restrict__ res, bf16_t* __restrict__ z, size_t n8, int C,
+// z = [relu]( y*scale[c] + shift[c] [+ res] ), NHWC (bf16 or fp32 storage), 8 channels per thread
+template <typename T>
+__global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, size_t n8, int C,
                            const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
     const int G = C >> 3;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
         const int c0 = (int)(i % G) * 8;
-        const bf16x8 v = *(const bf16x8*)(y + i * 8);
+        float v[8];
+        ld8<T>(y + i * 8, v);
         const f32x4 sa = *(const f32x4*)(scale + c0), sb = *(const f32x4*)(scale + c0 + 4);
         const f32x4 ha = *(const f32x4*)(shift + c0), hb = *(const f32x4*)(shift + c0 + 4);
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (float)v[e] * (e < 4 ? sa[e] : sb[e - 4]) + (e < 4 ? ha[e] : hb[e - 4]);
+        for (int e = 0; e < 8; ++e) o[e] = v[e] * (e < 4 ? sa[e] : sb[e - 4]) + (e < 4 ? ha[e] : hb[e - 4]);
         if (res) {
-            const bf16x8 r = *(const bf16x8*)(res + i * 8);
+            float r[8];
+            ld8<T>(res + i * 8, r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += (float)r[e];
+            for (int e = 0; e < 8; ++e) o[e] += r[e];
         }
-        bf16x8 ov;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)((relu && o[e] < 0.f) ? 0.f : o[e]);
-        *(bf16x8*)(z + i * 8) = ov;
+        for (int e = 0; e < 8; ++e) o[e] = (relu && o[e] < 0.f) ? 0.f : o[e];
+        st8<T>(z + i * 8, o);
     }
 }
 
@@ -296,7 +325,8 @@ __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restri
 
 // ------------------------------------------------------------------ max pooling (NHWC bf16)
 // 3x3 stride 2 pad 1 (ResNet stem).  Saves the winning tap (0..8, first max in (kh,kw) scan order like ATen) per element.
-__global__ void maxpool3x3s2_fwd_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
+template <typename T>
+__global__ void maxpool3x3s2_fwd_k(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
                                    int W, int C, int Ho, int Wo) {
     const int G = C >> 3;
     const size_t total = (size_t)N * Ho * Wo * G;
@@ -317,19 +347,17 @@ __global__ void maxpool3x3s2_fwd_k(const bf16_t* __restrict__ x, bf16_t* __restr
             for (int kw = 0; kw < 3; ++kw) {
                 const int h = ho * 2 - 1 + kh, w = wo * 2 - 1 + kw;
                 if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-                    const bf16x8 v = *(const bf16x8*)(x + (((size_t)n * H + h) * W + w) * C + g * 8);
+                    float v[8];
+                    ld8<T>(x + (((size_t)n * H + h) * W + w) * C + g * 8, v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float f = (float)v[e];
+                        const float f = v[e];
                         if (first || f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(kh * 3 + kw); }
                     }
                     first = false;
                 }
             }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
-        *(bf16x8*)(y + i * 8) = o;
+        st8<T>(y + i * 8, best);
         if (idx) {
             unsigned long long pk = 0;
 #pragma unroll
@@ -430,7 +458,12 @@ inline int grid_for(size_t items) {
 // ------------------------------------------------------------------ host launchers (internal C++ API; C-ABI wrappers in capi.hip)
 int pw_nchw_f32_to_nhwc_bf16(hipStream_t s, const float* src, bf16_t* dst, int N, int C, int HW, int Cp) {
     if (Cp % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_k, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, dst, N, C, HW, Cp);
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_k<bf16_t>, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, dst, N, C, HW, Cp);
+    return udapose_check_launch();
+}
+int pw_nchw_f32_to_nhwc_f32(hipStream_t s, const float* src, float* dst, int N, int C, int HW, int Cp) {
+    if (Cp % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_k<float>, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, dst, N, C, HW, Cp);
     return udapose_check_launch();
 }
 int pw_nhwc_to_nchw_f32(hipStream_t s, const void* src, int src_is_f32, float* dst, int N, int C, int HW, int Cs, const float* lo, const float* hi) {
@@ -446,11 +479,19 @@ int pw_cast_f32_bf16(hipStream_t s, const float* src, bf16_t* dst, size_t n) {
     return udapose_check_launch();
 }
 int pw_transpose_cast(hipStream_t s, const float* src, bf16_t* dst, int A, int T, int B) {
-    hipLaunchKernelGGL(transpose_cast_k, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
+    hipLaunchKernelGGL(transpose_cast_k<bf16_t>, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
+    return udapose_check_launch();
+}
+int pw_transpose_f32(hipStream_t s, const float* src, float* dst, int A, int T, int B) {
+    hipLaunchKernelGGL(transpose_cast_k<float>, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
     return udapose_check_launch();
 }
 int pw_pack_strided(hipStream_t s, const float* src, bf16_t* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
-    hipLaunchKernelGGL(pack_strided_k, dim3(grid_for((size_t)A * KH * KWp * Bp)), dim3(TPB), 0, s, src, dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
+    hipLaunchKernelGGL(pack_strided_k<bf16_t>, dim3(grid_for((size_t)A * KH * KWp * Bp)), dim3(TPB), 0, s, src, dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
+    return udapose_check_launch();
+}
+int pw_pack_strided_f32(hipStream_t s, const float* src, float* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
+    hipLaunchKernelGGL(pack_strided_k<float>, dim3(grid_for((size_t)A * KH * KWp * Bp)), dim3(TPB), 0, s, src, dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
     return udapose_check_launch();
 }
 int pw_unpack_strided(hipStream_t s, const float* src, float* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb, float beta) {
@@ -469,7 +510,12 @@ int pw_bn_eval_coeff(hipStream_t s, int C, const float* gamma, const float* beta
 }
 int pw_bn_apply(hipStream_t s, const bf16_t* y, const bf16_t* res, bf16_t* z, size_t n, int C, const float* scale, const float* shift, int relu) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(bn_apply_k, dim3(grid_for(n / 8)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    hipLaunchKernelGGL(bn_apply_k<bf16_t>, dim3(grid_for(n / 8)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    return udapose_check_launch();
+}
+int pw_bn_apply_f32(hipStream_t s, const float* y, const float* res, float* z, size_t n, int C, const float* scale, const float* shift, int relu) {
+    if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(bn_apply_k<float>, dim3(grid_for(n / 8)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
     return udapose_check_launch();
 }
 int pw_bn_bwd_rows(size_t npix) {
@@ -501,7 +547,12 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, con
 }
 int pw_maxpool3x3s2_fwd(hipStream_t s, const bf16_t* x, bf16_t* y, unsigned char* idx, int N, int H, int W, int C) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_fwd_k, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_k<bf16_t>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_maxpool3x3s2_fwd_f32(hipStream_t s, const float* x, float* y, unsigned char* idx, int N, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_k<float>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_bwd(hipStream_t s, const bf16_t* dy, const unsigned char* idx, bf16_t* dx, int N, int H, int W, int C) {

@@ -54,10 +54,10 @@ class Upsampling(nn.Sequential):
 class _NetHandle:
     """One executor plan (fixed N,H,W) plus its device work areas."""
 
-    def __init__(self, layers, K, N, H, W, device):
+    def __init__(self, layers, K, N, H, W, device, fp32=False):
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
-        check(lib().udapose_net_create(arr, K, N, H, W, C.byref(h)), "net_create")
+        check(lib().udapose_net_create(arr, K, N, H, W, int(fp32), C.byref(h)), "net_create")
         self.h = h
         self.n_params = lib().udapose_net_num_params(h)
         self.n_buffers = lib().udapose_net_num_buffers(h)
@@ -109,6 +109,9 @@ class PoseResNet(nn.Module):
             raise NotImplementedError("the MI355X executor implements the reference configuration: 3 x deconv(256, k=4), no bias")
         self.num_keypoints = num_keypoints
         self.bn_momentum = 0.1
+        # 'bf16': bf16 MFMA compute, fp32 accumulation (training and inference).  'fp32': exact fp32 MFMA, forward only -
+        # the precision the reference uses for the teacher and validate() (no autocast there); ~16x slower.
+        self.precision = 'bf16'
         self._handles = {}
         self._ptr_cache = None
         self._flat_grad = None
@@ -168,10 +171,13 @@ class PoseResNet(nn.Module):
         N, Cc, H, W = x.shape
         if Cc != 3:
             raise ValueError("PoseResNet expects [N,3,H,W] input")
-        key = (N, H, W, x.device.index)
+        fp32 = self.precision == 'fp32'
+        if self.precision not in ('bf16', 'fp32'):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        key = (N, H, W, x.device.index, fp32)
         hd = self._handles.get(key)
         if hd is None:
-            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device)
+            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, fp32)
             params = list(self.parameters())
             assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
             for i, p in enumerate(params):
@@ -186,6 +192,8 @@ class PoseResNet(nn.Module):
             x = x.float()
         x = x.contiguous()
         hd = self._handle(x)
+        if save and self.precision == 'fp32':
+            raise RuntimeError("precision='fp32' is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
         pa, ba, params = self._pointers()
         s = _hip.stream()
         version = sum(p._version for p in params)

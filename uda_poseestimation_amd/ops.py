@@ -10,7 +10,7 @@ import torch
 from . import _hip
 from ._hip import ConvDesc, check, lib, ptr, require_cuda, stream
 
-EPI_RELU, EPI_OUT_F32 = 1, 2
+EPI_RELU, EPI_OUT_F32, EPI_F32 = 1, 2, 4
 
 
 def conv_desc(N, Hi, Wi, Ci, Co, K, stride=1, pad=0, transposed=False, reflect=False, upsample=False):
@@ -51,14 +51,16 @@ def pack_weight(w, d, direction="fwd"):
 
 def conv2d_fwd(x, w_fwd, d, res=None, bias=None, relu=False, out_f32=False, want_stats=False):
     require_cuda(x, w_fwd)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (d.N, d.Hi, d.Wi, d.Ci)
+    f32 = x.dtype == torch.float32          # exact fp32 path: w_fwd must be fp32 [Co][taps][Ci] too
+    assert x.dtype in (torch.bfloat16, torch.float32) and w_fwd.dtype == x.dtype and x.is_contiguous()
+    assert tuple(x.shape) == (d.N, d.Hi, d.Wi, d.Ci)
     ho, wo = conv_out_hw(d)
-    y = torch.empty(d.N, ho, wo, d.Co, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    y = torch.empty(d.N, ho, wo, d.Co, dtype=torch.float32 if (out_f32 or f32) else torch.bfloat16, device=x.device)
     stats = None
     if want_stats:
         rows = lib().udapose_conv_stat_rows(C.byref(d))
         stats = torch.empty(rows, 2, d.Co, dtype=torch.float32, device=x.device)
-    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_F32 if f32 else 0)
     check(lib().udapose_conv2d_fwd(stream(), C.byref(d), ptr(x), ptr(w_fwd), ptr(y), ptr(res), ptr(bias), ptr(stats), flags), "conv2d_fwd")
     return (y, stats) if want_stats else y
 
