@@ -28,6 +28,7 @@ int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
+int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
 int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
 int pw_pack_strided_f32(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long);
@@ -88,7 +89,12 @@ struct Net {
     size_t ws_slab = 0, ws_coef = 0, ws_gbuf[6] = {0, 0, 0, 0, 0, 0}, ws_dyhead = 0, ws_dwtmp = 0, ws_headbwd = 0;
     size_t gbuf_bytes = 0;
     int Hout = 0, Wout = 0;
+    // batched weight packing: device job tables, rebuilt when the parameter / pack pointers change
+    struct PackTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0; const void* key0 = nullptr;
+                     const void* key1 = nullptr; const void* keyw = nullptr; };
+    PackTab pack_fwd, pack_all;
 };
+struct PackJobH { const float* src; bf16_t* dst; int A, T, B, kind; long long n; };
 
 size_t act_alloc(Net& n, size_t bytes) { size_t o = n.act_bytes; n.act_bytes = align_up(o + bytes); return o; }
 size_t wp_alloc(Net& n, size_t bytes) { size_t o = n.wpack_bytes; n.wpack_bytes = align_up(o + bytes); return o; }
@@ -269,9 +275,66 @@ size_t net_act_bytes(void* h) { return ((Net*)h)->act_bytes; }
 size_t net_ws_bytes(void* h) { return ((Net*)h)->ws_bytes; }
 void net_out_shape(void* h, int* shp) { Net& n = *(Net*)h; shp[0] = n.N; shp[1] = n.K; shp[2] = n.Hout; shp[3] = n.Wout; }
 
+namespace {
+void add_pack_jobs(const Net& n, const ConvL& c, const void* const* params, char* wpack, bool with_bwd, std::vector<PackJobH>& jobs) {
+    const ConvGeom& g = c.g;
+    if (g.smallc()) return;                       // stem: strided gather, launched separately
+    const float* w = (const float*)params[c.w_idx];
+    const int T = g.KH * g.KW;
+    bf16_t* wf = (bf16_t*)(wpack + c.wf_off);
+    bf16_t* wb = (bf16_t*)(wpack + c.wb_off);
+    if (!g.transposed) {
+        jobs.push_back(PackJobH{w, wf, 0, 0, 0, 0, (long long)g.Co * T * g.Ci});
+        if (with_bwd) jobs.push_back(PackJobH{w, wb, g.Co, T, g.Ci, 1, 0});
+    } else {
+        jobs.push_back(PackJobH{w, wf, g.Ci, T, g.Co, 1, 0});
+        if (with_bwd) jobs.push_back(PackJobH{w, wb, 0, 0, 0, 0, (long long)g.Ci * T * g.Co});
+    }
+}
+int build_pack_table(Net& n, Net::PackTab& tab, const void* const* params, char* wpack, bool with_bwd) {
+    std::vector<PackJobH> jobs;
+    for (auto& b : n.blocks) {
+        add_pack_jobs(n, b.c1, params, wpack, with_bwd, jobs);
+        add_pack_jobs(n, b.c2, params, wpack, with_bwd, jobs);
+        add_pack_jobs(n, b.c3, params, wpack, with_bwd, jobs);
+        if (b.has_ds) add_pack_jobs(n, b.cd, params, wpack, with_bwd, jobs);
+    }
+    for (int i = 0; i < 3; ++i) add_pack_jobs(n, n.up[i], params, wpack, with_bwd, jobs);
+    jobs.push_back(PackJobH{(const float*)params[n.head.w_idx], (bf16_t*)(wpack + n.head.wf_off), 0, 0, 0, 0, (long long)n.K * 256});
+    std::vector<int> bj, bs;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        const PackJobH& q = jobs[j];
+        const long nb = q.kind == 0 ? (long)((q.n + 8191) / 8192) : (long)((q.A + 31) / 32) * ((q.B + 31) / 32) * q.T;
+        for (long k = 0; k < nb; ++k) { bj.push_back((int)j); bs.push_back((int)k); }
+    }
+    if (tab.jobs) { (void)hipFree(tab.jobs); (void)hipFree(tab.blk_job); (void)hipFree(tab.blk_sub); }
+    if (hipMalloc(&tab.jobs, jobs.size() * sizeof(PackJobH)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMalloc((void**)&tab.blk_job, bj.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMalloc((void**)&tab.blk_sub, bs.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMemcpy(tab.jobs, jobs.data(), jobs.size() * sizeof(PackJobH), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMemcpy(tab.blk_job, bj.data(), bj.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMemcpy(tab.blk_sub, bs.data(), bs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    tab.nblocks = (int)bj.size();
+    tab.key0 = params[0]; tab.key1 = params[n.n_params - 1]; tab.keyw = wpack;
+    return UDAPOSE_OK;
+}
+}  // namespace
+
 int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wpack_, int with_bwd) {
     Net& n = *(Net*)h;
     char* wpack = (char*)wpack_;
+    if (!n.f32) {
+        // bf16: ONE launch casts / transposes every weight (table built on first use for these pointers: not capturable,
+        // so the first call must happen outside graph capture - the warm-up step does that)
+        Net::PackTab& tab = with_bwd ? n.pack_all : n.pack_fwd;
+        if (!tab.jobs || tab.key0 != params[0] || tab.key1 != params[n.n_params - 1] || tab.keyw != (const void*)wpack)
+            CK(build_pack_table(n, tab, params, wpack, with_bwd != 0));
+        CK(pack_conv(s, n, n.stem, params, wpack, false));
+        CK(pw_pack_multi(s, tab.jobs, tab.blk_job, tab.blk_sub, tab.nblocks));
+        if (with_bwd)   // head dgrad pack [256][1][64]: wb[ci][k] = w[k][ci], zero for k >= K
+            CK(pw_pack_strided(s, (const float*)params[n.head.w_idx], (bf16_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
+        return UDAPOSE_OK;
+    }
     CK(pack_conv(s, n, n.stem, params, wpack, false));
     for (auto& b : n.blocks) {
         CK(pack_conv(s, n, b.c1, params, wpack, with_bwd));

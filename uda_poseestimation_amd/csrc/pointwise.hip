@@ -91,6 +91,37 @@ __global__ void transpose_cast_k(const float* __restrict__ src, D* __restrict__ 
         if (a < A && b < B) dst[((size_t)b * T + t) * A + a] = (D)tile[tx][r];
     }
 }
+// One launch packs every weight of a network: a job is either a contiguous cast (T == 0: n elements) or a per-tap
+// transpose [A][T][B] fp32 -> [B][T][A] bf16; block b works on job blk_job[b], sub-block blk_sub[b].
+struct PackJob { const float* src; bf16_t* dst; int A, T, B, kind; long long n; };
+__global__ void pack_multi_k(const PackJob* __restrict__ jobs, const int* __restrict__ blk_job, const int* __restrict__ blk_sub) {
+    __shared__ float tile[32][33];
+    const PackJob j = jobs[blk_job[blockIdx.x]];
+    const int sub = blk_sub[blockIdx.x];
+    if (j.kind == 0) {
+        const long long base = (long long)sub * 8192;           // 8192 elements per block
+        for (long long i = base + threadIdx.x * 8; i < base + 8192 && i < j.n; i += TPB * 8) {
+            const f32x4 a = *(const f32x4*)(j.src + i), b = *(const f32x4*)(j.src + i + 4);
+            bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+            *(bf16x8*)(j.dst + i) = o;
+        }
+        return;
+    }
+    const int tb = (j.B + 31) / 32, ta = (j.A + 31) / 32;
+    const int t = sub / (ta * tb), rem = sub % (ta * tb);
+    const int a0 = (rem / tb) * 32, b0 = (rem % tb) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, b = b0 + tx;
+        tile[r][tx] = (a < j.A && b < j.B) ? j.src[((size_t)a * j.T + t) * j.B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int b = b0 + r, a = a0 + tx;
+        if (a < j.A && b < j.B) j.dst[((size_t)b * j.T + t) * j.A + a] = (bf16_t)tile[tx][r];
+    }
+}
+
 // generic strided gather with zero padding: dst[a][kh][kwp][bp] bf16 <- src[a*sa + kh*skh + kw*skw + b*sb] (kw<KW, b<B)
 template <typename D>
 __global__ void pack_strided_k(const float* __restrict__ src, D* __restrict__ dst, int A, int KH, int KWp, int KW, int Bp, int B,
@@ -484,6 +515,11 @@ int pw_transpose_cast(hipStream_t s, const float* src, bf16_t* dst, int A, int T
 }
 int pw_transpose_f32(hipStream_t s, const float* src, float* dst, int A, int T, int B) {
     hipLaunchKernelGGL(transpose_cast_k<float>, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
+    return udapose_check_launch();
+}
+int pw_pack_multi(hipStream_t s, const void* jobs, const int* blk_job, const int* blk_sub, int nblocks) {
+    if (nblocks <= 0) return UDAPOSE_OK;
+    hipLaunchKernelGGL(pack_multi_k, dim3(nblocks), dim3(TPB), 0, s, (const PackJob*)jobs, blk_job, blk_sub);
     return udapose_check_launch();
 }
 int pw_pack_strided(hipStream_t s, const float* src, bf16_t* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {

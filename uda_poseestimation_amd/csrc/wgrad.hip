@@ -433,18 +433,18 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
     static const int RT[4] = {128, 64, 64, 32}, CT[4] = {128, 64, 32, 128};
-    // measured (tools/tune_conv.py): 64x64 tiles win except for large weight tensors with a short pixel reduction
-    if (tile == 1 && g_wgrad_tile_override < 0 && Rdim >= 128 && Cdim >= 128 &&
-        (long)((Rdim + 127) / 128) * ((Cdim + 127) / 128) * p.total_taps >= 256)
-        tile = 0;
+    // measured (tools/tune_conv.py, LDS-DMA kernels): 128x128 tiles for multi-tap convs with >= 128 channels on both sides
+    // (3x3 trunk convs, 4x4 deconvs), 64x64 otherwise
+    if (tile == 1 && g_wgrad_tile_override < 0 && Rdim >= 128 && Cdim >= 128 && p.total_taps >= 9) tile = 0;
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
     const bool dma = !smallc && (tile == 0 || tile == 1) && (p.Ci % 64 == 0) && (p.Co % 64 == 0);
     const int ms_total = dma ? (p.M + 63) / 64 : (p.M + 31) / 32;
-    // split the pixel reduction until ~1024 workgroups exist, keeping >= 4 steps per split; every extra split adds one
-    // fp32 atomic pass over the weight tensor (chip-wide atomic rate 1.3 TB/s)
+    // split the pixel reduction until ~512 work-groups exist (2 per CU), keeping >= 16 (128x128) / 4 (64x64) stages per
+    // split; every extra split adds one fp32 atomic pass over the weight tensor (chip-wide atomic rate 1.3 TB/s)
+    const int min_stages = tile == 0 ? 16 : 4;
     int ks = 1;
-    while (tiles * ks < 1024 && ms_total / (ks * 2) >= 4) ks *= 2;
+    while (tiles * ks < 512 && ms_total / (ks * 2) >= min_stages) ks *= 2;
     if (g_wgrad_ksplit_override > 0) { ks = g_wgrad_ksplit_override; while (ks > 1 && ms_total / ks < 1) ks /= 2; }
     p.ksplit = ks;
     p.msteps_per_split = (ms_total + ks - 1) / ks;

@@ -71,6 +71,7 @@ class MeanTeacherTrainer:
         self.style_net, self.recover = style_net, recover
         self.s2t_freq, self.t2s_freq, self.s2t_alpha, self.t2s_alpha = s2t_freq, t2s_freq, s2t_alpha, t2s_alpha
         self.rng = rng if rng is not None else np.random   # the reference draws from the global np.random
+        self._side = None
 
     # ------------------------------------------------------------------ train_human.py:262-302
     def pretrain_step(self, x_s, label_s, weight_s, x_t=None):
@@ -116,11 +117,22 @@ class MeanTeacherTrainer:
             if self.style_net is not None and self.t2s_freq > self.rng.rand():
                 a = self.rng.uniform(*self.t2s_alpha)
                 x_t_teas = [self.style_net(x_t, x_s_ori, a, clamp=self.recover)[2] for x_t in x_t_teas]
+        # The teacher branch (forward + re-warp + confidence inputs) is independent of the student forwards until the
+        # consistency loss: it runs on a second HIP stream so its many short kernels fill the gaps of the student's.
+        main = torch.cuda.current_stream()
+        if self._side is None or self._side.device != x_s.device:
+            self._side = torch.cuda.Stream(device=x_s.device)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
             y_t_teas = [teacher(x_t) for x_t in x_t_teas]
             recons = [warp.warp_chain(y, th) for y, th in zip(y_t_teas, thetas_tea)]
             y_t_tea_recon = recons[0] if len(recons) == 1 else torch.stack(recons).mean(0)
         y_s = student(x_s)
         y_t_stu = student(x_t_stu)          # separate forwards: separate BN statistics per domain
+        main.wait_stream(side)
+        for t in y_t_teas + recons + [y_t_tea_recon]:
+            t.record_stream(main)
         y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
         loss_s = self.criterion(y_s, label_s, weight_s)
         with torch.no_grad():
