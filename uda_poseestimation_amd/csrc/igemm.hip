@@ -19,8 +19,14 @@
 
 namespace {
 
-// 16 bytes of zeros: the source of every padded / out-of-range lane of the LDS-DMA loads
-__device__ u32x4 g_zero16[2];
+// 8 KiB of zeros: the source of every padded / out-of-range lane of the LDS-DMA loads (large enough that a padded lane
+// may add the per-stage channel offset, < Ci * sizeof(T) <= 8 KiB, and still read zeros)
+__device__ u32x4 g_zero16[512];
+
+template <int U> struct IC { static constexpr int value = U; };
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(IC<N - 1>{}); }
+}
 
 // XOR swizzle of the 16-byte chunk index inside a 128-byte LDS row: makes the ds_read_b128 fragment reads (lane l ->
 // row l&15, chunk l>>4) conflict-free (2 rows per 256-byte bank row; derivation in DESIGN.md)
@@ -78,7 +84,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     IgTap* taps_l = (IgTap*)smem;
     char* stage = smem + C::TAP_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases stay scalar
     const int wm = wid / WN, wn = wid % WN;
     // XCD-aware order: each XCD owns a contiguous range of (class, m_tile) so its L2 holds a 1/8 slice of the activations
     const uint32_t tiles = (uint32_t)p.m_tiles * p.n_tiles;
@@ -132,18 +139,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 
     __syncthreads();   // tap table visible
 
-    // Fast path (zero padding, no upsample, Ci >= 64): everything that depends on the row is hoisted out of the K loop.
-    // Per row: element offset of its (tap 0,0) pixel and a bit mask of the taps that fall inside the image; per K step
-    // only a wave-uniform offset is added.  (The K loop is otherwise issue-bound on address arithmetic: measured 8
-    // VALU + 7 SALU instructions per MFMA before this.)
+    // Fast path (zero padding, no upsample, Ci >= one stage): everything that depends on the row is hoisted out of the K
+    // loop.  Per row: the byte pointer of its (tap 0,0) pixel and a bit mask of the taps that fall inside the image.  When
+    // the tap changes (every Ci/BKE stages) the per-row source pointers are re-selected once (pointer or zero page); inside
+    // a tap every stage only adds the wave-uniform channel offset.  The zero page is 8 KiB, so a padded lane may add the
+    // channel offset as well and still read zeros.  (The K loop was issue-bound on bookkeeping: 69 VALU + 59 SALU
+    // instructions per 8 MFMAs, profiles/r1_pmc_notes.md.)
     const bool fast = !smallc && !reflect && !up;
-    long long a_base[A_PW];
+    const char* a_ptr0[A_PW];
     unsigned long long a_mask[A_PW];
-    long long b_base[B_PW];
+    const char* b_ptr0[B_PW];
+    const char* a_cur[A_PW];
+    const char* b_cur[B_PW];
     if (fast) {
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
-            a_base[i] = ((long long)a_nb[i] + (long long)a_hi0[i] * p.Wi + a_wi0[i]) * p.Ci + a_lc[i] * EPC;
+            a_ptr0[i] = (const char*)(px + (((long long)a_nb[i] + (long long)a_hi0[i] * p.Wi + a_wi0[i]) * p.Ci + a_lc[i] * EPC));
             unsigned long long mk = 0ull;
             for (int t = 0; t < cls.ntaps; ++t) {
                 const IgTap tt = taps_l[t];
@@ -151,31 +162,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
                 if (a_ok[i] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) mk |= 1ull << t;
             }
             a_mask[i] = mk;
+            a_cur[i] = zsrc;
         }
 #pragma unroll
-        for (int i = 0; i < B_PW; ++i) b_base[i] = (long long)b_row[i] + b_lc[i] * EPC;
+        for (int i = 0; i < B_PW; ++i) { b_ptr0[i] = (const char*)(pw + ((long long)b_row[i] + b_lc[i] * EPC)); b_cur[i] = zsrc; }
     }
+    auto select_tap = [&]() __attribute__((always_inline)) {      // per-row source pointers of tap `tap_cur` (wave-uniform tap)
+        const IgTap t = taps_l[tap_cur];
+        const long long ab = (((long long)t.dy * p.Wi + t.dx) * p.Ci) * (long long)sizeof(T);
+        const long long bb = ((long long)t.widx * p.Ci) * (long long)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) a_cur[i] = ((a_mask[i] >> tap_cur) & 1ull) ? a_ptr0[i] + ab : zsrc;
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) b_cur[i] = b_ok[i] ? b_ptr0[i] + bb : zsrc;
+    };
 
-    auto issue_stage = [&](int buf) {
-        char* A = stage + buf * C::STAGE1;
+    // issue the LDS-DMA loads of the next K stage into ring buffer UB (compile-time: LDS addresses fold to constants)
+    auto issue_stage = [&](auto ub) __attribute__((always_inline)) {
+        constexpr int UB = decltype(ub)::value;
+        char* A = stage + UB * C::STAGE1;
         char* B = A + BM * 128;
         if (fast) {
-            const IgTap t = taps_l[tap_cur];                                 // wave-uniform
-            const long long aoff = ((long long)t.dy * p.Wi + t.dx) * p.Ci + c0_cur;
-            const long long boff = (long long)t.widx * p.Ci + c0_cur;
+            if (c0_cur == 0) select_tap();
+            const long long cb = (long long)c0_cur * (long long)sizeof(T);
 #pragma unroll
-            for (int i = 0; i < A_PW; ++i) {
-                const bool ok = (a_mask[i] >> tap_cur) & 1ull;
-                const char* src = ok ? (const char*)(px + (a_base[i] + aoff)) : zsrc;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            for (int i = 0; i < A_PW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_cur[i] + cb),
                                                  (__attribute__((address_space(3))) void*)(A + (i * 4 + wid) * 1024), 16, 0, 0);
-            }
 #pragma unroll
-            for (int i = 0; i < B_PW; ++i) {
-                const char* src = b_ok[i] ? (const char*)(pw + (b_base[i] + boff)) : zsrc;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            for (int i = 0; i < B_PW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_cur[i] + cb),
                                                  (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
-            }
             c0_cur += BKE;
             if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; }
             return;
@@ -213,68 +230,76 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // prologue: NS-1 stages in flight (empty stages are still issued from the zero page so that the counts stay exact)
-    int issued = 0;
+    // per-lane fragment offsets inside a stage (row * 128 + swizzled chunk), computed once
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int a_fo[MT][2], b_fo[NT][2];
 #pragma unroll
-    for (int st = 0; st < NS - 1; ++st) {
-        if (st < nsteps) { issue_stage(st); ++issued; }
+    for (int i = 0; i < MT; ++i) {
+        const int r = wm * TM + i * 16 + frow;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) a_fo[i][k] = r * 128 + (((F32 ? 2 * fchunk + k : fchunk + 4 * k) ^ swz(r)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int r = wn * TN + j * 16 + frow;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) b_fo[j][k] = BM * 128 + r * 128 + (((F32 ? 2 * fchunk + k : fchunk + 4 * k) ^ swz(r)) << 4);
     }
 
-    const int frow = lane & 15, fchunk = lane >> 4;
-    for (int st = 0; st < nsteps; ++st) {
-        const int buf = st % NS;
-        // stage st must have landed: at most (issued - st - 1) younger stages may still be in flight
-        if (issued - st - 1 >= NS - 2) wait_vmcnt<LPS*(NS - 2)>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                  // every wave's share of stage st is in LDS; buffer (st-1)%NS is free
-        if (issued < nsteps) { issue_stage(issued % NS); ++issued; }
-        const char* A = stage + buf * C::STAGE1;
-        const char* B = A + BM * 128;
-        if constexpr (!F32) {
+    // prologue: NS-1 stages in flight
+    int issued = 0;
+    static_for<NS - 1>([&](auto u) __attribute__((always_inline)) {
+        if (decltype(u)::value < nsteps) { issue_stage(u); ++issued; }
+    });
+
+    for (int st0 = 0; st0 < nsteps; st0 += NS) {
+        static_for<NS>([&](auto u) __attribute__((always_inline)) {
+            constexpr int U = decltype(u)::value;
+            const int st = st0 + U;
+            if (st < nsteps) {
+                // stage st must have landed: at most (issued - st - 1) younger stages may still be in flight
+                if (issued - st - 1 >= NS - 2) wait_vmcnt<LPS*(NS - 2)>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();          // every wave's share of stage st is in LDS; buffer (st-1)%NS is free
+                if (issued < nsteps) { issue_stage(IC<(U + NS - 1) % NS>{}); ++issued; }
+                const char* S = stage + U * C::STAGE1;
+                if constexpr (!F32) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[MT], bfr[NT];
+                    for (int kk = 0; kk < 2; ++kk) {
+                        bf16x8 af[MT], bfr[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int r = wm * TM + i * 16 + frow;
-                    af[i] = *(const bf16x8*)(A + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
-                }
+                        for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(S + a_fo[i][kk]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int r = wn * TN + j * 16 + frow;
-                    bfr[j] = *(const bf16x8*)(B + r * 128 + (((fchunk + 4 * kk) ^ swz(r)) << 4));
-                }
+                        for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_fo[j][kk]);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                        for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-            // fp32: lane group q = lane>>4 owns k = 8q..8q+7 of the 32-deep stage (two 16-byte chunks of its row); sub-step
-            // e feeds element e of both operands to one exact 16x16x4 MFMA (the k <-> lane-group assignment is the same for
-            // A and B, so the sum over k is unchanged)
-            f32x4 al[MT][2], bl[NT][2];
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    }
+                } else {
+                    // fp32: lane group q = lane>>4 owns k = 8q..8q+7 of the 32-deep stage (two 16-byte chunks of its row);
+                    // sub-step e feeds element e of both operands to one exact 16x16x4 MFMA (the k <-> lane-group
+                    // assignment is the same for A and B, so the sum over k is unchanged)
+                    f32x4 al[MT][2], bl[NT][2];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int r = wm * TM + i * 16 + frow;
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) al[i][h] = *(const f32x4*)(A + r * 128 + (((2 * fchunk + h) ^ swz(r)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int r = wn * TN + j * 16 + frow;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) bl[j][h] = *(const f32x4*)(B + r * 128 + (((2 * fchunk + h) ^ swz(r)) << 4));
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
+                        for (int h = 0; h < 2; ++h) al[i][h] = *(const f32x4*)(S + a_fo[i][h]);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[i][e >> 2][e & 3], bl[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
-        }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) bl[j][h] = *(const f32x4*)(S + b_fo[j][h]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[i][e >> 2][e & 3], bl[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
+                }
+            }
+        });
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // all LDS reads of the ring are done before the epilogue reuses it
@@ -404,15 +429,15 @@ int launch_cfg(IgParams& p, hipStream_t stream) {
 
 int g_igemm_tile_override = -1;   // debug/tuning hook (udapose_debug_set_tiles)
 
-// Tile selection (measured on MI355X over every PoseResNet-101 layer shape at N=32, tools/tune_conv.py): take the
-// largest tile that still yields >= 512 workgroups (2 per CU); 64x64 tiles use the 4-deep ring when K is long.
+// Tile selection (measured on MI355X over every PoseResNet-101 layer shape at N=32, tools/tune_conv.py): 128x64 tiles
+// when they still yield >= 512 work-groups (2 per CU), else 64x64 (4-deep ring when K is long).  128x128 tiles lose to
+// 128x64 everywhere since the K-loop rewrite (174 VGPRs -> 2 waves/SIMD); they stay instantiated for tuning only.
 // ids: 0 = 128x128 NS3, 1 = 128x64 NS3, 2 = 64x64 NS4, 3 = 128x32 NS3, 4 = 128x128 NS2, 5 = 64x64 NS2, 6 = 128x64 NS2
 int igemm_pick_tile(int M, int Co, int nclass, int K) {
     if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
     if (Co <= 32) return 3;
-    auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((Co + bn - 1) / bn) * nclass; };
-    if (Co > 64 && blocks(128, 128) >= 512) return 4;
-    if (blocks(128, 64) >= 512) return 6;
+    const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
+    if (b12864 >= 512) return 6;
     return K >= 1024 ? 2 : 5;
 }
 
