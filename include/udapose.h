@@ -156,6 +156,10 @@ int udapose_adain(void* stream, const void* content, const void* style, void* ou
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage,
                            int backward);
 
+/* occlusion paste (train_human.py:399-409): for image i of img[n][C][H][W] (fp32) and boxes[i] = (r0,r1,c0,c1,rs,cs):
+ * img[i][:, r0:r1, c0:c1] = img[i][:, rs:rs+(r1-r0), cs:cs+(c1-c0)] (source read completely before the write). */
+int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems);
+
 /* ---------------------------------------------------------------- per-launch timing of the MFMA kernels (bench.py roofline)
  * HIP events are recorded on the launch stream around every convolution launch between begin and end.
  * h_out9 (host): for kind in (fprop, dgrad, wgrad): launches, total milliseconds, total algorithmic FLOPs. */

@@ -41,7 +41,32 @@ __global__ void warp_chain_k(const float* __restrict__ src, float* __restrict__ 
         }
     }
 }
+// Occlusion paste (train_human.py:409): img[:, r0:r1, c0:c1] = img[:, rs:rs+(r1-r0), cs:cs+(c1-c0)] for each listed image,
+// reading the whole source patch before writing (one block per image; patches are at most 20x20x3 = 1200 values).
+__global__ void patch_paste_k(float* __restrict__ img, const int* __restrict__ boxes, int C, int H, int W) {
+    __shared__ float buf[4096];
+    const int* b = boxes + blockIdx.x * 6;          // r0, r1, c0, c1, rs, cs
+    const int r0 = b[0], r1 = b[1], c0 = b[2], c1 = b[3], rs = b[4], cs = b[5];
+    const int ph = r1 - r0, pw = c1 - c0, n = C * ph * pw;
+    float* base = img + (size_t)blockIdx.x * C * H * W;
+    for (int i = threadIdx.x; i < n; i += TPB) {
+        const int c = i / (ph * pw), r = (i / pw) % ph, q = i % pw;
+        buf[i] = base[((size_t)c * H + rs + r) * W + cs + q];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += TPB) {
+        const int c = i / (ph * pw), r = (i / pw) % ph, q = i % pw;
+        base[((size_t)c * H + r0 + r) * W + c0 + q] = buf[i];
+    }
+}
 }  // namespace
+
+int patch_paste(hipStream_t s, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems) {
+    if (n <= 0) return UDAPOSE_OK;
+    if (max_patch_elems > 4096) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(patch_paste_k, dim3(n), dim3(TPB), 0, s, img, boxes, C, H, W);
+    return udapose_check_launch();
+}
 
 int affine_warp_chain(hipStream_t s, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage, int backward) {
     if (nstage < 1 || nstage > 8) return UDAPOSE_ERR_ARG;

@@ -30,6 +30,7 @@ int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, c
             int, int, float);
 int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, float, float, float*);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
+int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
 extern int g_igemm_tile_override, g_wgrad_tile_override, g_wgrad_ksplit_override;
 void prof_begin();
 int prof_end(double*);
@@ -180,6 +181,9 @@ int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, 
     return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, stats_out);
 }
 
+int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems) {
+    return patch_paste(S(stream), img, boxes, n, C, H, W, max_patch_elems);
+}
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage, int backward) {
     return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);
 }

@@ -57,7 +57,7 @@ def gather_activates(act):
 class MeanTeacherTrainer:
     def __init__(self, student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=2, image_size=256,
                  heatmap_size=64, use_sgd=False, style_net=None, recover=None, s2t_freq=0.5, t2s_freq=0.5, s2t_alpha=(0.0, 1.0),
-                 t2s_alpha=(0.0, 1.0), rng=None):
+                 t2s_alpha=(0.0, 1.0), rng=None, occlude_rate=-1.0, occlude_thresh=0.9, occlude_size=10, image_px=None):
         self.student, self.teacher = student, teacher
         self.criterion, self.con_criterion = JointsMSELoss(), ConsLoss()
         if use_sgd:
@@ -72,6 +72,10 @@ class MeanTeacherTrainer:
         self.s2t_freq, self.t2s_freq, self.s2t_alpha, self.t2s_alpha = s2t_freq, t2s_freq, s2t_alpha, t2s_alpha
         self.rng = rng if rng is not None else np.random   # the reference draws from the global np.random
         self._side = None
+        # adaptive key-point occlusion (train_human.py:374-412); rate <= -1 disables it like `--occlude-rate -1`
+        self.occlude_rate, self.occlude_thresh, self.occlude_size = occlude_rate, occlude_thresh, occlude_size
+        self.image_px = image_px if image_px is not None else image_size
+        self._aug_stu = None
 
     # ------------------------------------------------------------------ train_human.py:262-302
     def pretrain_step(self, x_s, label_s, weight_s, x_t=None):
@@ -94,6 +98,7 @@ class MeanTeacherTrainer:
             x_t_teas, aug_params_tea = [x_t_teas], [aug_params_tea]
         n, dev = x_t_stu.shape[0], x_t_stu.device
         theta_stu = warp.recon_thetas(aug_param_stu, n, self.ratio, dev)
+        self._aug_stu = aug_param_stu
         thetas_tea = [warp.recon_thetas(ap, n, self.ratio, dev) for ap in aug_params_tea]
         out = self._forward_backward(x_s, label_s, weight_s, x_t_stu, list(x_t_teas), theta_stu, thetas_tea)
         self.sync()
@@ -128,11 +133,20 @@ class MeanTeacherTrainer:
             y_t_teas = [teacher(x_t) for x_t in x_t_teas]
             recons = [warp.warp_chain(y, th) for y, th in zip(y_t_teas, thetas_tea)]
             y_t_tea_recon = recons[0] if len(recons) == 1 else torch.stack(recons).mean(0)
-        y_s = student(x_s)
-        y_t_stu = student(x_t_stu)          # separate forwards: separate BN statistics per domain
+        occl = self.occlude_rate > -1 and self._aug_stu is not None
+        if not occl:
+            y_s = student(x_s)
+            y_t_stu = student(x_t_stu)      # separate forwards: separate BN statistics per domain
         main.wait_stream(side)
         for t in y_t_teas + recons + [y_t_tea_recon]:
             t.record_stream(main)
+        if occl:
+            # the occlusion needs the teacher's re-warped heat-maps first (one small D2H of confidences, as in the reference)
+            with torch.no_grad():
+                x_t_stu, _ = warp.occlude_keypoints(x_t_stu, y_t_tea_recon, self._aug_stu, self.ratio, self.image_px, self.occlude_rate,
+                                                   self.occlude_thresh, self.occlude_size, self.rng)
+            y_s = student(x_s)
+            y_t_stu = student(x_t_stu)
         y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
         loss_s = self.criterion(y_s, label_s, weight_s)
         with torch.no_grad():
@@ -158,7 +172,8 @@ class GraphedTrainStep:
     step and therefore stay on the eager path."""
 
     def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2):
-        assert trainer.style_net is None, "the graphed step covers the style-free configuration"
+        assert trainer.style_net is None and trainer.occlude_rate <= -1, \
+            "the graphed step covers the style-free, occlusion-free configuration (both draw host random numbers per step)"
         self.t = trainer
         dev = x_s.device
         n = x_s.shape[0]

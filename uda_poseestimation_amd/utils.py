@@ -72,6 +72,19 @@ def _bump_versions(params):
             p.detach()[:0].zero_()
 
 
+def get_max_preds_torch_raw(batch_heatmaps):
+    """(x = idx % W, y = idx // W) [B,K,2] and the maxima [B,K,1] WITHOUT the max>0 masking: what the occlusion code
+    computes inline with amax / view().argmax(-1) (train_human.py:378-381)."""
+    _hip.require_cuda(batch_heatmaps)
+    hm = batch_heatmaps.detach().float().contiguous()
+    B, K, H, W = hm.shape
+    idx = torch.empty(B, K, dtype=torch.int32, device=hm.device)
+    maxv = torch.empty(B, K, 1, dtype=torch.float32, device=hm.device)
+    check(lib().udapose_heatmap_argmax(_hip.stream(), ptr(hm), B * K, H, W, ptr(maxv), ptr(idx), None, None, None, 0), "heatmap_argmax")
+    idx = idx.long()
+    return torch.stack([idx % W, idx // W], -1), maxv
+
+
 def get_max_preds_torch(batch_heatmaps):
     """utils.py:54-75: (preds [B,K,2] float (x,y) zeroed where max<=0, maxvals [B,K,1])."""
     _hip.require_cuda(batch_heatmaps)

@@ -106,3 +106,52 @@ def warp_chain(x, theta):
 def recon_heatmaps(y, aug_param, ratio):
     """The loop's heat-map re-warp (train_human.py:361-372 / 418-423) for the whole batch."""
     return warp_chain(y, recon_thetas(aug_param, y.shape[0], ratio, y.device))
+
+
+def occlude_keypoints(x_t_stu, y_t_tea_recon, aug_param_stu, ratio, image_size, occlude_rate, occlude_thresh, occlude_size, rng):
+    """Adaptive key-point occlusion of the student's target images (train_human.py:374-412), batched on the device.
+
+    Host side (exactly the reference's draws, in its order, from `rng` = np.random): per sample with at least one confidence
+    >= thresh: rand() <= rate ?, choice(candidates), randint (rows), randint (cols).  The confidences / arg-max positions
+    come back to the host once (the reference moves them with .cpu() as well).  Device side: the selected images are
+    re-warped to the canonical frame (three nearest warps, with the reference's translate/ratio quirk), a random patch
+    of the same image is pasted over the chosen key-point, and one inverse warp takes them back.
+    Naming follows the reference's index math, not its variable names: `left/right` slice ROWS, `upper/bottom` slice COLUMNS.
+    """
+    import numpy as np
+    from . import utils as U
+    B, K, h, w = y_t_tea_recon.shape
+    preds, conf = U.get_max_preds_torch_raw(y_t_tea_recon)          # un-masked positions, like view().argmax(-1)
+    conf_np = conf.reshape(B, K).cpu().numpy()
+    pos_np = preds.cpu().numpy().astype(np.int64)                   # [B,K,2] = (x, y)
+    table = conf_np >= occlude_thresh
+    angle, (tx, ty), (sx, sy), scale = aug_param_stu
+    a_, tx_, ty_, sx_, sy_, sc_ = (_as_list(v, B) for v in (angle, tx, ty, sx, sy, scale))
+    sel, boxes = [], []
+    for b in range(B):
+        if table[b].sum() > 0 and rng.rand() <= occlude_rate:
+            cand = np.arange(0, K)[table[b]]
+            c = rng.choice(cand)
+            position = (pos_np[b, c] * ratio).astype(int)
+            left, right = max(position[1] - occlude_size, 0), min(position[1] + occlude_size, image_size)
+            upper, bottom = max(position[0] - occlude_size, 0), min(position[0] + occlude_size, image_size)
+            left_src = rng.randint(image_size - (right - left) + 1)
+            upper_src = rng.randint(image_size - (bottom - upper) + 1)
+            sel.append(b)
+            boxes.append([left, right, upper, bottom, left_src, upper_src])
+    if not sel:
+        return x_t_stu, sel
+    dev = x_t_stu.device
+    idx = torch.tensor(sel, device=dev)
+    sub = [[v[i] for i in sel] for v in (a_, tx_, ty_, sx_, sy_, sc_)]
+    n = len(sel)
+    fwd = recon_thetas([sub[0], [sub[1], sub[2]], [sub[3], sub[4]], sub[5]], n, ratio, dev)
+    back = single_thetas([-v for v in sub[0]], ([-v / ratio for v in sub[1]], [-v / ratio for v in sub[2]]), [1.0 / v for v in sub[5]],
+                         ([-v for v in sub[3]], [-v for v in sub[4]]), n, dev)
+    temp = warp_chain(x_t_stu.index_select(0, idx).float().contiguous(), fwd).contiguous()
+    bx = torch.tensor(boxes, dtype=torch.int32, device=dev)
+    maxel = int(max((b[1] - b[0]) * (b[3] - b[2]) for b in boxes)) * temp.shape[1]
+    check(lib().udapose_patch_paste(_hip.stream(), ptr(temp), ptr(bx), n, temp.shape[1], temp.shape[2], temp.shape[3], maxel), "patch_paste")
+    out = x_t_stu.clone()
+    out.index_copy_(0, idx, warp_chain(temp, back).to(x_t_stu.dtype))
+    return out, sel
