@@ -49,6 +49,8 @@ _SIGS = {
     "udapose_net_out_shape": (None, [vp, vp]),
     "udapose_net_pack_weights": (ci, [vp, vp, vp, vp, ci]),
     "udapose_net_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf]),
+    "udapose_net_apply_running": (ci, [vp, vp, vp, vp, cf]),
+    "udapose_axpy_f32": (ci, [vp, vp, vp, sz]),
     "udapose_net_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf]),
     "udapose_joints_mse_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),
     "udapose_joints_mse_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),

@@ -32,6 +32,8 @@ int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, i
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
 extern int g_igemm_tile_override, g_wgrad_tile_override, g_wgrad_ksplit_override;
+int net_apply_running(void*, hipStream_t, const void*, void* const*, float);
+int pw_axpy(hipStream_t, float*, const float*, size_t);
 void prof_begin();
 int prof_end(double*);
 void* net_create(const int layers[4], int K, int N, int H, int W, int f32);
@@ -134,6 +136,10 @@ int udapose_net_forward(udapose_net_t n, void* stream, const float* x, const voi
                         void* ws, float* out, int training, float momentum) {
     return net_forward(n, S(stream), x, params, buffers, wpack, act, ws, out, training, momentum);
 }
+int udapose_net_apply_running(udapose_net_t n, void* stream, const void* act, void* const* buffers, float momentum) {
+    return net_apply_running(n, S(stream), act, buffers, momentum);
+}
+int udapose_axpy_f32(void* stream, float* y, const float* x, size_t n) { return pw_axpy(S(stream), y, x, n); }
 int udapose_net_backward(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act, void* ws,
                          void* const* grads, float beta) {
     return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta);

@@ -28,6 +28,7 @@ int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
+int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
 int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
@@ -57,7 +58,7 @@ struct BnL {
     int C = 0;
     int g_idx = -1, b_idx = -1;             // parameter indices
     int rm_idx = -1, rv_idx = -1, nbt_idx = -1;   // buffer indices
-    size_t save_off = 0;    // fp32 [2][C] saved mean / invstd in the arena
+    size_t save_off = 0;    // fp32 [3][C] saved mean / invstd / unbiased var in the arena
     size_t z_off = 0;       // post-BN(-ReLU) output
     size_t npix = 0;
 };
@@ -71,6 +72,7 @@ struct Block {
 
 struct Net {
     int layers[4], K, N, H, W;
+    int update_running = 1; // per-call: 0 = leave the BN running statistics alone (deferred, see net_apply_running)
     int f32 = 0;            // 1: fp32 storage + exact fp32 MFMA (forward only: the reference's teacher / validate() precision)
     size_t es = 2;          // bytes per activation element
     int n_params = 0, n_buffers = 0;
@@ -115,7 +117,7 @@ void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true) {
     b.g_idx = n.n_params++; n.param_numel.push_back(C);
     b.b_idx = n.n_params++; n.param_numel.push_back(C);
     b.rm_idx = n.n_buffers++; b.rv_idx = n.n_buffers++; b.nbt_idx = n.n_buffers++;
-    b.save_off = act_alloc(n, (size_t)2 * C * 4);
+    b.save_off = act_alloc(n, (size_t)3 * C * 4);
     b.npix = npix;
     if (alloc_z) b.z_off = act_alloc(n, npix * C * n.es);
 }
@@ -238,6 +240,7 @@ int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* pa
 
 int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, void* const* buffers, const char* wpack,
                 char* act, char* ws, int training, float momentum, const bf16_t* res, int relu) {
+    const bool upd = n.update_running != 0;
     ConvEpilogue e;
     float* slab = (float*)(ws + n.ws_slab);
     float* scale = (float*)(ws + n.ws_coef);
@@ -250,8 +253,9 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
     if (training)
-        CK(pw_bn_finalize(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, (float*)buffers[b.rm_idx], (float*)buffers[b.rv_idx],
-                          (long long*)buffers[b.nbt_idx], momentum, 1e-5f, scale, shift, save, save + b.C));
+        CK(pw_bn_finalize(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, upd ? (float*)buffers[b.rm_idx] : nullptr,
+                          upd ? (float*)buffers[b.rv_idx] : nullptr, upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, scale, shift,
+                          save, save + b.C));
     else
         CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
     if (n.f32)
@@ -354,6 +358,8 @@ int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wp
 int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* params, void* const* buffers, const void* wpack_, void* act_, void* ws_,
                 float* out_nchw, int training, float momentum) {
     Net& n = *(Net*)h;
+    n.update_running = (training & 2) ? 0 : 1;      // bit 1 of `training`: defer the running-statistics update
+    training &= 1;
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
@@ -485,5 +491,24 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         if (hipMemsetAsync(grads[n.fc_b_idx], 0, (size_t)1000 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }
+    return UDAPOSE_OK;
+}
+
+// Apply the running-statistics update (momentum form, counter += 1) of every BN layer from the batch statistics saved in
+// `act` by a forward that ran with the update deferred (training | 2): keeps the reference's update ORDER when two
+// forwards of one module run concurrently on different streams.
+int net_apply_running(void* h, hipStream_t s, const void* act_, void* const* buffers, float momentum) {
+    Net& n = *(Net*)h;
+    const char* act = (const char*)act_;
+    auto one = [&](const BnL& b) {
+        return pw_bn_running_update(s, (const float*)(act + b.save_off), b.C, (float*)buffers[b.rm_idx], (float*)buffers[b.rv_idx],
+                                    (long long*)buffers[b.nbt_idx], momentum);
+    };
+    CK(one(n.stem_bn));
+    for (auto& b : n.blocks) {
+        CK(one(b.b1)); CK(one(b.b2)); CK(one(b.b3));
+        if (b.has_ds) CK(one(b.bd));
+    }
+    for (int i = 0; i < 3; ++i) CK(one(n.up_bn[i]));
     return UDAPOSE_OK;
 }

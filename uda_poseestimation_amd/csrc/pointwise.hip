@@ -206,10 +206,30 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_k(const float* __restrict__
     shift[c] = beta[c] - (float)mean * sc;
     save_mean[c] = (float)mean;
     save_invstd[c] = invstd;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    save_invstd[C + c] = (float)unb;          // third saved vector: unbiased variance (deferred running-stat update)
     if (running_mean) {
-        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+// deferred running-statistics update of one BN layer from its saved batch statistics [3][C] (mean, invstd, unbiased var):
+// used when a forward ran concurrently with another forward of the same module and must not race on the buffers
+__global__ void bn_running_update_k(const float* __restrict__ save, int C, float* __restrict__ rm, float* __restrict__ rv,
+                                    long long* __restrict__ nbt, float momentum) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * save[c];
+    rv[c] = (1.f - momentum) * rv[c] + momentum * save[2 * C + c];
+}
+// y += x over n floats (n % 4 == 0): sum of the two per-pass flat gradient buffers
+__global__ void axpy_k(float* __restrict__ y, const float* __restrict__ x, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (size_t)gridDim.x * TPB) {
+        f32x4 a = *(f32x4*)(y + i * 4);
+        const f32x4 b = *(const f32x4*)(x + i * 4);
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        *(f32x4*)(y + i * 4) = a;
     }
 }
 // eval mode: scale/shift from running statistics
@@ -538,6 +558,15 @@ int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double cou
                    long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
     hipLaunchKernelGGL(bn_finalize_k, dim3((C + 31) / 32), dim3(FIN_T), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
                        save_mean, save_invstd);
+    return udapose_check_launch();
+}
+int pw_bn_running_update(hipStream_t s, const float* save, int C, float* rm, float* rv, long long* nbt, float momentum) {
+    hipLaunchKernelGGL(bn_running_update_k, dim3(nblk(C)), dim3(TPB), 0, s, save, C, rm, rv, nbt, momentum);
+    return udapose_check_launch();
+}
+int pw_axpy(hipStream_t s, float* y, const float* x, size_t n) {
+    if (n % 4) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(axpy_k, dim3(grid_for(n / 4)), dim3(TPB), 0, s, y, x, n / 4);
     return udapose_check_launch();
 }
 int pw_bn_eval_coeff(hipStream_t s, int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift) {

@@ -75,10 +75,10 @@ class _NetHandle:
 
 class _PoseNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, net, need_grad, *params):
+    def forward(ctx, x, net, need_grad, defer_bn, *params):
         # (grad mode is always off inside Function.forward: the caller decides whether backward state is kept)
-        out, act, hd = net._run_forward(x, save=need_grad)
-        ctx.net, ctx.act, ctx.hd = net, act, hd
+        out, act, hd, ws = net._run_forward(x, save=need_grad, defer_bn=defer_bn)
+        ctx.net, ctx.act, ctx.hd, ctx.ws = net, act, hd, ws
         ctx.nparams = len(params)
         return out
 
@@ -87,10 +87,10 @@ class _PoseNetFn(torch.autograd.Function):
         net = ctx.net
         if ctx.act is None:
             raise RuntimeError("PoseResNet backward without saved activations (forward ran without grad, or backward ran twice)")
-        net._run_backward(dout, ctx.act, ctx.hd)
-        ctx.act = None
+        net._run_backward(dout, ctx.act, ctx.hd, ctx.ws)
+        ctx.act = ctx.ws = None
         # parameter gradients are accumulated straight into p.grad (views of the module's flat gradient buffer)
-        return (None, None, None) + (None,) * ctx.nparams
+        return (None, None, None, None) + (None,) * ctx.nparams
 
 
 class PoseResNet(nn.Module):
@@ -115,6 +115,9 @@ class PoseResNet(nn.Module):
         self._handles = {}
         self._ptr_cache = None
         self._flat_grad = None
+        self._flat_grad2 = None       # second per-pass gradient buffer (backward passes running on different streams)
+        self._grad_state = None       # (stream of the first backward of this step, pending second-buffer sum?)
+        self._deferred_bn = []        # forwards whose BN running-statistics update is still to be applied, in call order
         self._to_channels_last()
 
     # ------------------------------------------------------------------ layout / pointer bookkeeping
@@ -130,6 +133,9 @@ class PoseResNet(nn.Module):
         self._to_channels_last()
         self._ptr_cache = None
         self._flat_grad = None
+        self._flat_grad2 = None
+        self._grad_state = None
+        self._deferred_bn = []
         self._handles = {}
         return r
 
@@ -186,7 +192,21 @@ class PoseResNet(nn.Module):
         return hd
 
     # ------------------------------------------------------------------ executor calls
-    def _run_forward(self, x, save):
+    def prepare(self, x):
+        """Create the executor plan for x's shape and refresh the bf16 weight packs on the current stream (so that forwards
+        launched afterwards on OTHER streams only need to wait for this point)."""
+        hd = self._handle(x)
+        pa, ba, params = self._pointers()
+        self._pack(hd, pa, params, need_bwd=torch.is_grad_enabled() and any(p.requires_grad for p in params))
+        return hd
+
+    def _pack(self, hd, pa, params, need_bwd):
+        version = sum(p._version for p in params)
+        if hd.wpack_version != (version, need_bwd) and hd.wpack_version != (version, True):
+            check(lib().udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
+            hd.wpack_version = (version, need_bwd)
+
+    def _run_forward(self, x, save, defer_bn=False):
         _hip.require_cuda(x)
         if x.dtype != torch.float32:
             x = x.float()
@@ -196,29 +216,56 @@ class PoseResNet(nn.Module):
             raise RuntimeError("precision='fp32' is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
         pa, ba, params = self._pointers()
         s = _hip.stream()
-        version = sum(p._version for p in params)
-        need_bwd_pack = save
-        if hd.wpack_version != (version, need_bwd_pack) and hd.wpack_version != (version, True):
-            check(lib().udapose_net_pack_weights(hd.h, s, pa, ptr(hd.wpack), int(need_bwd_pack)), "net_pack_weights")
-            hd.wpack_version = (version, need_bwd_pack)
+        self._pack(hd, pa, params, need_bwd=save)
         if save:
+            # every differentiable forward owns its activation arena AND its scratch workspace, so that two forward /
+            # backward passes of the same module can run concurrently on different streams
             act = torch.empty(hd.act_bytes, dtype=torch.uint8, device=x.device)
+            ws = torch.empty(hd.ws.numel(), dtype=torch.uint8, device=x.device)
         else:
             if hd.act_nograd is None:
                 hd.act_nograd = torch.empty(hd.act_bytes, dtype=torch.uint8, device=x.device)
-            act = hd.act_nograd
+            act, ws = hd.act_nograd, hd.ws
         out = torch.empty(hd.out_shape, dtype=torch.float32, device=x.device)
-        check(lib().udapose_net_forward(hd.h, s, ptr(x), pa, ba, ptr(hd.wpack), ptr(act), ptr(hd.ws), ptr(out), int(self.training),
-                                        float(self.bn_momentum)), "net_forward")
-        return out, (act if save else None), hd
+        defer = bool(defer_bn) and self.training
+        check(lib().udapose_net_forward(hd.h, s, ptr(x), pa, ba, ptr(hd.wpack), ptr(act), ptr(ws), ptr(out),
+                                        int(self.training) | (2 if defer else 0), float(self.bn_momentum)), "net_forward")
+        if defer:
+            self._deferred_bn.append((hd, act))
+        return out, (act if save else None), hd, (ws if save else None)
 
-    def _run_backward(self, dout, act, hd):
+    def apply_deferred_bn(self):
+        """Apply, in call order and on the current stream, the BN running-statistics updates of forwards that ran with
+        `forward_deferred_bn` (the caller has already made this stream wait for those forwards)."""
+        pa, ba, params = self._pointers()
+        for hd, act in self._deferred_bn:
+            check(lib().udapose_net_apply_running(hd.h, _hip.stream(), ptr(act), ba, float(self.bn_momentum)), "net_apply_running")
+        self._deferred_bn = []
+
+    def finish_grads(self):
+        """Sum the second per-pass gradient buffer into p.grad's buffer (only needed when two backward passes ran on
+        different streams; the caller has already made the current stream wait for both)."""
+        st = self._grad_state
+        if st is not None and st[1]:
+            check(lib().udapose_axpy_f32(_hip.stream(), ptr(self._flat_grad), ptr(self._flat_grad2), self._flat_grad.numel()), "axpy")
+        self._grad_state = None
+
+    def _run_backward(self, dout, act, hd, ws):
         pa, ba, params = self._pointers()
         views = self._grad_views(params)
+        cur = torch.cuda.current_stream()
+        second_buffer = False
         if params[0].grad is None:
             beta = 0.0
+            self._grad_state = [cur, False]
         elif params[0].grad.data_ptr() == views[0].data_ptr():
             beta = 1.0
+            st = self._grad_state
+            if st is not None and st[0] != cur:
+                # the first backward of this step is (possibly still) running on another stream: write this pass into
+                # its own buffer and let finish_grads() add the two
+                second_buffer, beta = True, (1.0 if st[1] else 0.0)
+                st[1] = True
         else:   # foreign gradient tensors: adopt their values, then accumulate
             for p, v in zip(params, views):
                 if p.grad is not None:
@@ -230,8 +277,18 @@ class PoseResNet(nn.Module):
         if ga is None or ga[0] != views[0].data_ptr():
             ga = (views[0].data_ptr(), (C.c_void_p * len(views))(*[v.data_ptr() for v in views]))
             self._grad_ptrs = ga
+        gptrs = ga[1]
+        if second_buffer:
+            if self._flat_grad2 is None or self._flat_grad2.device != self._flat_grad.device:
+                self._flat_grad2 = torch.zeros_like(self._flat_grad)
+                off, arr = 0, []
+                for p in params:
+                    arr.append(self._flat_grad2.data_ptr() + 4 * off)
+                    off += p.numel()
+                self._grad_ptrs2 = (C.c_void_p * len(arr))(*arr)
+            gptrs = self._grad_ptrs2
         dout = dout.contiguous().float()
-        check(lib().udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(hd.ws), ga[1], beta), "net_backward")
+        check(lib().udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         for p, v in zip(params, views):
             if p.requires_grad:
                 p.grad = v
@@ -239,7 +296,15 @@ class PoseResNet(nn.Module):
     def forward(self, x):
         params = list(self.parameters())
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _PoseNetFn.apply(x, self, need_grad, *params)
+        return _PoseNetFn.apply(x, self, need_grad, False, *params)
+
+    def forward_deferred_bn(self, x):
+        """Same as forward(), but the BN running statistics are not touched by this call: they are updated later, in call
+        order, by apply_deferred_bn().  For forwards of one module that run concurrently on different streams (the batch
+        statistics used for normalisation are per call either way)."""
+        params = list(self.parameters())
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _PoseNetFn.apply(x, self, need_grad, True, *params)
 
     def get_parameters(self, lr=1.):
         return [
