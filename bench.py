@@ -141,7 +141,9 @@ def main():
             # the last timed step runs eagerly with HIP events recorded on the launch stream around every convolution
             # launch (events cannot be placed inside a replayed graph): it is the roofline sample
             lib.udapose_prof_begin()
+            trainer.concurrent = False        # one stream: per-launch durations comparable with rocprofv3's (which serialises)
             out = eager_step()
+            trainer.concurrent = True
         else:
             out = step()
     torch.cuda.synchronize()

@@ -35,7 +35,7 @@ for name, H, Ci, Co, K, s, p, tr, cnt in SHAPES:
     if which == "fwd":
         w = torch.randn(Co, K * K, Ci, device='cuda').bfloat16()
         res = []
-        for t in (0, 4, 1, 6, 2, 5):
+        for t in (0, 4, 1, 6, 2, 5, 7, 8):
             lib.udapose_debug_set_tiles(t, -1, -1)
             try:
                 us = timeit(lambda: ops.conv2d_fwd(x, w, d, want_stats=True))

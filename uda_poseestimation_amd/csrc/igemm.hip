@@ -67,7 +67,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Main loop: NS-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers), counted vmcnt waits and
 // ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
 // stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
@@ -246,6 +246,92 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         for (int k = 0; k < 2; ++k) b_fo[j][k] = BM * 128 + r * 128 + (((F32 ? 2 * fchunk + k : fchunk + 4 * k) ^ swz(r)) << 4);
     }
 
+    auto compute = [&](auto u) __attribute__((always_inline)) {
+        constexpr int U = decltype(u)::value;
+        const char* S = stage + U * C::STAGE1;
+        if constexpr (!F32) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[MT], bfr[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(S + a_fo[i][kk]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_fo[j][kk]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // fp32: lane group q = lane>>4 owns k = 8q..8q+7 of the 32-deep stage (two 16-byte chunks of its row);
+            // sub-step e feeds element e of both operands to one exact 16x16x4 MFMA (the k <-> lane-group
+            // assignment is the same for A and B, so the sum over k is unchanged)
+            f32x4 al[MT][2], bl[NT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) al[i][h] = *(const f32x4*)(S + a_fo[i][h]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bl[j][h] = *(const f32x4*)(S + b_fo[j][h]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[i][e >> 2][e & 3], bl[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if constexpr (RS) {
+        // Register-staged double buffer (fast path only): global_load_dwordx4 -> VGPRs -> ds_write_b128 into the SAME
+        // lane-linear LDS image the DMA variant produces.  Per K stage a wave issues (A_PW + B_PW) plain loads (a few
+        // issue cycles each) and as many 16-byte LDS stores, instead of (A_PW + B_PW) LDS-DMA instructions whose issue cost
+        // (60-185 cycles each next to MFMAs, MI355X guide) exceeds the 8 MFMAs (128 cycles) a 64x64 tile has per stage.
+        u32x4 ra[A_PW], rb[B_PW];
+        auto load_regs = [&]() __attribute__((always_inline)) {
+            if (c0_cur == 0) select_tap();
+            const long long cb = (long long)c0_cur * (long long)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) ra[i] = *(const u32x4*)(a_cur[i] + cb);
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i) rb[i] = *(const u32x4*)(b_cur[i] + cb);
+            c0_cur += BKE;
+            if (c0_cur >= p.Ci) { c0_cur = 0; ++tap_cur; }
+        };
+        auto write_lds = [&](auto ub) __attribute__((always_inline)) {
+            constexpr int UB = decltype(ub)::value;
+            char* A = stage + UB * C::STAGE1;
+            char* B = A + BM * 128;
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) *(u32x4*)(A + (i * 4 + wid) * 1024 + lane * 16) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i) *(u32x4*)(B + (i * 4 + wid) * 1024 + lane * 16) = rb[i];
+        };
+        if (nsteps > 0) {
+            load_regs();
+            write_lds(IC<0>{});
+            if (nsteps > 1) load_regs();
+        }
+        __syncthreads();
+        for (int st0 = 0; st0 < nsteps; st0 += 2) {
+            static_for<2>([&](auto u) __attribute__((always_inline)) {
+                constexpr int U = decltype(u)::value;
+                const int st = st0 + U;
+                if (st < nsteps) {
+                    if (st + 1 < nsteps) {
+                        write_lds(IC<(U + 1) % 2>{});        // stage st+1 (loaded one iteration ago) -> the free buffer
+                        if (st + 2 < nsteps) load_regs();     // stage st+2 in flight during the MFMAs below
+                    }
+                    compute(u);
+                    __syncthreads();
+                }
+            });
+        }
+    } else {
     // prologue: NS-1 stages in flight
     int issued = 0;
     static_for<NS - 1>([&](auto u) __attribute__((always_inline)) {
@@ -262,44 +348,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
                 else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();          // every wave's share of stage st is in LDS; buffer (st-1)%NS is free
                 if (issued < nsteps) { issue_stage(IC<(U + NS - 1) % NS>{}); ++issued; }
-                const char* S = stage + U * C::STAGE1;
-                if constexpr (!F32) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        bf16x8 af[MT], bfr[NT];
-#pragma unroll
-                        for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(S + a_fo[i][kk]);
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_fo[j][kk]);
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int j = 0; j < NT; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    }
-                } else {
-                    // fp32: lane group q = lane>>4 owns k = 8q..8q+7 of the 32-deep stage (two 16-byte chunks of its row);
-                    // sub-step e feeds element e of both operands to one exact 16x16x4 MFMA (the k <-> lane-group
-                    // assignment is the same for A and B, so the sum over k is unchanged)
-                    f32x4 al[MT][2], bl[NT][2];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) al[i][h] = *(const f32x4*)(S + a_fo[i][h]);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) bl[j][h] = *(const f32x4*)(S + b_fo[j][h]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int j = 0; j < NT; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[i][e >> 2][e & 3], bl[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
-                }
+                compute(u);
             }
         });
+    }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // all LDS reads of the ring are done before the epilogue reuses it
@@ -405,24 +457,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS>
 int launch_cfg_t(IgParams& p, hipStream_t stream) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Co + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS>), grid, dim3(256), C::LDS_BYTES, stream, p);
     return udapose_check_launch();
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool RS = false>
 int launch_cfg(IgParams& p, hipStream_t stream) {
-    return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS>(p, stream) : launch_cfg_t<bf16_t, BM, BN, WM, WN, NS>(p, stream);
+    if constexpr (RS) {
+        // register-staged variants exist for the bf16 fast path only (zero padding, no upsample, Ci >= 64)
+        if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) == 0) return launch_cfg_t<bf16_t, BM, BN, WM, WN, 2, true>(p, stream);
+        return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
+    } else {
+        return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS, false>(p, stream) : launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
+    }
 }
 
 }  // namespace
@@ -432,7 +490,9 @@ int g_igemm_tile_override = -1;   // debug/tuning hook (udapose_debug_set_tiles)
 // Tile selection (measured on MI355X over every PoseResNet-101 layer shape at N=32, tools/tune_conv.py): 128x64 tiles
 // when they still yield >= 512 work-groups (2 per CU), else 64x64 (4-deep ring when K is long).  128x128 tiles lose to
 // 128x64 everywhere since the K-loop rewrite (174 VGPRs -> 2 waves/SIMD); they stay instantiated for tuning only.
-// ids: 0 = 128x128 NS3, 1 = 128x64 NS3, 2 = 64x64 NS4, 3 = 128x32 NS3, 4 = 128x128 NS2, 5 = 64x64 NS2, 6 = 128x64 NS2
+// ids: 0 = 128x128 NS3, 1 = 128x64 NS3, 2 = 64x64 NS4, 3 = 128x32 NS3, 4 = 128x128 NS2, 5 = 64x64 NS2, 6 = 128x64 NS2,
+// 7 = 64x64 register-staged, 8 = 128x64 register-staged (measured within +-8 % of the LDS-DMA variants on every shape: the
+// feed rate per CU, ~16 B/clk from L2, is the same for both staging methods; kept for tuning, never selected)
 int igemm_pick_tile(int M, int Co, int nclass, int K) {
     if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
     if (Co <= 32) return 3;
@@ -443,7 +503,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K) {
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     switch (tile) {
-        case 2: case 5: return nclass * ((M + 63) / 64) * 2;
+        case 2: case 5: case 7: return nclass * ((M + 63) / 64) * 2;
         case 3: return nclass * ((M + 127) / 128) * 4;
         default: return nclass * ((M + 127) / 128) * 2;
     }
@@ -468,6 +528,8 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
         case 4: return launch_cfg<128, 128, 2, 2, 2>(p, stream);
         case 5: return launch_cfg<64, 64, 2, 2, 2>(p, stream);
         case 6: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
+        case 7: return launch_cfg<64, 64, 2, 2, 4, true>(p, stream);
+        case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
         default: return UDAPOSE_ERR_ARG;
     }
 }

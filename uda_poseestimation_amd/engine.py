@@ -72,6 +72,7 @@ class MeanTeacherTrainer:
         self.s2t_freq, self.t2s_freq, self.s2t_alpha, self.t2s_alpha = s2t_freq, t2s_freq, s2t_alpha, t2s_alpha
         self.rng = rng if rng is not None else np.random   # the reference draws from the global np.random
         self._side = None
+        self.concurrent = True      # False: run the three branches back to back on the current stream (profiling)
         # adaptive key-point occlusion (train_human.py:374-412); rate <= -1 disables it like `--occlude-rate -1`
         self.occlude_rate, self.occlude_thresh, self.occlude_size = occlude_rate, occlude_thresh, occlude_size
         self.image_px = image_px if image_px is not None else image_size
@@ -131,7 +132,7 @@ class MeanTeacherTrainer:
         main = torch.cuda.current_stream()
         if self._side is None or self._side[0].device != x_s.device:
             self._side = (torch.cuda.Stream(device=x_s.device), torch.cuda.Stream(device=x_s.device))
-        s_tea, s_stu = self._side
+        s_tea, s_stu = self._side if self.concurrent else (main, main)
         occl = self.occlude_rate > -1 and self._aug_stu is not None
         student.prepare(x_s)                # bf16 weight packs refreshed on `main` before the branches fork
         with torch.no_grad():
@@ -171,8 +172,8 @@ class MeanTeacherTrainer:
         loss_c = self.con_criterion(y_t_stu_recon, y_t_tea_rect, tea_mask=tea_mask)
         loss_all = loss_s + self.lambda_c * loss_c
         loss_all.backward()
-        if self._side is not None:
-            main.wait_stream(self._side[1])     # the target-domain backward ran on its own stream
+        if s_stu is not main:
+            main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
         student.finish_grads()              # adds the second pass's gradient buffer (no-op when both ran on one stream)
         return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": y_s.detach()}
 
