@@ -109,8 +109,8 @@ class MeanTeacherTrainer:
             out["acc_s"], out["cnt_s"] = avg_acc, cnt
         return out
 
-    def _forward_backward(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
-        """Device-only part up to the gradients (no host reads, no H2D copies: capturable in a hipGraph)."""
+    def _forward_part(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
+        """All forwards of the step (device-only, no host reads: capturable in a hipGraph)."""
         student, teacher = self.student, self.teacher
         student.train()
         teacher.train()                     # the teacher's BN uses batch statistics too (train_human.py:321)
@@ -163,19 +163,31 @@ class MeanTeacherTrainer:
             y_s = student(x_s)
             y_t_stu = student(x_t_stu)
             y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
-        loss_s = self.criterion(y_s, label_s, weight_s)
         with torch.no_grad():
-            # activations BEFORE rectify; threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats)
-            activates = mt.heatmap_activations(y_t_tea_recon)
-            tea_mask, _, _ = mt.confidence_mask(y_t_tea_recon, self.mask_ratio, None, gather_activates(activates), activates)
-            y_t_tea_rect = mt.rectify(y_t_tea_recon, sigma=self.sigma)
-        loss_c = self.con_criterion(y_t_stu_recon, y_t_tea_rect, tea_mask=tea_mask)
+            activates = mt.heatmap_activations(y_t_tea_recon)    # BEFORE rectify (train_human.py:427)
+        return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
+                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu}
+
+    def _loss_backward_part(self, st, gathered_activates):
+        """Losses and backward from the forward state; `gathered_activates` = all ranks' confidences (None on one rank)."""
+        student = self.student
+        main, s_stu = st["main"], st["s_stu"]
+        loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
+        with torch.no_grad():
+            # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
+            tea_mask, _, _ = mt.confidence_mask(st["y_t_tea_recon"], self.mask_ratio, None, gathered_activates, st["activates"])
+            y_t_tea_rect = mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
+        loss_c = self.con_criterion(st["y_t_stu_recon"], y_t_tea_rect, tea_mask=tea_mask)
         loss_all = loss_s + self.lambda_c * loss_c
         loss_all.backward()
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
         student.finish_grads()              # adds the second pass's gradient buffer (no-op when both ran on one stream)
-        return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": y_s.detach()}
+        return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": st["y_s"].detach()}
+
+    def _forward_backward(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
+        st = self._forward_part(x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea)
+        return self._loss_backward_part(st, gather_activates(st["activates"]))
 
     def _update(self):
         self.stu_optimizer.step()
@@ -189,7 +201,7 @@ class GraphedTrainStep:
     the batch's aug_param tuples exactly as in the eager step.  Style transfer / occlusion draw host random numbers per
     step and therefore stay on the eager path."""
 
-    def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2):
+    def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None):
         assert trainer.style_net is None and trainer.occlude_rate <= -1, \
             "the graphed step covers the style-free, occlusion-free configuration (both draw host random numbers per step)"
         self.t = trainer
@@ -211,10 +223,23 @@ class GraphedTrainStep:
                 trainer._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # Data parallel: the confidence all-gather sits between the forwards and the losses, the gradient all-reduce between
+        # backward and the optimizer; both stay eager, so the step is cut into three graphs around them.
+        self.split = _dist_on() if split is None else bool(split)
         self.g_fb, self.g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            self.out = trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
-                                                 [st["theta_tea"]])
+        if not self.split:
+            with torch.cuda.graph(self.g_fb):
+                self.out = trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
+                                                     [st["theta_tea"]])
+        else:
+            self.g_lb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb):
+                self.fwd_state = trainer._forward_part(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]],
+                                                       st["theta_stu"], [st["theta_tea"]])
+            g0 = gather_activates(self.fwd_state["activates"])
+            self.gathered = g0.clone() if g0 is not None else self.fwd_state["activates"].reshape(-1).clone()
+            with torch.cuda.graph(self.g_lb, pool=self.g_fb.pool()):
+                self.out = trainer._loss_backward_part(self.fwd_state, self.gathered)
         trainer.sync()
         with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
             trainer._update()
@@ -230,6 +255,10 @@ class GraphedTrainStep:
         if aug_param_tea is not None:
             st["theta_tea"].copy_(warp.recon_thetas(aug_param_tea, self.n, self.t.ratio), non_blocking=True)
         self.g_fb.replay()
+        if self.split:
+            g = gather_activates(self.fwd_state["activates"])
+            self.gathered.copy_(g if g is not None else self.fwd_state["activates"].reshape(-1))
+            self.g_lb.replay()
         self.t.sync()
         self.g_up.replay()
         return self.out
