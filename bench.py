@@ -73,9 +73,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spinup", type=float, default=3.0, help="seconds of untimed load before the warm-up steps (device clock ramp)")
+    ap.add_argument("--spinup", type=float, default=8.0, help="seconds of untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per domain (BASELINE: 32)")
     ap.add_argument("--arch", default="pose_resnet101")
+    ap.add_argument("--wgrad-group", type=int, default=1, help="tuning: 0 = one weight-gradient launch per layer")
+    ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
@@ -98,6 +100,7 @@ def main():
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
     import uda_poseestimation_amd.lib.models as models
     lib = _hip.lib()
+    lib.udapose_debug_set_wgrad_group(args.wgrad_group, args.wgrad_stages)
 
     N, K = args.batch, 16
     torch.manual_seed(0)

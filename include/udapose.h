@@ -170,6 +170,10 @@ int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C
  * h_out9 (host): for kind in (fprop, dgrad, wgrad): launches, total milliseconds, total algorithmic FLOPs. */
 /* tuning hook: force tile configuration ids / split count (-1 = heuristic); not for production use */
 void udapose_debug_set_tiles(int igemm_tile, int wgrad_tile, int wgrad_ksplit);
+/* tuning hook: udapose_net_backward computes all weight gradients of a pass in one grouped launch per tile class after
+ * the dgrad / BN-backward chain (on = 1, default) or layer by layer (on = 0); stages_per_block (> 0) = 64-pixel stages a
+ * work-group reduces before a layer's pixel range is split (default 128) */
+void udapose_debug_set_wgrad_group(int on, int stages_per_block);
 void udapose_prof_begin(void);
 int udapose_prof_end(double* h_out9);
 

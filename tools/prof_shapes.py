@@ -1,7 +1,7 @@
 """Dev tool: aggregate a rocprofv3 kernel trace by (kernel, grid) -> ms/step."""
 import csv, glob, collections, sys
 d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(lambda: [0, 0])
 tot = collections.defaultdict(lambda: [0, 0])

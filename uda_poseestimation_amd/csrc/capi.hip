@@ -38,6 +38,7 @@ void prof_begin();
 int prof_end(double*);
 void* net_create(const int layers[4], int K, int N, int H, int W, int f32);
 void net_destroy(void*);
+void net_set_wgrad_group(int, int);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -122,6 +123,7 @@ int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32
     return *out ? UDAPOSE_OK : UDAPOSE_ERR_ARG;
 }
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
+void udapose_debug_set_wgrad_group(int on, int stages_per_block) { net_set_wgrad_group(on, stages_per_block); }
 int udapose_net_num_params(udapose_net_t n) { return net_num_params(n); }
 int udapose_net_num_buffers(udapose_net_t n) { return net_num_buffers(n); }
 long long udapose_net_param_numel(udapose_net_t n, int i) { return net_param_numel(n, i); }

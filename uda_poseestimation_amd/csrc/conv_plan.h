@@ -31,6 +31,13 @@ int igemm_stat_rows(int M, int Co, int nclass, int tile);
 int igemm_launch(IgParams& p, int tile, hipStream_t stream);
 int wgrad_pick_tile(int Rdim, int Cdim, int smallc);
 int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream);
+// Grouped wgrad (many layers, one launch per tile class).  wgrad_group_plan completes p for the group kernels and returns
+// the tile class (0 = 128x128, 1 = 64x64) or < 0 when the layer needs its own launch; stages_per_block bounds a work-group's
+// pixel range (longer reductions are split and accumulated with fp32 atomics into a zeroed dW).
+int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block);
+// the x / dy / dw fields of the table entries are byte offsets from the three bases
+int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
+                       const void* dy_base, void* dw_base);
 
 struct ConvEpilogue {
     const bf16_t* res = nullptr;
@@ -46,4 +53,8 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* 
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32);
 // dw (fp32, [Co][wtaps][Ci]; transposed: [Ci][wtaps][Co]) (+)= ...;  rows_valid < 0 -> all rows
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid);
+// the same problem as a parameter block (for the grouped launch); returns the layer's algorithmic FLOPs in *flops
+int conv_wgrad_params(const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int rows_valid, WgParams* out, double* flops);
+int conv_prof_before(hipStream_t s, int kind, double flops);
+void conv_prof_after(hipStream_t s, int token);
 int conv_stat_rows(const ConvGeom& g);

@@ -131,7 +131,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     return rc;
 }
 
-int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid) {
+int conv_wgrad_params(const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int rows_valid, WgParams* out, double* flops) {
     if (g.reflect || g.upsample) return UDAPOSE_ERR_UNSUPPORTED;
     const TapPlan* tp = get_tap_plan(g, 0);
     if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
@@ -147,10 +147,24 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     p.total_taps = (int)tp->taps.size();
-    const int Rdim = g.transposed ? g.Ci : g.Co, Cdim = g.transposed ? g.Co : g.Ci;
+    const int Rdim = g.transposed ? g.Ci : g.Co;
     p.rows_valid = rows_valid < 0 ? Rdim : rows_valid;
-    const int tok = prof_before(s, 2, alg_flops(g));
+    *out = p;
+    if (flops) *flops = alg_flops(g);
+    return UDAPOSE_OK;
+}
+
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid) {
+    WgParams p;
+    double fl = 0.0;
+    const int rc0 = conv_wgrad_params(g, dy, x, dw, rows_valid, &p, &fl);
+    if (rc0 != UDAPOSE_OK) return rc0;
+    const int Rdim = g.transposed ? g.Ci : g.Co, Cdim = g.transposed ? g.Co : g.Ci;
+    const int tok = prof_before(s, 2, fl);
     const int rc = wgrad_launch(p, wgrad_pick_tile(Rdim, Cdim, g.smallc()), accumulate, s);
     prof_after(s, tok);
     return rc;
 }
+
+int conv_prof_before(hipStream_t s, int kind, double flops) { return prof_before(s, kind, flops); }
+void conv_prof_after(hipStream_t s, int token) { prof_after(s, token); }

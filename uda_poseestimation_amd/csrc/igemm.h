@@ -57,5 +57,6 @@ struct WgParams {
     int total_taps;
     int rows_valid;         // dW rows actually stored (<= R; head: Co is padded to 32 in dy)
 };
+struct WgGroupBlk { int prob, local; };   // grouped wgrad: problem index (< 0: padding) and linear block index inside it
 #define WG_FLAG_SWAP 32       // rows of dW come from x (deconv weight layout [Ci][tap][Co])
 #define WG_FLAG_ATOMIC 64     // accumulate into dw with fp32 atomics (ksplit>1 or beta=1)

@@ -6,6 +6,7 @@
 // Data layout in HBM: activations NHWC bf16 (pre-BN conv output y and post-BN/ReLU z both kept for backward), weights
 // bf16 packed [Co][taps][Ci] (fprop) and [Ci][taps][Co] (dgrad) from the fp32 channels_last master copies, BN statistics
 // fp32.  Parameters are addressed by index in torch `.parameters()` order, buffers in `.buffers()` order.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -46,6 +47,8 @@ static int dbg_sync() { static int v = -1; if (v < 0) { const char* e = getenv("
         if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "[udapose] FAILED at net.hip:%d\n", __LINE__); return UDAPOSE_ERR_LAUNCH; } } \
     if (_e != UDAPOSE_OK) return _e; } while (0)
 
+int g_wgrad_group = 1, g_wgrad_stages = 128;   // grouped weight-gradient launch (see build_wg_group); tuning hook
+
 struct ConvL {
     ConvGeom g;
     int w_idx = -1;         // parameter index of the weight
@@ -53,6 +56,7 @@ struct ConvL {
     size_t wf_off = 0, wb_off = 0;   // bf16 packs inside wpack (bytes)
     size_t in_off = 0;      // activation arena offset of the input (bytes)
     size_t y_off = 0;       // pre-BN output
+    size_t dy_off = 0;      // workspace offset of this layer's own dy buffer (backward)
 };
 struct BnL {
     int C = 0;
@@ -95,6 +99,17 @@ struct Net {
     struct PackTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0; const void* key0 = nullptr;
                      const void* key1 = nullptr; const void* keyw = nullptr; };
     PackTab pack_fwd, pack_all;
+    // grouped weight-gradient launch of one backward pass: device tables, rebuilt when the buffers change
+    struct WgGroup {
+        float k_beta = -1.f; int k_stages = 0;
+        std::vector<std::pair<int, ptrdiff_t>> rel;      // (parameter index, byte offset of its gradient from grads[0]) the table assumes
+        WgParams* d_tab[2] = {nullptr, nullptr}; WgGroupBlk* d_blk[2] = {nullptr, nullptr}; int per_xcd[2] = {0, 0};
+        double flops[2] = {0.0, 0.0};
+        std::vector<std::pair<ptrdiff_t, size_t>> zero;  // dW ranges (offset from grads[0], bytes) cleared first (split reductions, when overwriting)
+        unsigned long long last_use = 0;
+    };
+    std::vector<WgGroup> wg_groups;
+    unsigned long long wg_tick = 0;
 };
 struct PackJobH { const float* src; bf16_t* dst; int A, T, B, kind; long long n; };
 
@@ -200,6 +215,12 @@ Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
     for (int i = 0; i < 6; ++i) { n.ws_gbuf[i] = o; o += n.gbuf_bytes; }
     n.ws_dyhead = o; o = align_up(o + (size_t)N * Hc * Wc * 64 * 2);
     n.ws_dwtmp = o; o = align_up(o + std::max((size_t)64 * 56 * 8 * 4, (size_t)64 * 256 * 4));
+    // every conv layer owns its dy buffer: the weight gradients of the whole pass are computed by ONE grouped launch after
+    // the dgrad / BN-backward chain, so every dy must still be there
+    auto dyb = [&](ConvL& c) { c.dy_off = o; o = align_up(o + (size_t)n.N * c.g.Ho() * c.g.Wo() * c.g.Co * 2); };
+    dyb(n.stem);
+    for (auto& b : n.blocks) { dyb(b.c1); dyb(b.c2); dyb(b.c3); if (b.has_ds) dyb(b.cd); }
+    for (int i = 0; i < 3; ++i) dyb(n.up[i]);
     n.ws_bytes = o;
     return np;
 }
@@ -270,7 +291,14 @@ void* net_create(const int layers[4], int K, int N, int H, int W, int f32) {
     if (K < 1 || K > 64 || N < 1 || H % 32 || W % 32) return nullptr;
     return build(layers, K, N, H, W, f32);
 }
-void net_destroy(void* h) { delete (Net*)h; }
+void net_destroy(void* h) {
+    Net* n = (Net*)h;
+    if (!n) return;
+    for (auto& g : n->wg_groups)
+        for (int t = 0; t < 2; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
+    delete n;
+}
+void net_set_wgrad_group(int on, int stages) { g_wgrad_group = on; if (stages > 0) g_wgrad_stages = stages; }
 int net_num_params(void* h) { return ((Net*)h)->n_params; }
 int net_num_buffers(void* h) { return ((Net*)h)->n_buffers; }
 long long net_param_numel(void* h, int i) { return ((Net*)h)->param_numel[i]; }
@@ -396,12 +424,11 @@ namespace {
 // backward of conv+bn(+relu): dz (grad wrt z) -> parameter grads, returns dx of the conv input in a pool buffer
 int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, const char* wpack, char* act, char* ws,
                 void* const* grads, float beta, Pool& pool, const void* dz, int dz_f32, bf16_t* gout, int relu, const bf16_t* dx_res,
-                bf16_t** dx_out, bool need_dx, int dx_f32) {
+                bf16_t** dx_out, bool need_dx, int dx_f32, bool grouped_wgrad) {
     float* slab = (float*)(ws + n.ws_slab);
     float* coef = (float*)(ws + n.ws_coef) + 4096;
     const float* save = (const float*)(act + b.save_off);
-    bf16_t* dy = pool.get();
-    if (!dy) return UDAPOSE_ERR_ARG;
+    bf16_t* dy = (bf16_t*)(ws + c.dy_off);
     CK(pw_bn_bwd(s, dz, dz_f32, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx], save,
                  save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta));
     const bf16_t* xin = (const bf16_t*)(act + c.in_off);
@@ -410,7 +437,7 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         CK(conv_wgrad(s, c.g, dy, xin, tmp, 0, -1));
         CK(pw_unpack_strided(s, tmp, (float*)grads[c.w_idx], c.g.Co, c.g.KH, c.g.KWp(), c.g.KW, 8, 3, (long)c.g.KH * c.g.KW * 3, (long)c.g.KW * 3, 3, 1,
                              beta));
-    } else {
+    } else if (!grouped_wgrad) {
         CK(conv_wgrad(s, c.g, dy, xin, (float*)grads[c.w_idx], beta != 0.f, -1));
     }
     if (need_dx) {
@@ -419,7 +446,109 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         CK(conv_dgrad(s, c.g, dy, (const bf16_t*)(wpack + c.wb_off), dx, dx_res, dx_f32));
         *dx_out = dx;
     }
-    pool.put(dy);
+    return UDAPOSE_OK;
+}
+
+// ---- grouped weight gradients ------------------------------------------------------------------------------------------
+// The weight gradient of a layer needs only that layer's dy and saved input, and nobody reads it before the optimizer.
+// Launched layer by layer, most of these GEMMs are too small for the chip (a layer3 1x1: 4 GFLOP, 16 tiles of 128x128) and
+// had to split their pixel reduction 8-64 ways to fill it (fp32 atomics into a zeroed dW: ~1.3 TB/s chip-wide).  One
+// launch over ALL layers has thousands of tiles: most layers reduce all their pixels inside one work-group (plain stores,
+// deterministic, no memset), take 128x128 tiles, and only the large-image layers are still split.
+
+int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
+    std::vector<WgParams> tab[2];
+    struct Unit { int prob, z, nblk; long load; };
+    std::vector<Unit> units[2];
+    G.zero.clear();
+    G.rel.clear();
+    G.flops[0] = G.flops[1] = 0.0;
+    auto add = [&](const ConvL& c) -> int {
+        if (c.g.smallc()) return UDAPOSE_OK;
+        WgParams p;
+        double fl = 0.0;
+        // byte offsets from the workspace / activation arena / gradient bases in place of pointers (see wgrad_dma_group_kernel)
+        const ptrdiff_t drel = (const char*)grads[c.w_idx] - (const char*)grads[0];
+        G.rel.push_back({c.w_idx, drel});
+        CK(conv_wgrad_params(c.g, (const bf16_t*)c.dy_off, (const bf16_t*)c.in_off, (float*)drel, -1, &p, &fl));
+        const int t = wgrad_group_plan(p, beta != 0.f, g_wgrad_stages);
+        if (t < 0) return UDAPOSE_ERR_UNSUPPORTED;
+        const int prob = (int)tab[t].size();
+        tab[t].push_back(p);
+        G.flops[t] += fl;
+        const int nblk = p.r_tiles * p.c_tiles * p.total_taps;
+        const int ms_total = (p.M + 63) / 64, per = (ms_total + p.ksplit - 1) / p.ksplit;
+        for (int z = 0; z < p.ksplit; ++z) {
+            const int st = std::min(per, ms_total - z * per);
+            if (st > 0) units[t].push_back(Unit{prob, z, nblk, (long)nblk * (st + 4)});
+        }
+        if (p.ksplit > 1 && beta == 0.f) {
+            const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
+            G.zero.push_back({drel, (size_t)(swap ? p.Ci : p.Co) * p.wtaps * (swap ? p.Co : p.Ci) * sizeof(float)});
+        }
+        return UDAPOSE_OK;
+    };
+    for (int i = 2; i >= 0; --i) CK(add(n.up[i]));
+    for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
+        Block& b = n.blocks[bi];
+        CK(add(b.c3)); CK(add(b.c2));
+        if (b.has_ds) CK(add(b.cd));
+        CK(add(b.c1));
+    }
+    for (int t = 0; t < 2; ++t) {
+        if (G.d_tab[t]) { (void)hipFree(G.d_tab[t]); G.d_tab[t] = nullptr; }
+        if (G.d_blk[t]) { (void)hipFree(G.d_blk[t]); G.d_blk[t] = nullptr; }
+        G.per_xcd[t] = 0;
+        if (tab[t].empty()) continue;
+        // deal whole (layer, split) units to the 8 XCDs, largest first, each to the least loaded XCD
+        std::stable_sort(units[t].begin(), units[t].end(), [](const Unit& a, const Unit& b) { return a.load > b.load; });
+        std::vector<WgGroupBlk> lst[8];
+        long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (const Unit& u : units[t]) {
+            int x = 0;
+            for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+            load[x] += u.load;
+            for (int l = 0; l < u.nblk; ++l) lst[x].push_back(WgGroupBlk{u.prob, u.z * u.nblk + l});
+        }
+        size_t per = 0;
+        for (int k = 0; k < 8; ++k) per = std::max(per, lst[k].size());
+        std::vector<WgGroupBlk> flat(8 * per, WgGroupBlk{-1, 0});
+        for (int k = 0; k < 8; ++k) std::copy(lst[k].begin(), lst[k].end(), flat.begin() + k * per);
+        if (hipMalloc((void**)&G.d_tab[t], tab[t].size() * sizeof(WgParams)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMalloc((void**)&G.d_blk[t], flat.size() * sizeof(WgGroupBlk)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemcpy(G.d_tab[t], tab[t].data(), tab[t].size() * sizeof(WgParams), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemcpy(G.d_blk[t], flat.data(), flat.size() * sizeof(WgGroupBlk), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        G.per_xcd[t] = (int)per;
+    }
+    G.k_beta = beta; G.k_stages = g_wgrad_stages;
+    return UDAPOSE_OK;
+}
+
+// the tables are built (hipMalloc + synchronous copies) by the first pass with a given beta: like the tap plans, that first
+// pass must not be inside a stream capture.  They hold offsets, so later passes with other arenas / gradient buffers reuse
+// them as long as the gradients keep their relative placement (checked per call).
+int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta) {
+    Net::WgGroup* G = nullptr;
+    for (auto& g : n.wg_groups)
+        if (g.k_beta == beta && g.k_stages == g_wgrad_stages) G = &g;
+    if (G)
+        for (auto& r : G->rel)
+            if ((const char*)grads[r.first] - (const char*)grads[0] != r.second) { G = nullptr; break; }
+    if (!G) {
+        if (n.wg_groups.size() < 4) { n.wg_groups.emplace_back(); G = &n.wg_groups.back(); }
+        else { G = &n.wg_groups[0]; for (auto& g : n.wg_groups) if (g.last_use < G->last_use) G = &g; }
+        CK(build_wg_group(n, *G, grads, beta));
+    }
+    G->last_use = ++n.wg_tick;
+    for (auto& z : G->zero)
+        if (hipMemsetAsync((char*)grads[0] + z.first, 0, z.second, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    for (int t = 0; t < 2; ++t) {
+        if (!G->per_xcd[t]) continue;
+        const int tok = conv_prof_before(s, 2, G->flops[t]);
+        const int rc = wgrad_group_launch(s, t, G->d_tab[t], G->d_blk[t], G->per_xcd[t], act, ws, grads[0]);
+        conv_prof_after(s, tok);
+        CK(rc);
+    }
     return UDAPOSE_OK;
 }
 }  // namespace
@@ -435,6 +564,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     Pool pool;
     pool.base = ws;
     for (int i = 0; i < 6; ++i) pool.off[i] = n.ws_gbuf[i];
+    const bool grouped = g_wgrad_group != 0;
     const int HWo = n.Hout * n.Wout;
     // head
     bf16_t* dyh = (bf16_t*)(ws + n.ws_dyhead);
@@ -454,7 +584,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     // deconv stack
     for (int i = 2; i >= 0; --i) {
         bf16_t* dx = nullptr;
-        CK(conv_bn_bwd(s, n, n.up[i], n.up_bn[i], params, wpack, act, ws, grads, beta, pool, dz, 1, nullptr, 1, nullptr, &dx, true, i > 0));
+        CK(conv_bn_bwd(s, n, n.up[i], n.up_bn[i], params, wpack, act, ws, grads, beta, pool, dz, 1, nullptr, 1, nullptr, &dx, true, i > 0, grouped));
         pool.put(dz);
         dz = dx;
     }
@@ -463,16 +593,16 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         Block& b = n.blocks[bi];
         // bn3 (+ReLU of the block output): g = masked dz is written in place and feeds the skip branch
         bf16_t *dz2 = nullptr, *dz1 = nullptr, *dxd = nullptr, *dxin = nullptr;
-        CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, 0, dz, 1, nullptr, &dz2, true, 0));
-        CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, 0, nullptr, 1, nullptr, &dz1, true, 0));
+        CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, 0, dz, 1, nullptr, &dz2, true, 0, grouped));
+        CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, 0, nullptr, 1, nullptr, &dz1, true, 0, grouped));
         pool.put(dz2);
         const bool first = (bi == 0);
         const bf16_t* skip = dz;
         if (b.has_ds) {
-            CK(conv_bn_bwd(s, n, b.cd, b.bd, params, wpack, act, ws, grads, beta, pool, dz, 0, nullptr, 0, nullptr, &dxd, true, 0));
+            CK(conv_bn_bwd(s, n, b.cd, b.bd, params, wpack, act, ws, grads, beta, pool, dz, 0, nullptr, 0, nullptr, &dxd, true, 0, grouped));
             skip = dxd;
         }
-        CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, 0, nullptr, 1, skip, &dxin, true, 0));
+        CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, 0, nullptr, 1, skip, &dxin, true, 0, grouped));
         pool.put(dz1);
         if (dxd) pool.put(dxd);
         pool.put(dz);
@@ -484,8 +614,9 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     CK(pw_maxpool3x3s2_bwd(s, dz, (const unsigned char*)(act + n.poolidx_off), dzs, n.N, n.Hs, n.Ws, 64));
     pool.put(dz);
     bf16_t* none = nullptr;
-    CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 1, nullptr, &none, false, 0));
+    CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 1, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
+    if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta));
     // backbone.fc is not part of the forward: zero gradient when overwriting
     if (beta == 0.f) {
         if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;

@@ -226,28 +226,34 @@ struct WdCfg {
     static constexpr int LDS_BYTES = NS * STAGE1;
 };
 
+// One work-group: tile bx of dW tap `by`, pixel split bz of problem p.
 template <int RT, int CT, int WR, int WC, int NS>
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
+__device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
+                                               const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
+    // scalar copies of the fields used below (gp may live in global memory: read it once, up front, into SGPRs)
+    struct {
+        const bf16_t* dy; const bf16_t* x; float* dw; const IgTap* taps;
+        int Hi, Wi, Ci, Ho, Wo, Co, Hg, Wg, s, os, M, wtaps, flags, ksplit, c_tiles, rows_valid;
+        FastDiv div_hw, div_w;
+    } p = {(const bf16_t*)((uintptr_t)gp.dy + dy_base), (const bf16_t*)((uintptr_t)gp.x + x_base), (float*)((uintptr_t)gp.dw + dw_base), gp.taps, gp.Hi, gp.Wi, gp.Ci, gp.Ho, gp.Wo, gp.Co, gp.Hg, gp.Wg, gp.s, gp.os, gp.M, gp.wtaps, gp.flags, gp.ksplit,
+           gp.c_tiles, gp.rows_valid, gp.div_hw, gp.div_w};
     using C = WdCfg<RT, CT, WR, WC, NS>;
     constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
     constexpr int LPS = P_PW + Q_PW;
     constexpr int P_RPI = 1024 / C::PROW, Q_RPI = 1024 / C::QROW;    // rows per DMA instruction (8 or 4)
     constexpr int P_CPR = C::PROW / 16, Q_CPR = C::QROW / 16;        // 16-byte chunks per row (8 or 16)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WC, wc = wid % WC;
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
-    // XCD-aware order: the split index (pixel range) is the slowest coordinate, so each XCD's L2 serves one pixel range
-    const uint32_t gxy = gridDim.x * gridDim.y;
-    const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
-    const uint32_t bz = lin / gxy, bxy = lin - bz * gxy;
-    const uint32_t by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
     const int c_tile = bx % p.c_tiles, r_tile = bx / p.c_tiles;
     const int r0 = r_tile * RT, c0 = c_tile * CT;
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
     const bool p_is_x = swap;
     const IgTap tp = p.taps[by];
-    const IgClass cls = p.cls[tp.cls];
+    struct { int oa, ob; } cls = {gp.cls[0].oa, gp.cls[0].ob};       // (select chain: no dynamic index into the parameter block)
+    if (tp.cls == 1) { cls.oa = gp.cls[1].oa; cls.ob = gp.cls[1].ob; }
+    if (tp.cls == 2) { cls.oa = gp.cls[2].oa; cls.ob = gp.cls[2].ob; }
+    if (tp.cls == 3) { cls.oa = gp.cls[3].oa; cls.ob = gp.cls[3].ob; }
     const int ms_total = (p.M + 63) >> 6;                            // 64-pixel stages
     const int per = (ms_total + p.ksplit - 1) / p.ksplit;
     const int ms0 = bz * per;
@@ -382,6 +388,49 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
 }
 
 template <int RT, int CT, int WR, int WC, int NS>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware order: the split index (pixel range) is the slowest coordinate, so each XCD's L2 serves one pixel range
+    const uint32_t gxy = gridDim.x * gridDim.y;
+    const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
+    const uint32_t bz = lin / gxy, bxy = lin - bz * gxy;
+    const uint32_t by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
+    wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem);
+}
+
+// Grouped form: ONE launch computes the weight gradients of many layers.  blk is an [8][per_xcd] table (work-group b runs
+// on XCD b & 7, the hardware's round-robin, and takes entry [b & 7][b >> 3]); an entry names a problem of `tab` and the
+// work-group's linear index inside that problem's (tile, tap, split) grid, or prob < 0 = padding.  The host deals whole
+// (problem, split) units to XCDs by load, so the tiles that re-read one pixel range share an L2.  The table holds byte
+// OFFSETS in its x / dy / dw fields, relative to the three bases passed per launch, so one table serves every pass.
+template <int RT, int CT, int WR, int WC, int NS>
+__global__ __launch_bounds__(256) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
+                                                              const uint32_t per_xcd, const char* x_base, const char* dy_base, char* dw_base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WgGroupBlk b = blk[(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)];
+    if (b.prob < 0) return;
+    const WgParams& p = tab[b.prob];
+    const uint32_t gx = (uint32_t)(p.r_tiles * p.c_tiles), gxy = gx * (uint32_t)p.total_taps;
+    const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
+    const uint32_t by = bxy / gx, bx = bxy - by * gx;
+    wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+}
+
+template <int RT, int CT, int WR, int WC, int NS>
+int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
+                    hipStream_t stream) {
+    using C = WdCfg<RT, CT, WR, WC, NS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS>), dim3(8 * per_xcd), dim3(256), C::LDS_BYTES, stream, d_tab, d_blk,
+                       (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base);
+    return udapose_check_launch();
+}
+
+template <int RT, int CT, int WR, int WC, int NS>
 int launch_wd(WgParams& p, hipStream_t stream) {
     using C = WdCfg<RT, CT, WR, WC, NS>;
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
@@ -461,4 +510,34 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
         case 3: return launch_wg<32, 128, 1, 4>(p, stream);
         default: return UDAPOSE_ERR_ARG;
     }
+}
+
+int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block) {
+    const bool smallc = (p.flags & IG_FLAG_SMALLC) != 0;
+    const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
+    if (smallc || p.Ci % 64 != 0 || p.Co % 64 != 0) return -1;
+    const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
+    if (p.rows_valid != Rdim) return -1;
+    p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
+    p.div_w = make_fastdiv((uint32_t)p.Wg);
+    // inside a group the other layers fill the chip, so a layer takes the 128x128 tile (half the L2->LDS bytes per FLOP of
+    // 64x64) whenever both of its dimensions allow
+    const int tile = (Rdim >= 128 && Cdim >= 128) ? 0 : 1;
+    const int T = tile == 0 ? 128 : 64;
+    p.r_tiles = (Rdim + T - 1) / T;
+    p.c_tiles = (Cdim + T - 1) / T;
+    const int ms_total = (p.M + 63) / 64;
+    int ks = (ms_total + stages_per_block / 2) / stages_per_block;
+    if (ks < 1) ks = 1;
+    p.ksplit = ks;
+    p.msteps_per_split = (ms_total + ks - 1) / ks;
+    if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
+    return tile;
+}
+
+int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
+                       const void* dy_base, void* dw_base) {
+    if (per_xcd <= 0) return UDAPOSE_OK;
+    return tile == 0 ? launch_wd_group<128, 128, 2, 2, 2>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream)
+                     : launch_wd_group<64, 64, 2, 2, 4>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
 }
