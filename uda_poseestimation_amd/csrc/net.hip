@@ -30,6 +30,7 @@ int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
 int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
+int pw_bn_running_update_multi(hipStream_t, const BnRunJob*, int, int, const void*, float);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
 int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
@@ -109,6 +110,8 @@ struct Net {
         unsigned long long last_use = 0;
     };
     std::vector<WgGroup> wg_groups;
+    // batched deferred running-statistics update: device job table, rebuilt when the buffer pointers change
+    BnRunJob* d_runjobs = nullptr; int n_runjobs = 0; const void* runjobs_key = nullptr;
     unsigned long long wg_tick = 0;
 };
 struct PackJobH { const float* src; bf16_t* dst; int A, T, B, kind; long long n; };
@@ -294,6 +297,7 @@ void* net_create(const int layers[4], int K, int N, int H, int W, int f32) {
 void net_destroy(void* h) {
     Net* n = (Net*)h;
     if (!n) return;
+    if (n->d_runjobs) (void)hipFree(n->d_runjobs);
     for (auto& g : n->wg_groups)
         for (int t = 0; t < 2; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
     delete n;
@@ -463,14 +467,14 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
     G.zero.clear();
     G.rel.clear();
     G.flops[0] = G.flops[1] = 0.0;
-    auto add = [&](const ConvL& c) -> int {
-        if (c.g.smallc()) return UDAPOSE_OK;
+    auto add_geom = [&](const ConvGeom& g, int w_idx, size_t dy_off, size_t in_off, int rows_valid) -> int {
+        if (g.smallc()) return UDAPOSE_OK;
         WgParams p;
         double fl = 0.0;
         // byte offsets from the workspace / activation arena / gradient bases in place of pointers (see wgrad_dma_group_kernel)
-        const ptrdiff_t drel = (const char*)grads[c.w_idx] - (const char*)grads[0];
-        G.rel.push_back({c.w_idx, drel});
-        CK(conv_wgrad_params(c.g, (const bf16_t*)c.dy_off, (const bf16_t*)c.in_off, (float*)drel, -1, &p, &fl));
+        const ptrdiff_t drel = (const char*)grads[w_idx] - (const char*)grads[0];
+        G.rel.push_back({w_idx, drel});
+        CK(conv_wgrad_params(g, (const bf16_t*)dy_off, (const bf16_t*)in_off, (float*)drel, rows_valid, &p, &fl));
         const int t = wgrad_group_plan(p, beta != 0.f, g_wgrad_stages);
         if (t < 0) return UDAPOSE_ERR_UNSUPPORTED;
         const int prob = (int)tab[t].size();
@@ -484,10 +488,17 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         }
         if (p.ksplit > 1 && beta == 0.f) {
             const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
-            G.zero.push_back({drel, (size_t)(swap ? p.Ci : p.Co) * p.wtaps * (swap ? p.Co : p.Ci) * sizeof(float)});
+            G.zero.push_back({drel, (size_t)p.rows_valid * p.wtaps * (swap ? p.Co : p.Ci) * sizeof(float)});
         }
         return UDAPOSE_OK;
     };
+    auto add = [&](const ConvL& c) -> int { return add_geom(c.g, c.w_idx, c.dy_off, c.in_off, -1); };
+    {   // head: dy is channel-padded to 64, only the K real rows of dW exist
+        ConvGeom hg = n.head.g;
+        hg.Co = 64;
+        CK(add_geom(hg, n.head.w_idx, n.ws_dyhead, n.head.in_off, n.K));
+        G.flops[1] -= 2.0 * n.N * n.Hout * n.Wout * 256.0 * (64 - n.K);   // (count the K real channels only)
+    }
     for (int i = 2; i >= 0; --i) CK(add(n.up[i]));
     for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
         Block& b = n.blocks[bi];
@@ -573,8 +584,10 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     ConvGeom hg = n.head.g;
     hg.Co = 64;   // dy is channel-padded to 64 (one 64-wide K step)
     float* tmp = (float*)(ws + n.ws_dwtmp);
-    CK(conv_wgrad(s, hg, dyh, (const bf16_t*)(act + n.head.in_off), tmp, 0, n.K));
-    CK(pw_unpack_strided(s, tmp, (float*)grads[n.head.w_idx], n.K, 1, 1, 1, 256, 256, 256, 0, 0, 1, beta));
+    if (!grouped) {
+        CK(conv_wgrad(s, hg, dyh, (const bf16_t*)(act + n.head.in_off), tmp, 0, n.K));
+        CK(pw_unpack_strided(s, tmp, (float*)grads[n.head.w_idx], n.K, 1, 1, 1, 256, 256, 256, 0, 0, 1, beta));
+    }
     bf16_t* dz = pool.get();
     // Gradients entering the BatchNorm backward of the three deconv layers are kept in fp32: close to the loss the BN
     // projection (g - mean(g) - xhat*mean(g*xhat)) cancels ~90 % of g, so bf16 rounding of g is amplified ~10x in dy
@@ -630,16 +643,24 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
 // forwards of one module run concurrently on different streams.
 int net_apply_running(void* h, hipStream_t s, const void* act_, void* const* buffers, float momentum) {
     Net& n = *(Net*)h;
-    const char* act = (const char*)act_;
-    auto one = [&](const BnL& b) {
-        return pw_bn_running_update(s, (const float*)(act + b.save_off), b.C, (float*)buffers[b.rm_idx], (float*)buffers[b.rv_idx],
-                                    (long long*)buffers[b.nbt_idx], momentum);
-    };
-    CK(one(n.stem_bn));
-    for (auto& b : n.blocks) {
-        CK(one(b.b1)); CK(one(b.b2)); CK(one(b.b3));
-        if (b.has_ds) CK(one(b.bd));
+    // one launch for all layers; the job table (buffer pointers) is built on the first call with these buffers, which must
+    // not be inside a stream capture
+    if (!n.d_runjobs || n.runjobs_key != buffers[0]) {
+        std::vector<BnRunJob> jobs;
+        auto one = [&](const BnL& b) {
+            jobs.push_back(BnRunJob{b.save_off, (float*)buffers[b.rm_idx], (float*)buffers[b.rv_idx], (long long*)buffers[b.nbt_idx], b.C, 0});
+        };
+        one(n.stem_bn);
+        for (auto& b : n.blocks) {
+            one(b.b1); one(b.b2); one(b.b3);
+            if (b.has_ds) one(b.bd);
+        }
+        for (int i = 0; i < 3; ++i) one(n.up_bn[i]);
+        if (n.d_runjobs) { (void)hipFree(n.d_runjobs); n.d_runjobs = nullptr; }
+        if (hipMalloc((void**)&n.d_runjobs, jobs.size() * sizeof(BnRunJob)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemcpy(n.d_runjobs, jobs.data(), jobs.size() * sizeof(BnRunJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        n.n_runjobs = (int)jobs.size();
+        n.runjobs_key = buffers[0];
     }
-    for (int i = 0; i < 3; ++i) CK(one(n.up_bn[i]));
-    return UDAPOSE_OK;
+    return pw_bn_running_update_multi(s, n.d_runjobs, n.n_runjobs, 2048, act_, momentum);
 }

@@ -481,18 +481,37 @@ __global__ void maxpool2x2_ceil_k(const bf16_t* __restrict__ x, bf16_t* __restri
 }
 
 // per-plane sums of an NCHW fp32 tensor over (n, hw): out[c] (beta*old +) = sum  (head bias gradient)
-__global__ void plane_sum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW, float beta) {
+__global__ __launch_bounds__(1024) void plane_sum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW, float beta) {
     const int c = blockIdx.x;
     double s = 0.0;
-    for (int n = 0; n < N; ++n)
-        for (int i = threadIdx.x; i < HW; i += TPB) s += (double)x[((size_t)n * C + c) * HW + i];
-    __shared__ double red[TPB / 64];
+    if ((HW & 3) == 0) {
+        const int hw4 = HW >> 2;
+        for (int i = threadIdx.x; i < hw4; i += 1024) {
+            int n = 0;
+            for (; n + 4 <= N; n += 4) {          // four independent 16-byte loads in flight
+                const f32x4 a = *(const f32x4*)(x + ((size_t)n * C + c) * HW + 4 * i);
+                const f32x4 b = *(const f32x4*)(x + ((size_t)(n + 1) * C + c) * HW + 4 * i);
+                const f32x4 d = *(const f32x4*)(x + ((size_t)(n + 2) * C + c) * HW + 4 * i);
+                const f32x4 e = *(const f32x4*)(x + ((size_t)(n + 3) * C + c) * HW + 4 * i);
+                s += (double)((a[0] + a[1]) + (a[2] + a[3])) + (double)((b[0] + b[1]) + (b[2] + b[3])) +
+                     (double)((d[0] + d[1]) + (d[2] + d[3])) + (double)((e[0] + e[1]) + (e[2] + e[3]));
+            }
+            for (; n < N; ++n) {
+                const f32x4 a = *(const f32x4*)(x + ((size_t)n * C + c) * HW + 4 * i);
+                s += (double)((a[0] + a[1]) + (a[2] + a[3]));
+            }
+        }
+    } else {
+        for (int n = 0; n < N; ++n)
+            for (int i = threadIdx.x; i < HW; i += 1024) s += (double)x[((size_t)n * C + c) * HW + i];
+    }
+    __shared__ double red[16];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
-        for (int i = 0; i < TPB / 64; ++i) t += red[i];
+        for (int i = 0; i < 16; ++i) t += red[i];
         out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)t;
     }
 }
@@ -558,6 +577,20 @@ int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double cou
                    long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
     hipLaunchKernelGGL(bn_finalize_k, dim3((C + 31) / 32), dim3(FIN_T), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
                        save_mean, save_invstd);
+    return udapose_check_launch();
+}
+// the same for every BN layer of a net in one launch: jobs[blockIdx.x], channels blockIdx.y*TPB..; save = act + save_off
+__global__ void bn_running_update_multi_k(const BnRunJob* __restrict__ jobs, const char* __restrict__ act, float momentum) {
+    const BnRunJob j = jobs[blockIdx.x];
+    const int c = blockIdx.y * TPB + threadIdx.x;
+    if (c == 0 && j.nbt) *j.nbt += 1;
+    if (c >= j.C) return;
+    const float* save = (const float*)(act + j.save_off);
+    j.rm[c] = (1.f - momentum) * j.rm[c] + momentum * save[c];
+    j.rv[c] = (1.f - momentum) * j.rv[c] + momentum * save[2 * j.C + c];
+}
+int pw_bn_running_update_multi(hipStream_t s, const BnRunJob* d_jobs, int njobs, int maxC, const void* act, float momentum) {
+    hipLaunchKernelGGL(bn_running_update_multi_k, dim3(njobs, nblk(maxC)), dim3(TPB), 0, s, d_jobs, (const char*)act, momentum);
     return udapose_check_launch();
 }
 int pw_bn_running_update(hipStream_t s, const float* save, int C, float* rm, float* rv, long long* nbt, float momentum) {
@@ -631,6 +664,6 @@ int pw_maxpool2x2_ceil(hipStream_t s, const bf16_t* x, bf16_t* y, int N, int H, 
     return udapose_check_launch();
 }
 int pw_plane_sum(hipStream_t s, const float* x, float* out, int N, int C, int HW, float beta) {
-    hipLaunchKernelGGL(plane_sum_k, dim3(C), dim3(TPB), 0, s, x, out, N, C, HW, beta);
+    hipLaunchKernelGGL(plane_sum_k, dim3(C), dim3(1024), 0, s, x, out, N, C, HW, beta);
     return udapose_check_launch();
 }

@@ -517,7 +517,6 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block) {
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
     if (smallc || p.Ci % 64 != 0 || p.Co % 64 != 0) return -1;
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
-    if (p.rows_valid != Rdim) return -1;
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     // inside a group the other layers fill the chip, so a layer takes the 128x128 tile (half the L2->LDS bytes per FLOP of
