@@ -363,9 +363,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     const int cbase = n0 + wn * TN + cg * 8;
     const bool relu = (p.flags & IG_FLAG_RELU) != 0;
     const bool outf32 = F32 || (p.flags & IG_FLAG_OUT_F32) != 0;
-    float s1[8], s2[8];
+    if (p.stats) {
+        // BN partial statistics straight from the accumulators: a lane holds rows (lane>>4)*4+r of every 16-row tile for
+        // column j*16 + (lane&15), so the column sum is lane-local over (tile, r) plus two xor steps over lane>>4.
+        // (rows m >= M are zero-filled operand rows: they add 0)
+        const size_t srow = ((size_t)cls_id * p.m_tiles + m_tile) * WM + wm;
+        float* sp = p.stats + srow * 2 * p.Co;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        for (int j = 0; j < NT; ++j) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; a += v; b += v * v; }
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            const int col = n0 + wn * TN + j * 16 + lane;
+            if (lane < 16 && col < p.Co) { sp[col] = a; sp[p.Co + col] = b; }
+        }
+    }
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = (p.bias && cbase + e < p.Co) ? p.bias[cbase + e] : 0.f;
@@ -389,10 +405,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
             const f32x4 v1 = *(const f32x4*)(est + row * ELD + cg * 8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             const int m = m0 + wm * TM + ch * ER + row;
-            if (p.stats) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
-            }
             if (m < p.M && cbase < p.Co) {
                 const uint32_t n = fdiv((uint32_t)m, p.div_hw);
                 const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Hg * p.Wg);
@@ -438,22 +450,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) {
-                s1[e] += __shfl_xor(s1[e], o, 64);
-                s2[e] += __shfl_xor(s2[e], o, 64);
-            }
-        }
-        if (lane < LPR && cbase < p.Co) {
-            const size_t srow = ((size_t)cls_id * p.m_tiles + m_tile) * WM + wm;
-            float* sp = p.stats + srow * 2 * p.Co;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { sp[cbase + e] = s1[e]; sp[p.Co + cbase + e] = s2[e]; }
-        }
     }
 }
 
