@@ -76,10 +76,13 @@ int udapose_bn_eval_coeff(void* stream, int C, const float* gamma, const float* 
 int udapose_bn_apply(void* stream, const void* y, const void* res, void* z, size_t numel, int C, const float* scale, const float* shift,
                      int relu);
 int udapose_bn_bwd_rows(size_t npix);
-/* dz (bf16, or fp32 when dz_is_f32) -> dy (+ masked g); slab: [bn_bwd_rows][2][C] fp32 scratch, coef: [3][C] fp32 scratch */
+/* dz (bf16, or fp32 when dz_is_f32) -> dy (+ masked g); slab: [bn_bwd_rows][2][C] fp32 scratch, coef: [3][C] fp32 scratch.
+ * relu: 0 = none; 1 = ReLU mask from the saved output z (z > 0); 2 = mask recomputed from y as y*gamma*invstd +
+ * (beta - mean*gamma*invstd) > 0, the forward's own expression: z is not read (valid when the BN output had no residual
+ * added before its ReLU); beta = the BN bias parameter, needed for relu == 2 only. */
 int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
                    const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* slab, float* coef,
-                   float* dgamma, float* dbeta, float beta_acc);
+                   float* dgamma, float* dbeta, float beta_acc, const float* beta);
 
 /* ---------------------------------------------------------------- pooling (ResNet stem maxpool 3x3 s2 p1, resnet.py:30;
  * VGG MaxPool2d(2,2,ceil_mode=True), Style_net.py:72) */

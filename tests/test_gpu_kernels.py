@@ -197,6 +197,12 @@ def test_batchnorm_train_fwd_bwd(dev):
     close(dbeta.cpu(), bn.bias.grad, 5e-3)
     close(nchw(gmask), gm, 1.2e-2)
     assert ((nchw(z) > 0) != (zr.detach() > 0)).float().mean().item() < 1e-3
+    # BN + ReLU without a residual: the mask recomputed from y (relu=2, z not read) is the mask of the stored output
+    z2, mean2, invstd2 = ops.bn_train_fwd(y, stats, gamma.cuda(), beta.cuda(), rm, rv, nbt, res=None, relu=True)
+    a = ops.bn_bwd(nhwc(dz), z2, y, gamma.cuda(), mean2, invstd2, relu=1, want_g=True)
+    b = ops.bn_bwd(nhwc(dz), None, y, gamma.cuda(), mean2, invstd2, relu=2, want_g=True, beta=beta.cuda())
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
 
 
 def test_maxpool(dev):

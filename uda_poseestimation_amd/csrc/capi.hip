@@ -13,7 +13,7 @@ int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*,
 int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
-              float*, float*, float*, float*, float);
+              float*, float*, float*, float*, float, const float*);
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_maxpool2x2_ceil(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int);
@@ -103,9 +103,9 @@ int udapose_bn_apply(void* stream, const void* y, const void* res, void* z, size
 int udapose_bn_bwd_rows(size_t npix) { return pw_bn_bwd_rows(npix); }
 int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
                    const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
-                   float beta_acc) {
+                   float beta_acc, const float* beta) {
     return pw_bn_bwd(S(stream), dz, dz_is_f32, CB16(z), CB16(y), B16(dy), B16(gout), npix, C, gamma, mean, invstd, relu, slab, coef, dgamma, dbeta,
-                     beta_acc);
+                     beta_acc, beta);
 }
 int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C) {
     return pw_maxpool3x3s2_fwd(S(stream), CB16(x), B16(y), idx, N, H, W, C);

@@ -25,7 +25,7 @@ int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*,
 int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
-              float*, float*, float*, float*, float);
+              float*, float*, float*, float*, float, const float*);
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
@@ -426,6 +426,7 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
 
 namespace {
 // backward of conv+bn(+relu): dz (grad wrt z) -> parameter grads, returns dx of the conv input in a pool buffer
+// relu: 0 none, 1 mask from the saved z (bn3: z includes the residual), 2 mask recomputed from y (z is not read)
 int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, const char* wpack, char* act, char* ws,
                 void* const* grads, float beta, Pool& pool, const void* dz, int dz_f32, bf16_t* gout, int relu, const bf16_t* dx_res,
                 bf16_t** dx_out, bool need_dx, int dx_f32, bool grouped_wgrad) {
@@ -433,8 +434,10 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     float* coef = (float*)(ws + n.ws_coef) + 4096;
     const float* save = (const float*)(act + b.save_off);
     bf16_t* dy = (bf16_t*)(ws + c.dy_off);
+    static const int force_z = getenv("UDAPOSE_BN_MASK_Z") ? 1 : 0;
+    if (force_z && relu == 2) relu = 1;
     CK(pw_bn_bwd(s, dz, dz_f32, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx], save,
-                 save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta));
+                 save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx]));
     const bf16_t* xin = (const bf16_t*)(act + c.in_off);
     if (c.g.smallc()) {
         float* tmp = (float*)(ws + n.ws_dwtmp);
@@ -597,7 +600,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     // deconv stack
     for (int i = 2; i >= 0; --i) {
         bf16_t* dx = nullptr;
-        CK(conv_bn_bwd(s, n, n.up[i], n.up_bn[i], params, wpack, act, ws, grads, beta, pool, dz, 1, nullptr, 1, nullptr, &dx, true, i > 0, grouped));
+        CK(conv_bn_bwd(s, n, n.up[i], n.up_bn[i], params, wpack, act, ws, grads, beta, pool, dz, 1, nullptr, 2, nullptr, &dx, true, i > 0, grouped));
         pool.put(dz);
         dz = dx;
     }
@@ -607,7 +610,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         // bn3 (+ReLU of the block output): g = masked dz is written in place and feeds the skip branch
         bf16_t *dz2 = nullptr, *dz1 = nullptr, *dxd = nullptr, *dxin = nullptr;
         CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, 0, dz, 1, nullptr, &dz2, true, 0, grouped));
-        CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, 0, nullptr, 1, nullptr, &dz1, true, 0, grouped));
+        CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, 0, nullptr, 2, nullptr, &dz1, true, 0, grouped));
         pool.put(dz2);
         const bool first = (bi == 0);
         const bf16_t* skip = dz;
@@ -615,7 +618,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
             CK(conv_bn_bwd(s, n, b.cd, b.bd, params, wpack, act, ws, grads, beta, pool, dz, 0, nullptr, 0, nullptr, &dxd, true, 0, grouped));
             skip = dxd;
         }
-        CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, 0, nullptr, 1, skip, &dxin, true, 0, grouped));
+        CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, 0, nullptr, 2, skip, &dxin, true, 0, grouped));
         pool.put(dz1);
         if (dxd) pool.put(dxd);
         pool.put(dz);
@@ -627,7 +630,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     CK(pw_maxpool3x3s2_bwd(s, dz, (const unsigned char*)(act + n.poolidx_off), dzs, n.N, n.Hs, n.Ws, 64));
     pool.put(dz);
     bf16_t* none = nullptr;
-    CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 1, nullptr, &none, false, 0, grouped));
+    CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 2, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
     if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta));
     // backbone.fc is not part of the forward: zero gradient when overwriting

@@ -287,14 +287,18 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 template <typename DZ>
 __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
                                 size_t npix, int C, const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                float* __restrict__ slab, int pix_per_block) {
+                                float* __restrict__ slab, int pix_per_block, const float* __restrict__ gamma, const float* __restrict__ beta) {
     __shared__ float red[TPB][17];
     const int G = C >> 3;
     const int g = threadIdx.x % G, prow = threadIdx.x / G, pstep = TPB / G;
     const int c0 = g * 8;
-    float mu[8], is[8], s1[8], s2[8];
+    float mu[8], is[8], s1[8], s2[8], sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; s1[e] = 0.f; s2[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; s1[e] = 0.f; s2[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f; }
+    if (relu == 2) {   // ReLU mask recomputed from y with the forward's own scale / shift expressions (z is not read)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = gamma[c0 + e] * is[e]; sh[e] = beta[c0 + e] - mu[e] * sc[e]; }
+    }
     const size_t p0 = (size_t)blockIdx.x * pix_per_block;
     size_t p1 = p0 + pix_per_block;
     if (p1 > npix) p1 = npix;
@@ -303,12 +307,13 @@ __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restr
         float d[8];
         load8<DZ>(dz + off, d);
         const bf16x8 yy = *(const bf16x8*)(y + off);
-        bf16x8 zz;
-        if (relu) zz = *(const bf16x8*)(z + off);
+        bf16x8 zz = {};
+        if (relu == 1) zz = *(const bf16x8*)(z + off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float gv = d[e];
-            if (relu && !((float)zz[e] > 0.f)) gv = 0.f;
+            if (relu == 1 && !((float)zz[e] > 0.f)) gv = 0.f;
+            if (relu == 2 && !((float)yy[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
             s1[e] += gv;
             s2[e] += gv * (((float)yy[e] - mu[e]) * is[e]);
         }
@@ -350,23 +355,41 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_k(const float* __restri
 template <typename DZ>
 __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
                                bf16_t* __restrict__ dy, bf16_t* __restrict__ gout, size_t n8, int C, const float* __restrict__ mean,
-                               const float* __restrict__ invstd, const float* __restrict__ coef, int relu) {
+                               const float* __restrict__ invstd, const float* __restrict__ coef, int relu, const float* __restrict__ gamma,
+                               const float* __restrict__ beta) {
     const int G = C >> 3;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
         const int c0 = (int)(i % G) * 8;
         float d[8];
         load8<DZ>(dz + i * 8, d);
         const bf16x8 yy = *(const bf16x8*)(y + i * 8);
-        bf16x8 zz;
-        if (relu) zz = *(const bf16x8*)(z + i * 8);
+        bf16x8 zz = {};
+        if (relu == 1) zz = *(const bf16x8*)(z + i * 8);
+        // per-channel coefficients as 16-byte loads (8 consecutive channels)
+        float mu[8], is[8], ca[8], cb[8], cc[8], sc[8], sh[8];
+        load8<float>(mean + c0, mu);
+        load8<float>(invstd + c0, is);
+        load8<float>(coef + c0, ca);
+        load8<float>(coef + C + c0, cb);
+        load8<float>(coef + 2 * C + c0, cc);
+        if (relu == 2) {
+            float ga[8], be[8];
+            load8<float>(gamma + c0, ga);
+            load8<float>(beta + c0, be);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = ga[e] * is[e]; sh[e] = be[e] - mu[e] * sc[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
+        }
         bf16x8 o, go;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = c0 + e;
             float gv = d[e];
-            if (relu && !((float)zz[e] > 0.f)) gv = 0.f;
-            const float xh = ((float)yy[e] - mean[c]) * invstd[c];
-            o[e] = (bf16_t)(coef[c] * (gv - coef[C + c] - xh * coef[2 * C + c]));
+            if (relu == 1 && !((float)zz[e] > 0.f)) gv = 0.f;
+            if (relu == 2 && !((float)yy[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
+            const float xh = ((float)yy[e] - mu[e]) * is[e];
+            o[e] = (bf16_t)(ca[e] * (gv - cb[e] - xh * cc[e]));
             go[e] = (bf16_t)gv;
         }
         *(bf16x8*)(dy + i * 8) = o;
@@ -622,7 +645,9 @@ int pw_bn_bwd_rows(size_t npix) {
 }
 int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, const bf16_t* y, bf16_t* dy, bf16_t* gout, size_t npix, int C,
               const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
-              float beta_acc) {
+              float beta_acc, const float* beta) {
+    if (relu == 2 && !beta) return UDAPOSE_ERR_ARG;
+    if (relu == 1 && !z) return UDAPOSE_ERR_ARG;
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1))) return UDAPOSE_ERR_UNSUPPORTED;
     const int pstep = TPB / G;                                  // pixels a block covers per iteration
@@ -631,16 +656,16 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, con
     const int rows = (int)(want < 1 ? 1 : want);
     const int ppb = (int)((npix + rows - 1) / rows);
     if (dz_is_f32)
-        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(TPB), 0, s, (const float*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
+        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(TPB), 0, s, (const float*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb, gamma, beta);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb);
+        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb, gamma, beta);
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
     if (dz_is_f32)
         hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)dz, z, y, dy, gout, npix * G, C, mean, invstd,
-                           coef, relu);
+                           coef, relu, gamma, beta);
     else
         hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, dy, gout, npix * G, C, mean,
-                           invstd, coef, relu);
+                           invstd, coef, relu, gamma, beta);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_fwd(hipStream_t s, const bf16_t* x, bf16_t* y, unsigned char* idx, int N, int H, int W, int C) {

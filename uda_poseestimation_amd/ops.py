@@ -114,7 +114,8 @@ def bn_train_fwd(y, stats, gamma, beta, running_mean, running_var, nbt, momentum
     return z, mean, invstd
 
 
-def bn_bwd(dz, z, y, gamma, mean, invstd, relu=True, want_g=False):
+def bn_bwd(dz, z, y, gamma, mean, invstd, relu=True, want_g=False, beta=None):
+    """relu: False/0 none, True/1 mask from z, 2 mask recomputed from y (needs beta, z may be None)."""
     C_ = y.shape[-1]
     npix = y.numel() // C_
     dev = y.device
@@ -127,7 +128,7 @@ def bn_bwd(dz, z, y, gamma, mean, invstd, relu=True, want_g=False):
     g = torch.empty_like(y) if want_g else None
     check(lib().udapose_bn_bwd(stream(), ptr(dz), int(dz.dtype == torch.float32), ptr(z), ptr(y), ptr(dy), ptr(g), npix, C_, ptr(gamma), ptr(mean),
                                ptr(invstd), int(relu),
-                               ptr(slab), ptr(coef), ptr(dgamma), ptr(dbeta), 0.0), "bn_bwd")
+                               ptr(slab), ptr(coef), ptr(dgamma), ptr(dbeta), 0.0, ptr(beta)), "bn_bwd")
     return dy, dgamma, dbeta, g
 
 
