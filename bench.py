@@ -71,7 +71,7 @@ def cpu_baseline(n, arch_layers, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--spinup", type=float, default=8.0, help="seconds of untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per domain (BASELINE: 32)")
@@ -127,9 +127,16 @@ def main():
     # Device spin-up (untimed, before the W warm-up steps): an idle MI355X needs ~2-3 s of sustained load to reach its
     # steady clocks (measured: 770 img/s in a cold first run vs 970 img/s after 2.5 s of load, same binary, same box).
     t_spin = time.perf_counter()
+    spin_ms = []
     while time.perf_counter() - t_spin < args.spinup:
+        t_a = time.perf_counter()
         out = step()
         torch.cuda.synchronize()
+        spin_ms.append((time.perf_counter() - t_a) * 1e3)
+    if spin_ms and rank == 0:
+        k = max(1, len(spin_ms) // 10)
+        print("spin-up ms/step by tenths: " + " ".join(f"{sum(spin_ms[i:i + k]) / len(spin_ms[i:i + k]):.1f}" for i in range(0, len(spin_ms), k)),
+              file=sys.stderr)
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
