@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 import torch
 from uda_poseestimation_amd import ops
 torch.manual_seed(0)
-for (N, H, C_, f32) in ((4, 32, 256, True), (4, 32, 256, False), (4, 4, 2048, True), (4, 16, 64, False)):
+for (N, H, C_, f32) in ((4, 32, 256, True), (4, 32, 256, False), (8, 16, 2048, True), (32, 16, 1024, False), (4, 16, 64, False)):
     y = torch.randn(N, H, H, C_, device='cuda').bfloat16()
     gamma = (torch.rand(C_, device='cuda') + 0.5); beta = torch.randn(C_, device='cuda') * 0.1
     yf = y.float()

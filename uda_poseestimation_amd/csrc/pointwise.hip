@@ -1,6 +1,7 @@
 // Memory-bound kernels of the pose network for gfx950: layout conversion, weight packing, training-mode BatchNorm
 // (finalize / apply / backward), 3x3 s2 and 2x2 ceil max-pooling.  All activation tensors are NHWC bf16 and every
 // thread moves 16 bytes (8 channels) per access.  These kernels are HBM-roofline bound (8 TB/s peak).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -397,6 +398,131 @@ __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restri
     }
 }
 
+// ---- channel-chunked BN backward (wide, small-spatial layers: C >= 256, <= 32 K pixels) ------------------------------
+// Work-group = 64 channels (one 128-byte segment of every pixel row) x one pixel range; grid (C/64, S).  The reduce writes
+// S partial rows per chunk ([chunk][S][2][64] floats, <= 32 KB per chunk), and every apply work-group sums its chunk's rows
+// itself (fp64, fixed order) before streaming: the separate finalize launch (6-7 us on the critical path of every layer)
+// is gone, at the price of a <= 32 KB L2-resident prelude per work-group.
+template <typename DZ>
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_chunk_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+                                                             size_t npix, int C, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int relu, float* __restrict__ slab, int P,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta) {
+    __shared__ float red[32][8][17];
+    const int chunk = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const int cg = threadIdx.x & 7, prow = threadIdx.x >> 3;
+    const int c0 = chunk * 64 + cg * 8;
+    float mu[8], is[8], s1[8], s2[8], sc[8], sh[8];
+    load8<float>(mean + c0, mu);
+    load8<float>(invstd + c0, is);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f; }
+    if (relu == 2) {
+        float ga[8], be[8];
+        load8<float>(gamma + c0, ga);
+        load8<float>(beta + c0, be);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = ga[e] * is[e]; sh[e] = be[e] - mu[e] * sc[e]; }
+    }
+    const size_t p0 = (size_t)sp * P;
+    size_t p1 = p0 + P;
+    if (p1 > npix) p1 = npix;
+    for (size_t p = p0 + prow; p < p1; p += 32) {
+        const size_t off = p * C + c0;
+        float d[8];
+        load8<DZ>(dz + off, d);
+        const bf16x8 yy = *(const bf16x8*)(y + off);
+        bf16x8 zz = {};
+        if (relu == 1) zz = *(const bf16x8*)(z + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gv = d[e];
+            if (relu == 1 && !((float)zz[e] > 0.f)) gv = 0.f;
+            if (relu == 2 && !((float)yy[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
+            s1[e] += gv;
+            s2[e] += gv * (((float)yy[e] - mu[e]) * is[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[prow][cg][e] = s1[e]; red[prow][cg][8 + e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
+        float a = 0.f;
+        for (int k = 0; k < 32; ++k) a += red[k][g][e];
+        slab[(((size_t)chunk * S + sp) * 2 + (e >> 3)) * 64 + g * 8 + (e & 7)] = a;
+    }
+}
+template <typename DZ>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+                                                            bf16_t* __restrict__ dy, bf16_t* __restrict__ gout, size_t npix, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ slab, int P, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float beta_acc) {
+    __shared__ double tot[2][64];
+    const int chunk = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    if (threadIdx.x < 128) {
+        const int st = threadIdx.x >> 6, col = threadIdx.x & 63;
+        const float* q = slab + ((size_t)chunk * S * 2 + st) * 64 + col;
+        double a = 0.0;
+        int k = 0;
+        for (; k + 4 <= S; k += 4)        // four independent loads in flight; the order of the fp64 additions is fixed
+            a += ((double)q[(size_t)k * 128] + (double)q[(size_t)(k + 1) * 128]) + ((double)q[(size_t)(k + 2) * 128] + (double)q[(size_t)(k + 3) * 128]);
+        for (; k < S; ++k) a += (double)q[(size_t)k * 128];
+        tot[st][col] = a;
+    }
+    __syncthreads();
+    if (sp == 0 && threadIdx.x < 64 && dgamma) {
+        const int c = chunk * 64 + threadIdx.x;
+        dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)tot[1][threadIdx.x];
+        dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)tot[0][threadIdx.x];
+    }
+    const int cg = threadIdx.x & 7, prow = threadIdx.x >> 3;
+    const int c0 = chunk * 64 + cg * 8;
+    const double count = (double)npix;
+    float mu[8], is[8], ca[8], cb[8], cc[8], sc[8], sh[8], ga[8];
+    load8<float>(mean + c0, mu);
+    load8<float>(invstd + c0, is);
+    load8<float>(gamma + c0, ga);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ca[e] = ga[e] * is[e];
+        cb[e] = (float)(tot[0][cg * 8 + e] / count);
+        cc[e] = (float)(tot[1][cg * 8 + e] / count);
+        sc[e] = 0.f; sh[e] = 0.f;
+    }
+    if (relu == 2) {
+        float be[8];
+        load8<float>(beta + c0, be);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = ga[e] * is[e]; sh[e] = be[e] - mu[e] * sc[e]; }
+    }
+    const size_t p0 = (size_t)sp * P;
+    size_t p1 = p0 + P;
+    if (p1 > npix) p1 = npix;
+    for (size_t p = p0 + prow; p < p1; p += 32) {
+        const size_t off = p * C + c0;
+        float d[8];
+        load8<DZ>(dz + off, d);
+        const bf16x8 yy = *(const bf16x8*)(y + off);
+        bf16x8 zz = {};
+        if (relu == 1) zz = *(const bf16x8*)(z + off);
+        bf16x8 o, go;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gv = d[e];
+            if (relu == 1 && !((float)zz[e] > 0.f)) gv = 0.f;
+            if (relu == 2 && !((float)yy[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
+            const float xh = ((float)yy[e] - mu[e]) * is[e];
+            o[e] = (bf16_t)(ca[e] * (gv - cb[e] - xh * cc[e]));
+            go[e] = (bf16_t)gv;
+        }
+        *(bf16x8*)(dy + off) = o;
+        if (gout) *(bf16x8*)(gout + off) = go;
+    }
+}
+
 // ------------------------------------------------------------------ max pooling (NHWC bf16)
 // 3x3 stride 2 pad 1 (ResNet stem).  Saves the winning tap (0..8, first max in (kh,kw) scan order like ATen) per element.
 template <typename T>
@@ -639,6 +765,10 @@ int pw_bn_apply_f32(hipStream_t s, const float* y, const float* res, float* z, s
     hipLaunchKernelGGL(bn_apply_k<float>, dim3(grid_for(n / 8)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
     return udapose_check_launch();
 }
+static int bn_bwd_chunked() {   // tuning hook: UDAPOSE_BN_BWD_CHUNKED=0 restores reduce / finalize / apply everywhere
+    static const int v = getenv("UDAPOSE_BN_BWD_CHUNKED") ? atoi(getenv("UDAPOSE_BN_BWD_CHUNKED")) : 1;
+    return v;
+}
 int pw_bn_bwd_rows(size_t npix) {
     // upper bound used to size the scratch slab; the launch picks rows = min(1024, ceil(npix / pixels-per-iteration))
     return (int)(npix < 1024 ? (npix < 1 ? 1 : npix) : 1024);
@@ -650,6 +780,27 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, con
     if (relu == 1 && !z) return UDAPOSE_ERR_ARG;
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1))) return UDAPOSE_ERR_UNSUPPORTED;
+    if (bn_bwd_chunked() && C >= 256 && npix <= 32768 && npix >= 1024) {
+        // channel-chunked form without a finalize launch (see bn_bwd_reduce_chunk_k)
+        const int chunks = C / 64;
+        int S = 1024 / chunks;
+        if (S > 64) S = 64;
+        if (S < 1) S = 1;
+        int P = (int)((npix + S - 1) / S);
+        P = (P + 31) & ~31;
+        S = (int)((npix + P - 1) / P);
+        const dim3 grid(chunks, S);
+        if (dz_is_f32) {
+            hipLaunchKernelGGL(bn_bwd_reduce_chunk_k<float>, grid, dim3(TPB), 0, s, (const float*)dz, z, y, npix, C, mean, invstd, relu, slab, P, gamma, beta);
+            hipLaunchKernelGGL(bn_bwd_apply_chunk_k<float>, grid, dim3(TPB), 0, s, (const float*)dz, z, y, dy, gout, npix, C, mean, invstd, relu, gamma,
+                               beta, slab, P, dgamma, dbeta, beta_acc);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_reduce_chunk_k<bf16_t>, grid, dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, P, gamma, beta);
+            hipLaunchKernelGGL(bn_bwd_apply_chunk_k<bf16_t>, grid, dim3(TPB), 0, s, (const bf16_t*)dz, z, y, dy, gout, npix, C, mean, invstd, relu, gamma,
+                               beta, slab, P, dgamma, dbeta, beta_acc);
+        }
+        return udapose_check_launch();
+    }
     const int pstep = TPB / G;                                  // pixels a block covers per iteration
     size_t want = (npix + pstep - 1) / pstep;
     if (want > 1024) want = 1024;
