@@ -89,12 +89,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); the CPU oracle lives in oracle/ and is only the baseline leg")
+    # test hook (tests/test_gpu_hotpath.py): UDAPOSE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo backend, so
+    # the multi-rank control flow (three graphs around the two collectives) can be exercised on a one-GPU box
+    share = os.environ.get("UDAPOSE_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from uda_poseestimation_amd import _hip, synthetic
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
@@ -167,6 +175,13 @@ def main():
         elapsed = float(t.item())
     loss = float(out["loss_all"])
     assert loss == loss, "loss is NaN"
+    in_sync = None
+    if world > 1:
+        # data-parallel invariant (outside the timed region): every rank holds the same student and teacher after the run
+        chk = torch.stack([sum(p.detach().double().sum() for p in m.parameters()) for m in (student, teacher)]).to(dev)
+        every = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(every, chk)
+        in_sync = all(bool(torch.equal(e, every[0])) for e in every)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -185,6 +200,7 @@ def main():
                                    f"Adam, EMA), 256x256, b={N}/GPU, no AdaIN (BASELINE.json configs[1])",
                        "global_batch": world * N, "parallelism": f"dp{world}"},
             "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs) else "2 hipGraphs") + " (last timed step eager, instrumented)",
+            "replicas_in_sync": in_sync,
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if args.arch == "pose_resnet101" else None,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fprop+dgrad, bf16 MFMA 16x16x32)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
