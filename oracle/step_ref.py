@@ -52,3 +52,32 @@ def train_step_ref(student, teacher, optimizer, x_s, label_s, weight_s, x_t_stu,
     ema_step_ref(list(teacher.parameters()), list(student.parameters()), alpha)
     return {"loss_all": loss.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": y_s.detach(),
             "tea_mask": tea_mask, "thr": thr}
+
+
+def validate_ref(batches, model):
+    """validate() of the reference (train_human.py:461-500) with its meters (lib/meter.py:8-40,65-82): eval mode, no grad;
+    per-key-point running average weighted by batch size, a value of -1 (key point absent from the batch) is skipped;
+    mean loss weighted by batch size.  Returns (acc_per_keypoint list, mean_loss)."""
+    from .keypoints_ref import accuracy_ref
+    from .losses_ref import joints_mse_ref
+    was_training = model.training
+    model.eval()
+    sums = cnts = None
+    loss_sum, n_seen = 0.0, 0
+    with torch.no_grad():
+        for x, label, weight in batches:
+            y = model(x)
+            loss = float(joints_mse_ref(y, label, weight))
+            acc, _, _, _ = accuracy_ref(y.numpy(), label.numpy())
+            n = x.shape[0]
+            if sums is None:
+                sums, cnts = [0.0] * len(acc), [0] * len(acc)
+            for k, a in enumerate(acc):
+                if a != -1:
+                    sums[k] += float(a) * n
+                    cnts[k] += n
+            loss_sum += loss * n
+            n_seen += n
+    if was_training:
+        model.train()
+    return [s / c if c else 0 for s, c in zip(sums, cnts)], loss_sum / n_seen

@@ -367,3 +367,40 @@ def test_two_rank_step_on_one_gpu_gloo():
     assert d["value"] > 0 and d["loss"] == d["loss"]
     assert "3 hipGraphs" in d["launch"]
     assert d["replicas_in_sync"] is True               # same averaged gradients -> bit-identical replicas
+
+
+def test_validate_matches_cpu_oracle():
+    """validate() (train_human.py:461-500): eval-mode forward, device decode + PCK accumulated on the device, one
+    read-back; against the CPU restatement with the reference's meter semantics (absent key points = -1 are skipped,
+    batch-size weights, ragged last batch)."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import validate_ref
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import validate
+    from uda_poseestimation_amd.lib.models import pose_resnet as pr
+    K, S, layers = 5, 128, [1, 1, 1, 1]
+    torch.manual_seed(3)
+    ref = PoseResNetRef(layers, K)
+    torch.nn.init.normal_(ref.head.weight, std=0.05)       # distinct peaks (the default 0.001 head gives near-flat maps)
+    # trained-like statistics so that eval mode (running stats) is exercised with non-trivial values
+    ref.train()
+    with torch.no_grad():
+        for i in range(3):
+            ref(synthetic.images(4, S, 100 + i))
+    net = pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda()
+    net.precision = "fp32"                      # the reference validates in fp32 (no autocast there)
+    batches = []
+    for i, n in enumerate((4, 4, 3)):
+        b = synthetic.mean_teacher_batch(n, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=20 + i)
+        lab, w = b["label_s"].clone(), b["weight_s"].clone()
+        if i == 1:
+            lab[:, 2] = 0; w[:, 2] = 0          # key point 2 absent from the whole batch -> accuracy -1 -> skipped
+        batches.append((b["x_s"], lab, w))
+    acc_r, loss_r = validate_ref(batches, ref)
+    acc_d, loss_d = validate(batches, net)
+    assert len(acc_d) == K
+    np.testing.assert_allclose(acc_d, acc_r, atol=1e-6)
+    assert abs(loss_d - loss_r) <= 1e-4 * abs(loss_r) + 1e-9
+    assert net.training            # validate() restores the mode it found

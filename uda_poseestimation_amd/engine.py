@@ -194,6 +194,44 @@ class MeanTeacherTrainer:
         self.tea_optimizer.step()           # EMA after the optimizer step (train_human.py:437-438)
 
 
+def validate(batches, model, criterion=None):
+    """The reference's validate() (train_human.py:461-500) on the device: eval mode, no grad; per-key-point PCK@0.05
+    averaged over the set with batch-size weights, entries of -1 (key point absent from a batch) ignored exactly like
+    `AverageMeterList(ignore_val=-1)` (lib/meter.py:18-36,65-82), and the batch-size weighted mean loss.  `batches` yields
+    (x, label, weight[, meta]).  Decode and PCK run on the device and are ACCUMULATED there: one read-back at the end
+    instead of the reference's 2 x 8.4 MB device->host copy + sync per batch.  Returns (acc_per_keypoint list, mean_loss)
+    (the caller applies its dataset's group_accuracy)."""
+    criterion = criterion or JointsMSELoss()
+    was_training = model.training
+    model.eval()
+    acc_sum = acc_cnt = loss_sum = None
+    n_seen = 0
+    with torch.no_grad():
+        for batch in batches:
+            x, label, weight = batch[0], batch[1], batch[2]
+            dev = next(model.parameters()).device
+            x, label, weight = x.to(dev, non_blocking=True), label.to(dev, non_blocking=True), weight.to(dev, non_blocking=True)
+            y = model(x)
+            loss = criterion(y, label, weight)
+            acc, _, _ = kd.accuracy_device(y, label)
+            n = x.shape[0]
+            present = (acc != -1).to(torch.float32)
+            if acc_sum is None:
+                acc_sum, acc_cnt, loss_sum = torch.zeros_like(acc, dtype=torch.float64), torch.zeros_like(acc, dtype=torch.float64), \
+                    torch.zeros((), dtype=torch.float64, device=dev)
+            acc_sum += (acc * present).double() * n
+            acc_cnt += present.double() * n
+            loss_sum += loss.detach().double() * n
+            n_seen += n
+    if was_training:
+        model.train()
+    if acc_sum is None:
+        return [], float("nan")
+    avg = torch.where(acc_cnt > 0, acc_sum / acc_cnt.clamp(min=1), torch.zeros_like(acc_sum))     # AverageMeter.avg starts at 0
+    out = torch.cat([avg, (loss_sum / max(n_seen, 1)).reshape(1)]).cpu().tolist()                 # the one read-back
+    return out[:-1], out[-1]
+
+
 class GraphedTrainStep:
     """The mean-teacher step captured into two hipGraphs (forward/backward, then Adam+EMA) around the eager gradient
     all-reduce: ~2500 kernel launches per step are replayed by two graph launches, which removes the host launch gaps.

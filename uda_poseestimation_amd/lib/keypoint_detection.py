@@ -41,6 +41,20 @@ def get_max_preds(batch_heatmaps):
     return preds, maxv
 
 
+def accuracy_device(output, target, thr=0.5):
+    """`accuracy` without the read-back: (acc [K] float32 with -1 for key points absent from the batch, [avg_acc, cnt],
+    pred [B,K,2]) as CUDA tensors on the current stream - no host synchronisation (validate() accumulates them on the
+    device and reads the set's averages back once)."""
+    o, t = _dev_f32(output), _dev_f32(target)
+    B, K, H, W = o.shape
+    pred, _ = _decode(o)
+    gt, _ = _decode(t)
+    acc = torch.empty(K, dtype=torch.float32, device=o.device)
+    avg_cnt = torch.empty(2, dtype=torch.float32, device=o.device)
+    check(lib().udapose_pck(_hip.stream(), ptr(pred), ptr(gt), B, K, H / 10.0, W / 10.0, float(thr), ptr(acc), ptr(avg_cnt)), "pck")
+    return acc, avg_cnt, pred
+
+
 def accuracy(output, target, hm_type='gaussian', thr=0.5):
     """PCK@(thr/10 of the heat-map size) from GT heat-maps; returns (acc[K], avg_acc, cnt, pred[B,K,2]) like the reference."""
     if hm_type != 'gaussian':
