@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--spinup", type=float, default=8.0, help="seconds of untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per domain (BASELINE: 32)")
     ap.add_argument("--arch", default="pose_resnet101")
+    ap.add_argument("--igemm-tile", type=int, default=-1, help="tuning: force one igemm tile configuration id")
     ap.add_argument("--wgrad-group", type=int, default=1, help="tuning: 0 = one weight-gradient launch per layer")
     ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,6 +110,8 @@ def main():
     import uda_poseestimation_amd.lib.models as models
     lib = _hip.lib()
     lib.udapose_debug_set_wgrad_group(args.wgrad_group, args.wgrad_stages)
+    if args.igemm_tile >= 0:
+        lib.udapose_debug_set_tiles(args.igemm_tile, -1, -1)
 
     N, K = args.batch, 16
     torch.manual_seed(0)

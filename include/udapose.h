@@ -177,6 +177,9 @@ void udapose_debug_set_tiles(int igemm_tile, int wgrad_tile, int wgrad_ksplit);
  * the dgrad / BN-backward chain (on = 1, default) or layer by layer (on = 0); stages_per_block (> 0) = 64-pixel stages a
  * work-group reduces before a layer's pixel range is split (default 128) */
 void udapose_debug_set_wgrad_group(int on, int stages_per_block);
+/* tuning hook: device buffer ([work-groups][8] uint64, or NULL = off) into which every conv work-group writes s_memrealtime
+ * stamps (100 MHz): entry, prologue done, first K stage landed, K loop done, epilogue issued, stores drained */
+void udapose_debug_set_timeline(void* dev_buf);
 void udapose_prof_begin(void);
 int udapose_prof_end(double* h_out9);
 

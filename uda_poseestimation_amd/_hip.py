@@ -66,6 +66,7 @@ _SIGS = {
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_debug_set_tiles": (None, [ci, ci, ci]),
     "udapose_debug_set_wgrad_group": (None, [ci, ci]),
+    "udapose_debug_set_timeline": (None, [vp]),
     "udapose_patch_paste": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
     "udapose_prof_begin": (None, []),
     "udapose_prof_end": (ci, [vp]),

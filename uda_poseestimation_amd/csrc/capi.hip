@@ -124,6 +124,8 @@ int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32
 }
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
 void udapose_debug_set_wgrad_group(int on, int stages_per_block) { net_set_wgrad_group(on, stages_per_block); }
+extern unsigned long long* g_igemm_timeline;
+void udapose_debug_set_timeline(void* dev_buf) { g_igemm_timeline = (unsigned long long*)dev_buf; }
 int udapose_net_num_params(udapose_net_t n) { return net_num_params(n); }
 int udapose_net_num_buffers(udapose_net_t n) { return net_num_buffers(n); }
 long long udapose_net_param_numel(udapose_net_t n, int i) { return net_param_numel(n, i); }

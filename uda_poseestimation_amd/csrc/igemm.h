@@ -33,6 +33,7 @@ struct IgParams {
     IgClass cls[4];
     FastDiv div_hw, div_w;  // m / (Hg*Wg), rem / Wg
     int m_tiles, n_tiles;
+    unsigned long long* dbg;   // tuning: per-work-group timeline stamps [blocks][8] (s_memrealtime, 100 MHz), normally null
 };
 
 // wgrad: dW[r][tap][c] (fp32) (+)= sum_m P[pixP][r] * Q[pixQ][c]

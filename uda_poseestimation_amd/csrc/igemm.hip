@@ -15,6 +15,7 @@
 // consecutive channels (128-byte lines per pixel), with bias / residual / ReLU and the BatchNorm batch-statistic
 // partial sums (sum, sum of squares of the fp32 accumulators) fused in.  The partial sums are written to a slab
 // (one row per wave-row of the grid), not added atomically: every block would hit the same few cache lines.
+#include <stdlib.h>
 #include "igemm.h"
 
 namespace {
@@ -86,6 +87,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases stay scalar
+    unsigned long long* const dbg = p.dbg ? p.dbg + (size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 : nullptr;
+    if (dbg && tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
     const int wm = wid / WN, wn = wid % WN;
     // XCD-aware order: each XCD owns a contiguous range of (class, m_tile) so its L2 holds a 1/8 slice of the activations
     const uint32_t tiles = (uint32_t)p.m_tiles * p.n_tiles;
@@ -155,14 +158,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
             a_ptr0[i] = (const char*)(px + (((long long)a_nb[i] + (long long)a_hi0[i] * p.Wi + a_wi0[i]) * p.Ci + a_lc[i] * EPC));
-            unsigned long long mk = 0ull;
-            for (int t = 0; t < cls.ntaps; ++t) {
-                const IgTap tt = taps_l[t];
-                const int hi = a_hi0[i] + tt.dy, wi = a_wi0[i] + tt.dx;
-                if (a_ok[i] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) mk |= 1ull << t;
-            }
-            a_mask[i] = mk;
+            a_mask[i] = 0ull;
             a_cur[i] = zsrc;
+        }
+        // tap-validity masks: ONE LDS read per tap shared by this lane's rows (the row-outer form paid an LDS round trip per
+        // (row, tap): 36 dependent reads = 2-4 us of a 3x3 conv's prologue, measured with udapose_debug_set_timeline)
+#pragma unroll 4
+        for (int t = 0; t < cls.ntaps; ++t) {
+            const IgTap tt = taps_l[t];
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) {
+                const int hi = a_hi0[i] + tt.dy, wi = a_wi0[i] + tt.dx;
+                if (a_ok[i] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) a_mask[i] |= 1ull << t;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_PW; ++i) { b_ptr0[i] = (const char*)(pw + ((long long)b_row[i] + b_lc[i] * EPC)); b_cur[i] = zsrc; }
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         }
     } else {
     // prologue: NS-1 stages in flight
+    if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
     int issued = 0;
     static_for<NS - 1>([&](auto u) __attribute__((always_inline)) {
         if (decltype(u)::value < nsteps) { issue_stage(u); ++issued; }
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
                 if (issued - st - 1 >= NS - 2) wait_vmcnt<LPS*(NS - 2)>();
                 else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();          // every wave's share of stage st is in LDS; buffer (st-1)%NS is free
+                if (dbg && tid == 0 && st == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
                 if (issued < nsteps) { issue_stage(IC<(U + NS - 1) % NS>{}); ++issued; }
                 compute(u);
             }
@@ -355,6 +365,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // all LDS reads of the ring are done before the epilogue reuses it
+    if (dbg && tid == 0) dbg[3] = __builtin_amdgcn_s_memrealtime();
 
     // ---- epilogue: accumulators -> LDS (per-wave region) -> 8-channel vectors -> global
     constexpr int ER = C::ER, ELD = C::ELD, LPR = TN / 8 /*lanes per row*/, RPP = 64 / LPR /*rows per pass*/;
@@ -451,6 +462,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
+    if (dbg && tid == 0) {
+        dbg[4] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[5] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS>
@@ -482,6 +498,7 @@ int launch_cfg(IgParams& p, hipStream_t stream) {
 }  // namespace
 
 int g_igemm_tile_override = -1;   // debug/tuning hook (udapose_debug_set_tiles)
+unsigned long long* g_igemm_timeline = nullptr;   // tuning hook: device buffer for per-work-group timeline stamps
 
 // Tile selection (measured on MI355X over every PoseResNet-101 layer shape at N=32, tools/tune_conv.py): 128x64 tiles
 // when they still yield >= 512 work-groups (2 per CU), else 64x64 (4-deep ring when K is long).  128x128 tiles lose to
@@ -490,11 +507,14 @@ int g_igemm_tile_override = -1;   // debug/tuning hook (udapose_debug_set_tiles)
 // 7 = 64x64 register-staged, 8 = 128x64 register-staged (measured within +-8 % of the LDS-DMA variants on every shape: the
 // feed rate per CU, ~16 B/clk from L2, is the same for both staging methods; kept for tuning, never selected)
 int igemm_pick_tile(int M, int Co, int nclass, int K) {
-    if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
     if (Co <= 32) return 3;
+    if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
+    static const long thr = getenv("UDAPOSE_IG_THR") ? atol(getenv("UDAPOSE_IG_THR")) : 512;
+    static const int small_k = getenv("UDAPOSE_IG_SMALLK") ? atoi(getenv("UDAPOSE_IG_SMALLK")) : 5;
+    static const int big_k = getenv("UDAPOSE_IG_BIGK") ? atoi(getenv("UDAPOSE_IG_BIGK")) : 2;
     const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
-    if (b12864 >= 512) return 6;
-    return K >= 1024 ? 2 : 5;
+    if (b12864 >= thr) return 6;
+    return K >= 1024 ? big_k : small_k;
 }
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
@@ -506,6 +526,7 @@ int igemm_stat_rows(int M, int Co, int nclass, int tile) {
 }
 
 int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
+    p.dbg = g_igemm_timeline;
     const int bke = (p.flags & IG_FLAG_F32) ? 32 : 64;
     if (p.Ci % 8 != 0 || (!(p.flags & IG_FLAG_SMALLC) && p.Ci % bke != 0)) return UDAPOSE_ERR_ARG;
     if ((p.flags & IG_FLAG_SMALLC) && p.Ci != 8) return UDAPOSE_ERR_ARG;
