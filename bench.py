@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver stack
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
     const int cbase = n0 + wn * TN + cg * 8;
     const bool relu = (p.flags & IG_FLAG_RELU) != 0;
     const bool outf32 = F32 || (p.flags & IG_FLAG_OUT_F32) != 0;
+    const bool lin_out = p.os == 1 && cls.oa == 0 && cls.ob == 0 && p.Hg == p.Ho && p.Wg == p.Wo;
     if (p.stats) {
         // BN partial statistics straight from the accumulators: a lane holds rows (lane>>4)*4+r of every 16-row tile for
         // column j*16 + (lane&15), so the column sum is lane-local over (tile, r) plus two xor steps over lane>>4.
@@ -417,13 +418,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             const int m = m0 + wm * TM + ch * ER + row;
             if (m < p.M && cbase < p.Co) {
-                const uint32_t n = fdiv((uint32_t)m, p.div_hw);
-                const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Hg * p.Wg);
-                const uint32_t ii = fdiv(rem, p.div_w);
-                const uint32_t jj = rem - ii * (uint32_t)p.Wg;
-                const uint32_t oh = ii * p.os + cls.oa, ow = jj * p.os + cls.ob;
-                if (oh >= (uint32_t)p.Ho || ow >= (uint32_t)p.Wo) continue;
-                const size_t opix = ((size_t)n * p.Ho + oh) * p.Wo + ow;
+                size_t opix = (size_t)m;                 // row grid == output grid (every conv but the sub-pixel classes)
+                if (!lin_out) {
+                    const uint32_t n = fdiv((uint32_t)m, p.div_hw);
+                    const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Hg * p.Wg);
+                    const uint32_t ii = fdiv(rem, p.div_w);
+                    const uint32_t jj = rem - ii * (uint32_t)p.Wg;
+                    const uint32_t oh = ii * p.os + cls.oa, ow = jj * p.os + cls.ob;
+                    if (oh >= (uint32_t)p.Ho || ow >= (uint32_t)p.Wo) continue;
+                    opix = ((size_t)n * p.Ho + oh) * p.Wo + ow;
+                }
                 const size_t off = opix * p.Co + cbase;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias[e];
@@ -509,12 +513,11 @@ unsigned long long* g_igemm_timeline = nullptr;   // tuning hook: device buffer 
 int igemm_pick_tile(int M, int Co, int nclass, int K) {
     if (Co <= 32) return 3;
     if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
-    static const long thr = getenv("UDAPOSE_IG_THR") ? atol(getenv("UDAPOSE_IG_THR")) : 512;
-    static const int small_k = getenv("UDAPOSE_IG_SMALLK") ? atoi(getenv("UDAPOSE_IG_SMALLK")) : 5;
-    static const int big_k = getenv("UDAPOSE_IG_BIGK") ? atoi(getenv("UDAPOSE_IG_BIGK")) : 2;
+    // measured (tools/tune_conv.py, and re-checked under the three-stream step): 128x64 tiles as soon as they give two
+    // work-groups per CU, else 64x64 with the deeper ring for long K
     const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
-    if (b12864 >= thr) return 6;
-    return K >= 1024 ? big_k : small_k;
+    if (b12864 >= 512) return 6;
+    return K >= 1024 ? 2 : 5;
 }
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {

@@ -434,8 +434,6 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     float* coef = (float*)(ws + n.ws_coef) + 4096;
     const float* save = (const float*)(act + b.save_off);
     bf16_t* dy = (bf16_t*)(ws + c.dy_off);
-    static const int force_z = getenv("UDAPOSE_BN_MASK_Z") ? 1 : 0;
-    if (force_z && relu == 2) relu = 1;
     CK(pw_bn_bwd(s, dz, dz_f32, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx], save,
                  save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx]));
     const bf16_t* xin = (const bf16_t*)(act + c.in_off);
