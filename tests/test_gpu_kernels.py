@@ -205,6 +205,39 @@ def test_batchnorm_train_fwd_bwd(dev):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("shape", [(4, 32, 256, True), (8, 16, 512, False), (3, 20, 1024, False), (2, 24, 2048, True)])
+def test_batchnorm_backward_channel_chunked(dev, shape):
+    """The channel-chunked BN backward (C >= 256, 1 K..32 K pixels: reduce + apply with the finalize folded into every apply
+    work-group's prelude) against the closed form in fp64 on identical tensors; bf16 and fp32 incoming gradients, all three
+    ReLU-mask modes, ragged pixel counts (1200, 1152 pixels: partial last range)."""
+    from uda_poseestimation_amd import ops
+    N, H, C_, f32 = shape
+    g = torch.Generator().manual_seed(10 + C_)
+    y = torch.randn(N, H, H, C_, generator=g).bfloat16().cuda()
+    gamma = (torch.rand(C_, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C_, generator=g) * 0.1).cuda()
+    yf = y.double()
+    mean = yf.mean((0, 1, 2)); var = yf.var((0, 1, 2), unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5))
+    mean_f, invstd_f = mean.float(), invstd.float()
+    sc = gamma * invstd_f; sh = beta - mean_f * sc
+    z = torch.relu(y.float() * sc + sh).bfloat16()
+    dz = torch.randn(N, H, H, C_, generator=g).cuda()
+    dzk = dz if f32 else dz.bfloat16()
+    M = N * H * H
+    for mode in (0, 1, 2):
+        gm = dzk.double() * ((z.float() > 0) if mode else torch.ones_like(z, dtype=torch.bool))
+        xh = (yf - mean_f.double()) * invstd_f.double()
+        dbeta = gm.sum((0, 1, 2)); dgamma = (gm * xh).sum((0, 1, 2))
+        dy = (gamma * invstd_f).double() * (gm - dbeta / M - xh * dgamma / M)
+        o = ops.bn_bwd(dzk, z if mode == 1 else None, y, gamma, mean_f, invstd_f, relu=mode, want_g=True, beta=beta)
+        scale = float(dy.abs().max())
+        assert float((o[0].double() - dy).abs().max()) <= 6e-3 * scale + 1e-6          # bf16 output rounding
+        assert float((o[1].double() - dgamma).abs().max()) <= 2e-5 * float(dgamma.abs().max()) + 1e-4
+        assert float((o[2].double() - dbeta).abs().max()) <= 2e-5 * float(dbeta.abs().max()) + 1e-4
+        assert float((o[3].double() - gm).abs().max()) <= 4e-3 * float(gm.abs().max())
+
+
 def test_maxpool(dev):
     from uda_poseestimation_amd import ops
     g = torch.Generator().manual_seed(7)

@@ -229,3 +229,28 @@ def test_fp32_mode_meets_the_1e3_heatmap_bar_and_identical_argmax(arch):
             np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-3, atol=1e-4)
     with pytest.raises(RuntimeError):
         net(x.cuda())            # grad-enabled forward is refused in the forward-only precision
+
+
+def test_grouped_weight_gradients_equal_per_layer_launches():
+    """The grouped weight-gradient launch (one launch per tile class over all layers, offset tables, XCD-dealt work units,
+    128x128 tiles) against the per-layer launches on the same saved activations: same sums in a different order
+    (fp32), every conv weight and BN parameter; also covers accumulation into existing gradients (beta = 1)."""
+    from uda_poseestimation_amd import _hip
+    ref, net = _pair([2, 2, 2, 2], 6, seed=5)
+    lib = _hip.lib()
+    x = torch.randn(8, 3, 128, 128, generator=torch.Generator().manual_seed(2)).cuda()
+    R = torch.randn(8, 6, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    grads = {}
+    try:
+        for mode in (0, 1):
+            lib.udapose_debug_set_wgrad_group(mode, 0)
+            net.zero_grad(set_to_none=True)
+            (net(x) * R).sum().backward()
+            (net(x) * R).sum().backward()              # second backward accumulates (atomic adds into the kept buffer)
+            grads[mode] = {n_: p_.grad.clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
+    finally:
+        lib.udapose_debug_set_wgrad_group(1, 0)
+    assert len(grads[0]) == len(grads[1]) >= 90
+    for n_ in grads[0]:
+        a, b = grads[1][n_], grads[0][n_]
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, n_
