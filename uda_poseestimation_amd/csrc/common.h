@@ -47,6 +47,9 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 // one BN layer of the batched running-statistics update (pw_bn_running_update_multi)
 struct BnRunJob { size_t save_off; float* rm; float* rv; long long* nbt; int C, pad; };
 
+// one range of the multi-range clear (pw_zero_multi): byte offset from a base pointer, length in 16-byte units
+struct ZeroJob { long long off; long long n16; };
+
 // XCD-aware work-group remap (MI355X: 8 XCDs, each with a private 4 MiB L2; work-groups are dealt round-robin, so b and
 // b+8 share an L2).  Returns a bijective permutation of the linear block id that gives every XCD one CONTIGUOUS range of
 // work ids, so that blocks which re-read the same operand panels hit the same L2 instead of each XCD streaming the whole

@@ -31,6 +31,7 @@ int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
 int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
 int pw_bn_running_update_multi(hipStream_t, const BnRunJob*, int, int, const void*, float);
+int pw_zero_multi(hipStream_t, const ZeroJob*, int, void*);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
 int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
@@ -107,6 +108,7 @@ struct Net {
         WgParams* d_tab[2] = {nullptr, nullptr}; WgGroupBlk* d_blk[2] = {nullptr, nullptr}; int per_xcd[2] = {0, 0};
         double flops[2] = {0.0, 0.0};
         std::vector<std::pair<ptrdiff_t, size_t>> zero;  // dW ranges (offset from grads[0], bytes) cleared first (split reductions, when overwriting)
+        ZeroJob* d_zero = nullptr; int n_zero = 0;       // the same ranges as a device job table, when all are 16-byte granular
         unsigned long long last_use = 0;
     };
     std::vector<WgGroup> wg_groups;
@@ -300,6 +302,7 @@ void net_destroy(void* h) {
     if (n->d_runjobs) (void)hipFree(n->d_runjobs);
     for (auto& g : n->wg_groups)
         for (int t = 0; t < 2; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
+    for (auto& g : n->wg_groups) if (g.d_zero) (void)hipFree(g.d_zero);
     delete n;
 }
 void net_set_wgrad_group(int on, int stages) { g_wgrad_group = on; if (stages > 0) g_wgrad_stages = stages; }
@@ -532,6 +535,17 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         if (hipMemcpy(G.d_blk[t], flat.data(), flat.size() * sizeof(WgGroupBlk), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         G.per_xcd[t] = (int)per;
     }
+    if (G.d_zero) { (void)hipFree(G.d_zero); G.d_zero = nullptr; }
+    G.n_zero = 0;
+    bool granular = !G.zero.empty();
+    for (auto& z : G.zero) granular = granular && (z.second % 16 == 0) && ((((size_t)(const char*)grads[0]) + (size_t)z.first) % 16 == 0);
+    if (granular) {
+        std::vector<ZeroJob> zj;
+        for (auto& z : G.zero) zj.push_back(ZeroJob{(long long)z.first, (long long)(z.second / 16)});
+        if (hipMalloc((void**)&G.d_zero, zj.size() * sizeof(ZeroJob)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemcpy(G.d_zero, zj.data(), zj.size() * sizeof(ZeroJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        G.n_zero = (int)zj.size();
+    }
     G.k_beta = beta; G.k_stages = g_wgrad_stages;
     return UDAPOSE_OK;
 }
@@ -552,8 +566,12 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         CK(build_wg_group(n, *G, grads, beta));
     }
     G->last_use = ++n.wg_tick;
-    for (auto& z : G->zero)
-        if (hipMemsetAsync((char*)grads[0] + z.first, 0, z.second, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (G->d_zero) {
+        CK(pw_zero_multi(s, G->d_zero, G->n_zero, grads[0]));
+    } else {
+        for (auto& z : G->zero)
+            if (hipMemsetAsync((char*)grads[0] + z.first, 0, z.second, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    }
     for (int t = 0; t < 2; ++t) {
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);

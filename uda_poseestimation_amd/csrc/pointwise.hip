@@ -746,6 +746,18 @@ int pw_bn_running_update(hipStream_t s, const float* save, int C, float* rm, flo
     hipLaunchKernelGGL(bn_running_update_k, dim3(nblk(C)), dim3(TPB), 0, s, save, C, rm, rv, nbt, momentum);
     return udapose_check_launch();
 }
+// clears several ranges in one launch: grid (jobs, 32); replaces one hipMemsetAsync node per split weight gradient
+__global__ void zero_multi_k(const ZeroJob* __restrict__ jobs, char* __restrict__ base) {
+    const ZeroJob j = jobs[blockIdx.x];
+    u32x4* p = (u32x4*)(base + j.off);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (long long i = (long long)blockIdx.y * TPB + threadIdx.x; i < j.n16; i += (long long)gridDim.y * TPB) p[i] = z;
+}
+int pw_zero_multi(hipStream_t s, const ZeroJob* d_jobs, int njobs, void* base) {
+    if (njobs <= 0) return UDAPOSE_OK;
+    hipLaunchKernelGGL(zero_multi_k, dim3(njobs, 32), dim3(TPB), 0, s, d_jobs, (char*)base);
+    return udapose_check_launch();
+}
 int pw_axpy(hipStream_t s, float* y, const float* x, size_t n) {
     if (n % 4) return UDAPOSE_ERR_ARG;
     hipLaunchKernelGGL(axpy_k, dim3(grid_for(n / 4)), dim3(TPB), 0, s, y, x, n / 4);
