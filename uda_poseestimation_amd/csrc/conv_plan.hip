@@ -57,8 +57,13 @@ const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
     TapPlan* tp = new TapPlan();
     const int KWp = g.KWp();
     const bool sub = (direction == 0) ? (g.transposed != 0) : (g.transposed == 0 && g.stride > 1);
-    if (g.stride > 2 && sub) { delete tp; return nullptr; }
-    if (sub) {
+    if (g.stride > 2 && sub && direction != 2) { delete tp; return nullptr; }
+    if (direction == 2) {
+        // grouped wgrad of a Ci == 8 conv: one tap per filter ROW (its KWp column taps x 8 channels are contiguous in x)
+        tp->nclass = 1;
+        tp->cls[0] = IgClass{0, g.KH, 0, 0};
+        for (int kh = 0; kh < g.KH; ++kh) tp->taps.push_back(IgTap{kh - g.pad, -g.pad, kh, 0});
+    } else if (sub) {
         build_subpixel(*tp, g.KH, g.KW, KWp, g.stride, g.pad);
     } else if (direction == 0 || g.transposed) {
         build_direct(*tp, g.KH, g.KW, KWp, g.pad);          // fprop of a conv, or dgrad of a transposed conv
@@ -133,23 +138,26 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
 
 int conv_wgrad_params(const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int rows_valid, WgParams* out, double* flops) {
     if (g.reflect || g.upsample) return UDAPOSE_ERR_UNSUPPORTED;
-    const TapPlan* tp = get_tap_plan(g, 0);
+    const bool rowtap = rows_valid == -2;          // grouped Ci == 8 form (see wgrad_dma_body)
+    if (rowtap && (!g.smallc() || g.transposed || g.KWp() != 8)) return UDAPOSE_ERR_UNSUPPORTED;
+    const TapPlan* tp = get_tap_plan(g, rowtap ? 2 : 0);
     if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
     WgParams p{};
     p.dy = dy; p.x = x; p.dw = dw; p.taps = tp->d_taps;
+    p.kw = rowtap ? g.KW : 0;
     p.N = g.N; p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci;
     p.Ho = g.Ho(); p.Wo = g.Wo(); p.Co = g.Co;
     if (g.transposed) { p.Hg = g.Hi; p.Wg = g.Wi; p.s = 1; p.os = g.stride; }
     else { p.Hg = p.Ho; p.Wg = p.Wo; p.s = g.stride; p.os = 1; }
     p.M = g.N * p.Hg * p.Wg;
-    p.wtaps = g.wtaps();
+    p.wtaps = rowtap ? g.KH : g.wtaps();
     p.flags = (g.smallc() ? IG_FLAG_SMALLC : 0) | (g.transposed ? WG_FLAG_SWAP : 0);
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     p.total_taps = (int)tp->taps.size();
     const int Rdim = g.transposed ? g.Ci : g.Co;
     p.rows_valid = rows_valid < 0 ? Rdim : rows_valid;
-    *out = p;
+    *out = p;   // (rows_valid == -2 selects the row-tap form of a Ci == 8 conv for the grouped launch)
     if (flops) *flops = alg_flops(g);
     return UDAPOSE_OK;
 }

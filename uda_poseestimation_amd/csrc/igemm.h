@@ -57,7 +57,9 @@ struct WgParams {
     int r_tiles, c_tiles;
     int total_taps;
     int rows_valid;         // dW rows actually stored (<= R; head: Co is padded to 32 in dy)
+    int kw;                 // grouped Ci == 8 form only: real taps per filter row (the 8th column chunk is padding)
 };
 struct WgGroupBlk { int prob, local; };   // grouped wgrad: problem index (< 0: padding) and linear block index inside it
 #define WG_FLAG_SWAP 32       // rows of dW come from x (deconv weight layout [Ci][tap][Co])
+#define WG_FLAG_DW_WS 256     // grouped launch: dw is an offset into the workspace (dy base), not into the gradient buffer
 #define WG_FLAG_ATOMIC 64     // accumulate into dw with fp32 atomics (ksplit>1 or beta=1)

@@ -50,6 +50,7 @@ static int dbg_sync() { static int v = -1; if (v < 0) { const char* e = getenv("
     if (_e != UDAPOSE_OK) return _e; } while (0)
 
 int g_wgrad_group = 1, g_wgrad_stages = 128;   // grouped weight-gradient launch (see build_wg_group); tuning hook
+int g_wgrad_group_stem = 1;                    // the Ci == 8 stem joins the 64x64 group in its row-tap form
 
 struct ConvL {
     ConvGeom g;
@@ -440,7 +441,9 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     CK(pw_bn_bwd(s, dz, dz_f32, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx], save,
                  save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx]));
     const bf16_t* xin = (const bf16_t*)(act + c.in_off);
-    if (c.g.smallc()) {
+    if (c.g.smallc() && grouped_wgrad && g_wgrad_group_stem) {
+        // (the stem's weight gradient joins the grouped launch in its row-tap form, run_wg_group)
+    } else if (c.g.smallc()) {
         float* tmp = (float*)(ws + n.ws_dwtmp);
         CK(conv_wgrad(s, c.g, dy, xin, tmp, 0, -1));
         CK(pw_unpack_strided(s, tmp, (float*)grads[c.w_idx], c.g.Co, c.g.KH, c.g.KWp(), c.g.KW, 8, 3, (long)c.g.KH * c.g.KW * 3, (long)c.g.KW * 3, 3, 1,
@@ -502,6 +505,25 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         hg.Co = 64;
         CK(add_geom(hg, n.head.w_idx, n.ws_dyhead, n.head.in_off, n.K));
         G.flops[1] -= 2.0 * n.N * n.Hout * n.Wout * 256.0 * (64 - n.K);   // (count the K real channels only)
+    }
+    if (g_wgrad_group_stem) {
+        // stem (Ci == 8): row-tap form into the padded [Co][KH][8][8] scratch in the workspace (always zeroed, always split:
+        // 8192 stages), unpacked into the real [Co][KH][KW][3] gradient after the launch
+        WgParams p;
+        double fl = 0.0;
+        CK(conv_wgrad_params(n.stem.g, (const bf16_t*)n.stem.dy_off, (const bf16_t*)n.stem.in_off, (float*)n.ws_dwtmp, -2, &p, &fl));
+        p.flags |= WG_FLAG_DW_WS;
+        const int t = wgrad_group_plan(p, 1, g_wgrad_stages);      // (accumulate = 1: atomics into the zeroed scratch)
+        if (t != 1) return UDAPOSE_ERR_UNSUPPORTED;
+        const int prob = (int)tab[t].size();
+        tab[t].push_back(p);
+        G.flops[t] += fl;
+        const int nblk = p.r_tiles * p.c_tiles * p.total_taps;
+        const int ms_total = (p.M + 63) / 64, per = (ms_total + p.ksplit - 1) / p.ksplit;
+        for (int z = 0; z < p.ksplit; ++z) {
+            const int st = std::min(per, ms_total - z * per);
+            if (st > 0) units[t].push_back(Unit{prob, z, nblk, (long)nblk * (st + 4)});
+        }
     }
     for (int i = 2; i >= 0; --i) CK(add(n.up[i]));
     for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
@@ -572,6 +594,9 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         for (auto& z : G->zero)
             if (hipMemsetAsync((char*)grads[0] + z.first, 0, z.second, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }
+    const ConvGeom& sg = n.stem.g;
+    const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
+    if (g_wgrad_group_stem && hipMemsetAsync(ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     for (int t = 0; t < 2; ++t) {
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);
@@ -579,6 +604,9 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         conv_prof_after(s, tok);
         CK(rc);
     }
+    if (g_wgrad_group_stem)
+        CK(pw_unpack_strided(s, (const float*)(ws + n.ws_dwtmp), (float*)grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
+                             (long)sg.KH * sg.KW * 3, (long)sg.KW * 3, 3, 1, beta));
     return UDAPOSE_OK;
 }
 }  // namespace

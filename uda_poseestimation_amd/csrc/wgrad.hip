@@ -233,10 +233,10 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     // scalar copies of the fields used below (gp may live in global memory: read it once, up front, into SGPRs)
     struct {
         const bf16_t* dy; const bf16_t* x; float* dw; const IgTap* taps;
-        int Hi, Wi, Ci, Ho, Wo, Co, Hg, Wg, s, os, M, wtaps, flags, ksplit, c_tiles, rows_valid;
+        int Hi, Wi, Ci, Ho, Wo, Co, Hg, Wg, s, os, M, wtaps, flags, ksplit, c_tiles, rows_valid, kw;
         FastDiv div_hw, div_w;
-    } p = {(const bf16_t*)((uintptr_t)gp.dy + dy_base), (const bf16_t*)((uintptr_t)gp.x + x_base), (float*)((uintptr_t)gp.dw + dw_base), gp.taps, gp.Hi, gp.Wi, gp.Ci, gp.Ho, gp.Wo, gp.Co, gp.Hg, gp.Wg, gp.s, gp.os, gp.M, gp.wtaps, gp.flags, gp.ksplit,
-           gp.c_tiles, gp.rows_valid, gp.div_hw, gp.div_w};
+    } p = {(const bf16_t*)((uintptr_t)gp.dy + dy_base), (const bf16_t*)((uintptr_t)gp.x + x_base), (float*)((uintptr_t)gp.dw + ((gp.flags & WG_FLAG_DW_WS) ? dy_base : dw_base)), gp.taps, gp.Hi, gp.Wi, gp.Ci, gp.Ho, gp.Wo, gp.Co, gp.Hg, gp.Wg, gp.s, gp.os, gp.M, gp.wtaps, gp.flags, gp.ksplit,
+           gp.c_tiles, gp.rows_valid, gp.kw, gp.div_hw, gp.div_w};
     using C = WdCfg<RT, CT, WR, WC, NS>;
     constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
     constexpr int LPS = P_PW + Q_PW;
@@ -247,7 +247,10 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
     const int c_tile = bx % p.c_tiles, r_tile = bx / p.c_tiles;
     const int r0 = r_tile * RT, c0 = c_tile * CT;
-    const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
+    // grouped Ci == 8 form (the 3-channel stem): one tap of the table is a filter ROW; its 8 column taps x 8 channels are the
+    // 64 "channels" of the Q operand (contiguous in x, since C == 8), validity is per 16-byte chunk = per column tap
+    const bool rowtap = (p.flags & IG_FLAG_SMALLC) != 0;
+    const int Rdim = swap ? p.Ci : p.Co, Cdim = rowtap ? 64 : (swap ? p.Co : p.Ci);
     const bool p_is_x = swap;
     const IgTap tp = p.taps[by];
     struct { int oa, ob; } cls = {gp.cls[0].oa, gp.cls[0].ob};       // (select chain: no dynamic index into the parameter block)
@@ -292,8 +295,9 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
                 if (x_lin) sx = (const char*)(p.x + (size_t)m * p.Ci);
                 else {
                     const int hi = (int)ii * p.s + tp.dy, wi = (int)jj * p.s + tp.dx;
-                    if ((unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi)
-                        sx = (const char*)(p.x + (((size_t)n * p.Hi + hi) * p.Wi + wi) * p.Ci);
+                    const int wl = rowtap ? wi + lc : wi;            // this lane's chunk is column tap lc
+                    if ((unsigned)hi < (unsigned)p.Hi && (unsigned)wl < (unsigned)p.Wi && (!rowtap || lc < p.kw))
+                        sx = (const char*)(p.x + (((long long)n * p.Hi + hi) * p.Wi + wi) * p.Ci);   // (+ lc * 16 bytes below)
                 }
                 if (dy_lin) sd = (const char*)(p.dy + (size_t)m * p.Co);
                 else {
@@ -515,8 +519,9 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
 int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block) {
     const bool smallc = (p.flags & IG_FLAG_SMALLC) != 0;
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
-    if (smallc || p.Ci % 64 != 0 || p.Co % 64 != 0) return -1;
-    const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
+    if (smallc && (swap || p.Co % 64 != 0 || p.kw <= 0 || p.kw > 8)) return -1;
+    if (!smallc && (p.Ci % 64 != 0 || p.Co % 64 != 0)) return -1;
+    const int Rdim = swap ? p.Ci : p.Co, Cdim = smallc ? 64 : (swap ? p.Co : p.Ci);
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     // inside a group the other layers fill the chip, so a layer takes the 128x128 tile (half the L2->LDS bytes per FLOP of
