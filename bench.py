@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--spinup", type=float, default=8.0, help="seconds of untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per domain (BASELINE: 32)")
     ap.add_argument("--arch", default="pose_resnet101")
+    ap.add_argument("--image-size", type=int, default=256, help="other configs (BASELINE.json configs[4]: 384); default = the metric's 256")
+    ap.add_argument("--keypoints", type=int, default=16, help="other configs (configs[4]: 18)")
+    ap.add_argument("--sigma", type=float, default=2, help="label / rectify sigma (configs[4]: 1.0)")
     ap.add_argument("--igemm-tile", type=int, default=-1, help="tuning: force one igemm tile configuration id")
     ap.add_argument("--wgrad-group", type=int, default=1, help="tuning: 0 = one weight-gradient launch per layer")
     ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
@@ -115,12 +118,15 @@ def main():
     if args.igemm_tile >= 0:
         lib.udapose_debug_set_tiles(args.igemm_tile, -1, -1)
 
-    N, K = args.batch, 16
+    N, K = args.batch, args.keypoints
+    S = args.image_size
+    sigma = int(args.sigma) if float(args.sigma).is_integer() and args.sigma >= 2 else float(args.sigma)
     torch.manual_seed(0)
     student = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
     teacher = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
-    trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=2)
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, seed=rank)          # a different shard per rank (weak scaling)
+    trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
+                                 heatmap_size=S // 4)
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=rank)   # one shard per rank
     g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 
     def eager_step():
@@ -206,15 +212,15 @@ def main():
         achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         layers = {"pose_resnet101": [3, 4, 23, 3], "pose_resnet50": [3, 4, 6, 3]}[args.arch]
         res = {
-            "metric": "images/sec (student+teacher step) 256x256 b=32", "value": round(value, 2), "unit": "images/sec",
+            "metric": f"images/sec (student+teacher step) {S}x{S} b={N}", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "spinup_s": args.spinup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.arch} K=16 mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
-                                   f"Adam, EMA), 256x256, b={N}/GPU, no AdaIN (BASELINE.json configs[1])",
+            "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
+                                   f"Adam, EMA), {S}x{S}, b={N}/GPU, no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch) == (256, 16, 32, "pose_resnet101") else f", K={K}"),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
             "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs) else "2 hipGraphs") + " (last timed step eager, instrumented)",
             "replicas_in_sync": in_sync,
-            "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if args.arch == "pose_resnet101" else None,
+            "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fprop+dgrad, bf16 MFMA 16x16x32)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic_per_igemm_launch(),

@@ -111,7 +111,7 @@ int udapose_net_forward(udapose_net_t net, void* stream, const float* x_nchw, co
 /* training: bit 0 = batch statistics (train mode), bit 1 = do NOT update the running statistics in this call; apply them
  * later, in program order, with udapose_net_apply_running (two forwards of one module running on different streams). */
 int udapose_net_apply_running(udapose_net_t net, void* stream, const void* act, void* const* h_buffers, float momentum);
-/* y += x over n fp32 values (n % 4 == 0): sum of per-pass gradient buffers */
+/* y += x over n fp32 values (y, x 16-byte aligned): sum of per-pass gradient buffers */
 int udapose_axpy_f32(void* stream, float* y, const float* x, size_t n);
 int udapose_net_backward(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
                          void* act, void* ws, void* const* h_grads, float beta);

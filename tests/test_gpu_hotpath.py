@@ -347,6 +347,41 @@ def test_animal_config_shapes_384_k18():
     assert (y32.cpu() - y_ref).abs().max().item() < 1e-4
 
 
+def test_mean_teacher_step_animal_config_k18_float_sigma():
+    """A whole three-stream step at the configs[4] shape family (K = 18 -> a parameter count that is not a multiple of 4, float
+    sigma 1.0, 192x192 -> 48x48 maps): losses against oracle/step_ref, the two per-pass gradient buffers summed, replay of the
+    captured step equal to the eager one."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_ref
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    layers, K, N, S = [1, 1, 1, 1], 18, 3, 192
+    torch.manual_seed(1)
+    ref_s, ref_t = PoseResNetRef(layers, K), PoseResNetRef(layers, K)
+    nets = []
+    for _ in range(2):
+        stu = pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
+        tea = pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
+        stu.load_state_dict(ref_s.state_dict())
+        nets.append(MeanTeacherTrainer(stu.cuda(), tea.cuda(), sigma=1.0, image_size=S, heatmap_size=S // 4))
+    assert sum(p.numel() for p in nets[0].student.parameters()) % 4 != 0
+    ref_t.load_state_dict(ref_s.state_dict())
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=1.0, seed=11)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    out = nets[0].train_step(*args)
+    opt = torch.optim.Adam(ref_s.parameters(), lr=1e-4)
+    ref = train_step_ref(ref_s, ref_t, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"],
+                         b["aug_param_tea"], ratio=4.0, sigma=1.0)
+    assert abs(float(out["loss_s"]) - float(ref["loss_s"])) <= 2e-2 * float(ref["loss_s"])
+    assert abs(float(out["loss_c"]) - float(ref["loss_c"])) <= 8e-2 * float(ref["loss_c"]) + 1e-6
+    gs = GraphedTrainStep(nets[1], *args, warmup=1)          # (one eager step inside: both trainers have now done one step)
+    o_g = gs.step(*args)
+    o_e = nets[0].train_step(*args)
+    assert abs(float(o_g["loss_all"]) - float(o_e["loss_all"])) <= 3e-3 * abs(float(o_e["loss_all"])) + 1e-7
+
+
 def test_two_rank_step_on_one_gpu_gloo():
     """The data-parallel launch (one process per rank, three hipGraphs cut around the confidence all-gather and the gradient
     all-reduce, max-over-ranks timing) run for real with two ranks; both share cuda:0 and talk over gloo, because the

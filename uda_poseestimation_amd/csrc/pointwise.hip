@@ -233,6 +233,9 @@ __global__ void axpy_k(float* __restrict__ y, const float* __restrict__ x, size_
         *(f32x4*)(y + i * 4) = a;
     }
 }
+__global__ void axpy_tail_k(float* __restrict__ y, const float* __restrict__ x, int n) {
+    if ((int)threadIdx.x < n) y[threadIdx.x] += x[threadIdx.x];
+}
 // eval mode: scale/shift from running statistics
 __global__ void bn_eval_coeff_k(int C, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                 const float* __restrict__ rv, float eps, float* __restrict__ scale, float* __restrict__ shift) {
@@ -759,8 +762,9 @@ int pw_zero_multi(hipStream_t s, const ZeroJob* d_jobs, int njobs, void* base) {
     return udapose_check_launch();
 }
 int pw_axpy(hipStream_t s, float* y, const float* x, size_t n) {
-    if (n % 4) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(axpy_k, dim3(grid_for(n / 4)), dim3(TPB), 0, s, y, x, n / 4);
+    const size_t n4 = n / 4;
+    if (n4) hipLaunchKernelGGL(axpy_k, dim3(grid_for(n4)), dim3(TPB), 0, s, y, x, n4);
+    if (n % 4) hipLaunchKernelGGL(axpy_tail_k, dim3(1), dim3(64), 0, s, y + n4 * 4, x + n4 * 4, (int)(n % 4));
     return udapose_check_launch();
 }
 int pw_bn_eval_coeff(hipStream_t s, int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift) {
