@@ -586,6 +586,18 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         if (n.wg_groups.size() < 4) { n.wg_groups.emplace_back(); G = &n.wg_groups.back(); }
         else { G = &n.wg_groups[0]; for (auto& g : n.wg_groups) if (g.last_use < G->last_use) G = &g; }
         CK(build_wg_group(n, *G, grads, beta));
+        // build the other accumulate mode's table now as well: which of the two a pass needs depends on stream identity
+        // at run time (second pass on the same stream -> beta 1), and a first use inside a stream capture could not build it
+        const float other = beta != 0.f ? 0.f : 1.f;
+        bool have = false;
+        for (auto& g : n.wg_groups) have = have || (g.k_beta == other && g.k_stages == g_wgrad_stages);
+        if (!have && n.wg_groups.size() < 4) {
+            n.wg_groups.emplace_back();
+            CK(build_wg_group(n, n.wg_groups.back(), grads, other));
+            n.wg_groups.back().last_use = n.wg_tick;
+            for (auto& g : n.wg_groups)                      // (emplace_back may have moved the entries)
+                if (g.k_beta == beta && g.k_stages == g_wgrad_stages) G = &g;
+        }
     }
     G->last_use = ++n.wg_tick;
     if (G->d_zero) {
