@@ -379,7 +379,17 @@ def test_mean_teacher_step_animal_config_k18_float_sigma():
     gs = GraphedTrainStep(nets[1], *args, warmup=1)          # (one eager step inside: both trainers have now done one step)
     o_g = gs.step(*args)
     o_e = nets[0].train_step(*args)
-    assert abs(float(o_g["loss_all"]) - float(o_e["loss_all"])) <= 3e-3 * abs(float(o_e["loss_all"])) + 1e-7
+    loss_g1 = float(o_g["loss_all"])                 # (step() returns the graph's static output tensors: read the value now)
+    assert abs(loss_g1 - float(o_e["loss_all"])) <= 3e-3 * abs(float(o_e["loss_all"])) + 1e-7
+    # host batches staged by prefetch() (pinned memory -> copy stream -> staging buffers -> static inputs): same step
+    b2 = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=1.0, seed=12)
+    host = {k: v.pin_memory() for k, v in b2.items() if torch.is_tensor(v)}
+    gs.prefetch(host["x_s"], host["label_s"], host["weight_s"], host["x_t_stu"], host["x_t_tea"])
+    o_g2 = gs.step(None, None, None, None, None, b2["aug_param_stu"], b2["aug_param_tea"])
+    g2 = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b2.items()}
+    o_e2 = nets[0].train_step(g2["x_s"], g2["label_s"], g2["weight_s"], g2["x_t_stu"], g2["x_t_tea"], g2["aug_param_stu"], g2["aug_param_tea"])
+    assert abs(float(o_g2["loss_all"]) - float(o_e2["loss_all"])) <= 5e-3 * abs(float(o_e2["loss_all"])) + 1e-7
+    assert abs(float(o_g2["loss_all"]) - loss_g1) > 1e-6                          # (it really was a different batch)
 
 
 def test_two_rank_step_on_one_gpu_gloo():

@@ -243,6 +243,7 @@ class GraphedTrainStep:
         assert trainer.style_net is None and trainer.occlude_rate <= -1, \
             "the graphed step covers the style-free, occlusion-free configuration (both draw host random numbers per step)"
         self.t = trainer
+        self._stage, self._have_staged = None, False
         dev = x_s.device
         n = x_s.shape[0]
         self.n = n
@@ -283,8 +284,31 @@ class GraphedTrainStep:
             trainer._update()
         torch.cuda.synchronize()
 
+    def prefetch(self, x_s, label_s, weight_s, x_t_stu, x_t_tea):
+        """Start copying the NEXT batch (pinned host tensors) into staging buffers on a copy stream; it overlaps with the
+        replay of the current step.  The following step() call (with no tensors given) takes the staged batch with five
+        device-to-device copies (92 MB, ~30 us) instead of waiting for PCIe on the compute stream."""
+        if self._stage is None:
+            self._stage = {k: torch.empty_like(self.static[k]) for k in ("x_s", "label_s", "weight_s", "x_t_stu", "x_t_tea")}
+            self._copy_stream = torch.cuda.Stream(device=self.static["x_s"].device)
+            self._staged, self._consumed = torch.cuda.Event(), None
+        if self._consumed is not None:
+            self._copy_stream.wait_event(self._consumed)     # the previous step's D2D reads of the staging buffers come first
+        with torch.cuda.stream(self._copy_stream):
+            for k, v in (("x_s", x_s), ("label_s", label_s), ("weight_s", weight_s), ("x_t_stu", x_t_stu), ("x_t_tea", x_t_tea)):
+                self._stage[k].copy_(v, non_blocking=True)
+            self._staged.record(self._copy_stream)
+        self._have_staged = True
+
     def step(self, x_s=None, label_s=None, weight_s=None, x_t_stu=None, x_t_tea=None, aug_param_stu=None, aug_param_tea=None):
         st = self.static
+        if x_s is None and self._have_staged:
+            torch.cuda.current_stream().wait_event(self._staged)
+            for k in self._stage:
+                st[k].copy_(self._stage[k], non_blocking=True)
+            self._consumed = torch.cuda.Event()
+            self._consumed.record()
+            self._have_staged = False
         for k, v in (("x_s", x_s), ("label_s", label_s), ("weight_s", weight_s), ("x_t_stu", x_t_stu), ("x_t_tea", x_t_tea)):
             if v is not None and v.data_ptr() != st[k].data_ptr():
                 st[k].copy_(v, non_blocking=True)
