@@ -158,7 +158,11 @@ __global__ void unpack_strided_k(const float* __restrict__ src, float* __restric
 // ------------------------------------------------------------------ BatchNorm (training mode)
 // Column sums of a partial-sum slab [rows][2][C]: block = 32 channels x 32 row lanes (1024 threads), 128-byte coalesced
 // row segments, fp64 accumulation, LDS tree over the row lanes.  Result for channel c0+cl in (s1, s2) of lanes rl == 0.
-constexpr int FIN_T = 1024;
+#ifndef UDAPOSE_FIN_T
+#define UDAPOSE_FIN_T 1024
+#endif
+constexpr int FIN_T = UDAPOSE_FIN_T;
+constexpr int FIN_RL = FIN_T / 32;      // row lanes per block
 __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int rows, int C, int c, bool cvalid, double& s1, double& s2,
                                             double (*red)[32][2]) {
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -166,21 +170,22 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
     if (cvalid) {
         // 4 independent row loads in flight per thread (the loop is latency-bound otherwise)
         int r = rl;
-        for (; r + 96 < rows; r += 128) {
+        for (; r + 3 * FIN_RL < rows; r += 4 * FIN_RL) {
             const float* q = slab + (size_t)r * 2 * C + c;
-            const float a0 = q[0], b0 = q[C], a1 = q[(size_t)64 * C], b1 = q[(size_t)64 * C + C];
-            const float a2 = q[(size_t)128 * C], b2 = q[(size_t)128 * C + C], a3 = q[(size_t)192 * C], b3 = q[(size_t)192 * C + C];
+            const size_t st = (size_t)FIN_RL * 2 * C;
+            const float a0 = q[0], b0 = q[C], a1 = q[st], b1 = q[st + C];
+            const float a2 = q[2 * st], b2 = q[2 * st + C], a3 = q[3 * st], b3 = q[3 * st + C];
             a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
             b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
         }
-        for (; r < rows; r += 32) {
+        for (; r < rows; r += FIN_RL) {
             a += (double)slab[(size_t)r * 2 * C + c];
             b += (double)slab[(size_t)r * 2 * C + C + c];
         }
     }
     red[rl][cl][0] = a; red[rl][cl][1] = b;
     __syncthreads();
-    for (int st = 16; st > 0; st >>= 1) {
+    for (int st = FIN_RL / 2; st > 0; st >>= 1) {
         if (rl < st) { red[rl][cl][0] += red[rl + st][cl][0]; red[rl][cl][1] += red[rl + st][cl][1]; }
         __syncthreads();
     }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_k(const float* __restrict__
                               const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                               long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ scale,
                               float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    __shared__ double red[32][32][2];
+    __shared__ double red[FIN_RL][32][2];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     double s1, s2;
@@ -342,7 +347,7 @@ __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restr
 __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
                                   const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float beta_acc, float* __restrict__ coef) {
-    __shared__ double red[32][32][2];
+    __shared__ double red[FIN_RL][32][2];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     double s1, s2;
     slab_colsum(slab, rows, C, c, c < C, s1, s2, red);
