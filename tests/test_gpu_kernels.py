@@ -287,3 +287,46 @@ def test_conv_fp32_exact_path(dev, case):
     ref = F.conv2d(x, w, stride=s, padding=p)
     close(nchw(y), F.relu(ref + r), 2e-6)
     np.testing.assert_allclose(stats.double().sum(0)[0].cpu().numpy(), ref.double().sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+FULL_SIZE_LAYERS = [
+    # name, H, Ci, Co, K, stride, pad, transposed      (N = 32: the shapes bench.py runs; too large for the CPU oracle)
+    ("l1.c3 64->256 1x1 @64", 64, 64, 256, 1, 1, 0, False),
+    ("l3.c2 256->256 3x3 @16", 16, 256, 256, 3, 1, 1, False),
+    ("l3.c1 1024->256 1x1 @16", 16, 1024, 256, 1, 1, 0, False),
+    ("l2.c2 128->128 3x3 s2 @64", 64, 128, 128, 3, 2, 1, False),
+    ("up2 deconv 256->256 4x4 s2 @32", 32, 256, 256, 4, 2, 1, True),
+]
+
+
+@pytest.mark.parametrize("layer", FULL_SIZE_LAYERS, ids=[l[0] for l in FULL_SIZE_LAYERS])
+def test_conv_adjoint_identities_at_full_size(dev, layer):
+    """Size-independent property at BASELINE.json's sizes (N = 32): forward, data-gradient and weight-gradient kernels are
+    the three faces of one bilinear form, so <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(dy, x)> up to bf16 output
+    rounding.  Also linearity: conv(x1 + x2) = conv(x1) + conv(x2) within rounding."""
+    from uda_poseestimation_amd import ops
+    _, H, Ci, Co, K, s, p, tr = layer
+    N = 32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    d = ops.conv_desc(N, H, H, Ci, Co, K, s, p, transposed=tr)
+    ho, wo = ops.conv_out_hw(d)
+    x = torch.randn(N, H, H, Ci, device="cuda", generator=g).bfloat16()
+    wshape = (Ci, Co, K, K) if tr else (Co, Ci, K, K)
+    w = (torch.randn(wshape, device="cuda", generator=g) / (Ci * K * K) ** 0.5).bfloat16().float()
+    dy = torch.randn(N, ho, wo, Co, device="cuda", generator=g).bfloat16()
+    wf, wb = ops.pack_weight(w, d, "fwd"), ops.pack_weight(w, d, "bwd")
+    y = ops.conv2d_fwd(x, wf, d, out_f32=True)
+    dx = ops.conv2d_bwd_data(dy, wb, d, out_f32=True)
+    dw = ops.conv2d_bwd_weight(dy, x, d)                       # fp32 [Co][T][Ci] (transposed: [Ci][T][Co])
+    a = float((y.double() * dy.double()).sum())
+    b = float((dx.double() * x.double()).sum())
+    w_phys = (w.permute(0, 2, 3, 1).reshape(dw.shape)).double()   # [A][KH*KW][B], the layout dw uses
+    c = float((dw.double() * w_phys).sum())
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(a - b) <= 1e-4 * scale and abs(a - c) <= 1e-4 * scale, (a, b, c, scale)
+    x2 = torch.randn(N, H, H, Ci, device="cuda", generator=g).bfloat16()
+    xs = (x.float() + x2.float()).bfloat16()
+    lhs = ops.conv2d_fwd(xs, wf, d, out_f32=True)
+    rhs = y + ops.conv2d_fwd(x2, wf, d, out_f32=True)
+    # (x + x2 is rounded to bf16 once more than x and x2: 2^-9 relative per input element)
+    assert float((lhs - rhs).norm() / rhs.norm()) <= 6e-3
