@@ -476,3 +476,42 @@ def test_ema_closed_form_at_full_parameter_count():
         exp = an * p0.double() + (1.0 - an) * p_s.detach().double()
         worst = max(worst, float((p_t.detach().double() - exp).abs().max()))
     assert worst <= 2e-6, worst                                  # n fp32 roundings of O(1) values
+
+
+def test_heatmap_path_at_benchmark_size_against_oracle():
+    """The heat-map kernels at the benchmark's size ([32,16,64,64], and [32,18,96,96] of configs[4]) against the CPU oracle:
+    decode, rectify and PCK bit-exact; both losses and their gradients to fp32 rounding; k-th value mask identical."""
+    from oracle import keypoints_ref, losses_ref, mean_teacher_ref
+    from uda_poseestimation_amd import utils as U
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    from uda_poseestimation_amd.lib.models.loss import ConsLoss, JointsMSELoss
+    for (B, K, H, sigma) in ((32, 16, 64, 2), (32, 18, 96, 1.0)):
+        g = torch.Generator().manual_seed(K)
+        hm = torch.randn(B, K, H, H, generator=g) * 0.3
+        hm[:, 0] = -hm[:, 0].abs()                                      # one all-negative key point: decoded as (0, 0)
+        hm[1, 1, 5, 7] = hm[1, 1, 20, 3] = 9.0                          # an exact tie: first index wins
+        gt = mean_teacher_ref.rectify_ref(torch.randn(B, K, H, H, generator=g), sigma)
+        p_ref, v_ref = keypoints_ref.get_max_preds_torch_ref(hm)
+        p_dev, v_dev = U.get_max_preds_torch(hm.cuda())
+        assert torch.equal(p_dev.cpu(), p_ref) and torch.equal(v_dev.cpu(), v_ref)
+        assert torch.equal(U.rectify(hm.cuda(), sigma).cpu(), mean_teacher_ref.rectify_ref(hm, sigma))
+        acc_r, avg_r, cnt_r, _ = keypoints_ref.accuracy_ref(hm.numpy(), gt.numpy())
+        acc_d, avg_d, cnt_d, _ = kd.accuracy(hm.cuda(), gt.cuda())
+        np.testing.assert_allclose(acc_d, acc_r, atol=1e-6)
+        assert cnt_d == cnt_r and abs(avg_d - avg_r) < 1e-6
+        w = (torch.rand(B, K, 1, generator=g) > 0.2).float()
+        p1 = hm.clone().cuda().requires_grad_(True)
+        l1 = JointsMSELoss()(p1, gt.cuda(), w.cuda()); l1.backward()
+        p2 = hm.clone().requires_grad_(True)
+        l2 = losses_ref.joints_mse_ref(p2, gt, w); l2.backward()
+        assert abs(float(l1.detach()) - float(l2.detach())) <= 1e-5 * abs(float(l2.detach()))
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=1e-5, atol=1e-12)
+        mask_r, act_r, thr_r = mean_teacher_ref.conf_mask_ref(hm, 0.5)
+        mask_d, _, _ = U.confidence_mask(hm.cuda(), 0.5)
+        assert torch.equal(mask_d.cpu().bool(), mask_r.bool())
+        s1 = hm.clone().cuda().requires_grad_(True)
+        c1 = ConsLoss()(s1, gt.cuda(), tea_mask=mask_d); c1.backward()
+        s2 = hm.clone().requires_grad_(True)
+        c2 = losses_ref.cons_loss_ref(s2, gt, tea_mask=mask_r); c2.backward()
+        assert abs(float(c1.detach()) - float(c2.detach())) <= 1e-5 * abs(float(c2.detach()))
+        np.testing.assert_allclose(s1.grad.cpu().numpy(), s2.grad.numpy(), rtol=1e-5, atol=1e-12)
