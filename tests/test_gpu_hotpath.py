@@ -515,3 +515,54 @@ def test_heatmap_path_at_benchmark_size_against_oracle():
         c2 = losses_ref.cons_loss_ref(s2, gt, tea_mask=mask_r); c2.backward()
         assert abs(float(c1.detach()) - float(c2.detach())) <= 1e-5 * abs(float(c2.detach()))
         np.testing.assert_allclose(s1.grad.cpu().numpy(), s2.grad.numpy(), rtol=1e-5, atol=1e-12)
+
+
+def test_adam_over_all_poseresnet101_parameters_matches_torch():
+    """The multi-tensor Adam at the real size (325 tensors, 55.04 M values; the block -> (tensor, offset) table spans them
+    all) against torch.optim.Adam on the CPU, three steps."""
+    import uda_poseestimation_amd.lib.models as models
+    from uda_poseestimation_amd.optim import FusedAdam
+    torch.manual_seed(1)
+    net = models.pose_resnet101(num_keypoints=16, pretrained_backbone=False).cuda()
+    dev_p = list(net.parameters())
+    ref_p = [torch.nn.Parameter(p.detach().cpu().contiguous().clone()) for p in dev_p]
+    o_ref, o_dev = torch.optim.Adam(ref_p, lr=1e-3), FusedAdam(dev_p, lr=1e-3)
+    g = torch.Generator().manual_seed(2)
+    for it in range(3):
+        for a, b in zip(ref_p, dev_p):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad = gr
+            b.grad = gr.cuda().contiguous(memory_format=torch.channels_last) if gr.dim() == 4 else gr.cuda()
+        o_ref.step(); o_dev.step()
+    worst = max(float((b.detach().cpu() - a.detach()).abs().max()) for a, b in zip(ref_p, dev_p))
+    assert worst <= 2e-6, worst
+
+
+def test_batchnorm_backward_orthogonality_at_full_size():
+    """Size-independent property of the BN backward at a layer1-sized tensor (32 x 64 x 64 pixels, 256 channels; not the
+    chunked form) and a layer3-sized one (chunked form): dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) is orthogonal
+    to 1 and to x-hat per channel.  The stored dy is that quantity rounded to bf16 once: its channel sums equal the sums of
+    the rounded closed form, and all but a vanishing fraction of its elements are the correctly rounded values."""
+    from uda_poseestimation_amd import ops
+    for (N, H, C_) in ((32, 64, 256), (32, 16, 1024)):
+        g = torch.Generator(device="cuda").manual_seed(C_)
+        y = torch.randn(N, H, H, C_, device="cuda", generator=g).bfloat16()
+        yf = y.float()
+        mean = yf.mean((0, 1, 2)); invstd = 1.0 / torch.sqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+        gamma = torch.rand(C_, device="cuda", generator=g) + 0.5
+        beta = torch.randn(C_, device="cuda", generator=g) * 0.1
+        dz = torch.randn(N, H, H, C_, device="cuda", generator=g)
+        dy, dgamma, dbeta, gm = ops.bn_bwd(dz, None, y, gamma, mean, invstd, relu=2, want_g=True, beta=beta)
+        M = N * H * H
+        xh = ((yf - mean) * invstd).double()
+        sc = gamma * invstd; sh = beta - mean * sc
+        gd = dz.double() * ((yf * sc + sh) > 0)
+        ideal = (gamma * invstd).double() * (gd - gd.sum((0, 1, 2)) / M - xh * (gd * xh).sum((0, 1, 2)) / M)
+        assert float(ideal.sum((0, 1, 2)).abs().max()) <= 1e-3 and float((ideal * xh).sum((0, 1, 2)).abs().max()) <= 1e-1   # (fp32 mean / invstd)
+        rounded = ideal.float().bfloat16()
+        differ = (dy != rounded)
+        assert float(differ.float().mean()) <= 2e-3                      # (coefficients are fp32 on the device: rare 1-ulp flips)
+        assert float((dy.float() - rounded.float()).abs().max()) <= 2.0 ** -7 * float(ideal.abs().max())
+        assert float((dy.double().sum((0, 1, 2)) - rounded.double().sum((0, 1, 2))).abs().max()) <= 5e-2
+        np.testing.assert_allclose(dbeta.cpu().numpy(), gd.sum((0, 1, 2)).float().cpu().numpy(), rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(dgamma.cpu().numpy(), (gd * xh).sum((0, 1, 2)).float().cpu().numpy(), rtol=1e-4, atol=1e-2)
