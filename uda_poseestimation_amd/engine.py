@@ -266,21 +266,23 @@ class GraphedTrainStep:
         # backward and the optimizer; both stay eager, so the step is cut into three graphs around them.
         self.split = _dist_on() if split is None else bool(split)
         self.g_fb, self.g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # other threads (the RCCL watchdog of torch.distributed) may touch the runtime while this thread captures
+        mode = "thread_local" if _dist_on() else "global"
         if not self.split:
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
                 self.out = trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
                                                      [st["theta_tea"]])
         else:
             self.g_lb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
                 self.fwd_state = trainer._forward_part(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]],
                                                        st["theta_stu"], [st["theta_tea"]])
             g0 = gather_activates(self.fwd_state["activates"])
             self.gathered = g0.clone() if g0 is not None else self.fwd_state["activates"].reshape(-1).clone()
-            with torch.cuda.graph(self.g_lb, pool=self.g_fb.pool()):
+            with torch.cuda.graph(self.g_lb, pool=self.g_fb.pool(), capture_error_mode=mode):
                 self.out = trainer._loss_backward_part(self.fwd_state, self.gathered)
         trainer.sync()
-        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
+        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode):
             trainer._update()
         torch.cuda.synchronize()
 
