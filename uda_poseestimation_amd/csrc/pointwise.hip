@@ -256,12 +256,14 @@ template <typename T>
 __global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, size_t n8, int C,
                            const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
     const int G = C >> 3;
+    // the launcher keeps gridDim.x * TPB a multiple of G (G is a power of two <= TPB, or the grid is one block per G-aligned
+    // stride), so a thread's channel group never changes: its coefficients are loaded once
+    const int c0 = (int)(((size_t)blockIdx.x * TPB + threadIdx.x) % G) * 8;
+    const f32x4 sa = *(const f32x4*)(scale + c0), sb = *(const f32x4*)(scale + c0 + 4);
+    const f32x4 ha = *(const f32x4*)(shift + c0), hb = *(const f32x4*)(shift + c0 + 4);
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
-        const int c0 = (int)(i % G) * 8;
         float v[8];
         ld8<T>(y + i * 8, v);
-        const f32x4 sa = *(const f32x4*)(scale + c0), sb = *(const f32x4*)(scale + c0 + 4);
-        const f32x4 ha = *(const f32x4*)(shift + c0), hb = *(const f32x4*)(shift + c0 + 4);
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = v[e] * (e < 4 ? sa[e] : sb[e - 4]) + (e < 4 ? ha[e] : hb[e - 4]);
@@ -776,14 +778,25 @@ int pw_bn_eval_coeff(hipStream_t s, int C, const float* gamma, const float* beta
     hipLaunchKernelGGL(bn_eval_coeff_k, dim3(nblk(C)), dim3(TPB), 0, s, C, gamma, beta, rm, rv, eps, scale, shift);
     return udapose_check_launch();
 }
+// grid of bn_apply_k: every thread must keep its channel group over the grid-stride loop -> (grid * TPB) % (C/8) == 0
+static int bn_apply_grid(size_t n8, int C) {
+    const int G = C / 8;
+    int g = grid_for(n8);
+    if (g > 2048) g = 2048;             // 8 work-groups per CU: threads of the large tensors loop, coefficients stay in registers
+    if ((TPB % G) != 0) {               // C/8 not a divisor of the block size (e.g. C = 24): round the grid to a multiple of G
+        g = (g / G) * G;
+        if (g < G) g = G;
+    }
+    return g;
+}
 int pw_bn_apply(hipStream_t s, const bf16_t* y, const bf16_t* res, bf16_t* z, size_t n, int C, const float* scale, const float* shift, int relu) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(bn_apply_k<bf16_t>, dim3(grid_for(n / 8)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    hipLaunchKernelGGL(bn_apply_k<bf16_t>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
     return udapose_check_launch();
 }
 int pw_bn_apply_f32(hipStream_t s, const float* y, const float* res, float* z, size_t n, int C, const float* scale, const float* shift, int relu) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(bn_apply_k<float>, dim3(grid_for(n / 8)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    hipLaunchKernelGGL(bn_apply_k<float>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
     return udapose_check_launch();
 }
 static int bn_bwd_chunked() {   // tuning hook: UDAPOSE_BN_BWD_CHUNKED=0 restores reduce / finalize / apply everywhere
