@@ -513,16 +513,18 @@ unsigned long long* g_igemm_timeline = nullptr;   // tuning hook: device buffer 
 int igemm_pick_tile(int M, int Co, int nclass, int K) {
     if (Co <= 32) return 3;
     if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
-    // measured (tools/tune_conv.py, and re-checked under the three-stream step): 128x64 tiles as soon as they give two
-    // work-groups per CU, else 64x64 with the deeper ring for long K
     const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
+    // measured (tools/tune_conv.py, then re-tuned under the three-stream step): 128x64 tiles with a 2-stage ring as soon as
+    // they give two work-groups per CU, else 64x64 with a 3-stage ring for long K and a 2-stage ring otherwise.  Every
+    // choice lands on THREE resident work-groups per CU (48 KB of LDS each): deeper rings (4 stages = 2 per CU) and one deep
+    // 128x64 work-group per CU both measured slower - overlapping the fixed phases of several work-groups beats prefetch depth.
     if (b12864 >= 512) return 6;
-    return K >= 1024 ? 2 : 5;
+    return K >= 1024 ? 9 : 5;
 }
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     switch (tile) {
-        case 2: case 5: case 7: return nclass * ((M + 63) / 64) * 2;
+        case 2: case 5: case 7: case 9: return nclass * ((M + 63) / 64) * 2;
         case 3: return nclass * ((M + 127) / 128) * 4;
         default: return nclass * ((M + 127) / 128) * 2;
     }
@@ -550,6 +552,7 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
         case 6: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
         case 7: return launch_cfg<64, 64, 2, 2, 4, true>(p, stream);
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
+        case 9: return launch_cfg<64, 64, 2, 2, 3>(p, stream);
         default: return UDAPOSE_ERR_ARG;
     }
 }
