@@ -69,7 +69,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
 // stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
 template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgParams p) {
+// amdgpu_waves_per_eu(4): a register budget of 128 per lane.  Left alone the compiler spends 168 + 24 AGPRs on the 128x64 tile
+// (two resident work-groups per CU); with the hint it needs 110 and none of the configurations the heuristic picks spills
+// (the 128x128 ones, reachable only through the tuning override, do).  Measured: -0.65 ms per step.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
     // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.

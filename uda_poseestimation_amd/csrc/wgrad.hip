@@ -215,19 +215,19 @@ template <int CH> __device__ __forceinline__ int wswz(int row) {   // CH = chann
     return CH == 64 ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
 }
 
-template <int RT, int CT, int WR, int WC, int NS>
+template <int RT, int CT, int WR, int WC, int NS, int PX = 64>   // PX = pixels (K rows) per LDS stage: 64 or 32
 struct WdCfg {
     static constexpr int TR = RT / WR, TC = CT / WC;
     static constexpr int MT = TR / 16, NT = TC / 16;
     static constexpr int PROW = RT * 2, QROW = CT * 2;               // bytes per LDS row
-    static constexpr int P_BYTES = 64 * PROW, Q_BYTES = 64 * QROW;
+    static constexpr int P_BYTES = PX * PROW, Q_BYTES = PX * QROW;
     static constexpr int P_PW = P_BYTES / 4096, Q_PW = Q_BYTES / 4096; // DMA instructions per wave per stage
     static constexpr int STAGE1 = P_BYTES + Q_BYTES;
     static constexpr int LDS_BYTES = NS * STAGE1;
 };
 
 // One work-group: tile bx of dW tap `by`, pixel split bz of problem p.
-template <int RT, int CT, int WR, int WC, int NS>
+template <int RT, int CT, int WR, int WC, int NS, int PX = 64>
 __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
     // scalar copies of the fields used below (gp may live in global memory: read it once, up front, into SGPRs)
@@ -237,7 +237,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
         FastDiv div_hw, div_w;
     } p = {(const bf16_t*)((uintptr_t)gp.dy + dy_base), (const bf16_t*)((uintptr_t)gp.x + x_base), (float*)((uintptr_t)gp.dw + ((gp.flags & WG_FLAG_DW_WS) ? dy_base : dw_base)), gp.taps, gp.Hi, gp.Wi, gp.Ci, gp.Ho, gp.Wo, gp.Co, gp.Hg, gp.Wg, gp.s, gp.os, gp.M, gp.wtaps, gp.flags, gp.ksplit,
            gp.c_tiles, gp.rows_valid, gp.kw, gp.div_hw, gp.div_w};
-    using C = WdCfg<RT, CT, WR, WC, NS>;
+    using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
     constexpr int LPS = P_PW + Q_PW;
     constexpr int P_RPI = 1024 / C::PROW, Q_RPI = 1024 / C::QROW;    // rows per DMA instruction (8 or 4)
@@ -257,7 +257,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     if (tp.cls == 1) { cls.oa = gp.cls[1].oa; cls.ob = gp.cls[1].ob; }
     if (tp.cls == 2) { cls.oa = gp.cls[2].oa; cls.ob = gp.cls[2].ob; }
     if (tp.cls == 3) { cls.oa = gp.cls[3].oa; cls.ob = gp.cls[3].ob; }
-    const int ms_total = (p.M + 63) >> 6;                            // 64-pixel stages
+    const int ms_total = (p.M + PX - 1) / PX;                        // PX-pixel stages
     const int per = (ms_total + p.ksplit - 1) / p.ksplit;
     const int ms0 = bz * per;
     int ms1 = ms0 + per;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     const bool x_lin = p.s == 1 && tp.dy == 0 && tp.dx == 0 && p.Hg == p.Hi && p.Wg == p.Wi;
     const int lrow = lane / P_CPR, pch = lane % P_CPR;
     auto issue_stage = [&](int st, int buf) {
-        const int mb = (ms0 + st) << 6;
+        const int mb = (ms0 + st) * PX;
         char* P = smem + buf * C::STAGE1;
         char* Q = P + C::P_BYTES;
 #pragma unroll
@@ -338,7 +338,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
         const char* P = smem + buf * C::STAGE1;
         const char* Q = P + C::P_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < PX / 32; ++kk) {
             bf16x8 af[MT], bfr[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
 // work-group's linear index inside that problem's (tile, tap, split) grid, or prob < 0 = padding.  The host deals whole
 // (problem, split) units to XCDs by load, so the tiles that re-read one pixel range share an L2.  The table holds byte
 // OFFSETS in its x / dy / dw fields, relative to the three bases passed per launch, so one table serves every pass.
-template <int RT, int CT, int WR, int WC, int NS>
-__global__ __launch_bounds__(256) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
+template <int RT, int CT, int WR, int WC, int NS, int PX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
                                                               const uint32_t per_xcd, const char* x_base, const char* dy_base, char* dw_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgGroupBlk b = blk[(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)];
@@ -417,19 +417,19 @@ __global__ __launch_bounds__(256) void wgrad_dma_group_kernel(const WgParams* __
     const uint32_t gx = (uint32_t)(p.r_tiles * p.c_tiles), gxy = gx * (uint32_t)p.total_taps;
     const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
     const uint32_t by = bxy / gx, bx = bxy - by * gx;
-    wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
 }
 
-template <int RT, int CT, int WR, int WC, int NS>
+template <int RT, int CT, int WR, int WC, int NS, int PX>
 int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
                     hipStream_t stream) {
-    using C = WdCfg<RT, CT, WR, WC, NS>;
+    using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS>), dim3(8 * per_xcd), dim3(256), C::LDS_BYTES, stream, d_tab, d_blk,
+    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd), dim3(256), C::LDS_BYTES, stream, d_tab, d_blk,
                        (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base);
     return udapose_check_launch();
 }
@@ -542,6 +542,9 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block) {
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base) {
     if (per_xcd <= 0) return UDAPOSE_OK;
-    return tile == 0 ? launch_wd_group<128, 128, 2, 2, 2>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream)
-                     : launch_wd_group<64, 64, 2, 2, 4>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
+    // 32-pixel stages for the 128x128 tile (32 KB of LDS, 128 VGPRs: four resident work-groups per CU instead of two with
+    // 64-pixel stages) and a 3-stage ring of 64-pixel stages for the 64x64 tile (48 KB: three per CU): measured -0.7 ms per
+    // step against {64-pixel stages, 2 / 4-stage rings}; occupancy beats prefetch depth here as in the igemm
+    if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
+    return launch_wd_group<64, 64, 2, 2, 3, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
 }
