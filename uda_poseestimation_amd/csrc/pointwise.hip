@@ -158,14 +158,15 @@ __global__ void unpack_strided_k(const float* __restrict__ src, float* __restric
 // ------------------------------------------------------------------ BatchNorm (training mode)
 // Column sums of a partial-sum slab [rows][2][C]: block = 32 channels x 32 row lanes (1024 threads), 128-byte coalesced
 // row segments, fp64 accumulation, LDS tree over the row lanes.  Result for channel c0+cl in (s1, s2) of lanes rl == 0.
-#ifndef UDAPOSE_FIN_T
-#define UDAPOSE_FIN_T 1024
+#ifndef UDAPOSE_FIN_C
+#define UDAPOSE_FIN_C 32
 #endif
-constexpr int FIN_T = UDAPOSE_FIN_T;
-constexpr int FIN_RL = FIN_T / 32;      // row lanes per block
+constexpr int FIN_C = UDAPOSE_FIN_C;    // channels per block (32: 128-byte row segments; 8: 32-byte segments, 4x the blocks)
+constexpr int FIN_RL = 32;              // row lanes per block
+constexpr int FIN_T = FIN_C * FIN_RL;
 __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int rows, int C, int c, bool cvalid, double& s1, double& s2,
-                                            double (*red)[32][2]) {
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+                                            double (*red)[FIN_C][2]) {
+    const int cl = threadIdx.x % FIN_C, rl = threadIdx.x / FIN_C;
     double a = 0.0, b = 0.0;
     if (cvalid) {
         // 4 independent row loads in flight per thread (the loop is latency-bound otherwise)
@@ -197,12 +198,12 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_k(const float* __restrict__
                               const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                               long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ scale,
                               float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    __shared__ double red[FIN_RL][32][2];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    __shared__ double red[FIN_RL][FIN_C][2];
+    const int c = blockIdx.x * FIN_C + (threadIdx.x % FIN_C);
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     double s1, s2;
     slab_colsum(slab, rows, C, c, c < C, s1, s2, red);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    if ((threadIdx.x / FIN_C) != 0 || c >= C) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -349,11 +350,11 @@ __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restr
 __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
                                   const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float beta_acc, float* __restrict__ coef) {
-    __shared__ double red[FIN_RL][32][2];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    __shared__ double red[FIN_RL][FIN_C][2];
+    const int c = blockIdx.x * FIN_C + (threadIdx.x % FIN_C);
     double s1, s2;
     slab_colsum(slab, rows, C, c, c < C, s1, s2, red);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    if ((threadIdx.x / FIN_C) != 0 || c >= C) return;
     if (dgamma) {
         dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
         dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
@@ -734,7 +735,7 @@ int pw_unpack_strided(hipStream_t s, const float* src, float* dst, int A, int KH
 }
 int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
                    long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
-    hipLaunchKernelGGL(bn_finalize_k, dim3((C + 31) / 32), dim3(FIN_T), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
+    hipLaunchKernelGGL(bn_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
                        save_mean, save_invstd);
     return udapose_check_launch();
 }
@@ -844,7 +845,7 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, con
         hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(TPB), 0, s, (const float*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb, gamma, beta);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb, gamma, beta);
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 31) / 32), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
     if (dz_is_f32)
         hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)dz, z, y, dy, gout, npix * G, C, mean, invstd,
                            coef, relu, gamma, beta);
