@@ -47,6 +47,7 @@ struct IgCfg {
     static constexpr int STAGE_BYTES = NS * STAGE1;
     static constexpr int EPI_BYTES = 4 * ER * ELD * 4;
     static constexpr int LDS_BYTES = TAP_BYTES + (STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES);
+    static_assert(EPI_BYTES + WM * 2 * BN * 4 <= STAGE_BYTES, "the wave-row exchange of the BN statistics sits behind the epilogue regions");
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -380,10 +381,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
     const bool lin_out = p.os == 1 && cls.oa == 0 && cls.ob == 0 && p.Hg == p.Ho && p.Wg == p.Wo;
     if (p.stats) {
         // BN partial statistics straight from the accumulators: a lane holds rows (lane>>4)*4+r of every 16-row tile for
-        // column j*16 + (lane&15), so the column sum is lane-local over (tile, r) plus two xor steps over lane>>4.
-        // (rows m >= M are zero-filled operand rows: they add 0)
-        const size_t srow = ((size_t)cls_id * p.m_tiles + m_tile) * WM + wm;
-        float* sp = p.stats + srow * 2 * p.Co;
+        // column j*16 + (lane&15), so the column sum is lane-local over (tile, r) plus two xor steps over lane>>4; the WM wave
+        // rows of the work-group are then added through LDS, so the slab has ONE row per m-tile (the BN kernels that re-reduce
+        // it per work-group read half as much).  (rows m >= M are zero-filled operand rows: they add 0)
+        float* xch = (float*)(stage + C::EPI_BYTES);           // [WM][2][BN], behind the per-wave epilogue regions
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float a = 0.f, b = 0.f;
@@ -393,8 +394,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
                 for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; a += v; b += v * v; }
             a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
             a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-            const int col = n0 + wn * TN + j * 16 + lane;
-            if (lane < 16 && col < p.Co) { sp[col] = a; sp[p.Co + col] = b; }
+            const int cl = wn * TN + j * 16 + lane;
+            if (lane < 16) { xch[(wm * 2 + 0) * BN + cl] = a; xch[(wm * 2 + 1) * BN + cl] = b; }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid % BN, col = n0 + cl;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += xch[(w * 2 + st) * BN + cl];
+            const size_t srow = (size_t)cls_id * p.m_tiles + m_tile;
+            if (col < p.Co) p.stats[(srow * 2 + st) * p.Co + col] = t;
         }
     }
     float bias[8];
@@ -527,9 +537,8 @@ int igemm_pick_tile(int M, int Co, int nclass, int K) {
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     switch (tile) {
-        case 2: case 5: case 7: case 9: return nclass * ((M + 63) / 64) * 2;
-        case 3: return nclass * ((M + 127) / 128) * 4;
-        default: return nclass * ((M + 127) / 128) * 2;
+        case 2: case 5: case 7: case 9: return nclass * ((M + 63) / 64);       // one row per m-tile (wave rows added in-kernel)
+        default: return nclass * ((M + 127) / 128);
     }
 }
 

@@ -31,6 +31,8 @@ int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
 int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
 int pw_bn_running_update_multi(hipStream_t, const BnRunJob*, int, int, const void*, float);
+int pw_bn_train_fused(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, int, const float*, const float*, float*, float*,
+                      long long*, float, float, float*, int);
 int pw_zero_multi(hipStream_t, const ZeroJob*, int, void*);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
@@ -279,6 +281,14 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     CK(conv_fprop(s, c.g, (const bf16_t*)(act + c.in_off), (const bf16_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
+    if (training && !n.f32) {
+        // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
+        const int took = pw_bn_train_fused(s, (const bf16_t*)(act + c.y_off), res, (bf16_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
+                                           beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
+                                           upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu);
+        if (took < 0) return took;
+        if (took) return UDAPOSE_OK;
+    }
     if (training)
         CK(pw_bn_finalize(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, upd ? (float*)buffers[b.rm_idx] : nullptr,
                           upd ? (float*)buffers[b.rv_idx] : nullptr, upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, scale, shift,
