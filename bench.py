@@ -85,6 +85,7 @@ def main():
                     "(PCIe-inclusive rate, DESIGN.md section 5)")
     ap.add_argument("--igemm-tile", type=int, default=-1, help="tuning: force one igemm tile configuration id")
     ap.add_argument("--wgrad-group", type=int, default=1, help="tuning: 0 = one weight-gradient launch per layer")
+    ap.add_argument("--bn-bwd-fused", type=int, default=1, help="tuning: 0 = separate BN-backward reduce launches")
     ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
@@ -105,6 +106,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    force_dist = os.environ.get("UDAPOSE_FORCE_DIST", "0") == "1"     # test hook: one-rank RCCL group, data-parallel code path
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
@@ -117,6 +123,7 @@ def main():
     import uda_poseestimation_amd.lib.models as models
     lib = _hip.lib()
     lib.udapose_debug_set_wgrad_group(args.wgrad_group, args.wgrad_stages)
+    lib.udapose_debug_set_bn_bwd_fused(args.bn_bwd_fused)
     if args.igemm_tile >= 0:
         lib.udapose_debug_set_tiles(args.igemm_tile, -1, -1)
 
@@ -230,7 +237,7 @@ def main():
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
                                    f"Adam, EMA), {S}x{S}, b={N}/GPU, no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch) == (256, 16, 32, "pose_resnet101") else f", K={K}"),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
-            "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs) else "2 hipGraphs") + " (last timed step eager, instrumented)",
+            "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + " (last timed step eager, instrumented)",
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fprop+dgrad, bf16 MFMA 16x16x32)",
@@ -248,6 +255,7 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

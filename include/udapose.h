@@ -52,6 +52,16 @@ int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, 
  * feed a BatchNorm backward close to the loss, where the BN projection cancels most of the gradient) */
 int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res,
                             int out_f32);
+/* The same dgrad when dx is the gradient dz entering a training-mode BatchNorm (+ReLU) whose input was bn_y [N,Hi,Wi,Ci] bf16:
+ * the epilogue writes g = dz * mask to dx (mask: bn_z > 0 when bn_z is given - BN + residual + ReLU -, else
+ * bn_y*gamma*invstd + (beta - mean*gamma*invstd) > 0, the forward's own expression) and one partial row per m-tile of
+ * (sum g, sum g * (bn_y - mean) * invstd) to slab[rows][2][Ci] fp32, rows = the return value of udapose_conv_bwd_stat_rows.
+ * That BatchNorm's backward then needs no reduction pass (reference: torch autograd of lib/models/resnet.py's
+ * conv-bn-relu chains, train_human.py:338-444). */
+int udapose_conv_bwd_stat_rows(const udapose_conv_desc* d);
+int udapose_conv2d_bwd_data_bn(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res,
+                               int out_f32, const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd,
+                               const float* bn_gamma, const float* bn_beta, float* slab);
 /* dw fp32 [Co][KH*KWp][Ci] (transposed: [Ci][KH*KW][Co]) = (accumulate ? dw : 0) + sum_pixels dy * x */
 int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate);
 /* weight packing from fp32: cast (n % 8 == 0); per-tap transpose [A][T][B] -> [B][T][A]; strided gather with zero padding */
@@ -177,6 +187,9 @@ void udapose_debug_set_tiles(int igemm_tile, int wgrad_tile, int wgrad_ksplit);
  * the dgrad / BN-backward chain (on = 1, default) or layer by layer (on = 0); stages_per_block (> 0) = 64-pixel stages a
  * work-group reduces before a layer's pixel range is split (default 128) */
 void udapose_debug_set_wgrad_group(int on, int stages_per_block);
+/* tuning / test hook: udapose_net_backward lets every dgrad launch apply the ReLU mask of the BatchNorm that consumes its
+ * output and reduce that BN's backward sums in its epilogue (on = 1, default), or runs the separate reduce launches (on = 0) */
+void udapose_debug_set_bn_bwd_fused(int on);
 /* tuning hook: device buffer ([work-groups][8] uint64, or NULL = off) into which every conv work-group writes s_memrealtime
  * stamps (100 MHz): entry, prologue done, first K stage landed, K loop done, epilogue issued, stores drained */
 void udapose_debug_set_timeline(void* dev_buf);

@@ -330,3 +330,61 @@ def test_conv_adjoint_identities_at_full_size(dev, layer):
     rhs = y + ops.conv2d_fwd(x2, wf, d, out_f32=True)
     # (x + x2 is rounded to bf16 once more than x and x2: 2^-9 relative per input element)
     assert float((lhs - rhs).norm() / rhs.norm()) <= 6e-3
+
+
+DGRAD_BN_CASES = [
+    # name, N, H, Ci, Co, K, stride, pad, transposed, mask-from-z, residual, fp32 out
+    ("1x1_c3_mask_y", 4, 16, 64, 256, 1, 1, 0, False, False, False, False),          # dgrad c3 -> bn2
+    ("3x3_c2_mask_y", 3, 12, 64, 64, 3, 1, 1, False, False, False, False),           # dgrad c2 -> bn1 (ragged M)
+    ("3x3_s2_subpixel_odd", 2, 15, 128, 128, 3, 2, 1, False, False, False, False),   # stride-2 dgrad: 4 classes, odd size
+    ("1x1_c1_skip_mask_z", 4, 16, 256, 64, 1, 1, 0, False, True, True, False),       # dgrad c1 + skip -> bn3 of the block before
+    ("deconv_f32_mask_y", 2, 8, 256, 256, 4, 2, 1, True, False, False, True),        # dgrad of a deconv -> deconv BN (fp32 g)
+    ("head_like_f32", 2, 32, 256, 64, 1, 1, 0, False, False, False, True),           # head dgrad (64 padded channels) -> fp32
+    ("n32_l3_c1_mask_z", 32, 16, 1024, 256, 1, 1, 0, False, True, True, False),      # a bench-size launch (128x64 tiles, 64 rows)
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_BN_CASES, ids=[c[0] for c in DGRAD_BN_CASES])
+def test_dgrad_with_fused_bn_backward_reduction(dev, case):
+    """udapose_conv2d_bwd_data_bn against udapose_conv2d_bwd_data: the masked output equals the plain dgrad output under the
+    consumer BatchNorm's ReLU mask BIT FOR BIT, and the slab's column sums equal sum(g), sum(g * xhat) of exactly those stored
+    values (fp64 reference; fp32 partials per m-tile)."""
+    from uda_poseestimation_amd import ops
+    _, N, H, Ci, Co, K, s, p, tr, mask_z, with_res, f32 = case
+    g = torch.Generator(device="cuda").manual_seed(11)
+    d = ops.conv_desc(N, H, H, Ci, Co, K, s, p, transposed=tr)
+    ho, wo = ops.conv_out_hw(d)
+    wshape = (Ci, Co, K, K) if tr else (Co, Ci, K, K)
+    w = (torch.randn(wshape, device="cuda", generator=g) / (Co * K * K) ** 0.5).bfloat16().float()
+    wb = ops.pack_weight(w, d, "bwd")
+    dy = torch.randn(N, ho, wo, Co, device="cuda", generator=g).bfloat16()
+    res = torch.randn(N, H, H, Ci, device="cuda", generator=g).bfloat16() if with_res else None
+    bn_y = (torch.randn(N, H, H, Ci, device="cuda", generator=g) * 1.5 + 0.3).bfloat16()
+    mean = torch.randn(Ci, device="cuda", generator=g) * 0.2 + 0.3
+    invstd = torch.rand(Ci, device="cuda", generator=g) * 0.5 + 0.4
+    gamma = torch.rand(Ci, device="cuda", generator=g) + 0.5
+    beta = torch.randn(Ci, device="cuda", generator=g) * 0.3
+    bn_z = torch.relu(torch.randn(N, H, H, Ci, device="cuda", generator=g)).bfloat16() if mask_z else None
+    dx0 = ops.conv2d_bwd_data(dy, wb, d, res=res, out_f32=f32)
+    gq, slab = ops.conv2d_bwd_data_bn(dy, wb, d, bn_y, mean, invstd, bn_z=bn_z, bn_gamma=gamma, bn_beta=beta, res=res, out_f32=f32)
+    assert gq.dtype == dx0.dtype and slab.shape[1:] == (2, Ci)
+    if mask_z:
+        keep = bn_z.float() > 0
+        sure = torch.ones_like(keep)
+    else:
+        sc = gamma * invstd
+        t = bn_y.double() * sc.double() + (beta - mean * sc).double()
+        keep = t > 0
+        sure = t.abs() > 1e-5 * (bn_y.double().abs() * sc.double().abs() + 1.0)      # (fma vs mul+add can differ only at t ~ 0)
+    want = torch.where(keep, dx0, torch.zeros_like(dx0))
+    assert sure.float().mean() > 0.999
+    assert torch.equal(gq[sure], want[sure]), "masked dgrad output differs from mask * plain dgrad output"
+    assert 0.2 < float((gq != 0).float().mean()) < 0.8
+    xhat = (bn_y.double() - mean.double()) * invstd.double()
+    s1 = gq.double().sum((0, 1, 2))
+    s2 = (gq.double() * xhat).sum((0, 1, 2))
+    a1 = gq.double().abs().sum((0, 1, 2))
+    a2 = (gq.double() * xhat).abs().sum((0, 1, 2))
+    got = slab.double().sum(0)
+    assert float(((got[0] - s1).abs() / (a1 + 1e-30)).max()) < 2e-6, float(((got[0] - s1).abs() / (a1 + 1e-30)).max())
+    assert float(((got[1] - s2).abs() / (a2 + 1e-30)).max()) < 2e-6, float(((got[1] - s2).abs() / (a2 + 1e-30)).max())

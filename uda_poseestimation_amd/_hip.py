@@ -24,6 +24,8 @@ _SIGS = {
     "udapose_conv_stat_rows": (ci, [vp]),
     "udapose_conv2d_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci]),
     "udapose_conv2d_bwd_data": (ci, [vp, vp, vp, vp, vp, vp, ci]),
+    "udapose_conv_bwd_stat_rows": (ci, [vp]),
+    "udapose_conv2d_bwd_data_bn": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp]),
     "udapose_conv2d_bwd_weight": (ci, [vp, vp, vp, vp, vp, ci]),
     "udapose_cast_f32_bf16": (ci, [vp, vp, vp, sz]),
     "udapose_transpose_cast": (ci, [vp, vp, vp, ci, ci, ci]),
@@ -66,6 +68,7 @@ _SIGS = {
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_debug_set_tiles": (None, [ci, ci, ci]),
     "udapose_debug_set_wgrad_group": (None, [ci, ci]),
+    "udapose_debug_set_bn_bwd_fused": (None, [ci]),
     "udapose_debug_set_timeline": (None, [vp]),
     "udapose_patch_paste": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
     "udapose_prof_begin": (None, []),

@@ -39,6 +39,7 @@ int prof_end(double*);
 void* net_create(const int layers[4], int K, int N, int H, int W, int f32);
 void net_destroy(void*);
 void net_set_wgrad_group(int, int);
+void net_set_bn_bwd_fused(int);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -73,6 +74,15 @@ int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, 
 int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res, int out_f32) {
     if (!d || !dy || !w_bwd || !dx) return UDAPOSE_ERR_ARG;
     return conv_dgrad(S(stream), to_geom(d), CB16(dy), CB16(w_bwd), dx, CB16(res), out_f32);
+}
+int udapose_conv_bwd_stat_rows(const udapose_conv_desc* d) { return d ? conv_dgrad_stat_rows(to_geom(d)) : UDAPOSE_ERR_ARG; }
+int udapose_conv2d_bwd_data_bn(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res, int out_f32,
+                               const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                               const float* bn_beta, float* slab) {
+    if (!d || !dy || !w_bwd || !dx || !bn_y || !bn_mean || !bn_invstd || !slab) return UDAPOSE_ERR_ARG;
+    DgradBnStat st;
+    st.y = CB16(bn_y); st.z = CB16(bn_z); st.mean = bn_mean; st.invstd = bn_invstd; st.gamma = bn_gamma; st.beta = bn_beta; st.slab = slab;
+    return conv_dgrad(S(stream), to_geom(d), CB16(dy), CB16(w_bwd), dx, CB16(res), out_f32, &st);
 }
 int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate) {
     if (!d || !dy || !x || !dw) return UDAPOSE_ERR_ARG;
@@ -124,6 +134,7 @@ int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32
 }
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
 void udapose_debug_set_wgrad_group(int on, int stages_per_block) { net_set_wgrad_group(on, stages_per_block); }
+void udapose_debug_set_bn_bwd_fused(int on) { net_set_bn_bwd_fused(on); }
 extern unsigned long long* g_igemm_timeline;
 void udapose_debug_set_timeline(void* dev_buf) { g_igemm_timeline = (unsigned long long*)dev_buf; }
 int udapose_net_num_params(udapose_net_t n) { return net_num_params(n); }

@@ -49,8 +49,18 @@ struct ConvEpilogue {
 };
 // y = conv(x, w_fwd[Co][wtaps][Ci])
 int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e);
+// The BatchNorm whose backward consumes a dgrad's output (IgParams::bs_*): the dgrad epilogue masks dx with that BN's ReLU
+// and leaves the partial sums of g and g * xhat in slab[rows][2][C]; `rows` is set by conv_dgrad.
+struct DgradBnStat {
+    const bf16_t* y = nullptr;      // the BN's input (pre-BN conv output)
+    const bf16_t* z = nullptr;      // mask source (BN + residual + ReLU output) or null: mask recomputed from y
+    const float* mean = nullptr; const float* invstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    float* slab = nullptr;
+    int rows = 0;
+};
 // dx = conv^T(dy, w_bwd[Ci][wtaps][Co]) (+ res)
-int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32);
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32,
+               DgradBnStat* bs = nullptr);
 // dw (fp32, [Co][wtaps][Ci]; transposed: [Ci][wtaps][Co]) (+)= ...;  rows_valid < 0 -> all rows
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid);
 // the same problem as a parameter block (for the grouped launch); returns the layer's algorithmic FLOPs in *flops
@@ -58,3 +68,4 @@ int conv_wgrad_params(const ConvGeom& g, const bf16_t* dy, const bf16_t* x, floa
 int conv_prof_before(hipStream_t s, int kind, double flops);
 void conv_prof_after(hipStream_t s, int token);
 int conv_stat_rows(const ConvGeom& g);
+int conv_dgrad_stat_rows(const ConvGeom& g);   // rows of a DgradBnStat slab for this layer's dgrad

@@ -114,12 +114,11 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* 
     return rc;
 }
 
-int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32) {
+static int dgrad_params(const ConvGeom& g, IgParams& p) {
     if (g.reflect || g.upsample || g.smallc()) return UDAPOSE_ERR_UNSUPPORTED;
     const TapPlan* tp = get_tap_plan(g, 1);
     if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
-    IgParams p{};
-    p.x = dy; p.w = w_bwd; p.y = dx; p.res = res; p.taps = tp->d_taps;
+    p.taps = tp->d_taps;
     p.N = g.N; p.Hi = g.Ho(); p.Wi = g.Wo(); p.Ci = g.Co;     // igemm "input" is dy
     p.Ho = g.Hi; p.Wo = g.Wi; p.Co = g.Ci;                     // igemm "output" is dx
     if (g.transposed) { p.Hg = g.Hi; p.Wg = g.Wi; p.s = g.stride; p.os = 1; }
@@ -127,11 +126,33 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     else { p.Hg = g.Hi; p.Wg = g.Wi; p.s = 1; p.os = 1; }
     p.M = g.N * p.Hg * p.Wg;
     p.wtaps = g.wtaps();
-    p.flags = out_f32 ? IG_FLAG_OUT_F32 : 0;
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
+    return UDAPOSE_OK;
+}
+
+int conv_dgrad_stat_rows(const ConvGeom& g) {
+    IgParams p{};
+    const int rc = dgrad_params(g, p);
+    if (rc != UDAPOSE_OK) return rc;
+    return igemm_stat_rows(p.M, p.Co, p.nclass, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci));
+}
+
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32, DgradBnStat* bs) {
+    IgParams p{};
+    const int rc0 = dgrad_params(g, p);
+    if (rc0 != UDAPOSE_OK) return rc0;
+    p.x = dy; p.w = w_bwd; p.y = dx; p.res = res;
+    p.flags = out_f32 ? IG_FLAG_OUT_F32 : 0;
+    const int tile = igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci);
+    if (bs) {
+        p.bs_y = bs->y; p.bs_z = bs->z; p.bs_mean = bs->mean; p.bs_invstd = bs->invstd; p.bs_gamma = bs->gamma; p.bs_beta = bs->beta;
+        p.stats = bs->slab;
+        bs->rows = igemm_stat_rows(p.M, p.Co, p.nclass, tile);
+        if (!bs->y || !bs->slab || !bs->mean || !bs->invstd || (!bs->z && (!bs->gamma || !bs->beta))) return UDAPOSE_ERR_ARG;
+    }
     const int tok = prof_before(s, 1, alg_flops(g));
-    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci), s);
+    const int rc = igemm_launch(p, tile, s);
     prof_after(s, tok);
     return rc;
 }

@@ -34,6 +34,15 @@ struct IgParams {
     FastDiv div_hw, div_w;  // m / (Hg*Wg), rem / Wg
     int m_tiles, n_tiles;
     unsigned long long* dbg;   // tuning: per-work-group timeline stamps [blocks][8] (s_memrealtime, 100 MHz), normally null
+    // dgrad only: the BatchNorm that consumes this launch's output dz in the backward chain.  When bs_y is set the epilogue
+    // applies that BN's ReLU mask to dz (so y receives g = dz * mask), and writes per-m-tile partial sums of g and g * xhat to
+    // `stats` ([stat_rows][2][Co], the same slab layout as the forward statistics): the separate reduce launch disappears.
+    const bf16_t* bs_y;        // the consumer BN's input (pre-BN conv output), same shape as y
+    const bf16_t* bs_z;        // mask source z > 0 (BN + residual + ReLU); null: mask recomputed from y*scale + shift > 0
+    const float* bs_mean;      // [Co] saved batch mean / inverse std of the consumer BN
+    const float* bs_invstd;
+    const float* bs_gamma;     // [Co] (mask recomputation only)
+    const float* bs_beta;
 };
 
 // wgrad: dW[r][tap][c] (fp32) (+)= sum_m P[pixP][r] * Q[pixQ][c]

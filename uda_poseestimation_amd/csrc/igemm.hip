@@ -69,7 +69,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Main loop: NS-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers), counted vmcnt waits and
 // ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
 // stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false>
 // amdgpu_waves_per_eu(4): a register budget of 128 per lane.  Left alone the compiler spends 168 + 24 AGPRs on the 128x64 tile
 // (two resident work-groups per CU); with the hint it needs 110 and none of the configurations the heuristic picks spills
 // (the 128x128 ones, reachable only through the tuning override, do).  Measured: -0.65 ms per step.
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
     const bool relu = (p.flags & IG_FLAG_RELU) != 0;
     const bool outf32 = F32 || (p.flags & IG_FLAG_OUT_F32) != 0;
     const bool lin_out = p.os == 1 && cls.oa == 0 && cls.ob == 0 && p.Hg == p.Ho && p.Wg == p.Wo;
-    if (p.stats) {
+    if (!BS && p.stats) {
         // BN partial statistics straight from the accumulators: a lane holds rows (lane>>4)*4+r of every 16-row tile for
         // column j*16 + (lane&15), so the column sum is lane-local over (tile, r) plus two xor steps over lane>>4; the WM wave
         // rows of the work-group are then added through LDS, so the slab has ONE row per m-tile (the BN kernels that re-reduce
@@ -410,6 +410,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = (p.bias && cbase + e < p.Co) ? p.bias[cbase + e] : 0.f;
+    // BS (dgrad feeding a BatchNorm backward): per-lane coefficients of the consumer BN's 8 channels and the running partial
+    // sums of g and g * xhat over this lane's rows
+    float bmu[8], bis[8], bsc[8], bsh[8], bs1[8], bs2[8];
+    if constexpr (BS) {
+        const bool cok = cbase < p.Co;        // (Co % 8 == 0 is a launch requirement of this mode)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bmu[e] = cok ? p.bs_mean[cbase + e] : 0.f;
+            bis[e] = cok ? p.bs_invstd[cbase + e] : 0.f;
+            bs1[e] = 0.f; bs2[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f;
+        }
+        if (!p.bs_z && cok) {
+            // the forward's own scale / shift expressions (bn_finalize_k): the mask is z > 0 without reading z
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bsc[e] = p.bs_gamma[cbase + e] * bis[e]; bsh[e] = p.bs_beta[cbase + e] - bmu[e] * bsc[e]; }
+        }
+    }
 
 #pragma unroll
     for (int ch = 0; ch < TM / ER; ++ch) {
@@ -459,6 +476,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
+                if constexpr (BS) {
+                    const bf16x8 yy = *(const bf16x8*)(p.bs_y + off);
+                    bf16x8 zz = {};
+                    if (p.bs_z) zz = *(const bf16x8*)(p.bs_z + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool keep = p.bs_z ? ((float)zz[e] > 0.f) : ((float)yy[e] * bsc[e] + bsh[e] > 0.f);
+                        float gv = keep ? v[e] : 0.f;
+                        if (!outf32) gv = (float)(bf16_t)gv;       // the sums see exactly the value the BN apply kernel will read
+                        bs1[e] += gv;
+                        bs2[e] += gv * (((float)yy[e] - bmu[e]) * bis[e]);
+                        v[e] = gv;
+                    }
+                }
                 if (outf32) {
                     float* yo = (float*)p.y + off;
                     if (cbase + 8 <= p.Co && (p.Co & 3) == 0) {
@@ -479,6 +510,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (BS) {
+        // lane (rsub, cg) holds 16 partial sums (8 channels x {g, g*xhat}) over its rows: transposed through the wave-private
+        // staging region ([RPP row lanes][LPR*16 columns] = 4 KiB), every lane then adds one column over the row lanes; the WM
+        // wave rows meet in the exchange region behind the staging tiles and ONE slab row per m-tile is stored.
+        constexpr int NC = LPR * 16;
+        static_assert(RPP * NC * 4 <= ER * ELD * 4, "partial-sum transposition fits the wave's staging region");
+        float* tp = est + rsub * NC + cg * 16;
+        *(f32x4*)(tp + 0) = (f32x4){bs1[0], bs1[1], bs1[2], bs1[3]};
+        *(f32x4*)(tp + 4) = (f32x4){bs1[4], bs1[5], bs1[6], bs1[7]};
+        *(f32x4*)(tp + 8) = (f32x4){bs2[0], bs2[1], bs2[2], bs2[3]};
+        *(f32x4*)(tp + 12) = (f32x4){bs2[4], bs2[5], bs2[6], bs2[7]};
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        float* xch = (float*)(stage + C::EPI_BYTES);           // [WM][2][BN]
+#pragma unroll
+        for (int col = lane; col < NC; col += 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) t += est[r * NC + col];
+            const int e = col & 15, cl = wn * TN + (col >> 4) * 8 + (e & 7);
+            xch[(wm * 2 + (e >> 3)) * BN + cl] = t;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid % BN, col = n0 + cl;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += xch[(w * 2 + st) * BN + cl];
+            const size_t srow = (size_t)cls_id * p.m_tiles + m_tile;
+            if (col < p.Co) p.stats[(srow * 2 + st) * p.Co + col] = t;
+        }
+    }
     if (dbg && tid == 0) {
         dbg[4] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -486,18 +549,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false>
 int launch_cfg_t(IgParams& p, hipStream_t stream) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Co + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS>), grid, dim3(256), C::LDS_BYTES, stream, p);
     return udapose_check_launch();
 }
 
@@ -508,6 +571,11 @@ int launch_cfg(IgParams& p, hipStream_t stream) {
         if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) == 0) return launch_cfg_t<bf16_t, BM, BN, WM, WN, 2, true>(p, stream);
         return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
     } else {
+        if (p.bs_y) {
+            // dgrad with the consumer BatchNorm's backward reduction in the epilogue (bf16 operands; bf16 or fp32 output)
+            if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_RELU)) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
+            return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false, true>(p, stream);
+        }
         return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS, false>(p, stream) : launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
     }
 }

@@ -26,6 +26,8 @@ int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int,
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
               float*, float*, float*, float*, float, const float*);
+int pw_bn_bwd_pre(hipStream_t, const void*, int, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
+                  float*, float*, float);
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
@@ -53,6 +55,8 @@ static int dbg_sync() { static int v = -1; if (v < 0) { const char* e = getenv("
 
 int g_wgrad_group = 1, g_wgrad_stages = 128;   // grouped weight-gradient launch (see build_wg_group); tuning hook
 int g_wgrad_group_stem = 1;                    // the Ci == 8 stem joins the 64x64 group in its row-tap form
+// every dgrad masks its output with the consumer BatchNorm's ReLU and reduces that BN's backward sums in its epilogue
+int g_bn_bwd_fused = getenv("UDAPOSE_BN_BWD_FUSED") ? atoi(getenv("UDAPOSE_BN_BWD_FUSED")) : 1;
 
 struct ConvL {
     ConvGeom g;
@@ -97,7 +101,7 @@ struct Net {
     int fc_w_idx = -1, fc_b_idx = -1;
     size_t act_bytes = 0, wpack_bytes = 0, ws_bytes = 0;
     // workspace carve (bytes)
-    size_t ws_slab = 0, ws_coef = 0, ws_gbuf[6] = {0, 0, 0, 0, 0, 0}, ws_dyhead = 0, ws_dwtmp = 0, ws_headbwd = 0;
+    size_t ws_slab = 0, ws_slabf = 0, ws_coef = 0, ws_gbuf[6] = {0, 0, 0, 0, 0, 0}, ws_dyhead = 0, ws_dwtmp = 0, ws_headbwd = 0;
     size_t gbuf_bytes = 0;
     int Hout = 0, Wout = 0;
     // batched weight packing: device job tables, rebuilt when the parameter / pack pointers change
@@ -218,6 +222,7 @@ Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
     max_slab = std::max(max_slab, (size_t)1024 * 2 * 2048 * 4);   // bn backward partials: <=1024 rows x 2 x C
     size_t o = 0;
     n.ws_slab = o; o = align_up(o + max_slab);
+    n.ws_slabf = o; o = align_up(o + max_slab);     // partial sums written by dgrad epilogues (the downsample BN keeps ws_slab)
     n.ws_coef = o; o = align_up(o + (size_t)3 * 2048 * 4 + 2 * 2048 * 4);
     n.gbuf_bytes = align_up(2 * max_act);   // x2: the deconv-stage gradients are fp32
     for (int i = 0; i < 6; ++i) { n.ws_gbuf[i] = o; o += n.gbuf_bytes; }
@@ -317,6 +322,7 @@ void net_destroy(void* h) {
     delete n;
 }
 void net_set_wgrad_group(int on, int stages) { g_wgrad_group = on; if (stages > 0) g_wgrad_stages = stages; }
+void net_set_bn_bwd_fused(int on) { g_bn_bwd_fused = on; }
 int net_num_params(void* h) { return ((Net*)h)->n_params; }
 int net_num_buffers(void* h) { return ((Net*)h)->n_buffers; }
 long long net_param_numel(void* h, int i) { return ((Net*)h)->param_numel[i]; }
@@ -441,15 +447,21 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
 namespace {
 // backward of conv+bn(+relu): dz (grad wrt z) -> parameter grads, returns dx of the conv input in a pool buffer
 // relu: 0 none, 1 mask from the saved z (bn3: z includes the residual), 2 mask recomputed from y (z is not read)
+// pre:  the dgrad that produced dz already applied this BN's mask and left the partial sums in pre->slab (dz is g)
+// next: the BN that consumes dx; this layer's dgrad masks dx for it and reduces its sums (filled by bn_stat_of)
 int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, const char* wpack, char* act, char* ws,
                 void* const* grads, float beta, Pool& pool, const void* dz, int dz_f32, bf16_t* gout, int relu, const bf16_t* dx_res,
-                bf16_t** dx_out, bool need_dx, int dx_f32, bool grouped_wgrad) {
+                bf16_t** dx_out, bool need_dx, int dx_f32, bool grouped_wgrad, const DgradBnStat* pre = nullptr, DgradBnStat* next = nullptr) {
     float* slab = (float*)(ws + n.ws_slab);
     float* coef = (float*)(ws + n.ws_coef) + 4096;
     const float* save = (const float*)(act + b.save_off);
     bf16_t* dy = (bf16_t*)(ws + c.dy_off);
-    CK(pw_bn_bwd(s, dz, dz_f32, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx], save,
-                 save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx]));
+    if (pre)
+        CK(pw_bn_bwd_pre(s, dz, dz_f32, (const bf16_t*)(act + c.y_off), dy, b.npix, b.C, (const float*)params[b.g_idx], save, save + b.C, pre->slab,
+                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta));
+    else
+        CK(pw_bn_bwd(s, dz, dz_f32, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx],
+                     save, save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx]));
     const bf16_t* xin = (const bf16_t*)(act + c.in_off);
     if (c.g.smallc() && grouped_wgrad && g_wgrad_group_stem) {
         // (the stem's weight gradient joins the grouped launch in its row-tap form, run_wg_group)
@@ -464,10 +476,22 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     if (need_dx) {
         bf16_t* dx = pool.get();
         if (!dx) return UDAPOSE_ERR_ARG;
-        CK(conv_dgrad(s, c.g, dy, (const bf16_t*)(wpack + c.wb_off), dx, dx_res, dx_f32));
+        CK(conv_dgrad(s, c.g, dy, (const bf16_t*)(wpack + c.wb_off), dx, dx_res, dx_f32, next));
         *dx_out = dx;
     }
     return UDAPOSE_OK;
+}
+
+// the consumer-BN description a dgrad epilogue needs: relu 1 = mask from the saved z, 2 = mask recomputed from y
+DgradBnStat bn_stat_of(const Net& n, const ConvL& c, const BnL& b, const void* const* params, char* act, char* ws, int relu) {
+    DgradBnStat st;
+    const float* save = (const float*)(act + b.save_off);
+    st.y = (const bf16_t*)(act + c.y_off);
+    st.z = relu == 1 ? (const bf16_t*)(act + b.z_off) : nullptr;
+    st.mean = save; st.invstd = save + b.C;
+    st.gamma = (const float*)params[b.g_idx]; st.beta = (const float*)params[b.b_idx];
+    st.slab = (float*)(ws + n.ws_slabf);
+    return st;
 }
 
 // ---- grouped weight gradients ------------------------------------------------------------------------------------------
@@ -662,34 +686,57 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     // projection (g - mean(g) - xhat*mean(g*xhat)) cancels ~90 % of g, so bf16 rounding of g is amplified ~10x in dy
     // (measured against the backward of the bf16-storage emulation: 2.4 % / 8 % / 14 % relative error per layer with
     // bf16 g).  The tensors are small (N*64*64*256 and below).
-    CK(conv_dgrad(s, hg, dyh, (const bf16_t*)(wpack + n.head.wb_off), dz, nullptr, 1));
+    //
+    // Fused chain (g_bn_bwd_fused): every dgrad launch knows the BatchNorm that consumes its output; its epilogue applies
+    // that BN's ReLU mask and reduces sum(g), sum(g*xhat) per m-tile, so a BN backward is ONE launch (column sums of the
+    // slab + apply) for the wide layers and finalize + apply for the others.  `cur` describes the pending statistics of dz.
+    const bool fused = g_bn_bwd_fused != 0;
+    DgradBnStat cur, nxt;
+    bool have = false;
+    if (fused) { cur = bn_stat_of(n, n.up[2], n.up_bn[2], params, act, ws, 2); have = true; }
+    CK(conv_dgrad(s, hg, dyh, (const bf16_t*)(wpack + n.head.wb_off), dz, nullptr, 1, have ? &cur : nullptr));
     // deconv stack
     for (int i = 2; i >= 0; --i) {
         bf16_t* dx = nullptr;
-        CK(conv_bn_bwd(s, n, n.up[i], n.up_bn[i], params, wpack, act, ws, grads, beta, pool, dz, 1, nullptr, 2, nullptr, &dx, true, i > 0, grouped));
+        if (fused) {
+            if (i > 0) nxt = bn_stat_of(n, n.up[i - 1], n.up_bn[i - 1], params, act, ws, 2);
+            else nxt = bn_stat_of(n, n.blocks.back().c3, n.blocks.back().b3, params, act, ws, 1);
+        }
+        CK(conv_bn_bwd(s, n, n.up[i], n.up_bn[i], params, wpack, act, ws, grads, beta, pool, dz, 1, nullptr, 2, nullptr, &dx, true, i > 0, grouped,
+                       have ? &cur : nullptr, fused ? &nxt : nullptr));
+        if (fused) cur = nxt;
         pool.put(dz);
         dz = dx;
     }
     // bottlenecks, last to first
     for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
         Block& b = n.blocks[bi];
-        // bn3 (+ReLU of the block output): g = masked dz is written in place and feeds the skip branch
+        // bn3 (+ReLU of the block output): g = masked dz feeds the skip branch (written in place unless the producing dgrad
+        // already masked it)
         bf16_t *dz2 = nullptr, *dz1 = nullptr, *dxd = nullptr, *dxin = nullptr;
-        CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, 0, dz, 1, nullptr, &dz2, true, 0, grouped));
-        CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, 0, nullptr, 2, nullptr, &dz1, true, 0, grouped));
+        if (fused) nxt = bn_stat_of(n, b.c2, b.b2, params, act, ws, 2);
+        CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, 0, dz, 1, nullptr, &dz2, true, 0, grouped, have ? &cur : nullptr,
+                       fused ? &nxt : nullptr));
+        if (fused) { cur = nxt; nxt = bn_stat_of(n, b.c1, b.b1, params, act, ws, 2); }
+        CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, 0, nullptr, 2, nullptr, &dz1, true, 0, grouped,
+                       have ? &cur : nullptr, fused ? &nxt : nullptr));
+        if (fused) cur = nxt;
         pool.put(dz2);
-        const bool first = (bi == 0);
         const bf16_t* skip = dz;
         if (b.has_ds) {
+            // the downsample BN shares g with bn3 (already masked): its own reduce / apply, no ReLU
             CK(conv_bn_bwd(s, n, b.cd, b.bd, params, wpack, act, ws, grads, beta, pool, dz, 0, nullptr, 0, nullptr, &dxd, true, 0, grouped));
             skip = dxd;
         }
-        CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, 0, nullptr, 2, skip, &dxin, true, 0, grouped));
+        const bool chain = fused && bi > 0;      // dxin feeds bn3 of the previous block (block 0: the max-pool backward)
+        if (chain) nxt = bn_stat_of(n, n.blocks[bi - 1].c3, n.blocks[bi - 1].b3, params, act, ws, 1);
+        CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, 0, nullptr, 2, skip, &dxin, true, 0, grouped,
+                       have ? &cur : nullptr, chain ? &nxt : nullptr));
+        if (chain) cur = nxt;
         pool.put(dz1);
         if (dxd) pool.put(dxd);
         pool.put(dz);
         dz = dxin;
-        (void)first;
     }
     // stem: maxpool -> bn/relu -> conv (no input gradient)
     bf16_t* dzs = pool.get();

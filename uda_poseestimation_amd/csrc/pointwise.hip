@@ -618,6 +618,82 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict
     }
 }
 
+// ---- BN backward whose reduction was done by the producing dgrad's epilogue (igemm.hip, BS mode) -----------------------
+// dz already carries the ReLU mask (g), and slab[rows][2][C] holds one partial row of (sum g, sum g*xhat) per m-tile of that
+// dgrad launch.  Work-group = 64 channels x one pixel range, grid (C/64, S): prelude = fp64 column sums of the work-group's 64
+// channels (rows <= 128: <= 64 KB of L2-resident data read as 16-byte vectors, fixed order), then dy = ca*(g - cb - xhat*cc).
+template <typename DZ>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_chunk_k(const DZ* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ dy,
+                                                                size_t npix, int C, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ slab, int rows, int P, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, float beta_acc) {
+    __shared__ double part[8][128];
+    __shared__ double tot[2][64];
+    const int chunk = blockIdx.x, sp = blockIdx.y;
+    {
+        const int q = threadIdx.x & 31, rg = threadIdx.x >> 5;          // 16-byte column quad (16 per statistic), row group
+        const float* base = slab + (size_t)(q >> 4) * C + chunk * 64 + (q & 15) * 4;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int r = rg;
+        for (; r + 24 < rows; r += 32) {      // four independent 16-byte loads in flight
+            const f32x4 u = *(const f32x4*)(base + (size_t)r * 2 * C), v = *(const f32x4*)(base + (size_t)(r + 8) * 2 * C);
+            const f32x4 w = *(const f32x4*)(base + (size_t)(r + 16) * 2 * C), x = *(const f32x4*)(base + (size_t)(r + 24) * 2 * C);
+            a0 += ((double)u[0] + (double)v[0]) + ((double)w[0] + (double)x[0]);
+            a1 += ((double)u[1] + (double)v[1]) + ((double)w[1] + (double)x[1]);
+            a2 += ((double)u[2] + (double)v[2]) + ((double)w[2] + (double)x[2]);
+            a3 += ((double)u[3] + (double)v[3]) + ((double)w[3] + (double)x[3]);
+        }
+        for (; r < rows; r += 8) {
+            const f32x4 u = *(const f32x4*)(base + (size_t)r * 2 * C);
+            a0 += (double)u[0]; a1 += (double)u[1]; a2 += (double)u[2]; a3 += (double)u[3];
+        }
+        part[rg][q * 4 + 0] = a0; part[rg][q * 4 + 1] = a1; part[rg][q * 4 + 2] = a2; part[rg][q * 4 + 3] = a3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += part[k][threadIdx.x];
+        tot[threadIdx.x >> 6][threadIdx.x & 63] = a;
+    }
+    __syncthreads();
+    if (sp == 0 && threadIdx.x < 64 && dgamma) {
+        const int c = chunk * 64 + threadIdx.x;
+        dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)tot[1][threadIdx.x];
+        dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)tot[0][threadIdx.x];
+    }
+    const int cg = threadIdx.x & 7, prow = threadIdx.x >> 3;
+    const int c0 = chunk * 64 + cg * 8;
+    const double count = (double)npix;
+    float mu[8], is[8], ca[8], cb[8], cc[8], ga[8];
+    load8<float>(mean + c0, mu);
+    load8<float>(invstd + c0, is);
+    load8<float>(gamma + c0, ga);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ca[e] = ga[e] * is[e];
+        cb[e] = (float)(tot[0][cg * 8 + e] / count);
+        cc[e] = (float)(tot[1][cg * 8 + e] / count);
+    }
+    const size_t p0 = (size_t)sp * P;
+    size_t p1 = p0 + P;
+    if (p1 > npix) p1 = npix;
+    for (size_t p = p0 + prow; p < p1; p += 32) {
+        const size_t off = p * C + c0;
+        float d[8];
+        load8<DZ>(g + off, d);
+        const bf16x8 yy = *(const bf16x8*)(y + off);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)yy[e] - mu[e]) * is[e];
+            o[e] = (bf16_t)(ca[e] * (d[e] - cb[e] - xh * cc[e]));
+        }
+        *(bf16x8*)(dy + off) = o;
+    }
+}
+
 // ------------------------------------------------------------------ max pooling (NHWC bf16)
 // 3x3 stride 2 pad 1 (ResNet stem).  Saves the winning tap (0..8, first max in (kh,kw) scan order like ATen) per element.
 template <typename T>
@@ -956,6 +1032,38 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, con
     else
         hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, dy, gout, npix * G, C, mean,
                            invstd, coef, relu, gamma, beta);
+    return udapose_check_launch();
+}
+// BN backward after a dgrad that already masked dz and reduced it (DgradBnStat): slab[rows][2][C] -> dgamma / dbeta and
+// dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  One launch for the wide, small-spatial layers, finalize + apply otherwise.
+int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const bf16_t* y, bf16_t* dy, size_t npix, int C, const float* gamma, const float* mean,
+                  const float* invstd, const float* slab, int rows, float* coef, float* dgamma, float* dbeta, float beta_acc) {
+    const int G = C / 8;
+    if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
+    if (bn_bwd_chunked() && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
+        const int chunks = C / 64;
+        int S = 1024 / chunks;
+        if (S > 64) S = 64;
+        if (S < 1) S = 1;
+        int P = (int)((npix + S - 1) / S);
+        P = (P + 31) & ~31;
+        S = (int)((npix + P - 1) / P);
+        const dim3 grid(chunks, S);
+        if (g_is_f32)
+            hipLaunchKernelGGL(bn_bwd_apply_pre_chunk_k<float>, grid, dim3(TPB), 0, s, (const float*)g, y, dy, npix, C, mean, invstd, gamma, slab, rows, P,
+                               dgamma, dbeta, beta_acc);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_pre_chunk_k<bf16_t>, grid, dim3(TPB), 0, s, (const bf16_t*)g, y, dy, npix, C, mean, invstd, gamma, slab, rows, P,
+                               dgamma, dbeta, beta_acc);
+        return udapose_check_launch();
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
+    if (g_is_f32)
+        hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)g, (const bf16_t*)nullptr, y, dy, (bf16_t*)nullptr,
+                           npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)g, (const bf16_t*)nullptr, y, dy, (bf16_t*)nullptr,
+                           npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_fwd(hipStream_t s, const bf16_t* x, bf16_t* y, unsigned char* idx, int N, int H, int W, int C) {

@@ -72,6 +72,22 @@ def conv2d_bwd_data(dy, w_bwd, d, res=None, out_f32=False):
     return dx
 
 
+def conv2d_bwd_data_bn(dy, w_bwd, d, bn_y, bn_mean, bn_invstd, bn_z=None, bn_gamma=None, bn_beta=None, res=None, out_f32=False):
+    """dgrad whose output feeds a training-mode BatchNorm (+ReLU) backward: returns (g, slab) with g = dz * relu-mask and
+    slab[rows][2][Ci] the per-m-tile partial sums of g and g * xhat (udapose_conv2d_bwd_data_bn)."""
+    require_cuda(dy, w_bwd, bn_y, bn_mean, bn_invstd)
+    assert tuple(bn_y.shape) == (d.N, d.Hi, d.Wi, d.Ci) and bn_y.dtype == torch.bfloat16 and bn_y.is_contiguous()
+    assert bn_z is not None or (bn_gamma is not None and bn_beta is not None)
+    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dy.device)
+    rows = lib().udapose_conv_bwd_stat_rows(C.byref(d))
+    if rows < 1:
+        raise RuntimeError(f"conv_bwd_stat_rows: {rows}")
+    slab = torch.empty(rows, 2, d.Ci, dtype=torch.float32, device=dy.device)
+    check(lib().udapose_conv2d_bwd_data_bn(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res), int(out_f32), ptr(bn_y), ptr(bn_z),
+                                           ptr(bn_mean), ptr(bn_invstd), ptr(bn_gamma), ptr(bn_beta), ptr(slab)), "conv2d_bwd_data_bn")
+    return dx, slab
+
+
 def conv2d_bwd_weight(dy, x, d, dw=None):
     require_cuda(dy, x)
     T = d.KH * kwp(d)
