@@ -93,6 +93,12 @@ int udapose_bn_bwd_rows(size_t npix);
 int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
                    const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* slab, float* coef,
                    float* dgamma, float* dbeta, float beta_acc, const float* beta);
+/* The same backward when the dgrad that produced the gradient already applied the ReLU mask and reduced it
+ * (udapose_conv2d_bwd_data_bn): g (bf16, or fp32 when g_is_f32) and slab[rows][2][C] -> dgamma, dbeta (beta_acc*old + new) and
+ * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); coef: [3][C] fp32 scratch.  No reduction pass over the activations. */
+int udapose_bn_bwd_pre(void* stream, const void* g, int g_is_f32, const void* y, void* dy, size_t npix, int C, const float* gamma,
+                       const float* save_mean, const float* save_invstd, const float* slab, int rows, float* coef, float* dgamma,
+                       float* dbeta, float beta_acc);
 
 /* ---------------------------------------------------------------- pooling (ResNet stem maxpool 3x3 s2 p1, resnet.py:30;
  * VGG MaxPool2d(2,2,ceil_mode=True), Style_net.py:72) */

@@ -388,3 +388,11 @@ def test_dgrad_with_fused_bn_backward_reduction(dev, case):
     got = slab.double().sum(0)
     assert float(((got[0] - s1).abs() / (a1 + 1e-30)).max()) < 2e-6, float(((got[0] - s1).abs() / (a1 + 1e-30)).max())
     assert float(((got[1] - s2).abs() / (a2 + 1e-30)).max()) < 2e-6, float(((got[1] - s2).abs() / (a2 + 1e-30)).max())
+    # the BatchNorm backward that consumes (g, slab) without a reduction pass (udapose_bn_bwd_pre): closed form in fp64 on the
+    # same stored g and y; dgamma / dbeta are the column sums themselves
+    dyq, dgamma, dbeta = ops.bn_bwd_pre(gq, bn_y, gamma, mean, invstd, slab)
+    npix = N * H * H
+    ref = (gamma * invstd).double() * (gq.double() - s1 / npix - xhat * (s2 / npix))
+    close(dyq.double().cpu(), ref.cpu(), 6e-3)
+    np.testing.assert_allclose(dbeta.double().cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=2e-6 * float(a1.max()))
+    np.testing.assert_allclose(dgamma.double().cpu().numpy(), s2.cpu().numpy(), rtol=0, atol=2e-6 * float(a2.max()))

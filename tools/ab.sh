@@ -1,0 +1,14 @@
+#!/bin/bash
+# Dev tool: A/B two bench configurations on the same box, interleaved.  usage: tools/ab.sh "<env/args A>" "<env/args B>" [rounds] [steps]
+A="$1"; B="$2"; R="${3:-2}"; S="${4:-60}"
+for i in $(seq 1 $R); do
+  for cfg in "A:$A" "B:$B"; do
+    tag="${cfg%%:*}"; spec="${cfg#*:}"
+    env $spec timeout -k 10 200 python bench.py --steps $S --spinup 4 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('$tag [$spec]', d['ms_per_step'], d['value'])
+"
+  done
+done

@@ -37,6 +37,7 @@ _SIGS = {
     "udapose_bn_apply": (ci, [vp, vp, vp, vp, sz, ci, vp, vp, ci]),
     "udapose_bn_bwd_rows": (ci, [sz]),
     "udapose_bn_bwd": (ci, [vp, vp, ci, vp, vp, vp, vp, sz, ci, vp, vp, vp, ci, vp, vp, vp, vp, cf, vp]),
+    "udapose_bn_bwd_pre": (ci, [vp, vp, ci, vp, vp, sz, ci, vp, vp, vp, vp, ci, vp, vp, vp, cf]),
     "udapose_maxpool3x3s2_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
     "udapose_maxpool3x3s2_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
     "udapose_maxpool2x2_ceil": (ci, [vp, vp, vp, ci, ci, ci, ci]),

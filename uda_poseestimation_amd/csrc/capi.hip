@@ -12,6 +12,8 @@ int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, co
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
 int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
+int pw_bn_bwd_pre(hipStream_t, const void*, int, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
+                  float*, float*, float);
 int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
               float*, float*, float*, float*, float, const float*);
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
@@ -116,6 +118,11 @@ int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, c
                    float beta_acc, const float* beta) {
     return pw_bn_bwd(S(stream), dz, dz_is_f32, CB16(z), CB16(y), B16(dy), B16(gout), npix, C, gamma, mean, invstd, relu, slab, coef, dgamma, dbeta,
                      beta_acc, beta);
+}
+int udapose_bn_bwd_pre(void* stream, const void* g, int g_is_f32, const void* y, void* dy, size_t npix, int C, const float* gamma, const float* mean,
+                       const float* invstd, const float* slab, int rows, float* coef, float* dgamma, float* dbeta, float beta_acc) {
+    if (!g || !y || !dy || !gamma || !mean || !invstd || !slab || !coef) return UDAPOSE_ERR_ARG;
+    return pw_bn_bwd_pre(S(stream), g, g_is_f32, CB16(y), B16(dy), npix, C, gamma, mean, invstd, slab, rows, coef, dgamma, dbeta, beta_acc);
 }
 int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C) {
     return pw_maxpool3x3s2_fwd(S(stream), CB16(x), B16(y), idx, N, H, W, C);

@@ -618,6 +618,35 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict
     }
 }
 
+// dy = ca*(g - cb - xhat*cc) for an already masked g (pre-reduced form, layers the chunked kernel does not take): the grid
+// keeps gridDim.x * TPB a multiple of C/8 (bn_apply_grid), so a thread's 8 channels never change and its 40 coefficients are
+// loaded once instead of per 16-byte access; no integer division in the loop.
+template <typename DZ>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_k(const DZ* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ dy, size_t n8,
+                                                          int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ coef) {
+    const int G = C >> 3;
+    const int c0 = (int)(((size_t)blockIdx.x * TPB + threadIdx.x) % G) * 8;
+    float mu[8], is[8], ca[8], cb[8], cc[8];
+    load8<float>(mean + c0, mu);
+    load8<float>(invstd + c0, is);
+    load8<float>(coef + c0, ca);
+    load8<float>(coef + C + c0, cb);
+    load8<float>(coef + 2 * C + c0, cc);
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+        float d[8];
+        load8<DZ>(g + i * 8, d);
+        const bf16x8 yy = *(const bf16x8*)(y + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)yy[e] - mu[e]) * is[e];
+            o[e] = (bf16_t)(ca[e] * (d[e] - cb[e] - xh * cc[e]));
+        }
+        *(bf16x8*)(dy + i * 8) = o;
+    }
+}
+
 // ---- BN backward whose reduction was done by the producing dgrad's epilogue (igemm.hip, BS mode) -----------------------
 // dz already carries the ReLU mask (g), and slab[rows][2][C] holds one partial row of (sum g, sum g*xhat) per m-tile of that
 // dgrad launch.  Work-group = 64 channels x one pixel range, grid (C/64, S): prelude = fp64 column sums of the work-group's 64
@@ -1058,12 +1087,21 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const bf16_t* y, b
         return udapose_check_launch();
     }
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
+    static const int legacy = getenv("UDAPOSE_BN_BWD_PRE_LEGACY") ? atoi(getenv("UDAPOSE_BN_BWD_PRE_LEGACY")) : 0;    // A/B hook
+    if (legacy) {
+        if (g_is_f32)
+            hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)g, (const bf16_t*)nullptr, y, dy, (bf16_t*)nullptr,
+                               npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)g, (const bf16_t*)nullptr, y, dy,
+                               (bf16_t*)nullptr, npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
+        return udapose_check_launch();
+    }
+    const int grid = bn_apply_grid(npix * G, C);
     if (g_is_f32)
-        hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)g, (const bf16_t*)nullptr, y, dy, (bf16_t*)nullptr,
-                           npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_apply_pre_k<float>, dim3(grid), dim3(TPB), 0, s, (const float*)g, y, dy, npix * G, C, mean, invstd, coef);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)g, (const bf16_t*)nullptr, y, dy, (bf16_t*)nullptr,
-                           npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_apply_pre_k<bf16_t>, dim3(grid), dim3(TPB), 0, s, (const bf16_t*)g, y, dy, npix * G, C, mean, invstd, coef);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_fwd(hipStream_t s, const bf16_t* x, bf16_t* y, unsigned char* idx, int N, int H, int W, int C) {

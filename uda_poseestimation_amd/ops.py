@@ -148,6 +148,20 @@ def bn_bwd(dz, z, y, gamma, mean, invstd, relu=True, want_g=False, beta=None):
     return dy, dgamma, dbeta, g
 
 
+def bn_bwd_pre(g, y, gamma, mean, invstd, slab):
+    """BN backward from an already masked, already reduced gradient (conv2d_bwd_data_bn's outputs): (dy, dgamma, dbeta)."""
+    C_ = y.shape[-1]
+    npix = y.numel() // C_
+    dev = y.device
+    coef = torch.empty(3, C_, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C_, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C_, dtype=torch.float32, device=dev)
+    dy = torch.empty_like(y)
+    check(lib().udapose_bn_bwd_pre(stream(), ptr(g), int(g.dtype == torch.float32), ptr(y), ptr(dy), npix, C_, ptr(gamma), ptr(mean), ptr(invstd),
+                                   ptr(slab), slab.shape[0], ptr(coef), ptr(dgamma), ptr(dbeta), 0.0), "bn_bwd_pre")
+    return dy, dgamma, dbeta
+
+
 def maxpool3x3s2_fwd(x):
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
