@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=256, help="other configs (BASELINE.json configs[4]: 384); default = the metric's 256")
     ap.add_argument("--keypoints", type=int, default=16, help="other configs (configs[4]: 18)")
     ap.add_argument("--sigma", type=float, default=2, help="label / rectify sigma (configs[4]: 1.0)")
+    ap.add_argument("--strong", action="store_true", help="not the metric: strong scaling, global batch fixed at --batch (what the reference's "
+                    "nn.DataParallel does): every rank takes batch / world images per domain")
     ap.add_argument("--host-inputs", action="store_true", help="not the metric: every step copies its batch from pinned host memory "
                     "(PCIe-inclusive rate, DESIGN.md section 5)")
     ap.add_argument("--igemm-tile", type=int, default=-1, help="tuning: force one igemm tile configuration id")
@@ -128,6 +130,10 @@ def main():
         lib.udapose_debug_set_tiles(args.igemm_tile, -1, -1)
 
     N, K = args.batch, args.keypoints
+    if args.strong:
+        if N % world:
+            raise SystemExit(f"--strong: batch {N} is not divisible by {world} ranks")
+        N //= world
     S = args.image_size
     sigma = int(args.sigma) if float(args.sigma).is_integer() and args.sigma >= 2 else float(args.sigma)
     torch.manual_seed(0)
@@ -233,7 +239,7 @@ def main():
         res = {
             "metric": f"images/sec (student+teacher step) {S}x{S} b={N}", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "spinup_s": args.spinup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
                                    f"Adam, EMA), {S}x{S}, b={N}/GPU, no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch) == (256, 16, 32, "pose_resnet101") else f", K={K}"),
                        "global_batch": world * N, "parallelism": f"dp{world}"},

@@ -414,6 +414,30 @@ def test_two_rank_step_on_one_gpu_gloo():
     assert d["replicas_in_sync"] is True               # same averaged gradients -> bit-identical replicas
 
 
+def test_one_rank_rccl_step():
+    """The data-parallel code path on the REAL RCCL backend with a one-rank process group (bench.py's UDAPOSE_FORCE_DIST hook:
+    the test box has one GPU, and RCCL refuses two ranks on one device): backend "nccl" initialised with a device id, the
+    gradient all-reduce and the confidence all-gather issued eagerly between the three hipGraph replays while the RCCL watchdog
+    thread is alive, process-group teardown.  The same step without a process group gives the same loss (world size 1: the
+    collectives are identities)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--spinup", "0", "--arch", "pose_resnet50", "--batch", "4",
+              "--no-cpu-baseline"]
+    res = {}
+    for tag, extra in (("rccl", {"UDAPOSE_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"}), ("plain", {})):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        out = subprocess.run([sys.executable] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, tag + out.stdout[-2000:] + out.stderr[-4000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        res[tag] = json.loads(lines[0])
+    assert "3 hipGraphs" in res["rccl"]["launch"] and "2 hipGraphs" in res["plain"]["launch"]
+    assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
+    a, b = res["rccl"]["loss"], res["plain"]["loss"]
+    assert a == a and abs(a - b) <= 1e-3 * abs(b) + 1e-9, (a, b)
+
+
 def test_validate_matches_cpu_oracle():
     """validate() (train_human.py:461-500): eval-mode forward, device decode + PCK accumulated on the device, one
     read-back; against the CPU restatement with the reference's meter semantics (absent key points = -1 are skipped,
