@@ -73,7 +73,7 @@ def cpu_baseline(n, arch_layers, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--spinup", type=float, default=8.0, help="seconds of untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per domain (BASELINE: 32)")

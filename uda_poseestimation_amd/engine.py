@@ -47,8 +47,11 @@ class GradSync:
         flat = getattr(self.model, "_flat_grad", None)
         if flat is None:
             raise RuntimeError("GradSync: model has no flat gradient buffer yet (run backward first)")
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / dist.get_world_size())
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)      # RCCL averages in the collective: no second sweep over 212 MB
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)      # gloo (CPU tests, shared-GPU test) has no AVG
+            flat.mul_(1.0 / dist.get_world_size())
 
 
 def gather_activates(act):
