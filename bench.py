@@ -46,6 +46,17 @@ def measured_traffic_per_igemm_launch():
         return None
 
 
+def measured_traffic_per_step(eager_steps=4):
+    """HBM bytes per step of the three kernel families (igemm, BatchNorm, weight gradients) from the same committed PMC passes
+    (4 eager steps in the profiled run): what the whole step moves, next to the per-launch figure of the dominant kernel."""
+    try:
+        import ast
+        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.txt")).read().strip())
+        return {fam: (2.0 * d["fetch"][fam][1] + d["write"][fam][1]) * 1024.0 / eager_steps for fam in ("igemm", "bn", "wgrad")}
+    except Exception:
+        return None
+
+
 def cpu_baseline(n, arch_layers, seconds_budget=25.0):
     """CPU oracle step (kind 'port'): PoseResNet-101 mean-teacher step on `n` images, fp32, all host cores."""
     from oracle.pose_resnet_ref import PoseResNetRef
@@ -256,6 +267,13 @@ def main():
                          "wgrad": {"launches_per_step": int(wl), "kernel_ms_per_step": round(ms_w, 3),
                                    "achieved": round(fp_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else None}},
         }
+        per_step = measured_traffic_per_step()
+        if per_step and (args.arch, S, K, N) == ("pose_resnet101", 256, 16, 32):
+            tot = sum(per_step.values())
+            res["roofline"]["step_hbm"] = {"bytes_per_step": tot, "by_family": per_step, "achieved_TBps": round(tot / (ms * 1e-3) / 1e12, 3),
+                                           "peak_TBps": 8.0, "note": "whole-step HBM traffic of the conv / BN / weight-gradient kernels (PMC passes under "
+                                           "profiles/) over this run's step time: the step is bound by bytes and by latency-bound launch chains, "
+                                           "not by the MFMA pipes"}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_images, layers)
         print(json.dumps(res), flush=True)
