@@ -16,6 +16,7 @@
 // partial sums (sum, sum of squares of the fp32 accumulators) fused in.  The partial sums are written to a slab
 // (one row per wave-row of the grid), not added atomically: every block would hit the same few cache lines.
 #include <stdlib.h>
+#include <algorithm>
 #include "igemm.h"
 
 namespace {
@@ -73,7 +74,9 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS =
 // amdgpu_waves_per_eu(4): a register budget of 128 per lane.  Left alone the compiler spends 168 + 24 AGPRs on the 128x64 tile
 // (two resident work-groups per CU); with the hint it needs 110 and none of the configurations the heuristic picks spills
 // (the 128x128 ones, reachable only through the tuning override, do).  Measured: -0.65 ms per step.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void igemm_kernel(const IgParams p) {
+// The BS variants (dgrads with the consumer BatchNorm's backward reduction in the epilogue) take waves_per_eu(3) = 168 registers:
+// their tiles are resident three per CU by LDS either way, and the epilogue keeps a whole chunk's y / z / skip loads in flight.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BS ? 3 : 4))) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
     // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.
@@ -428,6 +431,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         }
     }
 
+    if constexpr (BS) {
+        // BS epilogue: the loads of a chunk's rows (consumer BN's y, its z when the mask is z > 0, the skip gradient) are all
+        // issued BEFORE the accumulators go through LDS, so one memory latency is exposed per chunk instead of two per row
+        // (the generic loop loads the residual, waits, loads y and z, waits: 8 exposed HBM latencies per 128-row tile, and these
+        // launches are HBM-bound: layer1's 64->256 data gradient moves 285 MB)
+        constexpr int NP = ER / RPP;
+        const bool use_z = p.bs_z != nullptr, use_res = p.res != nullptr;
+#pragma unroll
+        for (int ch = 0; ch < TM / ER; ++ch) {
+            size_t offs[NP];
+            bool oks[NP];
+            bf16x8 yv[NP], zv[NP], rv[NP];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int m = m0 + wm * TM + ch * ER + ps * RPP + rsub;
+                bool ok = m < p.M && cbase < p.Co;
+                size_t opix = (size_t)m;
+                if (!lin_out && ok) {
+                    const uint32_t n = fdiv((uint32_t)m, p.div_hw);
+                    const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Hg * p.Wg);
+                    const uint32_t ii = fdiv(rem, p.div_w);
+                    const uint32_t jj = rem - ii * (uint32_t)p.Wg;
+                    const uint32_t oh = ii * p.os + cls.oa, ow = jj * p.os + cls.ob;
+                    ok = oh < (uint32_t)p.Ho && ow < (uint32_t)p.Wo;
+                    opix = ((size_t)n * p.Ho + oh) * p.Wo + ow;
+                }
+                oks[ps] = ok;
+                offs[ps] = ok ? opix * p.Co + cbase : 0;
+                yv[ps] = bf16x8{}; zv[ps] = bf16x8{}; rv[ps] = bf16x8{};
+                if (ok) {
+                    yv[ps] = *(const bf16x8*)(p.bs_y + offs[ps]);
+                    if (use_z) zv[ps] = *(const bf16x8*)(p.bs_z + offs[ps]);
+                    if (use_res) rv[ps] = *(const bf16x8*)(p.res + offs[ps]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        est[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[ch * (ER / 16) + i][j][r];
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int row = ps * RPP + rsub;
+                const f32x4 v0 = *(const f32x4*)(est + row * ELD + cg * 8);
+                const f32x4 v1 = *(const f32x4*)(est + row * ELD + cg * 8 + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (oks[ps]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float yf = (float)yv[ps][e];
+                        const float val = v[e] + (float)rv[ps][e];             // (rv is zero without a skip gradient)
+                        const float ty = yf * bsc[e] + bsh[e];
+                        const float t = use_z ? (float)zv[ps][e] : ty;
+                        float gv = t > 0.f ? val : 0.f;
+                        if (!outf32) gv = (float)(bf16_t)gv;                    // the sums see exactly the value the BN apply kernel will read
+                        bs1[e] += gv;
+                        bs2[e] += gv * ((yf - bmu[e]) * bis[e]);
+                        v[e] = gv;
+                    }
+                    if (outf32) {
+                        float* yo = (float*)p.y + offs[ps];
+                        *(f32x4*)yo = (f32x4){v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(yo + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    } else {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                        *(bf16x8*)((bf16_t*)p.y + offs[ps]) = o;
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
 #pragma unroll
     for (int ch = 0; ch < TM / ER; ++ch) {
         // (the trailing __syncthreads of the K loop already ordered the last LDS reads before these writes)
@@ -476,20 +558,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
-                if constexpr (BS) {
-                    const bf16x8 yy = *(const bf16x8*)(p.bs_y + off);
-                    bf16x8 zz = {};
-                    if (p.bs_z) zz = *(const bf16x8*)(p.bs_z + off);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const bool keep = p.bs_z ? ((float)zz[e] > 0.f) : ((float)yy[e] * bsc[e] + bsh[e] > 0.f);
-                        float gv = keep ? v[e] : 0.f;
-                        if (!outf32) gv = (float)(bf16_t)gv;       // the sums see exactly the value the BN apply kernel will read
-                        bs1[e] += gv;
-                        bs2[e] += gv * (((float)yy[e] - bmu[e]) * bis[e]);
-                        v[e] = gv;
-                    }
-                }
                 if (outf32) {
                     float* yo = (float*)p.y + off;
                     if (cbase + 8 <= p.Co && (p.Co & 3) == 0) {
@@ -509,6 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+    }
     }
     if constexpr (BS) {
         // lane (rsub, cg) holds 16 partial sums (8 channels x {g, g*xhat}) over its rows: transposed through the wave-private
@@ -549,6 +618,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
     }
 }
 
+int g_igemm_short_lds = getenv("UDAPOSE_IGEMM_SHORT_LDS") ? atoi(getenv("UDAPOSE_IGEMM_SHORT_LDS")) : 1;   // A/B hook
+
 template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false>
 int launch_cfg_t(IgParams& p, hipStream_t stream) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
@@ -560,7 +631,19 @@ int launch_cfg_t(IgParams& p, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    // A launch whose K loop is ONE stage (K <= 128 bytes per row: layer1's 64-channel 1x1 convs and their data gradients, the
+    // head's data gradient) only ever touches ring buffer 0: it asks for one stage of LDS instead of NS, so four instead of
+    // three work-groups are resident per CU.  These launches are HBM-bound (33-285 MB each) and a work-group's life is a
+    // load - compute - store sequence with nothing to overlap inside it: residency is what hides the latency.
+    int lds = C::LDS_BYTES;
+    if (!RS && !(p.flags & IG_FLAG_SMALLC) && g_igemm_short_lds) {
+        constexpr int bke = 128 / (int)sizeof(T);
+        int nst = 0;
+        for (int c = 0; c < p.nclass; ++c) nst = std::max(nst, p.cls[c].ntaps * p.Ci / bke);
+        constexpr int one = C::TAP_BYTES + (C::STAGE1 > C::EPI_BYTES + WM * 2 * BN * 4 ? C::STAGE1 : C::EPI_BYTES + WM * 2 * BN * 4);
+        if (nst <= 1 && one < lds) lds = one;
+    }
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS>), grid, dim3(256), lds, stream, p);
     return udapose_check_launch();
 }
 
