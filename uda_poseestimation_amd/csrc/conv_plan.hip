@@ -49,6 +49,13 @@ void build_direct(TapPlan& tp, int KH, int KW, int KWp, int p) {
 
 }  // namespace
 
+// every tap of every class is (0, 0) -> weight slab 0 (1x1 kernels, any stride): the kernels then skip the tap-table read
+static int plan_is_tap0(const TapPlan& tp) {
+    for (const IgTap& t : tp.taps) if (t.dy != 0 || t.dx != 0 || t.widx != 0) return 0;
+    for (int c = 0; c < tp.nclass; ++c) if (tp.cls[c].ntaps > 1) return 0;
+    return 1;
+}
+
 const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
     const auto key = std::make_tuple(g.KH, g.KW, g.stride, g.pad, g.transposed, g.KWp(), direction);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -108,6 +115,7 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* 
               (e.out_f32 ? IG_FLAG_OUT_F32 : 0) | (g.smallc() ? IG_FLAG_SMALLC : 0) | (e.f32 ? IG_FLAG_F32 : 0);
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
+    p.tap0 = plan_is_tap0(*tp);
     const int tok = prof_before(s, 0, alg_flops(g));
     const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci), s);
     prof_after(s, tok);
@@ -128,6 +136,7 @@ static int dgrad_params(const ConvGeom& g, IgParams& p) {
     p.wtaps = g.wtaps();
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
+    p.tap0 = plan_is_tap0(*tp);
     return UDAPOSE_OK;
 }
 

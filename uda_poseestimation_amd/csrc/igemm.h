@@ -12,6 +12,7 @@ struct IgClass { int tap_off, ntaps, oa, ob; };
 #define IG_FLAG_RELU 4
 #define IG_FLAG_OUT_F32 8     // y is fp32 NHWC instead of bf16 NHWC
 #define IG_FLAG_F32 128      // x, w, res and y are fp32 (exact fp32 MFMA path, forward only)
+#define IG_FLAG_TAP0 1024     // every class has at most the one tap (dy, dx, widx) = (0, 0, 0): no tap-table read
 #define IG_FLAG_SMALLC 16     // Ci == 8: one 32-wide K step covers 4 taps (stem / first VGG conv)
 
 struct IgParams {
@@ -33,6 +34,7 @@ struct IgParams {
     IgClass cls[4];
     FastDiv div_hw, div_w;  // m / (Hg*Wg), rem / Wg
     int m_tiles, n_tiles;
+    int tap0;               // host: set by the conv entry points when every tap of the plan is (0, 0, 0) (1x1 kernels)
     unsigned long long* dbg;   // tuning: per-work-group timeline stamps [blocks][8] (s_memrealtime, 100 MHz), normally null
     // dgrad only: the BatchNorm that consumes this launch's output dz in the backward chain.  When bs_y is set the epilogue
     // applies that BN's ReLU mask to dz (so y receives g = dz * mask), and writes per-m-tile partial sums of g and g * xhat to

@@ -110,7 +110,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BS ? 3 : 4)
     const int up = (p.flags & IG_FLAG_UPSAMPLE) ? 1 : 0;
     const int Hl = p.Hi << up, Wl = p.Wi << up;
 
-    if (tid < cls.ntaps && tid < 64) taps_l[tid] = p.taps[cls.tap_off + tid];
+    // 1x1 convolutions (and the one non-empty class of their strided data gradients) have the single tap (0, 0) -> weight slab 0:
+    // the table entry is written from registers, which takes a dependent global-memory round trip out of every such work-group's
+    // prologue (two thirds of the launches of a step)
+    if (p.flags & IG_FLAG_TAP0) { if (tid == 0) taps_l[0] = IgTap{0, 0, 0, cls_id}; }
+    else if (tid < cls.ntaps && tid < 64) taps_l[tid] = p.taps[cls.tap_off + tid];
 
     // ---- per-lane loader state: DMA instruction i of this wave fills LDS rows (i*4+wid)*8 .. +8, lane -> (row, chunk)
     const int lrow = lane >> 3, pchunk = lane & 7;
@@ -666,6 +670,7 @@ int launch_cfg(IgParams& p, hipStream_t stream) {
 }  // namespace
 
 int g_igemm_tile_override = -1;   // debug/tuning hook (udapose_debug_set_tiles)
+int g_igemm_tap0 = getenv("UDAPOSE_IGEMM_TAP0") ? atoi(getenv("UDAPOSE_IGEMM_TAP0")) : 1;   // A/B hook
 unsigned long long* g_igemm_timeline = nullptr;   // tuning hook: device buffer for per-work-group timeline stamps
 
 // Tile selection (measured on MI355X over every PoseResNet-101 layer shape at N=32, tools/tune_conv.py): 128x64 tiles
@@ -695,6 +700,8 @@ int igemm_stat_rows(int M, int Co, int nclass, int tile) {
 
 int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
     p.dbg = g_igemm_timeline;
+    if (p.flags & IG_FLAG_TAP0) p.flags &= ~IG_FLAG_TAP0;
+    if (g_igemm_tap0 && p.tap0) p.flags |= IG_FLAG_TAP0;
     const int bke = (p.flags & IG_FLAG_F32) ? 32 : 64;
     if (p.Ci % 8 != 0 || (!(p.flags & IG_FLAG_SMALLC) && p.Ci % bke != 0)) return UDAPOSE_ERR_ARG;
     if ((p.flags & IG_FLAG_SMALLC) && p.Ci != 8) return UDAPOSE_ERR_ARG;
