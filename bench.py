@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--sigma", type=float, default=2, help="label / rectify sigma (configs[4]: 1.0)")
     ap.add_argument("--strong", action="store_true", help="not the metric: strong scaling, global batch fixed at --batch (what the reference's "
                     "nn.DataParallel does): every rank takes batch / world images per domain")
+    ap.add_argument("--config2", action="store_true", help="not the metric: BASELINE.json configs[2] = the same step + AdaIN s2t / t2s style "
+                    "passes (both forced on, alpha 0.5, randomly initialised VGG / decoder) + adaptive occlusion; runs eagerly (the occlusion "
+                    "reads confidences back to the host, as the reference does)")
     ap.add_argument("--host-inputs", action="store_true", help="not the metric: every step copies its batch from pinned host memory "
                     "(PCIe-inclusive rate, DESIGN.md section 5)")
     ap.add_argument("--igemm-tile", type=int, default=-1, help="tuning: force one igemm tile configuration id")
@@ -150,8 +153,20 @@ def main():
     torch.manual_seed(0)
     student = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
     teacher = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
+    extra = {}
+    if args.config2:
+        import numpy as np
+        from uda_poseestimation_amd.lib.models import Style_net
+        torch.manual_seed(1)
+        Style_net.vgg.to(dev); Style_net.decoder.to(dev)
+        style = Style_net.Net(torch.nn.Sequential(*list(Style_net.vgg.children())[:31]), Style_net.decoder).to(dev)
+        lo = torch.tensor([-2.1179, -2.0357, -1.8044], device=dev)      # (0 - mean) / std and (1 - mean) / std (train_human.py:32-33)
+        hi = torch.tensor([2.2489, 2.4285, 2.64], device=dev)
+        extra = dict(style_net=style, recover=(lo, hi), s2t_freq=1.0, t2s_freq=1.0, s2t_alpha=(0.5, 0.5), t2s_alpha=(0.5, 0.5),
+                     rng=np.random.RandomState(0), occlude_rate=0.5, occlude_thresh=0.9, occlude_size=10)
+        args.eager = True
     trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
-                                 heatmap_size=S // 4)
+                                 heatmap_size=S // 4, **extra)
     b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=rank)   # one shard per rank
     g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 
@@ -252,7 +267,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
-                                   f"Adam, EMA), {S}x{S}, b={N}/GPU, no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch) == (256, 16, 32, "pose_resnet101") else f", K={K}"),
+                                   f"Adam, EMA), {S}x{S}, b={N}/GPU, " + ("AdaIN s2t + t2s style passes and adaptive occlusion (BASELINE.json configs[2]; NOT the metric)" if args.config2 else "no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch) == (256, 16, 32, "pose_resnet101") else f", K={K}")),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
             "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + " (last timed step eager, instrumented)",
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
