@@ -196,6 +196,10 @@ void udapose_debug_set_wgrad_group(int on, int stages_per_block);
 /* tuning / test hook: udapose_net_backward lets every dgrad launch apply the ReLU mask of the BatchNorm that consumes its
  * output and reduce that BN's backward sums in its epilogue (on = 1, default), or runs the separate reduce launches (on = 0) */
 void udapose_debug_set_bn_bwd_fused(int on);
+/* tuning / test hook: the run-staged form of 3x3 stride-1 pad-1 convolutions and their data gradients (one stage of
+ * BM + 2(W+1) consecutive pixels per 64 channels instead of nine shifted tiles): 0 = off, 1 = measured per-shape policy
+ * (default), 2 = 64-row tiles for every eligible launch, 3 = 128-row tiles where the run fits (W <= 32), else 64-row */
+void udapose_debug_set_igemm_h3(int mode);
 /* tuning hook: device buffer ([work-groups][8] uint64, or NULL = off) into which every conv work-group writes s_memrealtime
  * stamps (100 MHz): entry, prologue done, first K stage landed, K loop done, epilogue issued, stores drained */
 void udapose_debug_set_timeline(void* dev_buf);

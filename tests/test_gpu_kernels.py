@@ -396,3 +396,52 @@ def test_dgrad_with_fused_bn_backward_reduction(dev, case):
     close(dyq.double().cpu(), ref.cpu(), 6e-3)
     np.testing.assert_allclose(dbeta.double().cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=2e-6 * float(a1.max()))
     np.testing.assert_allclose(dgamma.double().cpu().numpy(), s2.cpu().numpy(), rtol=0, atol=2e-6 * float(a2.max()))
+
+
+H3_CASES = [
+    # name, N, H, Ci, Co      (3x3, stride 1, pad 1)
+    ("w16", 2, 16, 64, 64), ("w12_ragged", 3, 12, 64, 128), ("w8_two_chunks", 2, 8, 128, 64), ("w32", 1, 32, 64, 64),
+    ("w64", 1, 64, 64, 64), ("w10_m300", 3, 10, 64, 64), ("w16_four_chunks", 1, 16, 256, 128), ("n32_l3", 32, 16, 256, 256),
+]
+
+
+@pytest.mark.parametrize("mode", [2, 3], ids=["rows64", "rows128"])
+@pytest.mark.parametrize("case", H3_CASES, ids=[c[0] for c in H3_CASES])
+def test_run_staged_3x3_form(dev, case, mode):
+    """The run-staged form of 3x3 stride-1 pad-1 convolutions (igemm.hip, H3: the A operand staged once per 64 channels as a
+    run of consecutive pixels, taps read at row offsets, padded taps from a zero row) in both tile heights, fprop with the
+    BatchNorm statistics and the data gradient (plain, and with the consumer BatchNorm's mask + sums), against torch on the
+    same bf16-rounded inputs and against the tap-staged form (mode 0): same products, other summation order."""
+    from uda_poseestimation_amd import ops, _hip
+    lib = _hip.lib()
+    _, N, H, Ci, Co = case
+    g = torch.Generator().manual_seed(4)
+    big = N * H * H * Ci > 1 << 21
+    x = bf(torch.randn(N, Ci, H, H, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5)
+    dy = bf(torch.randn(N, Co, H, H, generator=g))
+    d = ops.conv_desc(N, H, H, Ci, Co, 3, 1, 1)
+    wf, wb = ops.pack_weight(w.cuda(), d, "fwd"), ops.pack_weight(w.cuda(), d, "bwd")
+    bn_y = (torch.randn(N, H, H, Ci, generator=g) + 0.2).bfloat16().cuda()
+    mean, invstd, gamma, beta = (torch.rand(Ci, generator=g).cuda() + 0.5 for _ in range(4))
+    out = {}
+    try:
+        for m in (0, mode):
+            lib.udapose_debug_set_igemm_h3(m)
+            y, stats = ops.conv2d_fwd(nhwc(x), wf, d, want_stats=True)
+            dx = ops.conv2d_bwd_data(nhwc(dy), wb, d)
+            gq, slab = ops.conv2d_bwd_data_bn(nhwc(dy), wb, d, bn_y, mean, invstd, bn_gamma=gamma, bn_beta=beta)
+            out[m] = (y.float(), stats.double().sum(0), dx.float(), gq.float(), slab.double().sum(0))
+    finally:
+        lib.udapose_debug_set_igemm_h3(1)
+    for a, b in zip(out[0], out[mode]):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 8e-3 * scale, (float((a - b).abs().max()), scale)
+    if not big:
+        xr = x.clone().requires_grad_(True)
+        ref = F.conv2d(xr, w, padding=1)
+        ref.backward(dy)
+        close(nchw(out[mode][0].cuda()), ref.detach(), 1.2e-2)
+        close(nchw(out[mode][2].cuda()), xr.grad, 1.2e-2)
+        np.testing.assert_allclose(out[mode][1][0].cpu().numpy(), ref.detach().double().sum((0, 2, 3)).numpy(), rtol=2e-3,
+                                   atol=2e-3 * ref.abs().sum().item() / Co)

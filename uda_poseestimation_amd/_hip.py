@@ -71,6 +71,7 @@ _SIGS = {
     "udapose_debug_set_wgrad_group": (None, [ci, ci]),
     "udapose_debug_set_bn_bwd_fused": (None, [ci]),
     "udapose_debug_set_timeline": (None, [vp]),
+    "udapose_debug_set_igemm_h3": (None, [ci]),
     "udapose_patch_paste": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
     "udapose_prof_begin": (None, []),
     "udapose_prof_end": (ci, [vp]),

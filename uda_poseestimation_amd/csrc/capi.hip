@@ -142,6 +142,8 @@ int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
 void udapose_debug_set_wgrad_group(int on, int stages_per_block) { net_set_wgrad_group(on, stages_per_block); }
 void udapose_debug_set_bn_bwd_fused(int on) { net_set_bn_bwd_fused(on); }
+extern int g_igemm_h3;
+void udapose_debug_set_igemm_h3(int mode) { g_igemm_h3 = mode; }
 extern unsigned long long* g_igemm_timeline;
 void udapose_debug_set_timeline(void* dev_buf) { g_igemm_timeline = (unsigned long long*)dev_buf; }
 int udapose_net_num_params(udapose_net_t n) { return net_num_params(n); }

@@ -26,7 +26,8 @@ struct TapPlan {
 // direction 0: fprop (also the plan wgrad walks), 1: dgrad
 const TapPlan* get_tap_plan(const ConvGeom& g, int direction);
 
-int igemm_pick_tile(int M, int Co, int nclass, int K);
+int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok = 0);   // h3_ok: 3x3 stride-1 pad-1 same-size conv (conv_h3_ok)
+int conv_h3_ok(const ConvGeom& g);
 int igemm_stat_rows(int M, int Co, int nclass, int tile);
 int igemm_launch(IgParams& p, int tile, hipStream_t stream);
 int wgrad_pick_tile(int Rdim, int Cdim, int smallc);

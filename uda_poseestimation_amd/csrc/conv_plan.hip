@@ -91,12 +91,19 @@ const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
     return tp;
 }
 
+// geometry the 3x3 run-staged igemm form takes (fprop and data gradient alike: the gradient of such a conv is such a conv)
+int conv_h3_ok(const ConvGeom& g) {
+    const bool ok = g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && !g.reflect && !g.upsample && g.Ci % 64 == 0 &&
+                    g.Co % 64 == 0 && g.Wi <= 64;
+    return ok ? (g.Wi <= 32 ? 2 : 1) : 0;
+}
+
 int conv_stat_rows(const ConvGeom& g) {
     const int nclass = g.transposed ? g.stride * g.stride : 1;
     const int M = g.transposed ? g.N * g.Hi * g.Wi : g.N * g.Ho() * g.Wo();
     const TapPlan* tp = get_tap_plan(g, 0);
     const int K = (tp ? tp->cls[0].ntaps : g.KH * g.KW) * g.Ci;     // same K as conv_fprop passes
-    return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass, K));
+    return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass, K, conv_h3_ok(g)));
 }
 
 int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e) {
@@ -117,7 +124,7 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* 
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     p.tap0 = plan_is_tap0(*tp);
     const int tok = prof_before(s, 0, alg_flops(g));
-    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci), s);
+    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g)), s);
     prof_after(s, tok);
     return rc;
 }
@@ -144,7 +151,7 @@ int conv_dgrad_stat_rows(const ConvGeom& g) {
     IgParams p{};
     const int rc = dgrad_params(g, p);
     if (rc != UDAPOSE_OK) return rc;
-    return igemm_stat_rows(p.M, p.Co, p.nclass, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci));
+    return igemm_stat_rows(p.M, p.Co, p.nclass, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g)));
 }
 
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32, DgradBnStat* bs) {
@@ -153,7 +160,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     if (rc0 != UDAPOSE_OK) return rc0;
     p.x = dy; p.w = w_bwd; p.y = dx; p.res = res;
     p.flags = out_f32 ? IG_FLAG_OUT_F32 : 0;
-    const int tile = igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci);
+    const int tile = igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g));
     if (bs) {
         p.bs_y = bs->y; p.bs_z = bs->z; p.bs_mean = bs->mean; p.bs_invstd = bs->invstd; p.bs_gamma = bs->gamma; p.bs_beta = bs->beta;
         p.stats = bs->slab;

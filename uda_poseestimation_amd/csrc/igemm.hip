@@ -70,13 +70,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Main loop: NS-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers), counted vmcnt waits and
 // ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
 // stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, bool H3 = false>
 // amdgpu_waves_per_eu(4): a register budget of 128 per lane.  Left alone the compiler spends 168 + 24 AGPRs on the 128x64 tile
 // (two resident work-groups per CU); with the hint it needs 110 and none of the configurations the heuristic picks spills
 // (the 128x128 ones, reachable only through the tuning override, do).  Measured: -0.65 ms per step.
 // The BS variants (dgrads with the consumer BatchNorm's backward reduction in the epilogue) take waves_per_eu(3) = 168 registers:
 // their tiles are resident three per CU by LDS either way, and the epilogue keeps a whole chunk's y / z / skip loads in flight.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BS ? 3 : 4))) void igemm_kernel(const IgParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) ? 3 : 4))) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
     // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.
@@ -305,7 +305,142 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BS ? 3 : 4)
         }
     };
 
-    if constexpr (RS) {
+    if constexpr (H3) {
+        // ---- 3x3, stride 1, pad 1 (fprop, or the data gradient of such a conv): the A operand is staged ONCE per 64-channel
+        // chunk instead of once per tap.  Output rows m0 .. m0+BM-1 are consecutive pixels (n, i, j) and the input has the same
+        // geometry, so tap (dy, dx) of row m reads input pixel m + dy*W + dx: the stage holds the run of BM + 2(W+1)
+        // consecutive pixels m0-(W+1) .. m0+BM+W (rows outside the tensor come from the zero page) and every tap reads it at a
+        // constant row offset.  Taps that fall outside the image (zero padding; the run's neighbours belong to other image rows
+        // or images there) are zeroed per lane in the fragment registers.  L2->LDS bytes per 64 channels: (BM + 2W + 2) rows of A
+        // + 9 weight tiles, instead of 9 x (BM rows + weight tile): -41 % at W = 16 - and the L2->LDS feed is what bounds these
+        // launches.  Ring: two A buffers (chunk c+1 is loaded, one piece per wave per tap, under the taps of chunk c) and three
+        // weight-tile slots (tile s+2 is issued at sub-stage s; 9 taps = 3 x 3 slots, so the slot of a tap is a constant).
+        static_assert(!F32 && B_PW == 2 && BN == 64, "H3: bf16, 64 weight rows");
+        const int Wd = p.Wi, G = Wd + 1;
+        const int RA = (BM + 2 * G + 7) & ~7, NPc = RA >> 3;      // A rows per stage; 1 KiB pieces (8 rows) per stage, <= 28
+        char* const Ab0 = stage;                                   // RA rows + one row of zeros (what the padded taps read)
+        char* const Ab1 = stage + (RA + 1) * 128;
+        char* const Bq = stage + 2 * (RA + 1) * 128;               // 3 slots of BNL rows
+        char* const dump = Bq + 3 * BNL * 128;                     // 1 KiB: where the pieces beyond NPc go (uniform DMA counts)
+        const int nchunks = p.Ci / BKE, nsub = nchunks * 9;
+        // A 3x3 pad-1 plan is t -> (dy, dx) = +-(t/3 - 1, t%3 - 1), weight slab t (build_direct; mirrored for the data gradient):
+        // one sign read from the table, everything else follows from the compile-time tap index (no per-tap table reads, no
+        // arrays of scalars: the parameter block already fills most of the scalar registers)
+        const int sgn = __builtin_amdgcn_readfirstlane(taps_l[0].dy < 0 ? 1 : -1);
+        const int ataps = (NPc + 3) >> 2;                          // taps of a chunk during which A pieces of the next chunk are issued
+        const int rb8 = 8 * p.Ci * (int)sizeof(T);                 // bytes between two pieces in the source
+        const int idx0 = m0 - G + lrow;                            // source pixel of this lane's row of piece 0
+        const int lc0 = (pchunk ^ swz(lrow)) ^ ((wid & 1) << 2);   // piece k = 4t + wid: swz(8k + lrow) = swz(lrow) ^ ((k & 1) << 2)
+        const char* const a_p0 = (const char*)px + ((long long)idx0 * p.Ci + lc0 * EPC) * (long long)sizeof(T);
+        int bfo3[NT][2];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) bfo3[j][k] = b_fo[j][k] - BM * 128;
+        auto issue_a = [&](int k, int chunk, char* Ab) __attribute__((always_inline)) {        // k = 4j + wid: wave-uniform piece index
+            const bool real = k < NPc;
+            const int idx = idx0 + 8 * k;
+            const char* src = (real && (unsigned)idx < (unsigned)p.M) ? a_p0 + ((long long)k * rb8 + (long long)chunk * 128) : zsrc;
+            char* dst = real ? Ab + k * 1024 : dump;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        };
+        auto issue_b = [&](int tapi, int chunk, int slot) __attribute__((always_inline)) {
+            const long long bb = ((long long)tapi * p.Ci + (long long)chunk * BKE) * (long long)sizeof(T);
+            char* Bs = Bq + slot * (BNL * 128);
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ok[i] ? b_ptr0[i] + bb : zsrc),
+                                                 (__attribute__((address_space(3))) void*)(Bs + (i * 4 + wid) * 1024), 16, 0, 0);
+        };
+        // prologue, FIRST (the loads fly while the fragment offsets below are computed): the whole A stage of chunk 0 (ataps pieces per wave, the ones beyond NPc into the dump), weight tiles 0 and 1
+        if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
+        for (int j = 0; j < ataps; ++j) issue_a(j * 4 + wid, 0, Ab0);
+        issue_b(0, 0, 0);
+        issue_b(1, 0, 1);
+        // Per lane, per fragment row and tap: the LDS byte offset (inside an A buffer) of the 16-byte fragment piece - the run row
+        // of the tap's pixel with its swizzle, or the zero row when the tap falls outside the image.  Computed once: the K loop
+        // then spends ONE add per fragment read (the loop is VALU-issue bound: ~70 scalar / vector instructions per 8 MFMAs in
+        // the tap-staged form), and zero padding costs nothing there.
+        static_assert(MT % 2 == 0, "H3: fragment rows are packed in pairs");
+        unsigned fo3[MT / 2][2][9];                                 // two 16-bit LDS offsets per register (rows 2h, 2h+1)
+        if (tid < 16) {                                             // the two zero rows (visible after the first barrier)
+            *(u32x4*)(Ab0 + RA * 128 + (tid & 7) * 16 + (tid >> 3) * ((RA + 1) * 128)) = (u32x4){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int h = 0; h < MT / 2; ++h)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) fo3[h][kk][t] = 0u;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int r = wm * TM + i * 16 + frow, m = m0 + r;
+            int ii = -4, jj = -4;                                   // rows beyond M: every tap reads zeros
+            if (m < p.M) {
+                const uint32_t n = fdiv((uint32_t)m, p.div_hw);
+                const uint32_t rem = (uint32_t)m - n * (uint32_t)(p.Hg * p.Wg);
+                ii = (int)fdiv(rem, p.div_w);
+                jj = (int)rem - ii * p.Wg;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = sgn * (t / 3 - 1), dx = sgn * (t % 3 - 1);
+                const bool ok = (unsigned)(ii + dy) < (unsigned)p.Hi && (unsigned)(jj + dx) < (unsigned)p.Wi;
+                const int rr = r + G + dy * Wd + dx;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    fo3[i / 2][kk][t] |= (unsigned)(ok ? rr * 128 + (((fchunk + 4 * kk) ^ swz(rr)) << 4) : RA * 128 + ((fchunk + 4 * kk) << 4)) << (16 * (i & 1));
+            }
+        }
+        auto compute3 = [&](auto tc, const char* Ab) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            const char* Bs = Bq + (t % 3) * (BNL * 128);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[MT], bfr[NT];
+#pragma unroll
+                for (int h = 0; h < MT / 2; ++h) {
+                    unsigned w = fo3[h][kk][t];
+                    asm volatile("" : "+v"(w));       // (opaque: the unpacked offsets are loop-invariant, and hoisting 4 x 18 of them spills)
+                    af[2 * h] = *(const bf16x8*)(Ab + (w & 0xFFFFu));
+                    af[2 * h + 1] = *(const bf16x8*)(Ab + (w >> 16));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(Bs + bfo3[j][kk]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): the zero rows are written before the first barrier
+        for (int c = 0; c < nchunks; ++c) {
+            const bool has_next = c + 1 < nchunks;
+            const char* Acur = (c & 1) ? Ab1 : Ab0;
+            char* Anext = (c & 1) ? Ab0 : Ab1;
+            static_for<9>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value;
+                const int sidx = c * 9 + t;
+                // DMAs younger than weight tile s (which, with the A stage of this chunk, must have landed): tile s+1 (2 per wave)
+                // and the A pieces issued at sub-stages s-2 (after tile s) and s-1, where those taps issue one
+                int young = 0;
+                if (sidx + 1 < nsub) {
+                    young = 2;
+                    if (has_next) young += (t >= 1 && t - 1 < ataps ? 1 : 0) + (t >= 2 && t - 2 < ataps ? 1 : 0);
+                }
+                if (young == 0) wait_vmcnt<0>();
+                else if (young == 2) wait_vmcnt<2>();
+                else if (young == 3) wait_vmcnt<3>();
+                else wait_vmcnt<4>();
+                __builtin_amdgcn_s_barrier();
+                if (t == 0 && dbg && tid == 0 && c == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
+                if (sidx + 2 < nsub) issue_b((t + 2) % 9, c + ((t + 2) >= 9 ? 1 : 0), (t + 2) % 3);
+                if (t < ataps && has_next) issue_a(t * 4 + wid, c + 1, Anext);
+                compute3(tc, Acur);
+            });
+        }
+    } else if constexpr (RS) {
         // Register-staged double buffer (fast path only): global_load_dwordx4 -> VGPRs -> ds_write_b128 into the SAME
         // lane-linear LDS image the DMA variant produces.  Per K stage a wave issues (A_PW + B_PW) plain loads (a few
         // issue cycles each) and as many 16-byte LDS stores, instead of (A_PW + B_PW) LDS-DMA instructions whose issue cost
@@ -624,14 +759,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BS ? 3 : 4)
 
 int g_igemm_short_lds = getenv("UDAPOSE_IGEMM_SHORT_LDS") ? atoi(getenv("UDAPOSE_IGEMM_SHORT_LDS")) : 1;   // A/B hook
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, bool H3 = false>
 int launch_cfg_t(IgParams& p, hipStream_t stream) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Co + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, H3 ? 112 * 1024 : C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
@@ -647,7 +782,12 @@ int launch_cfg_t(IgParams& p, hipStream_t stream) {
         constexpr int one = C::TAP_BYTES + (C::STAGE1 > C::EPI_BYTES + WM * 2 * BN * 4 ? C::STAGE1 : C::EPI_BYTES + WM * 2 * BN * 4);
         if (nst <= 1 && one < lds) lds = one;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS>), grid, dim3(256), lds, stream, p);
+    if constexpr (H3) {
+        // two A buffers of BM + 2(W+1) rows (rounded to 8), three weight slots, the dump piece; at least the epilogue regions
+        const int ra = (BM + 2 * (p.Wi + 1) + 7) & ~7;
+        lds = C::TAP_BYTES + std::max(2 * (ra + 1) * 128 + 3 * C::BNL * 128 + 1024, C::EPI_BYTES + WM * 2 * BN * 4);
+    }
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>), grid, dim3(256), lds, stream, p);
     return udapose_check_launch();
 }
 
@@ -679,10 +819,18 @@ unsigned long long* g_igemm_timeline = nullptr;   // tuning hook: device buffer 
 // ids: 0 = 128x128 NS3, 1 = 128x64 NS3, 2 = 64x64 NS4, 3 = 128x32 NS3, 4 = 128x128 NS2, 5 = 64x64 NS2, 6 = 128x64 NS2,
 // 7 = 64x64 register-staged, 8 = 128x64 register-staged (measured within +-8 % of the LDS-DMA variants on every shape: the
 // feed rate per CU, ~16 B/clk from L2, is the same for both staging methods; kept for tuning, never selected)
-int igemm_pick_tile(int M, int Co, int nclass, int K) {
+int g_igemm_h3 = getenv("UDAPOSE_IGEMM_H3") ? atoi(getenv("UDAPOSE_IGEMM_H3")) : 1;   // 0 off, 1 measured policy (default), 2 / 3: force the 64- / 128-row form (tests)
+int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok) {
     if (Co <= 32) return 3;
     if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
     const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
+    // run-staged 3x3 form (measured per shape at N = 32, tools/time_shapes.py): 64-row tiles where the tap-staged form would take
+    // 64x64 (layer3: 21.0 vs 21.9 us, layer4: 27.3 vs 27.9), 128-row tiles where it would take 128x64 and the run fits (layer2:
+    // 20.7 vs 22.1); layer1 (W = 64: a 194-row run per 64 output rows) stays tap-staged (27.6 vs 35.0)
+    if (h3_ok && g_igemm_h3 == 1) { if (b12864 < 512) return 10; if (h3_ok == 2) return 11; }
+    if (h3_ok && g_igemm_h3 == 2) return 10;
+    if (h3_ok == 2 && g_igemm_h3 == 3) return 11;              // (h3_ok == 2: W <= 32, the 128-row form fits)
+    if (h3_ok && g_igemm_h3 == 3) return 10;
     // measured (tools/tune_conv.py, then re-tuned under the three-stream step): 128x64 tiles with a 2-stage ring as soon as
     // they give two work-groups per CU, else 64x64 with a 3-stage ring for long K and a 2-stage ring otherwise.  Every
     // choice lands on THREE resident work-groups per CU (48 KB of LDS each): deeper rings (4 stages = 2 per CU) and one deep
@@ -693,7 +841,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K) {
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     switch (tile) {
-        case 2: case 5: case 7: case 9: return nclass * ((M + 63) / 64);       // one row per m-tile (wave rows added in-kernel)
+        case 2: case 5: case 7: case 9: case 10: return nclass * ((M + 63) / 64);       // one row per m-tile (wave rows added in-kernel)
         default: return nclass * ((M + 127) / 128);
     }
 }
@@ -723,6 +871,30 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
         case 7: return launch_cfg<64, 64, 2, 2, 4, true>(p, stream);
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
         case 9: return launch_cfg<64, 64, 2, 2, 3>(p, stream);
+        case 10: {
+            // 3x3 stride-1 same-size form (tile id given by igemm_pick_tile only when h3_ok): re-checked here
+            const bool ok = !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.nclass == 1 && p.cls[0].ntaps == 9 &&
+                            p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hi == p.Ho && p.Wi == p.Wo && p.Wi <= 64 && p.Ci % 64 == 0 &&
+                            p.cls[0].oa == 0 && p.cls[0].ob == 0;
+            if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream);
+            if (p.bs_y) {
+                if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
+                return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, true, true>(p, stream);
+            }
+            return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, false, true>(p, stream);
+        }
+        case 11: {
+            // the same with 128-row tiles (the 9 weight tiles of a chunk serve twice the rows); run of 128 + 2(W+1) rows <= 28 pieces
+            const bool ok = !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.nclass == 1 && p.cls[0].ntaps == 9 &&
+                            p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hi == p.Ho && p.Wi == p.Wo && p.Wi <= 32 && p.Ci % 64 == 0 &&
+                            p.cls[0].oa == 0 && p.cls[0].ob == 0;
+            if (!ok) return launch_cfg<128, 64, 2, 2, 2>(p, stream);
+            if (p.bs_y) {
+                if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
+                return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, true, true>(p, stream);
+            }
+            return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, false, true>(p, stream);
+        }
         default: return UDAPOSE_ERR_ARG;
     }
 }
