@@ -95,7 +95,7 @@ const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
 int conv_h3_ok(const ConvGeom& g) {
     const bool ok = g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && !g.reflect && !g.upsample && g.Ci % 64 == 0 &&
                     g.Co % 64 == 0 && g.Wi <= 64;
-    return ok ? (g.Wi <= 32 ? 2 : 1) : 0;
+    return ok ? (g.Wi <= 16 ? 3 : (g.Wi <= 32 ? 2 : 1)) : 0;
 }
 
 int conv_stat_rows(const ConvGeom& g) {
@@ -159,7 +159,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     const int rc0 = dgrad_params(g, p);
     if (rc0 != UDAPOSE_OK) return rc0;
     p.x = dy; p.w = w_bwd; p.y = dx; p.res = res;
-    p.flags = out_f32 ? IG_FLAG_OUT_F32 : 0;
+    p.flags = (out_f32 ? IG_FLAG_OUT_F32 : 0) | ((!g.transposed && g.stride == 1) ? IG_FLAG_MIRROR : 0);   // (stride-1 data gradient: mirrored taps)
     const int tile = igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g));
     if (bs) {
         p.bs_y = bs->y; p.bs_z = bs->z; p.bs_mean = bs->mean; p.bs_invstd = bs->invstd; p.bs_gamma = bs->gamma; p.bs_beta = bs->beta;

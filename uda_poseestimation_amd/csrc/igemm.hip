@@ -54,6 +54,7 @@ struct IgCfg {
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 24, "vmcnt range");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -70,7 +71,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Main loop: NS-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers), counted vmcnt waits and
 // ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
 // stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, bool H3 = false>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0>
 // amdgpu_waves_per_eu(4): a register budget of 128 per lane.  Left alone the compiler spends 168 + 24 AGPRs on the 128x64 tile
 // (two resident work-groups per CU); with the hint it needs 110 and none of the configurations the heuristic picks spills
 // (the 128x128 ones, reachable only through the tuning override, do).  Measured: -0.65 ms per step.
@@ -113,7 +114,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
     // 1x1 convolutions (and the one non-empty class of their strided data gradients) have the single tap (0, 0) -> weight slab 0:
     // the table entry is written from registers, which takes a dependent global-memory round trip out of every such work-group's
     // prologue (two thirds of the launches of a step)
-    if (p.flags & IG_FLAG_TAP0) { if (tid == 0) taps_l[0] = IgTap{0, 0, 0, cls_id}; }
+    if constexpr (H3) {
+        // (the run-staged 3x3 form derives its taps from the compile-time tap index and IG_FLAG_MIRROR: no table)
+    } else if (p.flags & IG_FLAG_TAP0) { if (tid == 0) taps_l[0] = IgTap{0, 0, 0, cls_id}; }
     else if (tid < cls.ntaps && tid < 64) taps_l[tid] = p.taps[cls.tap_off + tid];
 
     // ---- per-lane loader state: DMA instruction i of this wave fills LDS rows (i*4+wid)*8 .. +8, lane -> (row, chunk)
@@ -321,12 +324,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
         char* const Ab0 = stage;                                   // RA rows + one row of zeros (what the padded taps read)
         char* const Ab1 = stage + (RA + 1) * 128;
         char* const Bq = stage + 2 * (RA + 1) * 128;               // 3 slots of BNL rows
-        char* const dump = Bq + 3 * BNL * 128;                     // 1 KiB: where the pieces beyond NPc go (uniform DMA counts)
+        constexpr int NBT = H3 == 2 ? 6 : 3;                       // weight-tile slots (H3 == 2: two groups of three taps)
+        char* const dump = Bq + NBT * BNL * 128;                   // 1 KiB: where the pieces beyond NPc go (uniform DMA counts)
         const int nchunks = p.Ci / BKE, nsub = nchunks * 9;
         // A 3x3 pad-1 plan is t -> (dy, dx) = +-(t/3 - 1, t%3 - 1), weight slab t (build_direct; mirrored for the data gradient):
-        // one sign read from the table, everything else follows from the compile-time tap index (no per-tap table reads, no
+        // one sign flag from the host (IG_FLAG_MIRROR), everything else follows from the compile-time tap index (no table reads, no
         // arrays of scalars: the parameter block already fills most of the scalar registers)
-        const int sgn = __builtin_amdgcn_readfirstlane(taps_l[0].dy < 0 ? 1 : -1);
+        const int sgn = (p.flags & IG_FLAG_MIRROR) ? -1 : 1;
         const int ataps = (NPc + 3) >> 2;                          // taps of a chunk during which A pieces of the next chunk are issued
         const int rb8 = 8 * p.Ci * (int)sizeof(T);                 // bytes between two pieces in the source
         const int idx0 = m0 - G + lrow;                            // source pixel of this lane's row of piece 0
@@ -352,11 +356,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ok[i] ? b_ptr0[i] + bb : zsrc),
                                                  (__attribute__((address_space(3))) void*)(Bs + (i * 4 + wid) * 1024), 16, 0, 0);
         };
-        // prologue, FIRST (the loads fly while the fragment offsets below are computed): the whole A stage of chunk 0 (ataps pieces per wave, the ones beyond NPc into the dump), weight tiles 0 and 1
+        // prologue, FIRST (the loads fly while the fragment offsets below are computed): the whole A stage of chunk 0 (the pieces
+        // beyond NPc go to the dump), and the first weight tiles
         if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
         for (int j = 0; j < ataps; ++j) issue_a(j * 4 + wid, 0, Ab0);
         issue_b(0, 0, 0);
         issue_b(1, 0, 1);
+        if constexpr (H3 == 2) issue_b(2, 0, 2);
         // Per lane, per fragment row and tap: the LDS byte offset (inside an A buffer) of the 16-byte fragment piece - the run row
         // of the tap's pixel with its swizzle, or the zero row when the tap falls outside the image.  Computed once: the K loop
         // then spends ONE add per fragment read (the loop is VALU-issue bound: ~70 scalar / vector instructions per 8 MFMAs in
@@ -392,9 +398,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
                     fo3[i / 2][kk][t] |= (unsigned)(ok ? rr * 128 + (((fchunk + 4 * kk) ^ swz(rr)) << 4) : RA * 128 + ((fchunk + 4 * kk) << 4)) << (16 * (i & 1));
             }
         }
-        auto compute3 = [&](auto tc, const char* Ab) __attribute__((always_inline)) {
+        auto compute3 = [&](auto tc, const char* Ab, const char* Bs) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
-            const char* Bs = Bq + (t % 3) * (BNL * 128);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 af[MT], bfr[NT];
@@ -415,6 +420,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
             }
         };
         __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): the zero rows are written before the first barrier
+        if constexpr (H3 == 2) {
+            // Three taps (one filter row) per barrier: a sub-stage of 8 MFMAs per wave spends most of its time in the wait - barrier -
+            // issue - read sequence (0.36 us per tap with two work-groups per CU), so the row form syncs once per 24 MFMAs.  Two
+            // groups of three weight tiles alternate; group g+1 and the next chunk's A pieces (apw per wave, rows 0 and 1 only, so
+            // that they are older than the group the next chunk's first row waits for) are issued right after the barrier of g.
+            const int apw = (NPc + 7) >> 3;                            // A pieces per wave and row sub-stage, <= 4
+            for (int c = 0; c < nchunks; ++c) {
+                const bool has_next = c + 1 < nchunks;
+                const char* Acur = (c & 1) ? Ab1 : Ab0;
+                char* Anext = (c & 1) ? Ab0 : Ab1;
+                static_for<3>([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int r = decltype(rc)::value;
+                    const int gidx = c * 3 + r;
+                    const int gs = (c + r) & 1;                         // = gidx & 1
+                    // younger than group g's tiles: the A pieces issued after them at sub-stage g-1 (rows 0 / 1 of this chunk)
+                    const int young = (r >= 1 && has_next) ? apw : 0;
+                    if (young == 0) wait_vmcnt<0>();
+                    else if (young == 1) wait_vmcnt<1>();
+                    else if (young == 2) wait_vmcnt<2>();
+                    else if (young == 3) wait_vmcnt<3>();
+                    else wait_vmcnt<4>();
+                    __builtin_amdgcn_s_barrier();
+                    if (r == 0 && dbg && tid == 0 && c == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
+                    if (gidx + 1 < nchunks * 3) {
+                        constexpr int rn = (r + 1) % 3;
+                        const int cn = c + (r == 2 ? 1 : 0), gn = (gs ^ 1) * 3;
+                        issue_b(rn * 3 + 0, cn, gn + 0);
+                        issue_b(rn * 3 + 1, cn, gn + 1);
+                        issue_b(rn * 3 + 2, cn, gn + 2);
+                    }
+                    if (r <= 1 && has_next)
+                        for (int j = 0; j < apw; ++j) issue_a((r * apw + j) * 4 + wid, c + 1, Anext);
+                    const char* Bg = Bq + gs * 3 * (BNL * 128);
+                    compute3(IC<r * 3 + 0>{}, Acur, Bg);
+                    compute3(IC<r * 3 + 1>{}, Acur, Bg + BNL * 128);
+                    compute3(IC<r * 3 + 2>{}, Acur, Bg + 2 * BNL * 128);
+                });
+            }
+        } else {
         for (int c = 0; c < nchunks; ++c) {
             const bool has_next = c + 1 < nchunks;
             const char* Acur = (c & 1) ? Ab1 : Ab0;
@@ -437,8 +481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
                 if (t == 0 && dbg && tid == 0 && c == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
                 if (sidx + 2 < nsub) issue_b((t + 2) % 9, c + ((t + 2) >= 9 ? 1 : 0), (t + 2) % 3);
                 if (t < ataps && has_next) issue_a(t * 4 + wid, c + 1, Anext);
-                compute3(tc, Acur);
+                compute3(tc, Acur, Bq + (t % 3) * (BNL * 128));
             });
+        }
         }
     } else if constexpr (RS) {
         // Register-staged double buffer (fast path only): global_load_dwordx4 -> VGPRs -> ds_write_b128 into the SAME
@@ -759,7 +804,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
 
 int g_igemm_short_lds = getenv("UDAPOSE_IGEMM_SHORT_LDS") ? atoi(getenv("UDAPOSE_IGEMM_SHORT_LDS")) : 1;   // A/B hook
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, bool H3 = false>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0>
 int launch_cfg_t(IgParams& p, hipStream_t stream) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
@@ -785,7 +830,7 @@ int launch_cfg_t(IgParams& p, hipStream_t stream) {
     if constexpr (H3) {
         // two A buffers of BM + 2(W+1) rows (rounded to 8), three weight slots, the dump piece; at least the epilogue regions
         const int ra = (BM + 2 * (p.Wi + 1) + 7) & ~7;
-        lds = C::TAP_BYTES + std::max(2 * (ra + 1) * 128 + 3 * C::BNL * 128 + 1024, C::EPI_BYTES + WM * 2 * BN * 4);
+        lds = C::TAP_BYTES + std::max(2 * (ra + 1) * 128 + (H3 == 2 ? 6 : 3) * C::BNL * 128 + 1024, C::EPI_BYTES + WM * 2 * BN * 4);
     }
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>), grid, dim3(256), lds, stream, p);
     return udapose_check_launch();
@@ -826,10 +871,14 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok) {
     const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
     // run-staged 3x3 form (measured per shape at N = 32, tools/time_shapes.py): 64-row tiles where the tap-staged form would take
     // 64x64 (layer3: 21.0 vs 21.9 us, layer4: 27.3 vs 27.9), 128-row tiles where it would take 128x64 and the run fits (layer2:
-    // 20.7 vs 22.1); layer1 (W = 64: a 194-row run per 64 output rows) stays tap-staged (27.6 vs 35.0)
-    if (h3_ok && g_igemm_h3 == 1) { if (b12864 < 512) return 10; if (h3_ok == 2) return 11; }
+    // 20.7 vs 22.1); layer1 (W = 64: a 194-row run per 64 output rows) stays tap-staged (27.6 vs 35.0).  The three-taps-per-barrier
+    // variant (tile 12, W <= 16) is faster alone (layer3 18.5 us, layer4 22.7) but its 77 KB of LDS leave room for two work-groups
+    // per CU, and inside the three-stream step that costs more than it gains (+0.13 ms per step against tile 10's -0.15 ms): the
+    // other streams' kernels need the residency.  It stays selectable (mode 4) for single-stream use.
+    if (h3_ok && g_igemm_h3 == 1) { if (b12864 < 512) return 10; if (h3_ok >= 2) return 11; }
     if (h3_ok && g_igemm_h3 == 2) return 10;
-    if (h3_ok == 2 && g_igemm_h3 == 3) return 11;              // (h3_ok == 2: W <= 32, the 128-row form fits)
+    if (h3_ok && g_igemm_h3 == 4) return 12;                  // (row-grouped 64-row form; falls back inside igemm_launch when W > 16)
+    if (h3_ok >= 2 && g_igemm_h3 == 3) return 11;              // (h3_ok >= 2: W <= 32, the 128-row form fits; 3: W <= 16)
     if (h3_ok && g_igemm_h3 == 3) return 10;
     // measured (tools/tune_conv.py, then re-tuned under the three-stream step): 128x64 tiles with a 2-stage ring as soon as
     // they give two work-groups per CU, else 64x64 with a 3-stage ring for long K and a 2-stage ring otherwise.  Every
@@ -841,7 +890,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok) {
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     switch (tile) {
-        case 2: case 5: case 7: case 9: case 10: return nclass * ((M + 63) / 64);       // one row per m-tile (wave rows added in-kernel)
+        case 2: case 5: case 7: case 9: case 10: case 12: return nclass * ((M + 63) / 64);       // one row per m-tile (wave rows added in-kernel)
         default: return nclass * ((M + 127) / 128);
     }
 }
@@ -879,9 +928,21 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
             if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, true, true>(p, stream);
+                return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, true, 1>(p, stream);
             }
-            return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, false, true>(p, stream);
+            return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, false, 1>(p, stream);
+        }
+        case 12: {
+            // 64-row tiles, three taps per barrier (two groups of weight tiles: 77 KB of LDS at W = 16, two work-groups per CU)
+            const bool ok = !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.nclass == 1 && p.cls[0].ntaps == 9 &&
+                            p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hi == p.Ho && p.Wi == p.Wo && p.Wi <= 16 && p.Ci % 64 == 0 &&
+                            p.cls[0].oa == 0 && p.cls[0].ob == 0;
+            if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream);
+            if (p.bs_y) {
+                if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
+                return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, true, 2>(p, stream);
+            }
+            return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, false, 2>(p, stream);
         }
         case 11: {
             // the same with 128-row tiles (the 9 weight tiles of a chunk serve twice the rows); run of 128 + 2(W+1) rows <= 28 pieces
@@ -891,9 +952,9 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
             if (!ok) return launch_cfg<128, 64, 2, 2, 2>(p, stream);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, true, true>(p, stream);
+                return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, true, 1>(p, stream);
             }
-            return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, false, true>(p, stream);
+            return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, false, 1>(p, stream);
         }
         default: return UDAPOSE_ERR_ARG;
     }
