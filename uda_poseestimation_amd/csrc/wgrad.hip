@@ -8,6 +8,7 @@
 // Both operands use the same pixel<->k permutation (k = 8g+4h+q  <->  LDS row 16h+4g+q), so the sum is unchanged.
 //
 // grid = (r_tiles*c_tiles, taps (or tap groups of 4 when Ci==8), ksplit).  ksplit>1 or accumulate -> fp32 atomics.
+#include <stdlib.h>
 #include "igemm.h"
 
 namespace {
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
 // (chunk ^ ((row>>1)&3)<<1 for 128-byte rows, chunk ^ (row&7)<<1 for 256-byte rows), which makes the transposing reads
 // of one 32-lane half (8 pixel rows x 32 bytes) hit 16 distinct 16-byte bank slots.
 __device__ u32x4 g_wzero16[2];
+int g_wgrad_fastgeo = getenv("UDAPOSE_WGRAD_FASTGEO") ? atoi(getenv("UDAPOSE_WGRAD_FASTGEO")) : 1;   // A/B hook
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,7 +229,7 @@ struct WdCfg {
 };
 
 // One work-group: tile bx of dW tap `by`, pixel split bz of problem p.
-template <int RT, int CT, int WR, int WC, int NS, int PX = 64>
+template <int RT, int CT, int WR, int WC, int NS, int PX = 64, bool FAST = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
     // scalar copies of the fields used below (gp may live in global memory: read it once, up front, into SGPRs)
@@ -272,10 +274,46 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     const bool dy_lin = p.os == 1 && cls.oa == 0 && cls.ob == 0 && p.Hg == p.Ho && p.Wg == p.Wo;
     const bool x_lin = p.s == 1 && tp.dy == 0 && tp.dx == 0 && p.Hg == p.Hi && p.Wg == p.Wi;
     const int lrow = lane / P_CPR, pch = lane % P_CPR;
+    // Fast geometry (every stride-1 convolution of the 256x256 networks: 1x1 and 3x3 pad 1 on power-of-two maps): the x pixel of
+    // row m and tap (dy, dx) is m + dy*W + dx, (i, j) are bit fields of m, and element offsets fit 32 bits with 24-bit factors -
+    // a stage's four source addresses cost ~35 vector instructions instead of ~200 (64-bit multiplies, two exact divisions per
+    // row): the loop has 16 MFMAs (256 cycles) per wave and stage and was issue-bound on its address arithmetic (18 % MFMA use).
+    const bool pow2hw = ((p.Hi & (p.Hi - 1)) | (p.Wi & (p.Wi - 1))) == 0;
+    // (FAST: a separate instantiation of the body, chosen per problem from WG_FLAG_FASTGEO - set by wg_fastgeo_ok - so that the two
+    // loaders do not add up their registers: the kernel sits at its 128-register budget)
+    (void)pow2hw;
+    const int toff = tp.dy * p.Wi + tp.dx;
+    const bool center = tp.dy == 0 && tp.dx == 0;
+    const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
+    const int lgw = 31 - __builtin_clz((unsigned)(p.Wi > 0 ? p.Wi : 1));
     auto issue_stage = [&](int st, int buf) {
         const int mb = (ms0 + st) * PX;
         char* P = smem + buf * C::STAGE1;
         char* Q = P + C::P_BYTES;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int i = 0; i < P_PW; ++i) {
+                const int row = (i * 4 + wid) * P_RPI + lrow;
+                const int lc = pch ^ wswz<RT>(row);
+                const int m = mb + row;
+                const bool okd = m < p.M;
+                bool okx = okd;
+                if (!center) {
+                    const unsigned rem = (unsigned)m & hw_mask;
+                    const int ii = (int)(rem >> lgw), jj = (int)(rem & w_mask);
+                    okx = okd && (unsigned)(ii + tp.dy) < (unsigned)p.Hi && (unsigned)(jj + tp.dx) < (unsigned)p.Wi;
+                }
+                const int pc = r0 + lc * 8, qc = c0 + lc * 8;
+                const unsigned od = __umul24((unsigned)m, (unsigned)p.Co) + (unsigned)pc;            // P rows come from dy (no swap)
+                const unsigned ox = __umul24((unsigned)(m + toff), (unsigned)p.Ci) + (unsigned)qc;   // Q rows from x
+                const char* sp = (okd && pc < Rdim) ? (const char*)p.dy + (size_t)od * 2 : zsrc;
+                const char* sq = (okx && qc < Cdim) ? (const char*)p.x + (size_t)ox * 2 : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                                 (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
+                                                 (__attribute__((address_space(3))) void*)(Q + (i * 4 + wid) * 1024), 16, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < P_PW; ++i) {
             const int row = (i * 4 + wid) * P_RPI + lrow;
@@ -314,6 +352,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
                                              (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq,
                                              (__attribute__((address_space(3))) void*)(Q + (i * 4 + wid) * 1024), 16, 0, 0);
+        }
         }
     };
 
@@ -399,7 +438,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
     const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
     const uint32_t bz = lin / gxy, bxy = lin - bz * gxy;
     const uint32_t by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
-    wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem);
+    if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, 64, true>(p, bx, by, bz, smem);
+    else wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem);
 }
 
 // Grouped form: ONE launch computes the weight gradients of many layers.  blk is an [8][per_xcd] table (work-group b runs
@@ -417,7 +457,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void w
     const uint32_t gx = (uint32_t)(p.r_tiles * p.c_tiles), gxy = gx * (uint32_t)p.total_taps;
     const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
     const uint32_t by = bxy / gx, bx = bxy - by * gx;
-    wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
 }
 
 template <int RT, int CT, int WR, int WC, int NS, int PX>
@@ -469,6 +510,14 @@ int launch_wg(WgParams& p, hipStream_t stream) {
 
 int g_wgrad_tile_override = -1, g_wgrad_ksplit_override = -1;   // debug/tuning hooks
 
+// host side of the loader's fast geometry (wgrad_dma_body): stride-1 same-size convolution on power-of-two maps, 24-bit factors
+static bool wg_fastgeo_ok(const WgParams& p) {
+    const bool pow2 = ((p.Hi & (p.Hi - 1)) | (p.Wi & (p.Wi - 1))) == 0;
+    return g_wgrad_fastgeo && !(p.flags & (IG_FLAG_SMALLC | WG_FLAG_SWAP)) && p.s == 1 && p.os == 1 && p.nclass == 1 && p.Hg == p.Hi && p.Wg == p.Wi &&
+           p.Hg == p.Ho && p.Wg == p.Wo && pow2 && p.Hi > 0 && p.M < (1 << 24) && p.Ci < (1 << 24) && p.Co < (1 << 24) &&
+           (long long)p.M * (p.Ci > p.Co ? p.Ci : p.Co) < (1ll << 31);
+}
+
 // tile ids: 0 = 128x128, 1 = 64x64, 2 = 64x32 (Ci==8 stem), 3 = 32x128 (narrow-row: head)
 int wgrad_pick_tile(int Rdim, int Cdim, int smallc) {
     if (smallc) return 2;
@@ -506,6 +555,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
         const size_t n = (size_t)Rdim * p.wtaps * Cdim;
         if (hipMemsetAsync(p.dw, 0, n * sizeof(float), stream) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }
+    if (wg_fastgeo_ok(p)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
     if (dma) return tile == 0 ? launch_wd<128, 128, 2, 2, 2>(p, stream) : launch_wd<64, 64, 2, 2, 4>(p, stream);
     switch (tile) {
         case 0: return launch_wg<128, 128, 2, 2>(p, stream);
@@ -536,6 +586,7 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block) {
     p.ksplit = ks;
     p.msteps_per_split = (ms_total + ks - 1) / ks;
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
+    if (wg_fastgeo_ok(p)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
     return tile;
 }
 
