@@ -77,7 +77,7 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS =
 // (the 128x128 ones, reachable only through the tuning override, do).  Measured: -0.65 ms per step.
 // The BS variants (dgrads with the consumer BatchNorm's backward reduction in the epilogue) take waves_per_eu(3) = 168 registers:
 // their tiles are resident three per CU by LDS either way, and the epilogue keeps a whole chunk's y / z / skip loads in flight.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) ? 3 : 4))) void igemm_kernel(const IgParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 == 1 || H3 == 2) ? 3 : 4))) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
     // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.
@@ -152,6 +152,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
 
     const int nsteps = smallc ? cls.ntaps / TPS : (cls.ntaps * p.Ci) / BKE;
     int tap_cur = 0, c0_cur = 0;   // uniform K cursor
+    // H3 == 3, "lean 1x1": a stride-1 1x1 convolution (or its data gradient) with full tiles.  Row m of A IS pixel m, so every DMA
+    // source is  uniform base (advanced 128 bytes per stage by the scalar unit) + a per-lane 32-bit offset that never changes:
+    // no vector instruction per stage goes into addresses (the generic loop spends ~70 scalar / vector instructions per 8 MFMAs)
+    unsigned a_off3[A_PW], b_off3[B_PW];
+    if constexpr (H3 == 3) {
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            const int r = (i * 4 + wid) * 8 + lrow;
+            a_off3[i] = ((unsigned)(m0 + r) * (unsigned)p.Ci + (unsigned)((pchunk ^ swz(r)) * EPC)) * (unsigned)sizeof(T);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) {
+            const int r = (i * 4 + wid) * 8 + lrow;
+            b_off3[i] = ((unsigned)(n0 + (r < BN ? r : 0)) * (unsigned)(p.wtaps * p.Ci) + (unsigned)((pchunk ^ swz(r)) * EPC)) * (unsigned)sizeof(T);
+        }
+    }
     const char* zsrc = (const char*)g_zero16;
 
     __syncthreads();   // tap table visible
@@ -204,6 +220,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
         constexpr int UB = decltype(ub)::value;
         char* A = stage + UB * C::STAGE1;
         char* B = A + BM * 128;
+        if constexpr (H3 == 3) {
+            // (scalar base = the kernel argument itself, 32-bit lane offsets advanced by one add each: the saddr form of the load)
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)px + a_off3[i]),
+                                                 (__attribute__((address_space(3))) void*)(A + (i * 4 + wid) * 1024), 16, 0, 0);
+                a_off3[i] += 128u;
+            }
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)pw + b_off3[i]),
+                                                 (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
+                b_off3[i] += 128u;
+            }
+            return;
+        }
         if (fast) {
             if (c0_cur == 0) select_tap();
             const long long cb = (long long)c0_cur * (long long)sizeof(T);
@@ -308,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
         }
     };
 
-    if constexpr (H3) {
+    if constexpr (H3 == 1 || H3 == 2) {
         // ---- 3x3, stride 1, pad 1 (fprop, or the data gradient of such a conv): the A operand is staged ONCE per 64-channel
         // chunk instead of once per tap.  Output rows m0 .. m0+BM-1 are consecutive pixels (n, i, j) and the input has the same
         // geometry, so tap (dy, dx) of row m reads input pixel m + dy*W + dx: the stage holds the run of BM + 2(W+1)
@@ -802,6 +834,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3) 
     }
 }
 
+int g_igemm_lean = getenv("UDAPOSE_IGEMM_LEAN") ? atoi(getenv("UDAPOSE_IGEMM_LEAN")) : 1;   // A/B hook: lean 1x1 form
 int g_igemm_short_lds = getenv("UDAPOSE_IGEMM_SHORT_LDS") ? atoi(getenv("UDAPOSE_IGEMM_SHORT_LDS")) : 1;   // A/B hook
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0>
@@ -811,7 +844,7 @@ int launch_cfg_t(IgParams& p, hipStream_t stream) {
     p.n_tiles = (p.Co + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, H3 ? 112 * 1024 : C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, (H3 == 1 || H3 == 2) ? 112 * 1024 : C::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
@@ -827,7 +860,7 @@ int launch_cfg_t(IgParams& p, hipStream_t stream) {
         constexpr int one = C::TAP_BYTES + (C::STAGE1 > C::EPI_BYTES + WM * 2 * BN * 4 ? C::STAGE1 : C::EPI_BYTES + WM * 2 * BN * 4);
         if (nst <= 1 && one < lds) lds = one;
     }
-    if constexpr (H3) {
+    if constexpr (H3 == 1 || H3 == 2) {
         // two A buffers of BM + 2(W+1) rows (rounded to 8), three weight slots, the dump piece; at least the epilogue regions
         const int ra = (BM + 2 * (p.Wi + 1) + 7) & ~7;
         lds = C::TAP_BYTES + std::max(2 * (ra + 1) * 128 + (H3 == 2 ? 6 : 3) * C::BNL * 128 + 1024, C::EPI_BYTES + WM * 2 * BN * 4);
@@ -843,11 +876,18 @@ int launch_cfg(IgParams& p, hipStream_t stream) {
         if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) == 0) return launch_cfg_t<bf16_t, BM, BN, WM, WN, 2, true>(p, stream);
         return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
     } else {
+        // lean 1x1 form: stride-1 single-tap convolution whose tiles are all full (M % BM, Co % BN), offsets in 32 bits
+        const bool lean = g_igemm_lean && BN >= 64 && !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.tap0 &&
+                          p.nclass == 1 && p.cls[0].ntaps == 1 && p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hg == p.Ho &&
+                          p.Wg == p.Wo && p.M % BM == 0 && p.Co % BN == 0 && p.Ci % 64 == 0 && p.wtaps == 1 &&
+                          (long long)p.M * p.Ci * 2 < (1ll << 32) && (long long)p.Co * p.Ci * 2 < (1ll << 32);
         if (p.bs_y) {
             // dgrad with the consumer BatchNorm's backward reduction in the epilogue (bf16 operands; bf16 or fp32 output)
             if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_RELU)) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
+            if (lean) return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false, true, 3>(p, stream);
             return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false, true>(p, stream);
         }
+        if (lean) return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false, false, 3>(p, stream);
         return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS, false>(p, stream) : launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
     }
 }
