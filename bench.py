@@ -123,16 +123,30 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     force_dist = os.environ.get("UDAPOSE_FORCE_DIST", "0") == "1"     # test hook: one-rank RCCL group, data-parallel code path
-    if force_dist and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # RCCL prints its version banner on stdout when the communicator is created (NCCL_DEBUG=VERSION in this image): stdout is
+    # pointed at stderr while the process group comes up, so that rank 0's stdout carries the ONE JSON line and nothing else
+    sys.stdout.flush()
+    saved_out = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if share:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.is_initialized():
+            t_init = torch.zeros(1, device=dev)
+            dist.all_reduce(t_init)                 # first collective: communicator creation (and its banner) happens here at the latest
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_out, 1)
+        os.close(saved_out)
 
     from uda_poseestimation_amd import _hip, synthetic
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
