@@ -9,10 +9,13 @@ K=16, 256x256, N=32 per GPU, bf16 compute / fp32 master weights (BASELINE.json c
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
         bench.py --gpus 8 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3      # no launcher: starts its own 8 ranks (fresh child processes, spawned
+                                                        # before this process touches the GPU) and relays rank 0's JSON line
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   "roofline":     MFMA roofline of the dominant kernel family (implicit-GEMM fprop/dgrad), from HIP events recorded on the
-                  launch stream around every convolution launch of the LAST timed step;
+                  launch stream around every convolution launch of ONE eager, instrumented step that runs AFTER the timed
+                  region (the timed region is K hipGraph replays and nothing else);
   "cpu_baseline": the CPU oracle's (oracle/step_ref.py, plain torch fp32) throughput on this host, bounded sample.
 """
 import argparse
@@ -81,6 +84,43 @@ def cpu_baseline(n, arch_layers, seconds_budget=25.0):
                       f"oracle/step_ref.py, {len(times)} iteration(s), best of the non-first: {best:.2f} s/step"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, rendezvous on
+    127.0.0.1), relay rank 0's stdout (the ONE JSON line), send the other ranks' stdout to stderr, and exit non-zero if any
+    rank fails.  Called before this process has made any GPU call (a process that has initialised the GPU must never be
+    replaced or forked on this pool: the children are brand-new interpreters)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), UDAPOSE_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(None if r == 0 else sys.stderr)))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:           # one rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +149,13 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))            # (nothing above this line touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {args.gpus}` (it starts its "
+                         f"own ranks) or `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"bench.py --gpus {args.gpus} ...`")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -223,36 +269,30 @@ def main():
               file=sys.stderr)
     for _ in range(args.warmup):
         out = step()
-    # one untimed dry run of the instrumented eager step: creates the profiler's HIP-event pool (≈1100 hipEventCreate calls,
-    # 50-200 ms of host time when done inside the timed region) and warms the eager path's caches
-    lib.udapose_prof_begin()
-    trainer.concurrent = False
-    out = eager_step()
-    trainer.concurrent = True
-    torch.cuda.synchronize()
-    _hip.check(lib.udapose_prof_end((ctypes.c_double * 9)()), "prof_end")
-    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    prof = (ctypes.c_double * 9)()
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            # the last timed step runs eagerly with HIP events recorded on the launch stream around every convolution
-            # launch (events cannot be placed inside a replayed graph): it is the roofline sample
-            lib.udapose_prof_begin()
-            trainer.concurrent = False        # one stream: per-launch durations comparable with rocprofv3's (which serialises)
-            out = eager_step()
-            trainer.concurrent = True
-        else:
-            out = step()
+    for i in range(args.steps):         # the timed region: EXACTLY K steps (hipGraph replays unless --eager), nothing else
+        out = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    _hip.check(lib.udapose_prof_end(prof), "prof_end")
+    # Roofline sample, UNTIMED, after the timed region: one eager step on ONE stream with HIP events recorded on the launch
+    # stream around every convolution launch (events cannot be placed inside a replayed graph; single-stream so that the
+    # per-launch durations are comparable with rocprofv3's, which serialises).  A dry run first creates the profiler's event
+    # pool (~1100 hipEventCreate calls).
+    prof = (ctypes.c_double * 9)()
+    trainer.concurrent = False
+    for dry in (True, False):
+        lib.udapose_prof_begin()
+        out_prof = eager_step()
+        torch.cuda.synchronize()
+        _hip.check(lib.udapose_prof_end(prof), "prof_end")
+    trainer.concurrent = True
+    torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -283,7 +323,8 @@ def main():
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
                                    f"Adam, EMA), {S}x{S}, b={N}/GPU, " + ("AdaIN s2t + t2s style passes and adaptive occlusion (BASELINE.json configs[2]; NOT the metric)" if args.config2 else "no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch) == (256, 16, 32, "pose_resnet101") else f", K={K}")),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
-            "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + " (last timed step eager, instrumented)",
+            "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
+            "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fprop+dgrad, bf16 MFMA 16x16x32)",

@@ -159,15 +159,18 @@ int udapose_multi_chunk(void);
 /* OldWeightEMA.step (utils.py:21-25): t = fl(fl(t*alpha) + fl(s*one_minus_alpha)), bit-exact two-rounding form */
 int udapose_ema_multi(void* stream, const long long* tgt_ptrs, const long long* src_ptrs, const long long* sizes, const int* blk_tensor,
                       const long long* blk_off, int nblocks, float alpha, float one_minus_alpha);
-/* torch.optim.Adam.step (train_human.py:139,286).  dev_state (optional, 4 floats, zero-initialised): device-resident step
- * counter + bias corrections, advanced by the call itself (hipGraph-replay safe); if NULL, `step` is the host's step. */
+/* torch.optim.Adam.step (train_human.py:139,286).  dev_state (optional, 8 floats: [step, 1-b1^step, sqrt(1-b2^step), lr,
+ * grad_scale, -, -, -]): the step counter and bias corrections are advanced by the call itself on the device, and lr /
+ * grad_scale are READ from it instead of the by-value arguments, so that a captured call follows an lr scheduler
+ * (MultiStepLR, train_human.py:143,202) through an 8-byte copy; if NULL, `step`, `lr`, `grad_scale` are the host's. */
 int udapose_adam_multi(void* stream, const long long* p, const long long* g, const long long* m, const long long* v,
                        const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state);
-/* torch.optim.SGD(momentum, nesterov) (train_human.py:137) */
+/* torch.optim.SGD(momentum, nesterov) (train_human.py:137); dev_state as for Adam ([0] = step counter, [3] = lr,
+ * [4] = grad_scale; first_step is then `step == 1` on the device) */
 int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes,
                       const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float momentum, float weight_decay,
-                      int nesterov, int first_step, float grad_scale);
+                      int nesterov, int first_step, float grad_scale, float* dev_state);
 
 /* ---------------------------------------------------------------- AdaIN (lib/models/Style_net.py:4-29,167-168), NHWC bf16
  * out = alpha*adain(content, style) + (1-alpha)*content; stats_out (optional) [N][C][4] = (mean_c, std_c, mean_s, std_s) */

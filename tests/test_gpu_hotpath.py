@@ -412,6 +412,28 @@ def test_two_rank_step_on_one_gpu_gloo():
     assert d["value"] > 0 and d["loss"] == d["loss"]
     assert "3 hipGraphs" in d["launch"]
     assert d["replicas_in_sync"] is True               # same averaged gradients -> bit-identical replicas
+    assert d["rccl_ranks"] == 0                        # (gloo here: the one-GPU box cannot host two RCCL ranks)
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and WORLD_SIZE unset: the parent spawns two fresh rank processes before
+    touching the GPU, relays rank 0's ONE JSON line and exits with the children's status (`--gpus` used to be
+    ignored).  A --gpus / WORLD_SIZE mismatch fails fast."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UDAPOSE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "0",
+           "--arch", "pose_resnet50", "--batch", "4", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["replicas_in_sync"] is True
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], cwd=root,
+                         env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)
 
 
 def test_one_rank_rccl_step():
@@ -434,6 +456,7 @@ def test_one_rank_rccl_step():
         res[tag] = json.loads(lines[0])
     assert "3 hipGraphs" in res["rccl"]["launch"] and "2 hipGraphs" in res["plain"]["launch"]
     assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
+    assert res["rccl"]["rccl_ranks"] == 1 and res["plain"]["rccl_ranks"] == 0
     a, b = res["rccl"]["loss"], res["plain"]["loss"]
     assert a == a and abs(a - b) <= 1e-3 * abs(b) + 1e-9, (a, b)
 

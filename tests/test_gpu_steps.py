@@ -1,0 +1,237 @@
+"""Whole-step property tests on the MI355X: the source-only `pretrain` step of BASELINE.json configs[0]
+against the CPU oracle, "loss decreases / PCK does not fall" over >= 50 HIP steps for both step kinds on fixed synthetic
+labels, and the state hand-offs between captured (hipGraph) steps and everything else that reads the weights."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny(K=16, layers=(1, 1, 1, 1), seed=0):
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    torch.manual_seed(seed)
+    return pr._pose_resnet("t", K, pr.Bottleneck_default, list(layers), False, False)
+
+
+def test_pretrain_step_config0_matches_oracle():
+    """BASELINE.json configs[0]: PoseResNet-50 source-only JointsMSELoss step on 16 synthetic 256x256 frames
+    (train_human.py:262-289) - engine.pretrain_step on the device vs oracle.step_ref.pretrain_step_ref on the host."""
+    import uda_poseestimation_amd.lib.models as models
+    from oracle.pose_resnet_ref import pose_resnet50_ref
+    from oracle.step_ref import pretrain_step_ref
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    torch.manual_seed(0)
+    ref = pose_resnet50_ref(16)
+    with torch.no_grad():
+        for m in ref.modules():
+            if hasattr(m, "bn3"):
+                m.bn3.weight.fill_(0.25)
+    stu = models.pose_resnet50(16, pretrained_backbone=False)
+    tea = models.pose_resnet50(16, pretrained_backbone=False)
+    stu.load_state_dict(ref.state_dict())
+    trainer = MeanTeacherTrainer(stu.cuda(), tea.cuda())
+    b = synthetic.mean_teacher_batch(16, seed=4)
+    w0 = [p.detach().clone() for p in ref.parameters()]
+    out = trainer.pretrain_step(b["x_s"].cuda(), b["label_s"].cuda(), b["weight_s"].cuda())
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    r = pretrain_step_ref(ref, opt, b["x_s"], b["label_s"], b["weight_s"])
+    lo, lr_ = float(out["loss_all"]), float(r["loss_all"])
+    print(f"configs[0] pretrain step: loss device {lo:.6e} oracle {lr_:.6e}")
+    assert abs(lo - lr_) <= 1e-2 * lr_
+    agree = total = 0
+    for p_dev, p_ref, p0 in zip(stu.parameters(), ref.parameters(), w0):
+        d_dev, d_ref = p_dev.detach().cpu() - p0, p_ref.detach() - p0
+        sel = d_ref.abs() > 5e-5
+        agree += int((torch.sign(d_dev[sel]) == torch.sign(d_ref[sel])).sum())
+        total += int(sel.sum())
+    print(f"  Adam update sign agreement with the fp32 oracle: {agree / max(total, 1):.4f} over {total} entries")
+    assert total > 1e7 and agree / total > 0.85
+    # the teacher is untouched by a pretrain step (no EMA there, train_human.py:285-287)
+    for a, p0 in zip(tea.parameters(), w0):
+        assert torch.equal(a.detach().cpu(), p0)
+
+
+@pytest.mark.parametrize("kind", ["pretrain", "train"])
+def test_loss_decreases_over_60_steps_on_fixed_labels(kind):
+    """repeated steps on ONE fixed synthetic batch must drive the supervised loss down and the source PCK
+    must not fall (the net memorises the Gaussian labels); for the mean-teacher step the EMA teacher follows the student."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    N, K, S = 8, 16, 128
+    stu, tea = _tiny(K, seed=1).cuda(), _tiny(K, seed=2).cuda()
+    trainer = MeanTeacherTrainer(stu, tea, lr=1e-3, teacher_alpha=0.9, image_size=S, heatmap_size=S // 4)
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=9)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    losses, accs = [], []
+    for it in range(60):
+        if kind == "pretrain":
+            out = trainer.pretrain_step(g["x_s"], g["label_s"], g["weight_s"])
+            loss = out["loss_all"]
+        else:
+            out = trainer.train_step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+            loss = out["loss_s"]
+        losses.append(float(loss))
+        accs.append(float(kd.accuracy_device(out["y_s"], g["label_s"])[1][0]))
+    first, last = float(np.mean(losses[:5])), float(np.mean(losses[-5:]))
+    print(f"{kind}: loss_s {first:.4e} -> {last:.4e}; PCK@0.05 {np.mean(accs[:5]):.3f} -> {np.mean(accs[-5:]):.3f}")
+    assert all(np.isfinite(losses)) and last < 0.7 * first
+    assert np.mean(accs[-5:]) >= np.mean(accs[:5])
+    if kind == "train":
+        # EMA with alpha 0.9 over 60 steps: the teacher has left its initial copy and sits between it and the student
+        d = sum(float((a.detach() - c.detach()).abs().sum()) for a, c in zip(tea.parameters(), stu.parameters()))
+        assert 0 < d < float("inf")
+
+
+def test_graph_replays_then_eval_forward_at_another_batch_size_sees_fresh_weights():
+    """replays of the captured Adam / EMA kernels change parameters without torch's version counters
+    moving; an eager forward on ANOTHER executor plan (validate() with another batch size, the teacher after training) must
+    not reuse its stale bf16 weight packs."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    stu, tea = _tiny(K, seed=3).cuda(), _tiny(K, seed=3).cuda()
+    trainer = MeanTeacherTrainer(stu, tea, lr=1e-2, teacher_alpha=0.5, image_size=S, heatmap_size=S // 4)   # large steps: stale packs would show
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=5)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    xe = synthetic.images(2, S, 77).cuda()                  # another batch size -> another executor plan
+    for m in (stu, tea):
+        m.eval()
+    with torch.no_grad():
+        before = [m(xe).clone() for m in (stu, tea)]        # packs of the N=2 plans are now cached
+    gs = GraphedTrainStep(trainer, *args, warmup=1)
+    for _ in range(6):
+        gs.step(*args)
+    for m in (stu, tea):
+        m.eval()
+    with torch.no_grad():
+        after = [m(xe).clone() for m in (stu, tea)]
+        for m in (stu, tea):                                # force a re-pack of every plan, whatever the caches say
+            for hd in m._handles.values():
+                hd.wpack_version = None
+        forced = [m(xe).clone() for m in (stu, tea)]
+    for a, f, b0 in zip(after, forced, before):
+        assert torch.equal(a, f), "eval forward after graph replays ran on stale weight packs"
+        assert not torch.equal(a, b0)                       # (the weights really moved)
+    # ... and the graph itself re-packs inside every replay: a further replay is not disturbed by the eager forwards
+    out = gs.step(*args)
+    assert torch.isfinite(out["loss_all"])
+
+
+def test_captured_steps_equal_eager_steps_from_identical_state_with_varying_batches():
+    """the split (three-graph, data-parallel form) and unsplit captured steps against an eager twin started from
+    IDENTICAL model and optimizer state, over several steps with DIFFERENT batches: parameters and teacher must agree to
+    summation-order noise (a wrong mask threshold, a missed gradient sum or a stale pack is orders of magnitude larger)."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    batches = []
+    for s in (31, 32, 33, 34):
+        b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=s)
+        g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+        batches.append((g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"]))
+    base = _tiny(K, seed=8)
+    for split in (False, True):
+        nets = []
+        for _ in range(2):
+            s_, t_ = _tiny(K, seed=8), _tiny(K, seed=8)
+            s_.load_state_dict(base.state_dict())
+            nets.append((s_.cuda(), t_.cuda()))
+        tr_g = MeanTeacherTrainer(*nets[0], lr=1e-4, image_size=S, heatmap_size=S // 4)
+        tr_e = MeanTeacherTrainer(*nets[1], lr=1e-4, image_size=S, heatmap_size=S // 4)
+        p0 = [p.detach().clone() for p in nets[0][0].parameters()]
+        gs = GraphedTrainStep(tr_g, *batches[0], warmup=1, split=split)       # the warm-up step IS step 1 (on batch 0)
+        tr_e.train_step(*batches[0])
+        for bt in batches[1:]:
+            og = gs.step(*bt)
+            oe = tr_e.train_step(*bt)
+            assert abs(float(og["loss_all"]) - float(oe["loss_all"])) <= 2e-3 * abs(float(oe["loss_all"]))
+            assert abs(float(og["loss_c"]) - float(oe["loss_c"])) <= 5e-3 * abs(float(oe["loss_c"])) + 1e-7
+        for (sg, se, tg, te) in ((nets[0][0], nets[1][0], nets[0][1], nets[1][1]),):
+            num = den = 0.0
+            for pg, pe, q0 in zip(sg.parameters(), se.parameters(), p0):
+                num += float(((pg.detach() - pe.detach()) ** 2).sum())
+                den += float(((pe.detach() - q0) ** 2).sum())
+            rel = (num / max(den, 1e-30)) ** 0.5
+            print(f"split={split}: ||student(graph) - student(eager)|| / ||student(eager) - start|| = {rel:.3e} after {len(batches)} steps")
+            assert rel < 0.2
+            tn = sum(float(((a.detach() - c.detach()) ** 2).sum()) for a, c in zip(tg.parameters(), te.parameters()))
+            td = sum(float(((c.detach() - q0) ** 2).sum()) for c, q0 in zip(te.parameters(), p0))
+            assert (tn / max(td, 1e-30)) ** 0.5 < 0.1
+
+
+def test_lr_schedule_reaches_a_captured_step_and_optimizer_checkpoint_round_trip(tmp_path):
+    """lr lives in device memory (a MultiStepLR milestone must change what a REPLAYED Adam does),
+    replays advance the step counter that state_dict() reports, the optimizer state_dict is torch's plain layout, and a
+    checkpoint written by torch.optim.Adam loads."""
+    from uda_poseestimation_amd import optim as fo, synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    stu, tea = _tiny(K, seed=4).cuda(), _tiny(K, seed=4).cuda()
+    trainer = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
+    sched = torch.optim.lr_scheduler.MultiStepLR(trainer.stu_optimizer, [1], 0.0)      # lr -> 0 after one scheduler step
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=6)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    gs = GraphedTrainStep(trainer, *args, warmup=1)
+    w = [p.detach().clone() for p in stu.parameters()]
+    gs.step(*args)
+    assert any(not torch.equal(a.detach(), b_) for a, b_ in zip(stu.parameters(), w))          # lr 1e-3: the replay moved the student
+    sched.step()
+    assert trainer.stu_optimizer.param_groups[0]["lr"] == 0.0
+    w = [p.detach().clone() for p in stu.parameters()]
+    gs.step(*args)
+    assert all(torch.equal(a.detach(), b_) for a, b_ in zip(stu.parameters(), w)), "a replayed Adam ignored the scheduler's lr"
+    sd = trainer.stu_optimizer.state_dict()
+    assert sd["param_groups"][0]["step"] == 3                                                   # 1 warm-up + 2 replays
+    assert {"lr", "betas", "eps", "weight_decay", "grad_scale", "step", "params"} <= set(sd["param_groups"][0])
+    assert not any(k.startswith("_") for k in sd["param_groups"][0])                            # no device tables in the checkpoint
+    torch.save(sd, tmp_path / "opt.pt")                                                         # no device tables / raw pointers inside
+    sd2 = torch.load(tmp_path / "opt.pt", map_location="cpu")
+    opt2 = fo.FusedAdam(stu.parameters(), lr=1e-3)
+    opt2.load_state_dict(sd2)
+    assert opt2.param_groups[0]["step"] == 3
+    stu(g["x_s"]).square().mean().backward()
+    opt2.step()                                                                                 # CPU-loaded moments move to the device
+    assert opt2.state_dict()["param_groups"][0]["step"] == 4
+    # a checkpoint written by torch.optim.Adam (per-parameter `step`, no group `step` / `grad_scale`) loads and steps
+    ref_opt = torch.optim.Adam(stu.parameters(), lr=1e-3)
+    ref_opt.step()
+    ref_opt.step()
+    opt3 = fo.FusedAdam(stu.parameters(), lr=1e-3)
+    opt3.load_state_dict(ref_opt.state_dict())
+    assert opt3.param_groups[0]["step"] == 2
+    opt3.step()
+    assert opt3.state_dict()["param_groups"][0]["step"] == 3
+
+
+def test_kth_mask_radix_select_matches_torch_for_large_n_and_nan():
+    """train_human.py:429-430 at data-parallel sizes (n = 8 ranks x 32 x 21) and beyond; ties; NaN orders as the largest
+    value (torch.kthvalue) and a NaN threshold gives an all-false mask."""
+    from uda_poseestimation_amd import utils as U
+    g = torch.Generator().manual_seed(0)
+    for n_rows, K in ((32, 16), (256, 21), (2048, 32)):
+        act = torch.rand(n_rows, K, generator=g).cuda()
+        act[act < 0.1] = 0.25                                    # many exact ties
+        recon = torch.zeros(n_rows, K, 4, 4, device="cuda")
+        recon[:, :, 1, 2] = act
+        for ratio in (0.5, 0.07, 1.0):
+            k = int(ratio * act.numel())
+            mask, a, thr = U.confidence_mask(recon, ratio)
+            thr_t = torch.kthvalue(act.reshape(-1), k)[0]
+            assert torch.equal(a, act) and float(thr) == float(thr_t)
+            assert torch.equal(mask, act > thr_t)
+    act = torch.rand(8, 16, generator=g).cuda() - 0.5            # negative values too
+    act[0, 0] = float("nan"); act[3, 5] = float("nan")
+    recon = torch.full((8, 16, 4, 4), -2.0, device="cuda")
+    recon[:, :, 0, 0] = act
+    a = U.heatmap_activations(recon)
+    assert torch.equal(torch.isnan(a), torch.isnan(act))         # amax propagates NaN like torch
+    for k_ratio, expect_nan in ((0.5, False), (1.0, True)):
+        mask, _, thr = U.confidence_mask(recon, k_ratio, activates=act.clone())
+        thr_t = torch.kthvalue(act.reshape(-1), int(k_ratio * act.numel()))[0]
+        assert bool(torch.isnan(thr)) == bool(torch.isnan(thr_t)) == expect_nan
+        assert torch.equal(mask, act > thr_t)

@@ -65,7 +65,7 @@ _SIGS = {
     "udapose_multi_chunk": (ci, []),
     "udapose_ema_multi": (ci, [vp, vp, vp, vp, vp, vp, ci, cf, cf]),
     "udapose_adam_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, cf, vp]),
-    "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf]),
+    "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf, vp]),
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_debug_set_tiles": (None, [ci, ci, ci]),
     "udapose_debug_set_wgrad_group": (None, [ci, ci]),

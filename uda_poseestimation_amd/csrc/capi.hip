@@ -29,7 +29,7 @@ int opt_ema(hipStream_t, const long long*, const long long*, const long long*, c
 int opt_adam(hipStream_t, const long long*, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int,
              float, float, float, float, float, int, float, float*);
 int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float, float,
-            int, int, float);
+            int, int, float, float*);
 int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, float, float, float*);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
@@ -204,8 +204,8 @@ int udapose_adam_multi(void* stream, const long long* p, const long long* g, con
     return opt_adam(S(stream), p, g, m, v, sizes, bt, bo, nb, lr, b1, b2, eps, wd, step, gscale, dev_state);
 }
 int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes, const int* bt,
-                      const long long* bo, int nb, float lr, float mom, float wd, int nesterov, int first, float gscale) {
-    return opt_sgd(S(stream), p, g, buf, sizes, bt, bo, nb, lr, mom, wd, nesterov, first, gscale);
+                      const long long* bo, int nb, float lr, float mom, float wd, int nesterov, int first, float gscale, float* dev_state) {
+    return opt_sgd(S(stream), p, g, buf, sizes, bt, bo, nb, lr, mom, wd, nesterov, first, gscale, dev_state);
 }
 int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha, float* stats_out) {
     return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, stats_out);

@@ -64,6 +64,24 @@ __global__ void sqdiff_bwd_k(const float* __restrict__ a, const float* __restric
     }
 }
 
+// torch's total order on floats for max / kthvalue: NaN is the LARGEST value (and all NaNs are equal)
+__device__ __forceinline__ bool hm_better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;
+    if (vn) return i < bi;
+    return v > bv || (v == bv && i < bi);
+}
+// order-preserving float -> uint32 key (NaN -> 0xffffffff, the largest: torch.kthvalue's order)
+__device__ __forceinline__ unsigned int hm_key(float v) {
+    if (v != v) return 0xffffffffu;
+    const unsigned int b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float hm_unkey(unsigned int k) {
+    if (k == 0xffffffffu) return __uint_as_float(0x7fc00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 // per row: max value, first flat arg-max, (x,y) zeroed when max <= 0  (utils.py:54-75 / keypoint_detection.py:9-37);
 // optionally stamps the rectify patch (utils.py:77-109) into out (full row written: zeros elsewhere).
 __global__ void argmax_rectify_k(const float* __restrict__ hm, int H, int W, float* __restrict__ maxv, int* __restrict__ idx_out,
@@ -77,19 +95,19 @@ __global__ void argmax_rectify_k(const float* __restrict__ hm, int H, int W, flo
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < HW; i += TPB) {
         const float v = p[i];
-        if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }
+        if (hm_better(v, i, bv, bi)) { bv = v; bi = i; }      // (NaN counts as the maximum, first index on ties: torch / numpy)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bv, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        if (hm_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     bv = sv[0]; bi = si[0];
     for (int k = 1; k < TPB / 64; ++k)
-        if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) { bv = sv[k]; bi = si[k]; }
+        if (hm_better(sv[k], si[k], bv, bi)) { bv = sv[k]; bi = si[k]; }
     const bool pos = bv > 0.f;
     const int mx = pos ? bi % W : 0, my = pos ? bi / W : 0;
     if (threadIdx.x == 0) {
@@ -113,21 +131,52 @@ __global__ void argmax_rectify_k(const float* __restrict__ hm, int H, int W, flo
     }
 }
 
-// k-th smallest (1-indexed) of n values by rank counting, then mask[i] = (tm[i]*act[i]) > thr  (train_human.py:429-430)
+// k-th smallest (1-indexed) of n values, then mask[i] = (tm[i]*act[i]) > thr  (train_human.py:429-430).
+// MSB-first radix select in ONE work-group: 4 passes of 8 bits, each a 256-bin LDS histogram of the keys that still match
+// the prefix found so far, then a scan of the bins for the one that holds rank k.  O(n) per pass (the previous rank-count
+// form was O(n^2): 23 us at n = 512, ~0.7 ms at the n = 4096 of an 8-rank global batch); n = 4096 costs 16 key loads per
+// thread in all.  Values are read from L2 each pass (n <= 65536 floats = 256 KiB).  NaN orders as the largest value and a
+// NaN threshold gives an all-false mask, exactly like torch.kthvalue + `>`.
 __global__ void kth_mask_k(const float* __restrict__ act, const float* __restrict__ tm, int n, int k, float* __restrict__ thr_out,
                            unsigned char* __restrict__ mask, const float* __restrict__ act_local, int n_local) {
-    __shared__ float thr_s;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float v = act[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const float u = act[j];
-            rank += (u < v) || (u == v && j < i);
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int sel_bin, sel_rank;
+    unsigned int prefix = 0, pmask = 0, rank = (unsigned int)(k - 1);     // 0-based rank inside the surviving set
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned int key = hm_key(act[i]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
-        if (rank == k - 1) thr_s = v;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // wave 0: each lane owns 4 consecutive bins; exclusive prefix over lanes, then the owner of the rank reports
+            const int b0 = threadIdx.x * 4;
+            const unsigned int c0 = hist[b0], c1 = hist[b0 + 1], c2 = hist[b0 + 2], c3 = hist[b0 + 3];
+            const unsigned int tot = c0 + c1 + c2 + c3;
+            unsigned int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int up = __shfl_up(incl, o, 64);
+                if ((int)threadIdx.x >= o) incl += up;
+            }
+            const unsigned int excl = incl - tot;
+            if (rank >= excl && rank < incl) {
+                unsigned int r = rank - excl;
+                int b = b0;
+                if (r >= c0) { r -= c0; ++b; if (r >= c1) { r -= c1; ++b; if (r >= c2) { r -= c2; ++b; } } }
+                sel_bin = (unsigned int)b;
+                sel_rank = r;
+            }
+        }
+        __syncthreads();
+        prefix |= sel_bin << shift;
+        pmask |= 255u << shift;
+        rank = sel_rank;
+        __syncthreads();
     }
-    __syncthreads();
-    const float thr = thr_s;
+    const float thr = hm_unkey(prefix);
     if (threadIdx.x == 0 && thr_out) thr_out[0] = thr;
     const float* al = act_local ? act_local : act;
     const int nl = act_local ? n_local : n;
@@ -187,7 +236,7 @@ int hm_argmax_rectify(hipStream_t s, const float* hm, int R, int H, int W, float
 }
 int hm_kth_mask(hipStream_t s, const float* act, const float* tm, int n, int k, float* thr_out, unsigned char* mask, const float* act_local,
                 int n_local) {
-    if (k < 1 || k > n || n > 65536) return UDAPOSE_ERR_ARG;
+    if (k < 1 || k > n || n > (1 << 22)) return UDAPOSE_ERR_ARG;
     hipLaunchKernelGGL(kth_mask_k, dim3(1), dim3(1024), 0, s, act, tm, n, k, thr_out, mask, act_local, n_local);
     return udapose_check_launch();
 }

@@ -52,7 +52,10 @@ __global__ void ema_k(MtTable t, float alpha, float one_minus_alpha) {
     }
 }
 
-// device-resident step counter (graph-replay safe): state = [step, 1-beta1^step, sqrt(1-beta2^step), -]
+// device-resident optimizer state (graph-replay safe): state = [step, 1-beta1^step, sqrt(1-beta2^step), lr, grad_scale, -, -, -].
+// The step counter ticks on the device; lr and grad_scale are READ from it by the sweep, so that an lr scheduler
+// (MultiStepLR in the reference, train_human.py:143,202) or a loss-scale change reaches a captured step through a
+// 8-byte host-to-device copy instead of being frozen into the graph as kernel arguments.
 __global__ void adam_tick_k(float* __restrict__ state, float beta1, float beta2) {
     const double t = (double)state[0] + 1.0;
     state[0] = (float)t;
@@ -63,7 +66,7 @@ __global__ void adam_tick_k(float* __restrict__ state, float beta1, float beta2)
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0): operands a=param b=grad c=exp_avg d=exp_avg_sq
 __global__ void adam_k(MtTable t, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
                        const float* __restrict__ dev_state) {
-    if (dev_state) { bc1 = dev_state[1]; bc2_sqrt = dev_state[2]; }
+    if (dev_state) { bc1 = dev_state[1]; bc2_sqrt = dev_state[2]; lr = dev_state[3]; gscale = dev_state[4]; }
     const int ti = t.blk_tensor[blockIdx.x];
     const long long off = t.blk_off[blockIdx.x];
     float* p = (float*)t.a[ti];
@@ -86,8 +89,11 @@ __global__ void adam_k(MtTable t, float lr, float beta1, float beta2, float eps,
 }
 
 // torch.optim.SGD(momentum, nesterov, weight_decay): a=param b=grad c=momentum buffer
-__global__ void sgd_k(MtTable t, float lr, float momentum, float wd, int nesterov, int first_step, float gscale) {
+__global__ void sgd_tick_k(float* __restrict__ state) { state[0] += 1.f; }
+__global__ void sgd_k(MtTable t, float lr, float momentum, float wd, int nesterov, int first_step, float gscale,
+                      const float* __restrict__ dev_state) {
     // (first_step: torch initialises the momentum buffer with the first gradient)
+    if (dev_state) { first_step = dev_state[0] == 1.f; lr = dev_state[3]; gscale = dev_state[4]; }
     const int ti = t.blk_tensor[blockIdx.x];
     const long long off = t.blk_off[blockIdx.x];
     float* p = (float*)t.a[ti];
@@ -128,9 +134,11 @@ int opt_adam(hipStream_t s, const long long* p, const long long* g, const long l
     return udapose_check_launch();
 }
 int opt_sgd(hipStream_t s, const long long* p, const long long* g, const long long* buf, const long long* sizes, const int* blk_tensor,
-            const long long* blk_off, int nblocks, float lr, float momentum, float wd, int nesterov, int first_step, float gscale) {
+            const long long* blk_off, int nblocks, float lr, float momentum, float wd, int nesterov, int first_step, float gscale,
+            float* dev_state) {
     MtTable t{p, g, buf, nullptr, sizes, blk_tensor, blk_off};
     if (nblocks <= 0) return UDAPOSE_OK;
-    hipLaunchKernelGGL(sgd_k, dim3(nblocks), dim3(TPB), 0, s, t, lr, momentum, wd, nesterov, first_step, gscale);
+    if (dev_state) hipLaunchKernelGGL(sgd_tick_k, dim3(1), dim3(1), 0, s, dev_state);
+    hipLaunchKernelGGL(sgd_k, dim3(nblocks), dim3(TPB), 0, s, t, lr, momentum, wd, nesterov, first_step, gscale, dev_state);
     return udapose_check_launch();
 }

@@ -274,6 +274,12 @@ class GraphedTrainStep:
         # Data parallel: the confidence all-gather sits between the forwards and the losses, the gradient all-reduce between
         # backward and the optimizer; both stay eager, so the step is cut into three graphs around them.
         self.split = _dist_on() if split is None else bool(split)
+        # hyper-parameters that are kernel ARGUMENTS of the captured launches stay what they were at capture: step() checks
+        # them.  (lr / grad_scale are read from device memory and follow the optimizer's param_groups, see optim.py.)
+        self._frozen = self._frozen_hyper()
+        token = object()
+        for m in (trainer.student, trainer.teacher):
+            m._capture_token = token            # weight packs: captured once per network, unconditionally (pose_resnet._pack)
         self.g_fb, self.g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # other threads (the RCCL watchdog of torch.distributed) may touch the runtime while this thread captures
         mode = "thread_local" if _dist_on() else "global"
@@ -293,7 +299,21 @@ class GraphedTrainStep:
         trainer.sync()
         with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode):
             trainer._update()
+        for m in (trainer.student, trainer.teacher):
+            m._capture_token = None
+            m.weights_changed()
         torch.cuda.synchronize()
+
+    def _frozen_hyper(self):
+        t = self.t
+        opt = t.stu_optimizer
+        frozen = [("teacher_alpha", float(t.tea_optimizer.alpha)), ("lambda_c", float(t.lambda_c)), ("mask_ratio", float(t.mask_ratio)),
+                  ("sigma", float(t.sigma)), ("bn_momentum", float(t.student.bn_momentum))]
+        for gi, g in enumerate(opt.param_groups):
+            for k in ("betas", "eps", "weight_decay", "momentum", "nesterov"):
+                if k in g:
+                    frozen.append((f"group{gi}.{k}", g[k]))
+        return frozen
 
     def prefetch(self, x_s, label_s, weight_s, x_t_stu, x_t_tea):
         """Start copying the NEXT batch (pinned host tensors) into staging buffers on a copy stream; it overlaps with the
@@ -327,11 +347,20 @@ class GraphedTrainStep:
             st["theta_stu"].copy_(warp.recon_thetas(aug_param_stu, self.n, self.t.ratio), non_blocking=True)
         if aug_param_tea is not None:
             st["theta_tea"].copy_(warp.recon_thetas(aug_param_tea, self.n, self.t.ratio), non_blocking=True)
+        if self._frozen_hyper() != self._frozen:
+            changed = [a[0] for a, b in zip(self._frozen_hyper(), self._frozen) if a != b]
+            raise RuntimeError(f"GraphedTrainStep: {changed} changed after capture; these are baked into the captured launches - "
+                               "build a new GraphedTrainStep (lr and grad_scale may change freely)")
         self.g_fb.replay()
         if self.split:
             g = gather_activates(self.fwd_state["activates"])
             self.gathered.copy_(g if g is not None else self.fwd_state["activates"].reshape(-1))
             self.g_lb.replay()
         self.t.sync()
+        self.t.stu_optimizer.sync_hyper()        # lr scheduler / loss scale -> device state read by the captured sweep
         self.g_up.replay()
+        # the replayed Adam / EMA kernels changed both networks' parameters behind torch's back: every executor plan (other
+        # batch sizes, validate(), fp32 mode) must re-pack its bf16 weights before its next forward
+        self.t.student.weights_changed()
+        self.t.teacher.weights_changed()
         return self.out

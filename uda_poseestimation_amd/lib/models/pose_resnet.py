@@ -118,6 +118,11 @@ class PoseResNet(nn.Module):
         self._flat_grad2 = None       # second per-pass gradient buffer (backward passes running on different streams)
         self._grad_state = None       # (stream of the first backward of this step, pending second-buffer sum?)
         self._deferred_bn = []        # forwards whose BN running-statistics update is still to be applied, in call order
+        # Weights epoch: bumped by whoever changes parameter VALUES without torch seeing it (hipGraph replays of the fused
+        # Adam / EMA kernels): the bf16 weight packs of EVERY executor plan are stale once it moves.  In-place torch ops and
+        # the eager fused optimizers are caught by the parameters' version counters as well.
+        self._wepoch = 0
+        self._capture_token = None    # set by GraphedTrainStep around a capture: pack once per capture, unconditionally
         self._to_channels_last()
 
     # ------------------------------------------------------------------ layout / pointer bookkeeping
@@ -200,8 +205,25 @@ class PoseResNet(nn.Module):
         self._pack(hd, pa, params, need_bwd=torch.is_grad_enabled() and any(p.requires_grad for p in params))
         return hd
 
+    def weights_changed(self):
+        """Tell the executor that parameter values changed behind torch's back (raw-pointer kernels replayed from a
+        hipGraph): every plan re-packs its bf16 weights before its next forward."""
+        self._wepoch += 1
+
     def _pack(self, hd, pa, params, need_bwd):
-        version = sum(p._version for p in params)
+        version = (self._wepoch, sum(p._version for p in params))
+        if torch.cuda.is_current_stream_capturing():
+            # inside a capture the pack kernels must be IN the graph (a replay runs on the weights of that moment, whatever
+            # the host-side cache says): once per capture when the capturer handed out a token, on every call otherwise
+            tok = self._capture_token
+            cap_tok, cap_bwd = getattr(hd, "_cap", (None, False))
+            same = tok is not None and cap_tok is tok
+            if same and (cap_bwd or not need_bwd):
+                return
+            check(lib().udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
+            hd._cap = (tok, bool(need_bwd) or (same and cap_bwd))
+            hd.wpack_version = None       # what a replay leaves in the pack is unknown to the host-side cache
+            return
         if hd.wpack_version != (version, need_bwd) and hd.wpack_version != (version, True):
             check(lib().udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
             hd.wpack_version = (version, need_bwd)
@@ -289,9 +311,16 @@ class PoseResNet(nn.Module):
             gptrs = self._grad_ptrs2
         dout = dout.contiguous().float()
         check(lib().udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
+        # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not
+        # zeros: SGD's weight decay and Adam must skip it exactly as torch.optim skips parameters without .grad)
+        nograd = self._no_grad_ids()
         for p, v in zip(params, views):
-            if p.requires_grad:
+            if p.requires_grad and id(p) not in nograd:
                 p.grad = v
+
+    def _no_grad_ids(self):
+        fc = getattr(self.backbone, "fc", None)
+        return {id(p) for p in fc.parameters()} if fc is not None else set()
 
     def forward(self, x):
         params = list(self.parameters())

@@ -1,6 +1,13 @@
 """Fused multi-tensor optimizers on MI355X kernels: drop-in torch.optim.Optimizer subclasses for the reference's
 `Adam(student.parameters(), lr)` / `SGD(..., momentum=0.9, weight_decay=1e-4, nesterov=True)` (train_human.py:136-139).
 One kernel launch sweeps all parameter tensors (28 B/param for Adam), instead of torch's per-group foreach chains.
+
+Graph-replay safe: the step counter, the learning rate and the gradient scale live in an 8-float device tensor per
+parameter group (`udapose_adam_multi`'s dev_state).  `sync_hyper()` uploads lr / grad_scale when the host values changed
+(an lr scheduler, a loss-scale update); GraphedTrainStep calls it before every replay.  `state_dict()` is torch's plain
+layout (device tables and state tensors are kept on the optimizer object, not in param_groups) with `step` read back from
+the device counter; checkpoints written by torch.optim.Adam / SGD load (per-parameter `step` entries are folded into the
+group counter).
 """
 import torch
 
@@ -10,7 +17,15 @@ from .utils import _MultiTensorTable, _bump_versions
 
 
 class _FusedBase(torch.optim.Optimizer):
-    def _gather(self, group, state_names):
+    _state_names = ()
+
+    def __init__(self, params, defaults):
+        super().__init__(params, defaults)
+        self._tables = {}        # group index -> _MultiTensorTable (raw device pointers: never serialised)
+        self._dev = {}           # group index -> (device state tensor [8], uploaded (lr, grad_scale))
+
+    # ------------------------------------------------------------------ tables / device state
+    def _gather(self, gi, group):
         ps = [p for p in group["params"] if p.grad is not None]
         if not ps:
             return None
@@ -21,60 +36,111 @@ class _FusedBase(torch.optim.Optimizer):
             if p.grad.stride() != p.stride():
                 p.grad = p.grad.clone(memory_format=torch.preserve_format).as_strided(p.shape, p.stride()).copy_(p.grad)
             st = self.state[p]
-            for n in state_names:
-                if n not in st:
+            for n in self._state_names:
+                if n not in st or not torch.is_tensor(st[n]) or st[n].device != p.device or st[n].stride() != p.stride():
+                    old = st.get(n)
                     st[n] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        lists = [[p.data for p in ps], [p.grad for p in ps]] + [[self.state[p][n] for p in ps] for n in state_names]
+                    if torch.is_tensor(old) and old.shape == p.shape:     # state loaded from a checkpoint (CPU / other layout)
+                        st[n].copy_(old)
+        lists = [[p.data for p in ps], [p.grad for p in ps]] + [[self.state[p][n] for p in ps] for n in self._state_names]
         key = _MultiTensorTable.key_of(lists)
-        tab = group.get("_table")
+        tab = self._tables.get(gi)
         if tab is None or tab.key != key:
             tab = _MultiTensorTable(lists)
-            group["_table"] = tab
+            self._tables[gi] = tab
         return ps, tab
+
+    def _dev_state(self, gi, group, device):
+        """[step, bc1, bc2sqrt, lr, grad_scale, 0, 0, 0] on the device; created from the host's group values."""
+        ent = self._dev.get(gi)
+        if ent is None or ent[0].device != device:
+            hyper = (float(group["lr"]), float(group.get("grad_scale", 1.0)))
+            ds = torch.tensor([float(group.get("step", 0)), 0.0, 0.0, hyper[0], hyper[1], 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+            ent = [ds, hyper]
+            self._dev[gi] = ent
+        return ent
+
+    def sync_hyper(self):
+        """Upload lr / grad_scale of every group whose host value changed since the last upload (stream-ordered 8-byte copy;
+        call before replaying a captured step)."""
+        for gi, group in enumerate(self.param_groups):
+            ent = self._dev.get(gi)
+            if ent is None:
+                continue
+            hyper = (float(group["lr"]), float(group.get("grad_scale", 1.0)))
+            if hyper != ent[1]:
+                ent[0][3:5].copy_(torch.tensor(hyper, dtype=torch.float32), non_blocking=True)
+                ent[1] = hyper
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        for gi, group in enumerate(self.param_groups):
+            ent = self._dev.get(gi)
+            if ent is not None:
+                group["step"] = int(round(float(ent[0][0].item())))       # replays tick the device counter only
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            if "step" not in group or group["step"] is None:
+                # torch.optim.Adam / SGD checkpoints keep `step` per parameter (or not at all)
+                steps = [float(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
+                group["step"] = int(max(steps)) if steps else 0
+            group.setdefault("grad_scale", 1.0)
+        self._tables, self._dev = {}, {}          # rebuilt (from group['step'], on the parameters' device) at the next step()
 
 
 class FusedAdam(_FusedBase):
+    _state_names = ("exp_avg", "exp_avg_sq")
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale, step=0))
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            got = self._gather(group, ("exp_avg", "exp_avg_sq"))
+        capturing = torch.cuda.is_current_stream_capturing()
+        for gi, group in enumerate(self.param_groups):
+            got = self._gather(gi, group)
             if got is None:
                 continue
             ps, t = got
-            group["step"] += 1
+            ent = self._dev_state(gi, group, ps[0].device)          # (created with the number of steps done so far)
+            group["step"] = group.get("step", 0) + 1
             b1, b2 = group["betas"]
-            # the step counter / bias corrections live on the device so that a captured step replays correctly
-            ds = group.get("_dev_state")
-            if ds is None or ds.device != ps[0].device:
-                ds = torch.zeros(4, dtype=torch.float32, device=ps[0].device)
-                ds[0] = group["step"] - 1
-                group["_dev_state"] = ds
+            if not capturing:
+                self.sync_hyper()
             check(lib().udapose_adam_multi(_hip.stream(), ptr(t.ptrs[0]), ptr(t.ptrs[1]), ptr(t.ptrs[2]), ptr(t.ptrs[3]), ptr(t.sizes), ptr(t.blk_t),
                                            ptr(t.blk_o), t.nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                           float(group["weight_decay"]), int(group["step"]), float(group["grad_scale"]), ptr(ds)), "adam_multi")
+                                           float(group["weight_decay"]), int(group["step"]), float(group.get("grad_scale", 1.0)), ptr(ent[0])),
+                  "adam_multi")
             _bump_versions(ps)
         return loss
 
 
 class FusedSGD(_FusedBase):
+    _state_names = ("momentum_buffer",)
+
     def __init__(self, params, lr, momentum=0.9, weight_decay=0.0, nesterov=False, grad_scale=1.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, grad_scale=grad_scale, step=0))
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            got = self._gather(group, ("momentum_buffer",))
+        capturing = torch.cuda.is_current_stream_capturing()
+        for gi, group in enumerate(self.param_groups):
+            got = self._gather(gi, group)
             if got is None:
                 continue
             ps, t = got
-            group["step"] += 1
+            ent = self._dev_state(gi, group, ps[0].device)
+            group["step"] = group.get("step", 0) + 1
+            if not capturing:
+                self.sync_hyper()
             check(lib().udapose_sgd_multi(_hip.stream(), ptr(t.ptrs[0]), ptr(t.ptrs[1]), ptr(t.ptrs[2]), ptr(t.sizes), ptr(t.blk_t), ptr(t.blk_o),
                                           t.nblocks, float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]),
-                                          int(group["nesterov"]), int(group["step"] == 1), float(group["grad_scale"])), "sgd_multi")
+                                          int(group["nesterov"]), int(group["step"] == 1), float(group.get("grad_scale", 1.0)), ptr(ent[0])),
+                  "sgd_multi")
             _bump_versions(ps)
         return loss

@@ -1,4 +1,10 @@
 """Mean-teacher helpers (API mirror of the reference's utils.py:9-109) on MI355X kernels."""
+if not __package__:
+    # `from utils import *` with this package's directory on sys.path (train_human.py:29): bind the name `utils` to
+    # uda_poseestimation_amd.utils (import returns that module; this top-level copy is discarded)
+    import _dropin
+    _dropin.alias(["utils"])
+    __package__ = "uda_poseestimation_amd"
 import ctypes as C
 
 import numpy as np
@@ -42,6 +48,7 @@ class OldWeightEMA(object):
         self._table = None
         for p, src_p in zip(self.target_params, self.source_params):
             p.data[:] = src_p.data[:]
+        _bump_versions(self.target_params)       # (`.data` writes are invisible to the version counters the pack cache reads)
 
     def step(self):
         tp = [p.data for p in self.target_params]

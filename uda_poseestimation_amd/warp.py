@@ -103,6 +103,25 @@ def warp_chain(x, theta):
     return _WarpFn.apply(x, theta)
 
 
+def affine(img, angle, translate, scale, shear, interpolation=None, fill=None):
+    """`torchvision.transforms.functional.affine` for CUDA tensors as the reference's loop calls it (train_human.py:366-368,
+    388-390, 412, 421-423): img [C,H,W] or [N,C,H,W], nearest interpolation, zero fill, centre of rotation = image centre;
+    differentiable (the student's heat-maps are warped under autograd, :421-423).  One launch of the batched kernel with a
+    single stage; the loop's three-call chains can use `warp_chain` / `recon_heatmaps` instead (one launch for the batch)."""
+    if interpolation not in (None, 0, "nearest") and getattr(interpolation, "value", interpolation) != "nearest":
+        raise NotImplementedError("only nearest interpolation (torchvision's default, the one the reference uses)")
+    if fill not in (None, 0, 0.0):
+        raise NotImplementedError("only zero fill")
+    if not isinstance(shear, (list, tuple)):
+        shear = [float(shear), 0.0]
+    squeeze = img.dim() == 3
+    x = img.unsqueeze(0) if squeeze else img
+    m = inverse_affine_matrix(float(angle), [float(translate[0]), float(translate[1])], float(scale), [float(shear[0]), float(shear[1])])
+    theta = torch.tensor(m, dtype=torch.float32).reshape(1, 1, 6).expand(x.shape[0], 1, 6).contiguous().to(x.device, non_blocking=True)
+    out = warp_chain(x, theta)
+    return out.squeeze(0) if squeeze else out
+
+
 def recon_heatmaps(y, aug_param, ratio):
     """The loop's heat-map re-warp (train_human.py:361-372 / 418-423) for the whole batch."""
     return warp_chain(y, recon_thetas(aug_param, y.shape[0], ratio, y.device))
