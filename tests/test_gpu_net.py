@@ -127,17 +127,18 @@ def test_gradient_accumulation_and_zero_grad():
     x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(9)).cuda()
     net.train()
     net(x).square().mean().backward()
-    g1 = [p.grad.clone() for p in net.parameters()]
+    g1 = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    assert sum(a is None for a in g1) == 2          # backbone.fc.{weight,bias}: not in forward, no gradient
     # second backward without zero_grad accumulates (two student forwards per step, train_human.py:415-416,436)
     net(x).square().mean().backward()
     for p, a in zip(net.parameters(), g1):
-        if a.abs().max() > 0:
+        if a is not None and a.abs().max() > 0:
             assert _rel(p.grad, 2 * a) < 2e-2
     net.zero_grad(set_to_none=True)
     assert all(p.grad is None for p in net.parameters())
     net(x).square().mean().backward()
     for p, a in zip(net.parameters(), g1):
-        if a.abs().max() > 0:
+        if a is not None and a.abs().max() > 0:
             assert _rel(p.grad, a) < 2e-2
 
 
@@ -307,13 +308,16 @@ def test_fused_bn_backward_reduction_equals_separate_reduce_launches(layers, N, 
     print("fused vs separate BN-backward reduction: worst relative L2 difference of a parameter gradient", worst)
 
 
-def test_poseresnet101_bf16_forward_backward_256_n2_vs_oracle():
+@pytest.mark.parametrize("gamma3", [0.1, 0.25])
+def test_poseresnet101_bf16_forward_backward_256_n2_vs_oracle(gamma3):
     """The BENCHED network and precision, whole: PoseResNet-101, K=16, 256x256, bf16, N=2, forward + backward against
-    oracle/pose_resnet_ref.py (fp32) and its bf16-storage emulation, with trained-like conditioning (bn3.gamma = 0.25).
-    Reports error growth per stage: what bf16 storage does to each stage's output on the CPU (emulation vs fp32), and the
-    device's parameter-gradient error per stage group against both."""
+    oracle/pose_resnet_ref.py (fp32) and its bf16-storage emulation, with trained-like conditioning (bn3.gamma = 0.1 /
+    0.25: 33 train-mode-BN bottlenecks amplify ANY perturbation - with 0.25 the CPU emulation of bf16 storage alone moves
+    the fp32 heat-maps by ~18 % of their maximum, so the bars are relative to that storage noise).
+    Reports error growth per stage: the fp32 stage outputs' scale, and the device's parameter-gradient error per stage
+    group next to what bf16 storage alone does to the same gradients on the CPU."""
     from oracle.bf16_emulation import forward_bf16_emulated
-    ref, net = _pair((3, 4, 23, 3), 16, seed=3, gamma3=0.25)
+    ref, net = _pair((3, 4, 23, 3), 16, seed=3, gamma3=gamma3)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 3, 256, 256, generator=g).clamp(-2.1, 2.6)
     ref.train(); net.train()
@@ -330,7 +334,7 @@ def test_poseresnet101_bf16_forward_backward_256_n2_vs_oracle():
     scale = y_ref.abs().max().item()
     err, err_emu = (y.cpu() - y_ref.detach()).abs().max().item(), (y.cpu() - y_emu.detach()).abs().max().item()
     noise = (y_emu.detach() - y_ref.detach()).abs().max().item()
-    print(f"R101 bf16 256x256 N=2: max|y|={scale:.4f} |device-fp32|={err:.3e} |device-emulated|={err_emu:.3e} |emulated-fp32|={noise:.3e}")
+    print(f"R101 bf16 256x256 N=2 bn3.gamma={gamma3}: max|y|={scale:.4f} |device-fp32|={err:.3e} |device-emulated|={err_emu:.3e} |emulated-fp32|={noise:.3e}")
     for n_, o in stage_out.items():
         print(f"  fp32 stage output {n_:10s} max|.|={o.abs().max().item():.3e} shape {tuple(o.shape)}")
     assert err <= 1.5 * noise + 2e-3 * scale and err_emu <= 1.5 * noise + 2e-3 * scale, (err, err_emu, noise, scale)
