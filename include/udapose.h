@@ -72,6 +72,8 @@ int udapose_pack_strided(void* stream, const float* src, void* dst, int A, int K
 
 /* ---------------------------------------------------------------- layout conversion at the NCHW fp32 boundary */
 int udapose_nchw_f32_to_nhwc_bf16(void* stream, const float* src, void* dst, int N, int C, int HW, int Cpad);
+/* the same into fp32 NHWC (style path at the reference's precision: it runs outside autocast, train_human.py:347-356) */
+int udapose_nchw_f32_to_nhwc_f32(void* stream, const float* src, float* dst, int N, int C, int HW, int Cpad);
 /* optional per-channel clamp lo/hi[C] = the "recover" clamp of train_human.py:32-33,276,351,356 */
 int udapose_nhwc_to_nchw_f32(void* stream, const void* src, int src_is_f32, float* dst, int N, int C, int HW, int Cstride,
                              const float* lo, const float* hi);
@@ -105,6 +107,7 @@ int udapose_bn_bwd_pre(void* stream, const void* g, int g_is_f32, const void* y,
 int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C);
 int udapose_maxpool3x3s2_bwd(void* stream, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C);
 int udapose_maxpool2x2_ceil(void* stream, const void* x, void* y, int N, int H, int W, int C);
+int udapose_maxpool2x2_ceil_f32(void* stream, const float* x, float* y, int N, int H, int W, int C);   /* fp32 NHWC (Style_net.py:72) */
 
 /* ---------------------------------------------------------------- whole pose network (lib/models/pose_resnet.py:59-126:
  * PoseResNet.forward = head(upsampling(backbone(x)))), parameters by index in .parameters() order (host arrays of
@@ -143,6 +146,14 @@ int udapose_cons_loss_fwd(void* stream, const float* stu, const float* tea, cons
                           float* mean_out);
 int udapose_cons_loss_bwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const float* gscale, int R,
                           int HW, float* dstu);
+/* ConsLoss(valid_mask=) (lib/models/loss.py:129-130: loss_map[valid_mask].mean()): `valid` [R/K][HW] selects (b,h,w) positions of
+ * loss_map = mean over the K channels; valid_count = number of selected positions, on the device (udapose_mask_count):
+ * mean_out = sum over selected of mask*(s-t)^2 / (K * valid_count) */
+int udapose_mask_count(void* stream, const unsigned char* mask, size_t n, float* count);
+int udapose_cons_loss_valid_fwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const unsigned char* valid,
+                                const float* valid_count, int R, int K, int HW, float* rows, float* mean_out);
+int udapose_cons_loss_valid_bwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const unsigned char* valid,
+                                const float* valid_count, const float* gscale, int R, int K, int HW, float* dstu);
 /* get_max_preds(_torch) (lib/keypoint_detection.py:9-37, utils.py:54-75) and rectify (utils.py:77-109): any output may
  * be NULL.  patch: [(2*rad+1)^2] fp32 Gaussian table built by the caller exactly as utils.py:93-98 does. */
 int udapose_heatmap_argmax(void* stream, const float* hm, int R, int H, int W, float* maxvals, int* flat_idx, float* preds_xy,
@@ -176,6 +187,9 @@ int udapose_sgd_multi(void* stream, const long long* p, const long long* g, cons
  * out = alpha*adain(content, style) + (1-alpha)*content; stats_out (optional) [N][C][4] = (mean_c, std_c, mean_s, std_s) */
 int udapose_adain(void* stream, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps,
                   float alpha, float* stats_out);
+/* the same on fp32 NHWC features (the reference's precision); out may be NULL: statistics only (calc_mean_std) */
+int udapose_adain_f32(void* stream, const float* content, const float* style, float* out, int N, int HWc, int HWs, int C, float eps,
+                      float alpha, float* stats_out);
 
 /* ---------------------------------------------------------------- batched nearest inverse-affine re-warp
  * (torchvision.transforms.functional.affine x3 per sample, train_human.py:366-368,388-390,412,421-423): NCHW fp32;

@@ -4,7 +4,10 @@
   * adain_ref         <- lib/models/Style_net.py:21-29
   * make_vgg_ref / make_decoder_ref <- lib/models/Style_net.py:32-118 (VGG-19 with reflection padding; mirrored decoder)
   * style_forward_ref <- lib/models/Style_net.py:163-177, returning only g_t: the sole output the training loop
-    consumes (train_human.py:275,350,355 take [2]); the loss-only re-encode of g_t is not restated.
+    consumes (train_human.py:275,350,355 take [2])
+  * gram_matrix_ref   <- lib/models/Style_net.py:14-19
+  * style_forward_full_ref <- lib/models/Style_net.py:136-177: (loss_c, loss_s, g_t) with the re-encode of g_t, the content
+    MSE on relu4_1 and the four Gram-matrix MSEs (relu1_1 .. relu4_1)
 """
 import torch
 import torch.nn as nn
@@ -59,3 +62,34 @@ def style_forward_ref(vgg31, decoder, content, style, alpha=1.0):
     t = adain_ref(cf, sf)
     t = alpha * t + (1 - alpha) * cf
     return decoder(t)
+
+
+def gram_matrix_ref(y):
+    b, ch, h, w = y.shape
+    f = y.reshape(b, ch, w * h)
+    return f.bmm(f.transpose(1, 2)) / (ch * h * w)
+
+
+def encode_with_intermediate_ref(vgg31, x):
+    """relu1_1, relu2_1, relu3_1, relu4_1: the slices [:4], [4:11], [11:18], [18:31] of the encoder (Style_net.py:126-129)."""
+    ch = list(vgg31.children())
+    outs = []
+    for lo, hi in ((0, 4), (4, 11), (11, 18), (18, 31)):
+        for m in ch[lo:hi]:
+            x = m(x)
+        outs.append(x)
+    return outs
+
+
+def style_forward_full_ref(vgg31, decoder, content, style, alpha=1.0):
+    assert 0 <= alpha <= 1
+    style_feats = encode_with_intermediate_ref(vgg31, style)
+    cf = vgg31(content)
+    t = adain_ref(cf, style_feats[-1])
+    t = alpha * t + (1 - alpha) * cf
+    g_t = decoder(t)
+    g_feats = encode_with_intermediate_ref(vgg31, g_t)
+    mse = torch.nn.functional.mse_loss
+    loss_c = mse(g_feats[-1], t)
+    loss_s = sum(mse(gram_matrix_ref(a), gram_matrix_ref(b)) for a, b in zip(g_feats, style_feats))
+    return loss_c, loss_s, g_t

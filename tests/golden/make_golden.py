@@ -41,8 +41,11 @@ def main():
     gt = torch.rand(B, K, H, W, generator=g)
     w = (torch.rand(B, K, 1, generator=g) > 0.3).float()
     mask = torch.rand(B, K, generator=g) > 0.5
+    valid = torch.rand(B, H, W, generator=torch.Generator().manual_seed(123)) > 0.4      # (own generator: later draws unchanged)
     np.savez_compressed(
-        os.path.join(OUT, "losses.npz"), pred=pred.numpy(), gt=gt.numpy(), w=w.numpy(), mask=mask.numpy(),
+        os.path.join(OUT, "losses.npz"), pred=pred.numpy(), gt=gt.numpy(), w=w.numpy(), mask=mask.numpy(), valid=valid.numpy(),
+        cons_valid=ref_loss.ConsLoss()(pred, gt, valid_mask=valid, tea_mask=mask).numpy(),
+        cons_valid_only=ref_loss.ConsLoss()(pred, gt, valid_mask=valid).numpy(),
         mse_mean=ref_loss.JointsMSELoss()(pred, gt, w).numpy(),
         mse_mean_now=ref_loss.JointsMSELoss()(pred, gt).numpy(),
         mse_none=ref_loss.JointsMSELoss(reduction="none")(pred, gt, w).numpy(),
@@ -117,7 +120,8 @@ def main():
         feat = vgg31(content)
     np.savez_compressed(
         os.path.join(OUT, "style.npz"), c=c.numpy(), s=s.numpy(), mean=m.numpy(), std=sd.numpy(), adain=ad.numpy(),
-        content=content.numpy(), style=style.numpy(), alpha=np.float64(0.6), g_t=g_t.numpy(), feat=feat.numpy())
+        content=content.numpy(), style=style.numpy(), alpha=np.float64(0.6), g_t=g_t.numpy(), feat=feat.numpy(),
+        loss_c=lc.numpy(), loss_s=ls.numpy(), gram=ref_style.gram_matrix(feat).numpy())
 
     # ---- reference-owned Upsampling + head wrapper (A3, A4) under a throw-away torchvision stand-in:
     # only the reference's own pose_resnet.py code (deconv stack, head, init, state_dict names) is exercised.

@@ -21,6 +21,9 @@ def test_losses_match_reference(golden_dir):
     np.testing.assert_allclose(losses_ref.joints_mse_ref(pred, gt, w, "none").numpy(), z["mse_none"], rtol=1e-6)
     np.testing.assert_allclose(losses_ref.cons_loss_ref(pred, gt, tea_mask=mask).numpy(), z["cons_masked"], rtol=1e-6)
     np.testing.assert_allclose(losses_ref.cons_loss_ref(pred, gt).numpy(), z["cons_plain"], rtol=1e-6)
+    valid = torch.from_numpy(z["valid"])          # ConsLoss(valid_mask=) (loss.py:129-130)
+    np.testing.assert_allclose(losses_ref.cons_loss_ref(pred, gt, valid_mask=valid, tea_mask=mask).numpy(), z["cons_valid"], rtol=1e-6)
+    np.testing.assert_allclose(losses_ref.cons_loss_ref(pred, gt, valid_mask=valid).numpy(), z["cons_valid_only"], rtol=1e-6)
     # closed form of SURVEY Appendix F
     closed = (mask[:, :, None, None] * (pred - gt) ** 2).sum() / pred.numel()
     np.testing.assert_allclose(closed.numpy(), z["cons_masked"], rtol=1e-5)
@@ -92,6 +95,14 @@ def test_style_matches_reference(golden_dir):
                                           float(z["alpha"]))
     np.testing.assert_allclose(feat.numpy(), z["feat"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(g_t.numpy(), z["g_t"], rtol=1e-4, atol=1e-4)
+    # the full forward (Style_net.py:163-177): content loss on relu4_1 + four Gram-matrix style losses
+    np.testing.assert_allclose(style_ref.gram_matrix_ref(feat).numpy(), z["gram"], rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        lc, ls, g2 = style_ref.style_forward_full_ref(vgg31, dec, torch.from_numpy(z["content"]), torch.from_numpy(z["style"]),
+                                                      float(z["alpha"]))
+    np.testing.assert_allclose(g2.numpy(), z["g_t"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(float(lc), float(z["loss_c"]), rtol=1e-4)
+    np.testing.assert_allclose(float(ls), float(z["loss_s"]), rtol=1e-4)
 
 
 def test_upsampling_head_match_reference(golden_dir):

@@ -31,6 +31,7 @@ _SIGS = {
     "udapose_transpose_cast": (ci, [vp, vp, vp, ci, ci, ci]),
     "udapose_pack_strided": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, cl, cl, cl, cl]),
     "udapose_nchw_f32_to_nhwc_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_nchw_f32_to_nhwc_f32": (ci, [vp, vp, vp, ci, ci, ci, ci]),
     "udapose_nhwc_to_nchw_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
     "udapose_bn_finalize": (ci, [vp, vp, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp]),
     "udapose_bn_eval_coeff": (ci, [vp, ci, vp, vp, vp, vp, cf, vp, vp]),
@@ -41,6 +42,7 @@ _SIGS = {
     "udapose_maxpool3x3s2_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
     "udapose_maxpool3x3s2_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci]),
     "udapose_maxpool2x2_ceil": (ci, [vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_maxpool2x2_ceil_f32": (ci, [vp, vp, vp, ci, ci, ci, ci]),
     "udapose_net_create": (ci, [vp, ci, ci, ci, ci, ci, vp]),
     "udapose_net_destroy": (None, [vp]),
     "udapose_net_num_params": (ci, [vp]),
@@ -59,6 +61,9 @@ _SIGS = {
     "udapose_joints_mse_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
     "udapose_cons_loss_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),
     "udapose_cons_loss_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
+    "udapose_mask_count": (ci, [vp, vp, sz, vp]),
+    "udapose_cons_loss_valid_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp]),
+    "udapose_cons_loss_valid_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "udapose_heatmap_argmax": (ci, [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci]),
     "udapose_kth_mask": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci]),
     "udapose_pck": (ci, [vp, vp, vp, ci, ci, cf, cf, cf, vp, vp]),
@@ -67,6 +72,7 @@ _SIGS = {
     "udapose_adam_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, cf, vp]),
     "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf, vp]),
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
+    "udapose_adain_f32": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_debug_set_tiles": (None, [ci, ci, ci]),
     "udapose_debug_set_wgrad_group": (None, [ci, ci]),
     "udapose_debug_set_bn_bwd_fused": (None, [ci]),

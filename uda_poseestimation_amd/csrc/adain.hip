@@ -7,7 +7,33 @@
 namespace {
 constexpr int TPB = 256;
 
-__global__ void adain_k(const bf16_t* __restrict__ content, const bf16_t* __restrict__ style, bf16_t* __restrict__ out, int HWc, int HWs, int C,
+// 8 consecutive channel values <-> fp32 registers, bf16 or fp32 storage (fp32: the reference's own precision for the style
+// path, train_human.py:347-356 runs it outside autocast)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *(bf16x8*)p = o;
+}
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+
+template <typename T>
+__global__ void adain_k(const T* __restrict__ content, const T* __restrict__ style, T* __restrict__ out, int HWc, int HWs, int C,
                         float eps, float alpha, float* __restrict__ stats_out) {
     __shared__ float red[32][8][4][8];   // [pixel lane][cg][stat][e]  32 KiB
     __shared__ float coef[64][2];
@@ -18,17 +44,19 @@ __global__ void adain_k(const bf16_t* __restrict__ content, const bf16_t* __rest
     float cs[8], cq[8], ss[8], sq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cq[e] = ss[e] = sq[e] = 0.f;
-    const bf16_t* cp = content + (size_t)n * HWc * C + c0;
-    const bf16_t* sp = style + (size_t)n * HWs * C + c0;
+    const T* cp = content + (size_t)n * HWc * C + c0;
+    const T* sp = style + (size_t)n * HWs * C + c0;
     for (int p = pl; p < HWc; p += 32) {
-        const bf16x8 v = *(const bf16x8*)(cp + (size_t)p * C);
+        float v[8];
+        ld8<T>(cp + (size_t)p * C, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; cs[e] += f; cq[e] += f * f; }
+        for (int e = 0; e < 8; ++e) { const float f = v[e]; cs[e] += f; cq[e] += f * f; }
     }
     for (int p = pl; p < HWs; p += 32) {
-        const bf16x8 v = *(const bf16x8*)(sp + (size_t)p * C);
+        float v[8];
+        ld8<T>(sp + (size_t)p * C, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ss[e] += f; sq[e] += f * f; }
+        for (int e = 0; e < 8; ++e) { const float f = v[e]; ss[e] += f; sq[e] += f * f; }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[pl][cg][0][e] = cs[e]; red[pl][cg][1][e] = cq[e]; red[pl][cg][2][e] = ss[e]; red[pl][cg][3][e] = sq[e]; }
@@ -54,13 +82,14 @@ __global__ void adain_k(const bf16_t* __restrict__ content, const bf16_t* __rest
     float k0[8], k1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { k0[e] = coef[cg * 8 + e][0]; k1[e] = coef[cg * 8 + e][1]; }
-    bf16_t* op = out + (size_t)n * HWc * C + c0;
+    if (!out) return;                     // statistics only (calc_mean_std)
+    T* op = out + (size_t)n * HWc * C + c0;
     for (int p = pl; p < HWc; p += 32) {
-        const bf16x8 v = *(const bf16x8*)(cp + (size_t)p * C);
-        bf16x8 o;
+        float v[8], o[8];
+        ld8<T>(cp + (size_t)p * C, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)v[e] * k0[e] + k1[e]);
-        *(bf16x8*)(op + (size_t)p * C) = o;
+        for (int e = 0; e < 8; ++e) o[e] = v[e] * k0[e] + k1[e];
+        st8<T>(op + (size_t)p * C, o);
     }
 }
 }  // namespace
@@ -68,6 +97,12 @@ __global__ void adain_k(const bf16_t* __restrict__ content, const bf16_t* __rest
 int adain_launch(hipStream_t s, const bf16_t* content, const bf16_t* style, bf16_t* out, int N, int HWc, int HWs, int C, float eps, float alpha,
                  float* stats_out) {
     if (C % 64 || HWc < 2 || HWs < 2) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(adain_k, dim3(N * (C / 64)), dim3(TPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, stats_out);
+    hipLaunchKernelGGL(adain_k<bf16_t>, dim3(N * (C / 64)), dim3(TPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, stats_out);
+    return udapose_check_launch();
+}
+int adain_launch_f32(hipStream_t s, const float* content, const float* style, float* out, int N, int HWc, int HWs, int C, float eps, float alpha,
+                     float* stats_out) {
+    if (C % 64 || HWc < 2 || HWs < 2) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(adain_k<float>, dim3(N * (C / 64)), dim3(TPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, stats_out);
     return udapose_check_launch();
 }

@@ -19,8 +19,14 @@ int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_
 int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
 int pw_maxpool2x2_ceil(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int);
-int hm_sqdiff_rows(hipStream_t, const float*, const float*, const float*, const unsigned char*, int, int, float, float*, float*);
-int hm_sqdiff_bwd(hipStream_t, const float*, const float*, const float*, const unsigned char*, const float*, float, int, int, float*);
+int hm_sqdiff_rows(hipStream_t, const float*, const float*, const float*, const unsigned char*, int, int, float, float*, float*,
+                   const unsigned char*, const float*, int);
+int hm_sqdiff_bwd(hipStream_t, const float*, const float*, const float*, const unsigned char*, const float*, float, int, int, float*,
+                  const unsigned char*, const float*, int);
+int hm_mask_count(hipStream_t, const unsigned char*, size_t, float*);
+int pw_maxpool2x2_ceil_f32(hipStream_t, const float*, float*, int, int, int, int);
+int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
+int adain_launch_f32(hipStream_t, const float*, const float*, float*, int, int, int, int, float, float, float*);
 int hm_argmax_rectify(hipStream_t, const float*, int, int, int, float*, int*, float*, float*, const float*, int);
 int hm_kth_mask(hipStream_t, const float*, const float*, int, int, float*, unsigned char*, const float*, int);
 int hm_pck(hipStream_t, const float*, const float*, int, int, float, float, float, float*, float*);
@@ -133,6 +139,12 @@ int udapose_maxpool3x3s2_bwd(void* stream, const void* dy, const unsigned char* 
 int udapose_maxpool2x2_ceil(void* stream, const void* x, void* y, int N, int H, int W, int C) {
     return pw_maxpool2x2_ceil(S(stream), CB16(x), B16(y), N, H, W, C);
 }
+int udapose_maxpool2x2_ceil_f32(void* stream, const float* x, float* y, int N, int H, int W, int C) {
+    return pw_maxpool2x2_ceil_f32(S(stream), x, y, N, H, W, C);
+}
+int udapose_nchw_f32_to_nhwc_f32(void* stream, const float* src, float* dst, int N, int C, int HW, int Cpad) {
+    return pw_nchw_f32_to_nhwc_f32(S(stream), src, dst, N, C, HW, Cpad);
+}
 
 int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32, udapose_net_t* out) {
     if (!out) return UDAPOSE_ERR_ARG;
@@ -170,16 +182,30 @@ int udapose_net_backward(udapose_net_t n, void* stream, const float* dout, const
 }
 
 int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out) {
-    return hm_sqdiff_rows(S(stream), pred, gt, w, nullptr, R, HW, 0.5f, rows, mean_out);
+    return hm_sqdiff_rows(S(stream), pred, gt, w, nullptr, R, HW, 0.5f, rows, mean_out, nullptr, nullptr, 1);
 }
 int udapose_joints_mse_bwd(void* stream, const float* pred, const float* gt, const float* w, const float* gscale, int R, int HW, float* dpred) {
-    return hm_sqdiff_bwd(S(stream), pred, gt, w, nullptr, gscale, (float)(1.0 / ((double)R * HW)), R, HW, dpred);
+    return hm_sqdiff_bwd(S(stream), pred, gt, w, nullptr, gscale, (float)(1.0 / ((double)R * HW)), R, HW, dpred, nullptr, nullptr, 1);
 }
 int udapose_cons_loss_fwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, int R, int HW, float* rows, float* mean_out) {
-    return hm_sqdiff_rows(S(stream), stu, tea, nullptr, mask, R, HW, 1.0f, rows, mean_out);
+    return hm_sqdiff_rows(S(stream), stu, tea, nullptr, mask, R, HW, 1.0f, rows, mean_out, nullptr, nullptr, 1);
 }
 int udapose_cons_loss_bwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const float* gscale, int R, int HW, float* dstu) {
-    return hm_sqdiff_bwd(S(stream), stu, tea, nullptr, mask, gscale, (float)(2.0 / ((double)R * HW)), R, HW, dstu);
+    return hm_sqdiff_bwd(S(stream), stu, tea, nullptr, mask, gscale, (float)(2.0 / ((double)R * HW)), R, HW, dstu, nullptr, nullptr, 1);
+}
+int udapose_mask_count(void* stream, const unsigned char* mask, size_t n, float* count) {
+    if (!mask || !count) return UDAPOSE_ERR_ARG;
+    return hm_mask_count(S(stream), mask, n, count);
+}
+int udapose_cons_loss_valid_fwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const unsigned char* valid,
+                                const float* valid_count, int R, int K, int HW, float* rows, float* mean_out) {
+    if (!valid || !valid_count) return UDAPOSE_ERR_ARG;
+    return hm_sqdiff_rows(S(stream), stu, tea, nullptr, mask, R, HW, 1.0f, rows, mean_out, valid, valid_count, K);
+}
+int udapose_cons_loss_valid_bwd(void* stream, const float* stu, const float* tea, const unsigned char* mask, const unsigned char* valid,
+                                const float* valid_count, const float* gscale, int R, int K, int HW, float* dstu) {
+    if (!valid || !valid_count) return UDAPOSE_ERR_ARG;
+    return hm_sqdiff_bwd(S(stream), stu, tea, nullptr, mask, gscale, (float)(2.0 / ((double)R * HW)), R, HW, dstu, valid, valid_count, K);
 }
 int udapose_heatmap_argmax(void* stream, const float* hm, int R, int H, int W, float* maxvals, int* flat_idx, float* preds, float* rect,
                            const float* patch, int rad) {
@@ -209,6 +235,10 @@ int udapose_sgd_multi(void* stream, const long long* p, const long long* g, cons
 }
 int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha, float* stats_out) {
     return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, stats_out);
+}
+int udapose_adain_f32(void* stream, const float* c, const float* s, float* out, int N, int HWc, int HWs, int C, float eps, float alpha,
+                      float* stats_out) {
+    return adain_launch_f32(S(stream), c, s, out, N, HWc, HWs, C, eps, alpha, stats_out);
 }
 
 int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems) {

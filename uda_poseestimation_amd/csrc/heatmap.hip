@@ -18,14 +18,20 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 
 // rows[r] = 0.5 * w[r] * sum((p-g)^2) / HW           (JointsMSE 'none' rows; mean of rows = 'mean' loss)
 // rows[r] = m[r] * sum((s-t)^2) / HW                  (ConsLoss: mode 1)
+// `valid` (optional, ConsLoss(valid_mask=), loss.py:129-130): per-PIXEL selection [B][HW] shared by the Kc rows of an image;
+// unselected pixels contribute nothing and the caller divides by the selected count instead of B*HW.
 __global__ void sqdiff_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w,
-                              const unsigned char* __restrict__ mask, int HW, float half, float* __restrict__ rows) {
+                              const unsigned char* __restrict__ mask, int HW, float half, float* __restrict__ rows,
+                              const unsigned char* __restrict__ valid, int Kc) {
     __shared__ double red[TPB / 64];
     const size_t r = blockIdx.x;
     const float* pa = a + r * HW;
     const float* pb = b + r * HW;
     double s = 0.0;
-    if ((HW & 3) == 0) {
+    if (valid) {
+        const unsigned char* pv = valid + (r / Kc) * HW;
+        for (int i = threadIdx.x; i < HW; i += TPB) { const float d = pv[i] ? pa[i] - pb[i] : 0.f; s += (double)(d * d); }
+    } else if ((HW & 3) == 0) {
         for (int i = threadIdx.x * 4; i < HW; i += TPB * 4) {
             const f32x4 x = *(const f32x4*)(pa + i), y = *(const f32x4*)(pb + i);
 #pragma unroll
@@ -42,25 +48,42 @@ __global__ void sqdiff_rows_k(const float* __restrict__ a, const float* __restri
         rows[r] = (float)(t / HW) * f;
     }
 }
-__global__ void mean_rows_k(const float* __restrict__ rows, int R, float* __restrict__ out) {
+// out = sum(rows) / R, or - with a pixel selection - sum(rows) * HW / (Kc * count): rows carry sum/HW, the mean runs over
+// the `count` selected (b, h, w) positions of loss_map = mean over the Kc channels
+__global__ void mean_rows_k(const float* __restrict__ rows, int R, float* __restrict__ out, const float* __restrict__ count, int HW, int Kc) {
     __shared__ double red[TPB / 64];
     double s = 0.0;
     for (int i = threadIdx.x; i < R; i += TPB) s += (double)rows[i];
     const double t = block_sum_d(s, red);
-    if (threadIdx.x == 0) out[0] = (float)(t / R);
+    if (threadIdx.x == 0) out[0] = count ? (float)(t * HW / ((double)Kc * (double)count[0])) : (float)(t / R);
+}
+// count[0] = number of non-zero bytes of m[0..n)
+__global__ void mask_count_k(const unsigned char* __restrict__ m, size_t n, float* __restrict__ count) {
+    __shared__ double red[TPB / 64];
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += TPB) s += m[i] ? 1.0 : 0.0;
+    const double t = block_sum_d(s, red);
+    if (threadIdx.x == 0) count[0] = (float)t;
 }
 // da = gscale[0] * coef * f[r] * (a-b), f = w or mask (or 1)
 __global__ void sqdiff_bwd_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w,
                              const unsigned char* __restrict__ mask, const float* __restrict__ gscale, float coef, int HW,
-                             size_t total, float* __restrict__ da) {
-    const float gs = gscale ? gscale[0] : 1.f;
+                             size_t total, float* __restrict__ da, const unsigned char* __restrict__ valid, const float* __restrict__ count, int Kc) {
+    float gs = gscale ? gscale[0] : 1.f;
+    if (count) gs *= (float)(((double)(total / HW) / Kc) * HW / (double)count[0]);     // B*HW / count: the mean runs over the selected pixels
     for (size_t i = ((size_t)blockIdx.x * TPB + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * TPB * 4) {
         const size_t r = i / HW;     // HW % 4 == 0 enforced by the launcher
         float f = gs * coef;
         if (w) f *= w[r];
         if (mask) f *= mask[r] ? 1.f : 0.f;
         const f32x4 x = *(const f32x4*)(a + i), y = *(const f32x4*)(b + i);
-        *(f32x4*)(da + i) = (f32x4){f * (x[0] - y[0]), f * (x[1] - y[1]), f * (x[2] - y[2]), f * (x[3] - y[3])};
+        f32x4 o = (f32x4){f * (x[0] - y[0]), f * (x[1] - y[1]), f * (x[2] - y[2]), f * (x[3] - y[3])};
+        if (valid) {
+            const unsigned char* pv = valid + (r / Kc) * HW + (i - r * HW);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!pv[e]) o[e] = 0.f;
+        }
+        *(f32x4*)(da + i) = o;
     }
 }
 
@@ -214,19 +237,27 @@ __global__ void pck_k(const float* __restrict__ pred, const float* __restrict__ 
 }
 }  // namespace
 
+// valid / count / Kc: optional per-pixel selection [R/Kc][HW] of ConsLoss(valid_mask=) and its device-resident count (hm_mask_count)
 int hm_sqdiff_rows(hipStream_t s, const float* a, const float* b, const float* w, const unsigned char* mask, int R, int HW, float half,
-                   float* rows, float* mean_out) {
-    hipLaunchKernelGGL(sqdiff_rows_k, dim3(R), dim3(TPB), 0, s, a, b, w, mask, HW, half, rows);
-    if (mean_out) hipLaunchKernelGGL(mean_rows_k, dim3(1), dim3(TPB), 0, s, rows, R, mean_out);
+                   float* rows, float* mean_out, const unsigned char* valid, const float* count, int Kc) {
+    if (valid && (!count || Kc < 1 || R % Kc)) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(sqdiff_rows_k, dim3(R), dim3(TPB), 0, s, a, b, w, mask, HW, half, rows, valid, Kc);
+    if (mean_out) hipLaunchKernelGGL(mean_rows_k, dim3(1), dim3(TPB), 0, s, rows, R, mean_out, valid ? count : nullptr, HW, Kc);
     return udapose_check_launch();
 }
 int hm_sqdiff_bwd(hipStream_t s, const float* a, const float* b, const float* w, const unsigned char* mask, const float* gscale, float coef,
-                  int R, int HW, float* da) {
+                  int R, int HW, float* da, const unsigned char* valid, const float* count, int Kc) {
     if (HW % 4) return UDAPOSE_ERR_ARG;
+    if (valid && (!count || Kc < 1 || R % Kc)) return UDAPOSE_ERR_ARG;
     const size_t total = (size_t)R * HW;
     size_t blocks = (total / 4 + TPB - 1) / TPB;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sqdiff_bwd_k, dim3((int)blocks), dim3(TPB), 0, s, a, b, w, mask, gscale, coef, HW, total, da);
+    hipLaunchKernelGGL(sqdiff_bwd_k, dim3((int)blocks), dim3(TPB), 0, s, a, b, w, mask, gscale, coef, HW, total, da, valid, valid ? count : nullptr,
+                       Kc);
+    return udapose_check_launch();
+}
+int hm_mask_count(hipStream_t s, const unsigned char* m, size_t n, float* count) {
+    hipLaunchKernelGGL(mask_count_k, dim3(1), dim3(TPB), 0, s, m, n, count);
     return udapose_check_launch();
 }
 int hm_argmax_rectify(hipStream_t s, const float* hm, int R, int H, int W, float* maxv, int* idx, float* preds, float* rect, const float* patch,

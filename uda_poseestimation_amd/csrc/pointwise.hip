@@ -801,7 +801,8 @@ __global__ void maxpool3x3s2_bwd_k(const bf16_t* __restrict__ dy, const unsigned
     }
 }
 // 2x2 stride 2 ceil-mode (VGG encoder, inference only)
-__global__ void maxpool2x2_ceil_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+template <typename T>
+__global__ void maxpool2x2_ceil_k(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
     const int G = C >> 3;
     const size_t total = (size_t)N * Ho * Wo * G;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
@@ -817,15 +818,13 @@ __global__ void maxpool2x2_ceil_k(const bf16_t* __restrict__ x, bf16_t* __restri
             for (int kw = 0; kw < 2; ++kw) {
                 const int h = ho * 2 + kh, w = wo * 2 + kw;
                 if (h < H && w < W) {
-                    const bf16x8 v = *(const bf16x8*)(x + (((size_t)n * H + h) * W + w) * C + g * 8);
+                    float v[8];
+                    ld8<T>(x + (((size_t)n * H + h) * W + w) * C + g * 8, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], (float)v[e]);
+                    for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
                 }
             }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
-        *(bf16x8*)(y + i * 8) = o;
+        st8<T>(y + i * 8, best);
     }
 }
 
@@ -1121,7 +1120,13 @@ int pw_maxpool3x3s2_bwd(hipStream_t s, const bf16_t* dy, const unsigned char* id
 }
 int pw_maxpool2x2_ceil(hipStream_t s, const bf16_t* x, bf16_t* y, int N, int H, int W, int C) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    hipLaunchKernelGGL(maxpool2x2_ceil_k, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool2x2_ceil_k<bf16_t>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_maxpool2x2_ceil_f32(hipStream_t s, const float* x, float* y, int N, int H, int W, int C) {
+    if (C % 8) return UDAPOSE_ERR_ARG;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(maxpool2x2_ceil_k<float>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, N, H, W, C, Ho, Wo);
     return udapose_check_launch();
 }
 int pw_plane_sum(hipStream_t s, const float* x, float* out, int N, int C, int HW, float beta) {

@@ -5,11 +5,17 @@ training script's `Style_net.decoder.load_state_dict(...)`, `Style_net.vgg.load_
 `nn.Sequential(*list(vgg.children())[:31])` and `Style_net.Net(vgg, decoder)` (train_human.py:120-131) work unchanged.
 The children are parameter containers: `Net.forward` walks them and issues one fused kernel per
 [ReflectionPad2d -> Conv2d -> ReLU] group (reflection, nearest x2 upsample, bias and ReLU live inside the conv
-kernel), the ceil-mode max-pools, and the AdaIN kernel.  Activations are NHWC bf16 with fp32 accumulation.
+kernel), the ceil-mode max-pools, and the AdaIN kernel, on NHWC activations.
 
-Only the inference path the training loop consumes is implemented: `forward(...)[2]` (= g_t).  The reference also
-re-encodes g_t to compute a content and a Gram style loss that the loop discards (train_human.py:350 takes [2]);
-those two values are returned as zeros unless `compute_losses=True` is requested, which is not supported on device.
+Two precisions (`Net.precision`):
+  'bf16' (default): bf16 storage, bf16 MFMA, fp32 accumulation - the fast mode; g_t within ~8e-2 * max of the fp32 result
+                    after 19 un-normalised conv layers (tests/test_gpu_hotpath.py).
+  'fp32':           fp32 storage and the exact fp32 MFMA (v_mfma_f32_16x16x4_f32) - the reference's own precision (the loop
+                    runs the style net outside autocast, train_human.py:347-356); ~1e-5 of the reference, ~10x slower.
+
+`forward` returns (loss_c, loss_s, g_t) like the reference.  The training loop consumes only [2] (train_human.py:275,350,355)
+and the two losses cost a third encoder pass plus eight Gram matrices, so they are computed only when
+`Net.compute_losses = True`; otherwise they are NaN (not a silent zero): a caller that does use them notices at once.
 """
 import torch
 import torch.nn as nn
@@ -25,55 +31,69 @@ def _nchw_feat(feat):
 
 
 def calc_mean_std(feat, eps=1e-5):
-    """Per-(n,c) mean and sqrt(unbiased var + eps) over H*W (Style_net.py:4-12), from the AdaIN kernel's statistics."""
+    """Per-(n,c) mean and sqrt(unbiased var + eps) over H*W (Style_net.py:4-12), from the AdaIN kernel's fp32 statistics."""
     size = feat.size()
     assert (len(size) == 4)
     N, C = size[:2]
-    x = ops.to_nhwc_bf16(_nchw_feat(feat), (C + 63) // 64 * 64)
-    _, st = ops.adain(x, x, alpha=0.0, eps=eps, want_stats=True)
+    x = ops.to_nhwc_f32(_nchw_feat(feat), (C + 63) // 64 * 64)
+    st = ops.adain(x, x, alpha=0.0, eps=eps, stats_only=True)
     return st[:, :C, 0].reshape(N, C, 1, 1).to(feat.dtype), st[:, :C, 1].reshape(N, C, 1, 1).to(feat.dtype)
 
 
 def adain(content_feat, style_feat):
-    """(content - mean_c) / std_c * std_s + mean_s (Style_net.py:21-29); NCHW in/out at the API boundary."""
+    """(content - mean_c) / std_c * std_s + mean_s (Style_net.py:21-29); NCHW fp32 in/out at the API boundary, fp32 inside."""
     assert (content_feat.size()[:2] == style_feat.size()[:2])
     N, C, H, W = content_feat.shape
     Cp = (C + 63) // 64 * 64
-    out = ops.adain(ops.to_nhwc_bf16(_nchw_feat(content_feat), Cp), ops.to_nhwc_bf16(_nchw_feat(style_feat), Cp), alpha=1.0)
+    out = ops.adain(ops.to_nhwc_f32(_nchw_feat(content_feat), Cp), ops.to_nhwc_f32(_nchw_feat(style_feat), Cp), alpha=1.0)
     return ops.to_nchw_f32(out, C).to(content_feat.dtype)
 
 
-decoder = nn.Sequential(
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(512, 256, (3, 3)),
-    nn.ReLU(),
-    nn.Upsample(scale_factor=2, mode='nearest'),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(256, 256, (3, 3)),
-    nn.ReLU(),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(256, 256, (3, 3)),
-    nn.ReLU(),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(256, 256, (3, 3)),
-    nn.ReLU(),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(256, 128, (3, 3)),
-    nn.ReLU(),
-    nn.Upsample(scale_factor=2, mode='nearest'),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(128, 128, (3, 3)),
-    nn.ReLU(),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(128, 64, (3, 3)),
-    nn.ReLU(),
-    nn.Upsample(scale_factor=2, mode='nearest'),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(64, 64, (3, 3)),
-    nn.ReLU(),
-    nn.ReflectionPad2d((1, 1, 1, 1)),
-    nn.Conv2d(64, 3, (3, 3)),
-)
+def gram_matrix(y):
+    """features @ features^T / (ch*h*w) per image (Style_net.py:14-19).  One exact-fp32 MFMA launch per image: the NCHW
+    feature map of an image IS the [ch][h*w] matrix F, and F F^T is the 1x1 "convolution" of F (ch pixels, h*w channels)
+    with F itself as the weight."""
+    f = _nchw_feat(y)
+    b, ch, h, w = f.shape
+    if (h * w) % 64 or ch % 8:
+        raise NotImplementedError("gram_matrix on the device needs h*w % 64 == 0")
+    d = ops.conv_desc(1, ch, 1, h * w, ch, 1)
+    out = torch.empty(b, ch, ch, dtype=torch.float32, device=f.device)
+    for n in range(b):
+        g = ops.conv2d_fwd(f[n].reshape(1, ch, 1, h * w), f[n].reshape(ch, 1, h * w), d)
+        out[n] = g.reshape(ch, ch)
+    return out / (ch * h * w)
+
+
+def _mse(a, b):
+    """nn.MSELoss() of two equally shaped fp32 tensors on the device (one sweep)."""
+    a, b = a.detach().float().contiguous(), b.detach().float().contiguous()
+    assert a.shape == b.shape
+    R = a.shape[0] * a.shape[1]
+    HW = a.numel() // R
+    rows = torch.empty(R, dtype=torch.float32, device=a.device)
+    mean = torch.empty((), dtype=torch.float32, device=a.device)
+    check(lib().udapose_cons_loss_fwd(_hip.stream(), ptr(a), ptr(b), None, R, HW, ptr(rows), ptr(mean)), "mse")
+    return mean
+
+
+# decoder (Style_net.py:32-62): mirror of the encoder; 'U' = nearest x2 upsample; the last conv has no ReLU
+_DECODER_CFG = [(512, 256), 'U', (256, 256), (256, 256), (256, 256), (256, 128), 'U', (128, 128), (128, 64), 'U', (64, 64), (64, 3)]
+
+
+def _decoder_layers():
+    mods = []
+    for i, v in enumerate(_DECODER_CFG):
+        if v == 'U':
+            mods.append(nn.Upsample(scale_factor=2, mode='nearest'))
+        else:
+            mods += [nn.ReflectionPad2d((1, 1, 1, 1)), nn.Conv2d(v[0], v[1], (3, 3))]
+            if i != len(_DECODER_CFG) - 1:
+                mods.append(nn.ReLU())
+    return mods
+
+
+decoder = nn.Sequential(*_decoder_layers())
 
 
 def _vgg_layers():
@@ -128,17 +148,18 @@ def _compile(children):
 
 
 class _SeqRunner:
-    """Runs a compiled step list on NHWC bf16 tensors; packed weights are cached until a parameter changes."""
+    """Runs a compiled step list on NHWC tensors (bf16 or fp32: the input's dtype decides); packed weights are cached per
+    precision until a parameter changes."""
 
     def __init__(self, children):
         self.steps = _compile(children)
         self._packs = {}
 
-    def _packed(self, st, d):
+    def _packed(self, st, d, f32):
         conv = st.conv
         ver = (conv.weight._version, conv.bias._version, conv.weight.data_ptr(),
                None if st.pre1x1 is None else (st.pre1x1.weight._version, st.pre1x1.bias._version))
-        hit = self._packs.get(id(conv))
+        hit = self._packs.get((id(conv), f32))
         if hit is None or hit[0] != ver:
             w, b = conv.weight.detach().float(), conv.bias.detach().float()
             if st.pre1x1 is not None:
@@ -146,20 +167,29 @@ class _SeqRunner:
                 b1 = st.pre1x1.bias.detach().float()
                 b = b + torch.einsum("omhw,m->o", w, b1)
                 w = torch.einsum("omhw,mc->ochw", w, w1)
-            hit = (ver, ops.pack_weight(w.contiguous(), d, "fwd"), b.contiguous())
-            self._packs[id(conv)] = hit
+            if not f32:
+                wp = ops.pack_weight(w.contiguous(), d, "fwd")
+            elif d.Ci == 8:
+                # [Co][KH][KWp = 8][8] fp32: three real channels, three real column taps, zero elsewhere
+                wp = torch.zeros(d.Co, d.KH, ops.kwp(d), 8, dtype=torch.float32, device=w.device)
+                wp[:, :, :d.KW, :w.shape[1]] = w.permute(0, 2, 3, 1)
+            else:
+                wp = w.permute(0, 2, 3, 1).contiguous()             # [Co][KH][KW][Ci] = the GEMM layout [Co][taps][Ci]
+            hit = (ver, wp, b.contiguous())
+            self._packs[(id(conv), f32)] = hit
         return hit[1], hit[2]
 
     def run(self, x, taps=None, final_f32=False):
-        """x NHWC bf16.  `taps`: step indices after which to record the activation (encode_with_intermediate)."""
+        """x NHWC bf16 or fp32.  `taps`: step indices after which to record the activation (encode_with_intermediate)."""
         outs = []
+        f32 = x.dtype == torch.float32
         for si, st in enumerate(self.steps):
             if st.kind == "pool":
                 x = ops.maxpool2x2_ceil(x)
             else:
                 N, H, W, Cin = x.shape
                 d = ops.conv_desc(N, H, W, Cin, st.conv.out_channels, 3, 1, 1, reflect=True, upsample=st.upsample)
-                w, b = self._packed(st, d)
+                w, b = self._packed(st, d, f32)
                 last = si == len(self.steps) - 1
                 x = ops.conv2d_fwd(x, w, d, bias=b, relu=st.relu, out_f32=(final_f32 and last))
             if taps is not None and si in taps:
@@ -180,6 +210,8 @@ class Net(nn.Module):
         for name in ['enc_1', 'enc_2', 'enc_3', 'enc_4']:
             for param in getattr(self, name).parameters():
                 param.requires_grad = False
+        self.precision = 'bf16'           # 'fp32': the reference's precision (module docstring)
+        self.compute_losses = False       # True: loss_c / loss_s as in Style_net.py:151-177 (a third encoder pass + Gram matrices)
         self._enc = _SeqRunner(enc_layers[:31])
         self._dec = _SeqRunner(list(decoder.children()))
         # step indices that end enc_1..enc_4 (relu1_1, relu2_1, relu3_1, relu4_1)
@@ -212,26 +244,54 @@ class Net(nn.Module):
 
     def _image_in(self, img):
         _hip.require_cuda(img)
-        return ops.to_nhwc_bf16(img.detach().float().contiguous(), 8)
+        if self.precision not in ('bf16', 'fp32'):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        x = img.detach().float().contiguous()
+        return ops.to_nhwc_f32(x, 8) if self.precision == 'fp32' else ops.to_nhwc_bf16(x, 8)
+
+    def _intermediate(self, x_nhwc):
+        """(relu4_1 NHWC, [relu1_1 .. relu4_1] as NCHW fp32)"""
+        last, feats = self._enc.run(x_nhwc, taps=set(self._enc_taps))
+        return last, [ops.to_nchw_f32(f) for f in feats]
 
     def encode_with_intermediate(self, input):
         """relu1_1, relu2_1, relu3_1, relu4_1 as NCHW fp32 tensors (Style_net.py:136-142)."""
-        _, feats = self._enc.run(self._image_in(input), taps=set(self._enc_taps))
-        return [ops.to_nchw_f32(f) for f in feats]
+        return self._intermediate(self._image_in(input))[1]
 
     def encode(self, input):
         return ops.to_nchw_f32(self._enc.run(self._image_in(input)))
 
+    def calc_content_loss(self, input, target):
+        assert (input.size() == target.size())
+        assert (target.requires_grad is False)
+        return _mse(input, target)
+
+    def calc_style_loss(self, input, target):
+        assert (input.size() == target.size())
+        assert (target.requires_grad is False)
+        return _mse(gram_matrix(input), gram_matrix(target))
+
     def forward(self, content, style, alpha=1.0, clamp=None):
-        """-> (loss_c, loss_s, g_t).  `clamp=(lo[3], hi[3])` fuses the loop's recover clamp (train_human.py:351) into the
-        output conversion."""
+        """-> (loss_c, loss_s, g_t) (Style_net.py:163-177).  `clamp=(lo[3], hi[3])` fuses the loop's recover clamp
+        (train_human.py:351) into the output conversion (the losses, when computed, see the unclamped g_t like the reference)."""
         assert 0 <= alpha <= 1
         with torch.no_grad():
-            sf = self._enc.run(self._image_in(style))
+            if self.compute_losses:
+                sf, style_feats = self._intermediate(self._image_in(style))
+            else:
+                sf = self._enc.run(self._image_in(style))
             cf = self._enc.run(self._image_in(content))
             t = ops.adain(cf, sf, alpha=float(alpha))              # alpha-blend fused (Style_net.py:167-168)
             g = self._dec.run(t, final_f32=True)                    # [N,H,W,3] fp32
             lo, hi = (None, None) if clamp is None else (clamp[0].float().contiguous(), clamp[1].float().contiguous())
             g_t = ops.to_nchw_f32(g, 3, lo, hi)
-        zero = torch.zeros((), device=g_t.device)
-        return zero, zero.clone(), g_t
+            if not self.compute_losses:
+                nan = torch.full((), float("nan"), device=g_t.device)
+                return nan, nan.clone(), g_t
+            g_plain = g_t if clamp is None else ops.to_nchw_f32(g, 3)
+            g_t_feats = self.encode_with_intermediate(g_plain)
+            loss_c = self.calc_content_loss(g_t_feats[-1], ops.to_nchw_f32(t))
+            loss_s = self.calc_style_loss(g_t_feats[0], style_feats[0])
+            for i in range(1, 4):
+                loss_s = loss_s + self.calc_style_loss(g_t_feats[i], style_feats[i])
+        return loss_c, loss_s, g_t

@@ -65,35 +65,52 @@ class JointsMSELoss(nn.Module):
 
 class _ConsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stu, tea, mask):
-        _hip.require_cuda(stu, tea, mask)
+    def forward(ctx, stu, tea, mask, valid):
+        _hip.require_cuda(stu, tea, mask, valid)
         R, HW = _rows(stu)
+        K = stu.shape[1]
         s, t = _f32c(stu), _f32c(tea)
         m = None if mask is None else (mask.detach() != 0).to(torch.uint8).reshape(-1).contiguous()
         rows = torch.empty(R, dtype=torch.float32, device=s.device)
         mean = torch.empty((), dtype=torch.float32, device=s.device)
-        check(lib().udapose_cons_loss_fwd(_hip.stream(), ptr(s), ptr(t), ptr(m), R, HW, ptr(rows), ptr(mean)), "cons_loss_fwd")
-        ctx.save_for_backward(s, t, m if m is not None else torch.empty(0, dtype=torch.uint8, device=s.device))
-        ctx.has_m, ctx.shape, ctx.in_dtype = m is not None, stu.shape, stu.dtype
+        v = cnt = None
+        if valid is None:
+            check(lib().udapose_cons_loss_fwd(_hip.stream(), ptr(s), ptr(t), ptr(m), R, HW, ptr(rows), ptr(mean)), "cons_loss_fwd")
+        else:
+            # loss_map[valid_mask].mean() (loss.py:129-130): boolean selection over (b, h, w)
+            if tuple(valid.shape) != (stu.shape[0],) + tuple(stu.shape[2:]):
+                raise IndexError(f"valid_mask shape {tuple(valid.shape)} does not index loss_map {(stu.shape[0],) + tuple(stu.shape[2:])}")
+            v = (valid.detach() != 0).to(torch.uint8).reshape(-1).contiguous()
+            cnt = torch.empty((), dtype=torch.float32, device=s.device)
+            check(lib().udapose_mask_count(_hip.stream(), ptr(v), v.numel(), ptr(cnt)), "mask_count")
+            check(lib().udapose_cons_loss_valid_fwd(_hip.stream(), ptr(s), ptr(t), ptr(m), ptr(v), ptr(cnt), R, K, HW, ptr(rows), ptr(mean)),
+                  "cons_loss_valid_fwd")
+        empty = torch.empty(0, dtype=torch.uint8, device=s.device)
+        ctx.save_for_backward(s, t, m if m is not None else empty, v if v is not None else empty,
+                              cnt if cnt is not None else torch.empty(0, device=s.device))
+        ctx.has_m, ctx.has_v, ctx.shape, ctx.in_dtype = m is not None, v is not None, stu.shape, stu.dtype
         return mean
 
     @staticmethod
     def backward(ctx, g):
-        s, t, m = ctx.saved_tensors
+        s, t, m, v, cnt = ctx.saved_tensors
         R, HW = _rows(s)
         d = torch.empty_like(s)
         gs = g.detach().float().reshape(1).contiguous()
-        check(lib().udapose_cons_loss_bwd(_hip.stream(), ptr(s), ptr(t), ptr(m) if ctx.has_m else None, ptr(gs), R, HW, ptr(d)), "cons_loss_bwd")
-        return d.reshape(ctx.shape).to(ctx.in_dtype), None, None
+        if ctx.has_v:
+            check(lib().udapose_cons_loss_valid_bwd(_hip.stream(), ptr(s), ptr(t), ptr(m) if ctx.has_m else None, ptr(v), ptr(cnt), ptr(gs), R,
+                                                    ctx.shape[1], HW, ptr(d)), "cons_loss_valid_bwd")
+        else:
+            check(lib().udapose_cons_loss_bwd(_hip.stream(), ptr(s), ptr(t), ptr(m) if ctx.has_m else None, ptr(gs), R, HW, ptr(d)), "cons_loss_bwd")
+        return d.reshape(ctx.shape).to(ctx.in_dtype), None, None, None
 
 
 class ConsLoss(nn.Module):
-    """mean over (b,h,w) of mean_c (mask[b,c] * (stu - tea))^2  ==  sum(mask*(stu-tea)^2) / (B*C*H*W)."""
+    """mean over (b,h,w) of mean_c (mask[b,c] * (stu - tea))^2  ==  sum(mask*(stu-tea)^2) / (B*C*H*W); with `valid_mask`
+    (bool [B,H,W]) the mean runs over the selected positions only (loss.py:129-130)."""
 
     def __init__(self):
         super(ConsLoss, self).__init__()
 
     def forward(self, stu_out, tea_out, valid_mask=None, tea_mask=None):
-        if valid_mask is not None:
-            raise NotImplementedError("valid_mask is never passed by the reference scripts (train_human.py:432); not on the MI355X path")
-        return _ConsFn.apply(stu_out, tea_out, tea_mask)
+        return _ConsFn.apply(stu_out, tea_out, tea_mask, valid_mask)

@@ -108,6 +108,16 @@ def to_nhwc_bf16(x_nchw, cpad=None):
     return out
 
 
+def to_nhwc_f32(x_nchw, cpad=None):
+    """NCHW fp32 -> NHWC fp32 (channels zero-padded to cpad): the style path at the reference's precision."""
+    require_cuda(x_nchw)
+    N, Cc, H, W = x_nchw.shape
+    cpad = cpad or (Cc + 7) // 8 * 8
+    out = torch.empty(N, H, W, cpad, dtype=torch.float32, device=x_nchw.device)
+    check(lib().udapose_nchw_f32_to_nhwc_f32(stream(), ptr(x_nchw.float().contiguous()), ptr(out), N, Cc, H * W, cpad), "to_nhwc_f32")
+    return out
+
+
 def to_nchw_f32(x_nhwc, channels=None, lo=None, hi=None):
     require_cuda(x_nhwc)
     N, H, W, Cs = x_nhwc.shape
@@ -180,15 +190,20 @@ def maxpool3x3s2_bwd(dy, idx, H, W):
 
 def maxpool2x2_ceil(x):
     N, H, W, C_ = x.shape
-    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C_, dtype=torch.bfloat16, device=x.device)
-    check(lib().udapose_maxpool2x2_ceil(stream(), ptr(x), ptr(y), N, H, W, C_), "maxpool2x2")
+    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C_, dtype=x.dtype, device=x.device)
+    fn = lib().udapose_maxpool2x2_ceil_f32 if x.dtype == torch.float32 else lib().udapose_maxpool2x2_ceil
+    check(fn(stream(), ptr(x), ptr(y), N, H, W, C_), "maxpool2x2")
     return y
 
 
-def adain(content, style, alpha=1.0, eps=1e-5, want_stats=False):
+def adain(content, style, alpha=1.0, eps=1e-5, want_stats=False, stats_only=False):
+    """NHWC bf16 or fp32 (both operands alike).  stats_only: no output tensor, [N,C,4] = (mean_c, std_c, mean_s, std_s)."""
     N, H, W, C_ = content.shape
-    out = torch.empty_like(content)
-    st = torch.empty(N, C_, 4, dtype=torch.float32, device=content.device) if want_stats else None
-    check(lib().udapose_adain(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps, float(alpha), ptr(st)),
-          "adain")
+    assert content.dtype == style.dtype and content.dtype in (torch.bfloat16, torch.float32) and style.shape[0] == N and style.shape[3] == C_
+    out = None if stats_only else torch.empty_like(content)
+    st = torch.empty(N, C_, 4, dtype=torch.float32, device=content.device) if (want_stats or stats_only) else None
+    fn = lib().udapose_adain_f32 if content.dtype == torch.float32 else lib().udapose_adain
+    check(fn(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps, float(alpha), ptr(st)), "adain")
+    if stats_only:
+        return st
     return (out, st) if want_stats else out
