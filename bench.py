@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=256, help="other configs (BASELINE.json configs[4]: 384); default = the metric's 256")
     ap.add_argument("--keypoints", type=int, default=16, help="other configs (configs[4]: 18)")
     ap.add_argument("--sigma", type=float, default=2, help="label / rectify sigma (configs[4]: 1.0)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="storage / MFMA element type: bf16 = the metric; fp16 = the "
+                    "reference's autocast dtype (BASELINE.json configs[4]), with GradScaler-style loss scaling kept on the device")
     ap.add_argument("--strong", action="store_true", help="not the metric: strong scaling, global batch fixed at --batch (what the reference's "
                     "nn.DataParallel does): every rank takes batch / world images per domain")
     ap.add_argument("--config2", action="store_true", help="not the metric: BASELINE.json configs[2] = the same step + AdaIN s2t / t2s style "
@@ -197,7 +199,7 @@ def main():
     from uda_poseestimation_amd import _hip, synthetic
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
     import uda_poseestimation_amd.lib.models as models
-    lib = _hip.lib()
+    lib = _hip.lib(args.dtype)
     lib.udapose_debug_set_wgrad_group(args.wgrad_group, args.wgrad_stages)
     lib.udapose_debug_set_bn_bwd_fused(args.bn_bwd_fused)
     if args.igemm_tile >= 0:
@@ -226,7 +228,7 @@ def main():
                      rng=np.random.RandomState(0), occlude_rate=0.5, occlude_thresh=0.9, occlude_size=10)
         args.eager = True
     trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
-                                 heatmap_size=S // 4, **extra)
+                                 heatmap_size=S // 4, precision=args.dtype, **extra)
     b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=rank)   # one shard per rank
     g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 
@@ -319,15 +321,17 @@ def main():
         res = {
             "metric": f"images/sec (student+teacher step) {S}x{S} b={N}", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
-                                   f"Adam, EMA), {S}x{S}, b={N}/GPU, " + ("AdaIN s2t + t2s style passes and adaptive occlusion (BASELINE.json configs[2]; NOT the metric)" if args.config2 else "no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch) == (256, 16, 32, "pose_resnet101") else f", K={K}")),
+                                   f"Adam, EMA), {S}x{S}, b={N}/GPU, " + ("AdaIN s2t + t2s style passes and adaptive occlusion (BASELINE.json configs[2]; NOT the metric)" if args.config2 else "no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch, args.dtype) == (256, 16, 32, "pose_resnet101", "bf16") else
+                                                    (f", K={K}, {args.dtype} (BASELINE.json configs[4] shape and dtype on one GPU; NOT the metric)"
+                                                     if (S, K, args.arch, args.dtype) == (384, 18, "pose_resnet101", "fp16") else f", K={K}, {args.dtype}"))),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
             "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fprop+dgrad, bf16 MFMA 16x16x32)",
+            "roofline": {"bound": "mfma", "kernel": f"igemm_kernel (implicit-GEMM conv fprop+dgrad, {args.dtype} MFMA 16x16x32)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic_per_igemm_launch(),
                          "traffic_note": "HBM bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "

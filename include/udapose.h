@@ -26,6 +26,9 @@ extern "C" {
 #define UDAPOSE_ERR_UNSUPPORTED (-3)
 
 int udapose_version(void);
+/* element type this build stores and multiplies: 0 = bf16 (libudapose_hip.so), 1 = fp16 (libudapose_hip_f16.so: the same
+ * sources with -DUDAPOSE_ELEM_F16; every `void*` activation / packed-weight pointer below is then fp16) */
+int udapose_elem_kind(void);
 
 /* ---------------------------------------------------------------- convolution family
  * Replaces torch.nn.Conv2d / ConvTranspose2d as used by torchvision Bottleneck (lib/models/resnet.py:8-10,25-40),
@@ -182,6 +185,14 @@ int udapose_adam_multi(void* stream, const long long* p, const long long* g, con
 int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes,
                       const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float momentum, float weight_decay,
                       int nesterov, int first_step, float grad_scale, float* dev_state);
+
+/* Dynamic loss scaling = torch.cuda.amp.GradScaler (train_human.py:260,285-287,324,436-440) on the device, for the fp16 build.
+ * dev_state is the optimizer's 8-float state: [5] = found_inf, [6] = loss scale S, [7] = growth tracker, [4] = 1/S.
+ * check: raises found_inf if any gradient is inf / nan (then adam_multi / sgd_multi skip the step, counter included);
+ * update: S *= backoff on found_inf, S *= growth after `interval` clean steps; clears found_inf, refreshes 1/S. */
+int udapose_grad_scaler_check(void* stream, const long long* g, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                              int nblocks, float* dev_state);
+int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, float backoff, int interval);
 
 /* ---------------------------------------------------------------- AdaIN (lib/models/Style_net.py:4-29,167-168), NHWC bf16
  * out = alpha*adain(content, style) + (1-alpha)*content; stats_out (optional) [N][C][4] = (mean_c, std_c, mean_s, std_s) */

@@ -30,7 +30,11 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/udapose.h but not exported"
     assert set(_hip.EXPORTS) <= set(declared), set(_hip.EXPORTS) - set(declared)
-    assert lib.udapose_version() >= 100
+    assert lib.udapose_version() >= 200 and lib.udapose_elem_kind() == 0
+    lib16 = _hip.lib("fp16")                      # the fp16 build exports the same surface
+    for name in declared:
+        assert hasattr(lib16, name), f"{name} missing from libudapose_hip_f16.so"
+    assert lib16.udapose_elem_kind() == 1
     assert lib.udapose_multi_chunk() > 0          # a pure host query (no GPU needed)
 
 

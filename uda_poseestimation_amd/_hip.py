@@ -9,7 +9,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libudapose_hip.so")
-_lib = None
+# the same sources built twice (csrc/Makefile): element type bf16 (the benched precision) and fp16 (the reference's autocast dtype)
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libudapose_hip_f16.so")}
+_libs = {}
 
 vp, ci, cf, cd, sz, ll, cl = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_longlong, C.c_long
 
@@ -20,6 +22,9 @@ class ConvDesc(C.Structure):
 
 _SIGS = {
     "udapose_version": (ci, []),
+    "udapose_elem_kind": (ci, []),
+    "udapose_grad_scaler_check": (ci, [vp, vp, vp, vp, vp, ci, vp]),
+    "udapose_grad_scaler_update": (ci, [vp, vp, cf, cf, ci]),
     "udapose_conv_out_hw": (None, [vp, vp, vp]),
     "udapose_conv_stat_rows": (ci, [vp]),
     "udapose_conv2d_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci]),
@@ -90,21 +95,37 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
-def lib():
-    """Load the shared library (raises loudly if it has not been built: there is no fallback path)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(kind="bf16"):
+    """Load a shared library (raises loudly if it has not been built: there is no fallback path).  kind: 'bf16' (default) or
+    'fp16' = the element type of activations / packed weights / MFMA operands; everything else (losses, heat-map kernels,
+    optimizers, warps) is fp32 and identical in both builds."""
+    l = _libs.get(kind)
+    if l is None:
+        path = LIB_PATHS[kind]
+        if not os.path.exists(path):
             raise HipLibraryMissing(
-                f"{LIB_PATH} not found: build it with `make -C uda_poseestimation_amd/csrc` (or __graft_entry__.build()). "
+                f"{path} not found: build it with `make -C uda_poseestimation_amd/csrc` (or __graft_entry__.build()). "
                 "uda_poseestimation_amd has no CPU / eager fallback.")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = l
-    return _lib
+        if l.udapose_elem_kind() != {"bf16": 0, "fp16": 1}[kind]:
+            raise HipLibraryMissing(f"{path} was built for another element type")
+        _libs[kind] = l
+    return l
+
+
+def lib_for(*tensors):
+    """The build whose element type matches the 16-bit tensors given (fp16 -> the fp16 build, otherwise bf16)."""
+    for t in tensors:
+        if t is not None and torch.is_tensor(t) and t.dtype == torch.float16:
+            return lib("fp16")
+    return lib("bf16")
+
+
+ELEM_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def check(code, what=""):

@@ -10,8 +10,8 @@ constexpr int TPB = 256;
 // 8 consecutive channel values <-> fp32 registers, bf16 or fp32 storage (fp32: the reference's own precision for the style
 // path, train_human.py:347-356 runs it outside autocast)
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
-template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) {
-    const bf16x8 v = *(const bf16x8*)p;
+template <> __device__ __forceinline__ void ld8<elem_t>(const elem_t* p, float (&o)[8]) {
+    const elem8 v = *(const elem8*)p;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
 }
@@ -21,11 +21,11 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o
     for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
 }
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
-template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-    bf16x8 o;
+template <> __device__ __forceinline__ void st8<elem_t>(elem_t* p, const float (&v)[8]) {
+    elem8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *(bf16x8*)p = o;
+    for (int e = 0; e < 8; ++e) o[e] = (elem_t)v[e];
+    *(elem8*)p = o;
 }
 template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
     *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
@@ -94,10 +94,10 @@ __global__ void adain_k(const T* __restrict__ content, const T* __restrict__ sty
 }
 }  // namespace
 
-int adain_launch(hipStream_t s, const bf16_t* content, const bf16_t* style, bf16_t* out, int N, int HWc, int HWs, int C, float eps, float alpha,
+int adain_launch(hipStream_t s, const elem_t* content, const elem_t* style, elem_t* out, int N, int HWc, int HWs, int C, float eps, float alpha,
                  float* stats_out) {
     if (C % 64 || HWc < 2 || HWs < 2) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(adain_k<bf16_t>, dim3(N * (C / 64)), dim3(TPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, stats_out);
+    hipLaunchKernelGGL(adain_k<elem_t>, dim3(N * (C / 64)), dim3(TPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, stats_out);
     return udapose_check_launch();
 }
 int adain_launch_f32(hipStream_t s, const float* content, const float* style, float* out, int N, int HWc, int HWs, int C, float eps, float alpha,

@@ -2,23 +2,23 @@
 #include "conv_plan.h"
 #include "../../include/udapose.h"
 
-int pw_nchw_f32_to_nhwc_bf16(hipStream_t, const float*, bf16_t*, int, int, int, int);
+int pw_nchw_f32_to_nhwc_bf16(hipStream_t, const float*, elem_t*, int, int, int, int);
 int pw_nhwc_to_nchw_f32(hipStream_t, const void*, int, float*, int, int, int, int, const float*, const float*);
-int pw_cast_f32_bf16(hipStream_t, const float*, bf16_t*, size_t);
-int pw_transpose_cast(hipStream_t, const float*, bf16_t*, int, int, int);
-int pw_pack_strided(hipStream_t, const float*, bf16_t*, int, int, int, int, int, int, long, long, long, long);
+int pw_cast_f32_bf16(hipStream_t, const float*, elem_t*, size_t);
+int pw_transpose_cast(hipStream_t, const float*, elem_t*, int, int, int);
+int pw_pack_strided(hipStream_t, const float*, elem_t*, int, int, int, int, int, int, long, long, long, long);
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
                    float*, float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
-int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
+int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
-int pw_bn_bwd_pre(hipStream_t, const void*, int, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
+int pw_bn_bwd_pre(hipStream_t, const void*, int, const elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
                   float*, float*, float);
-int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
+int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
               float*, float*, float*, float*, float, const float*);
-int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
-int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
-int pw_maxpool2x2_ceil(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int);
+int pw_maxpool3x3s2_fwd(hipStream_t, const elem_t*, elem_t*, unsigned char*, int, int, int, int);
+int pw_maxpool3x3s2_bwd(hipStream_t, const elem_t*, const unsigned char*, elem_t*, int, int, int, int);
+int pw_maxpool2x2_ceil(hipStream_t, const elem_t*, elem_t*, int, int, int, int);
 int hm_sqdiff_rows(hipStream_t, const float*, const float*, const float*, const unsigned char*, int, int, float, float*, float*,
                    const unsigned char*, const float*, int);
 int hm_sqdiff_bwd(hipStream_t, const float*, const float*, const float*, const unsigned char*, const float*, float, int, int, float*,
@@ -36,7 +36,9 @@ int opt_adam(hipStream_t, const long long*, const long long*, const long long*, 
              float, float, float, float, float, int, float, float*);
 int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float, float,
             int, int, float, float*);
-int adain_launch(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, float, float, float*);
+int opt_grad_check(hipStream_t, const long long*, const long long*, const int*, const long long*, int, float*);
+int opt_scaler_update(hipStream_t, float*, float, float, int);
+int adain_launch(hipStream_t, const elem_t*, const elem_t*, elem_t*, int, int, int, int, float, float, float*);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
 extern int g_igemm_tile_override, g_wgrad_tile_override, g_wgrad_ksplit_override;
@@ -63,12 +65,13 @@ static ConvGeom to_geom(const udapose_conv_desc* d) {
     return ConvGeom{d->N, d->Hi, d->Wi, d->Ci, d->Co, d->KH, d->KW, d->stride, d->pad, d->transposed, d->reflect, d->upsample};
 }
 #define S(x) ((hipStream_t)(x))
-#define B16(x) ((bf16_t*)(x))
-#define CB16(x) ((const bf16_t*)(x))
+#define B16(x) ((elem_t*)(x))
+#define CB16(x) ((const elem_t*)(x))
 
 extern "C" {
 
-int udapose_version(void) { return 100; }
+int udapose_version(void) { return 200; }
+int udapose_elem_kind(void) { return UDAPOSE_ELEM_KIND; }      // 0: this build stores / multiplies bf16, 1: fp16
 
 void udapose_conv_out_hw(const udapose_conv_desc* d, int* Ho, int* Wo) { ConvGeom g = to_geom(d); *Ho = g.Ho(); *Wo = g.Wo(); }
 int udapose_conv_stat_rows(const udapose_conv_desc* d) { return conv_stat_rows(to_geom(d)); }
@@ -232,6 +235,12 @@ int udapose_adam_multi(void* stream, const long long* p, const long long* g, con
 int udapose_sgd_multi(void* stream, const long long* p, const long long* g, const long long* buf, const long long* sizes, const int* bt,
                       const long long* bo, int nb, float lr, float mom, float wd, int nesterov, int first, float gscale, float* dev_state) {
     return opt_sgd(S(stream), p, g, buf, sizes, bt, bo, nb, lr, mom, wd, nesterov, first, gscale, dev_state);
+}
+int udapose_grad_scaler_check(void* stream, const long long* g, const long long* sizes, const int* bt, const long long* bo, int nb, float* dev_state) {
+    return opt_grad_check(S(stream), g, sizes, bt, bo, nb, dev_state);
+}
+int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, float backoff, int interval) {
+    return opt_scaler_update(S(stream), dev_state, growth, backoff, interval);
 }
 int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha, float* stats_out) {
     return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, stats_out);

@@ -9,9 +9,23 @@
 #define UDAPOSE_ERR_LAUNCH (-2)
 #define UDAPOSE_ERR_UNSUPPORTED (-3)
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// Storage / MFMA-operand element type of this build of the library.  The same sources are compiled twice:
+//   libudapose_hip.so      elem_t = bf16  (v_mfma_f32_16x16x32_bf16)   - BASELINE.json's benched precision
+//   libudapose_hip_f16.so  elem_t = fp16  (v_mfma_f32_16x16x32_f16)    - the reference's autocast dtype (train_human.py:280,414)
+// Accumulation, BatchNorm statistics, master weights, gradients of weights and every loss are fp32 in both.
+#if defined(UDAPOSE_ELEM_F16)
+typedef _Float16 elem_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 elem8;
+typedef __attribute__((ext_vector_type(4))) _Float16 elem4;
+#define UDAPOSE_ELEM_KIND 1
+#define UDAPOSE_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
+typedef __bf16 elem_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 elem8;
+typedef __attribute__((ext_vector_type(4))) __bf16 elem4;
+#define UDAPOSE_ELEM_KIND 0
+#define UDAPOSE_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -57,10 +71,6 @@ struct ZeroJob { long long off; long long n16; };
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t total) {
     const uint32_t q = total >> 3, r = total & 7u, xcd = bid & 7u, local = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-}
-
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
-    return __uint_as_float(((unsigned int)b) << 16);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -41,7 +41,7 @@ int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, cons
                        const void* dy_base, void* dw_base);
 
 struct ConvEpilogue {
-    const bf16_t* res = nullptr;
+    const elem_t* res = nullptr;
     const float* bias = nullptr;
     float* stats = nullptr;
     int relu = 0;
@@ -49,23 +49,23 @@ struct ConvEpilogue {
     int f32 = 0;            // x, w, res, y are fp32 (exact fp32 MFMA path; forward only)
 };
 // y = conv(x, w_fwd[Co][wtaps][Ci])
-int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e);
+int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* w_fwd, void* y, const ConvEpilogue& e);
 // The BatchNorm whose backward consumes a dgrad's output (IgParams::bs_*): the dgrad epilogue masks dx with that BN's ReLU
 // and leaves the partial sums of g and g * xhat in slab[rows][2][C]; `rows` is set by conv_dgrad.
 struct DgradBnStat {
-    const bf16_t* y = nullptr;      // the BN's input (pre-BN conv output)
-    const bf16_t* z = nullptr;      // mask source (BN + residual + ReLU output) or null: mask recomputed from y
+    const elem_t* y = nullptr;      // the BN's input (pre-BN conv output)
+    const elem_t* z = nullptr;      // mask source (BN + residual + ReLU output) or null: mask recomputed from y
     const float* mean = nullptr; const float* invstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
     float* slab = nullptr;
     int rows = 0;
 };
 // dx = conv^T(dy, w_bwd[Ci][wtaps][Co]) (+ res)
-int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32,
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t* w_bwd, void* dx, const elem_t* res, int out_f32,
                DgradBnStat* bs = nullptr);
 // dw (fp32, [Co][wtaps][Ci]; transposed: [Ci][wtaps][Co]) (+)= ...;  rows_valid < 0 -> all rows
-int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid);
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t* x, float* dw, int accumulate, int rows_valid);
 // the same problem as a parameter block (for the grouped launch); returns the layer's algorithmic FLOPs in *flops
-int conv_wgrad_params(const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int rows_valid, WgParams* out, double* flops);
+int conv_wgrad_params(const ConvGeom& g, const elem_t* dy, const elem_t* x, float* dw, int rows_valid, WgParams* out, double* flops);
 int conv_prof_before(hipStream_t s, int kind, double flops);
 void conv_prof_after(hipStream_t s, int token);
 int conv_stat_rows(const ConvGeom& g);

@@ -106,7 +106,7 @@ int conv_stat_rows(const ConvGeom& g) {
     return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass, K, conv_h3_ok(g)));
 }
 
-int conv_fprop(hipStream_t s, const ConvGeom& g, const bf16_t* x, const bf16_t* w_fwd, void* y, const ConvEpilogue& e) {
+int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* w_fwd, void* y, const ConvEpilogue& e) {
     const TapPlan* tp = get_tap_plan(g, 0);
     if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
     if (g.transposed && (g.reflect || g.upsample)) return UDAPOSE_ERR_UNSUPPORTED;
@@ -154,7 +154,7 @@ int conv_dgrad_stat_rows(const ConvGeom& g) {
     return igemm_stat_rows(p.M, p.Co, p.nclass, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g)));
 }
 
-int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* w_bwd, void* dx, const bf16_t* res, int out_f32, DgradBnStat* bs) {
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t* w_bwd, void* dx, const elem_t* res, int out_f32, DgradBnStat* bs) {
     IgParams p{};
     const int rc0 = dgrad_params(g, p);
     if (rc0 != UDAPOSE_OK) return rc0;
@@ -173,7 +173,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t*
     return rc;
 }
 
-int conv_wgrad_params(const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int rows_valid, WgParams* out, double* flops) {
+int conv_wgrad_params(const ConvGeom& g, const elem_t* dy, const elem_t* x, float* dw, int rows_valid, WgParams* out, double* flops) {
     if (g.reflect || g.upsample) return UDAPOSE_ERR_UNSUPPORTED;
     const bool rowtap = rows_valid == -2;          // grouped Ci == 8 form (see wgrad_dma_body)
     if (rowtap && (!g.smallc() || g.transposed || g.KWp() != 8)) return UDAPOSE_ERR_UNSUPPORTED;
@@ -199,7 +199,7 @@ int conv_wgrad_params(const ConvGeom& g, const bf16_t* dy, const bf16_t* x, floa
     return UDAPOSE_OK;
 }
 
-int conv_wgrad(hipStream_t s, const ConvGeom& g, const bf16_t* dy, const bf16_t* x, float* dw, int accumulate, int rows_valid) {
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t* x, float* dw, int accumulate, int rows_valid) {
     WgParams p;
     double fl = 0.0;
     const int rc0 = conv_wgrad_params(g, dy, x, dw, rows_valid, &p, &fl);

@@ -17,10 +17,10 @@ struct IgClass { int tap_off, ntaps, oa, ob; };
 #define IG_FLAG_SMALLC 16     // Ci == 8: one 32-wide K step covers 4 taps (stem / first VGG conv)
 
 struct IgParams {
-    const bf16_t* x;        // NHWC bf16 [N, Hi, Wi, Ci]
-    const bf16_t* w;        // [Co][wtaps][Ci] bf16 (K-contiguous per output channel)
+    const elem_t* x;        // NHWC bf16 [N, Hi, Wi, Ci]
+    const elem_t* w;        // [Co][wtaps][Ci] bf16 (K-contiguous per output channel)
     void* y;                // NHWC [N, Ho, Wo, Co] bf16 (or fp32)
-    const bf16_t* res;      // optional residual, same shape as y (bf16), added before ReLU
+    const elem_t* res;      // optional residual, same shape as y (bf16), added before ReLU
     const float* bias;      // optional [Co]
     float* stats;           // optional per-channel partial sums: [stat_rows][2][Co] fp32 (sum, sumsq of fp32 acc)
     const IgTap* taps;      // device tap table
@@ -40,8 +40,8 @@ struct IgParams {
     // dgrad only: the BatchNorm that consumes this launch's output dz in the backward chain.  When bs_y is set the epilogue
     // applies that BN's ReLU mask to dz (so y receives g = dz * mask), and writes per-m-tile partial sums of g and g * xhat to
     // `stats` ([stat_rows][2][Co], the same slab layout as the forward statistics): the separate reduce launch disappears.
-    const bf16_t* bs_y;        // the consumer BN's input (pre-BN conv output), same shape as y
-    const bf16_t* bs_z;        // mask source z > 0 (BN + residual + ReLU); null: mask recomputed from y*scale + shift > 0
+    const elem_t* bs_y;        // the consumer BN's input (pre-BN conv output), same shape as y
+    const elem_t* bs_z;        // mask source z > 0 (BN + residual + ReLU); null: mask recomputed from y*scale + shift > 0
     const float* bs_mean;      // [Co] saved batch mean / inverse std of the consumer BN
     const float* bs_invstd;
     const float* bs_gamma;     // [Co] (mask recomputation only)
@@ -50,8 +50,8 @@ struct IgParams {
 
 // wgrad: dW[r][tap][c] (fp32) (+)= sum_m P[pixP][r] * Q[pixQ][c]
 struct WgParams {
-    const bf16_t* dy;       // NHWC [N, Ho, Wo, Co]   (gradient of the conv output)
-    const bf16_t* x;        // NHWC [N, Hi, Wi, Ci]   (conv input)
+    const elem_t* dy;       // NHWC [N, Ho, Wo, Co]   (gradient of the conv output)
+    const elem_t* x;        // NHWC [N, Hi, Wi, Ci]   (conv input)
     float* dw;              // fp32, layout [R][wtaps][C] where (R,C) = (Co,Ci) or, with swap, (Ci,Co)
     const IgTap* taps;
     int N, Hi, Wi, Ci;

@@ -306,16 +306,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
         if constexpr (!F32) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[MT], bfr[NT];
+                elem8 af[MT], bfr[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(S + a_fo[i][kk]);
+                for (int i = 0; i < MT; ++i) af[i] = *(const elem8*)(S + a_fo[i][kk]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_fo[j][kk]);
+                for (int j = 0; j < NT; ++j) bfr[j] = *(const elem8*)(S + b_fo[j][kk]);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = UDAPOSE_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
             }
         } else {
             // fp32: lane group q = lane>>4 owns k = 8q..8q+7 of the 32-deep stage (two 16-byte chunks of its row);
@@ -434,21 +434,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
             constexpr int t = decltype(tc)::value;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[MT], bfr[NT];
+                elem8 af[MT], bfr[NT];
 #pragma unroll
                 for (int h = 0; h < MT / 2; ++h) {
                     unsigned w = fo3[h][kk][t];
                     asm volatile("" : "+v"(w));       // (opaque: the unpacked offsets are loop-invariant, and hoisting 4 x 18 of them spills)
-                    af[2 * h] = *(const bf16x8*)(Ab + (w & 0xFFFFu));
-                    af[2 * h + 1] = *(const bf16x8*)(Ab + (w >> 16));
+                    af[2 * h] = *(const elem8*)(Ab + (w & 0xFFFFu));
+                    af[2 * h + 1] = *(const elem8*)(Ab + (w >> 16));
                 }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(Bs + bfo3[j][kk]);
+                for (int j = 0; j < NT; ++j) bfr[j] = *(const elem8*)(Bs + bfo3[j][kk]);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = UDAPOSE_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
             }
         };
         __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): the zero rows are written before the first barrier
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
         for (int ch = 0; ch < TM / ER; ++ch) {
             size_t offs[NP];
             bool oks[NP];
-            bf16x8 yv[NP], zv[NP], rv[NP];
+            elem8 yv[NP], zv[NP], rv[NP];
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
                 const int m = m0 + wm * TM + ch * ER + ps * RPP + rsub;
@@ -675,11 +675,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
                 }
                 oks[ps] = ok;
                 offs[ps] = ok ? opix * p.Co + cbase : 0;
-                yv[ps] = bf16x8{}; zv[ps] = bf16x8{}; rv[ps] = bf16x8{};
+                yv[ps] = elem8{}; zv[ps] = elem8{}; rv[ps] = elem8{};
                 if (ok) {
-                    yv[ps] = *(const bf16x8*)(p.bs_y + offs[ps]);
-                    if (use_z) zv[ps] = *(const bf16x8*)(p.bs_z + offs[ps]);
-                    if (use_res) rv[ps] = *(const bf16x8*)(p.res + offs[ps]);
+                    yv[ps] = *(const elem8*)(p.bs_y + offs[ps]);
+                    if (use_z) zv[ps] = *(const elem8*)(p.bs_z + offs[ps]);
+                    if (use_res) rv[ps] = *(const elem8*)(p.res + offs[ps]);
                 }
             }
 #pragma unroll
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
                         const float ty = yf * bsc[e] + bsh[e];
                         const float t = use_z ? (float)zv[ps][e] : ty;
                         float gv = t > 0.f ? val : 0.f;
-                        if (!outf32) gv = (float)(bf16_t)gv;                    // the sums see exactly the value the BN apply kernel will read
+                        if (!outf32) gv = (float)(elem_t)gv;                    // the sums see exactly the value the BN apply kernel will read
                         bs1[e] += gv;
                         bs2[e] += gv * ((yf - bmu[e]) * bis[e]);
                         v[e] = gv;
@@ -715,10 +715,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
                         *(f32x4*)yo = (f32x4){v[0], v[1], v[2], v[3]};
                         *(f32x4*)(yo + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                     } else {
-                        bf16x8 o;
+                        elem8 o;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                        *(bf16x8*)((bf16_t*)p.y + offs[ps]) = o;
+                        for (int e = 0; e < 8; ++e) o[e] = (elem_t)v[e];
+                        *(elem8*)((elem_t*)p.y + offs[ps]) = o;
                     }
                 }
             }
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
                     } else {
-                        const bf16x8 rv = *(const bf16x8*)(p.res + off);
+                        const elem8 rv = *(const elem8*)(p.res + off);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                     }
@@ -784,10 +784,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
                         for (int e = 0; e < 8; ++e) if (cbase + e < p.Co) yo[e] = v[e];
                     }
                 } else {
-                    bf16x8 o;
+                    elem8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                    *(bf16x8*)((bf16_t*)p.y + off) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (elem_t)v[e];
+                    *(elem8*)((elem_t*)p.y + off) = o;
                 }
             }
         }
@@ -873,8 +873,8 @@ template <int BM, int BN, int WM, int WN, int NS, bool RS = false>
 int launch_cfg(IgParams& p, hipStream_t stream) {
     if constexpr (RS) {
         // register-staged variants exist for the bf16 fast path only (zero padding, no upsample, Ci >= 64)
-        if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) == 0) return launch_cfg_t<bf16_t, BM, BN, WM, WN, 2, true>(p, stream);
-        return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
+        if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) == 0) return launch_cfg_t<elem_t, BM, BN, WM, WN, 2, true>(p, stream);
+        return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false>(p, stream);
     } else {
         // lean 1x1 form: stride-1 single-tap convolution whose tiles are all full (M % BM, Co % BN), offsets in 32 bits
         const bool lean = g_igemm_lean && BN >= 64 && !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.tap0 &&
@@ -884,11 +884,11 @@ int launch_cfg(IgParams& p, hipStream_t stream) {
         if (p.bs_y) {
             // dgrad with the consumer BatchNorm's backward reduction in the epilogue (bf16 operands; bf16 or fp32 output)
             if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_RELU)) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-            if (lean) return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false, true, 3>(p, stream);
-            return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false, true>(p, stream);
+            if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, true, 3>(p, stream);
+            return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, true>(p, stream);
         }
-        if (lean) return launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false, false, 3>(p, stream);
-        return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS, false>(p, stream) : launch_cfg_t<bf16_t, BM, BN, WM, WN, NS, false>(p, stream);
+        if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, false, 3>(p, stream);
+        return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS, false>(p, stream) : launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false>(p, stream);
     }
 }
 
@@ -968,9 +968,9 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
             if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, true, 1>(p, stream);
+                return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, true, 1>(p, stream);
             }
-            return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, false, 1>(p, stream);
+            return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, false, 1>(p, stream);
         }
         case 12: {
             // 64-row tiles, three taps per barrier (two groups of weight tiles: 77 KB of LDS at W = 16, two work-groups per CU)
@@ -980,9 +980,9 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
             if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, true, 2>(p, stream);
+                return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, true, 2>(p, stream);
             }
-            return launch_cfg_t<bf16_t, 64, 64, 2, 2, 3, false, false, 2>(p, stream);
+            return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, false, 2>(p, stream);
         }
         case 11: {
             // the same with 128-row tiles (the 9 weight tiles of a chunk serve twice the rows); run of 128 + 2(W+1) rows <= 28 pieces
@@ -992,9 +992,9 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
             if (!ok) return launch_cfg<128, 64, 2, 2, 2>(p, stream);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, true, 1>(p, stream);
+                return launch_cfg_t<elem_t, 128, 64, 2, 2, 2, false, true, 1>(p, stream);
             }
-            return launch_cfg_t<bf16_t, 128, 64, 2, 2, 2, false, false, 1>(p, stream);
+            return launch_cfg_t<elem_t, 128, 64, 2, 2, 2, false, false, 1>(p, stream);
         }
         default: return UDAPOSE_ERR_ARG;
     }

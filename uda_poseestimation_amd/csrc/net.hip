@@ -13,27 +13,27 @@
 #include <vector>
 #include "conv_plan.h"
 
-int pw_nchw_f32_to_nhwc_bf16(hipStream_t, const float*, bf16_t*, int, int, int, int);
+int pw_nchw_f32_to_nhwc_bf16(hipStream_t, const float*, elem_t*, int, int, int, int);
 int pw_nhwc_to_nchw_f32(hipStream_t, const void*, int, float*, int, int, int, int, const float*, const float*);
-int pw_cast_f32_bf16(hipStream_t, const float*, bf16_t*, size_t);
-int pw_transpose_cast(hipStream_t, const float*, bf16_t*, int, int, int);
-int pw_pack_strided(hipStream_t, const float*, bf16_t*, int, int, int, int, int, int, long, long, long, long);
+int pw_cast_f32_bf16(hipStream_t, const float*, elem_t*, size_t);
+int pw_transpose_cast(hipStream_t, const float*, elem_t*, int, int, int);
+int pw_pack_strided(hipStream_t, const float*, elem_t*, int, int, int, int, int, int, long, long, long, long);
 int pw_unpack_strided(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long, float);
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
                    float*, float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
-int pw_bn_apply(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, int);
+int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
-int pw_bn_bwd(hipStream_t, const void*, int, const bf16_t*, const bf16_t*, bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, int,
+int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
               float*, float*, float*, float*, float, const float*);
-int pw_bn_bwd_pre(hipStream_t, const void*, int, const bf16_t*, bf16_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
+int pw_bn_bwd_pre(hipStream_t, const void*, int, const elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
                   float*, float*, float);
-int pw_maxpool3x3s2_fwd(hipStream_t, const bf16_t*, bf16_t*, unsigned char*, int, int, int, int);
-int pw_maxpool3x3s2_bwd(hipStream_t, const bf16_t*, const unsigned char*, bf16_t*, int, int, int, int);
+int pw_maxpool3x3s2_fwd(hipStream_t, const elem_t*, elem_t*, unsigned char*, int, int, int, int);
+int pw_maxpool3x3s2_bwd(hipStream_t, const elem_t*, const unsigned char*, elem_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
 int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
 int pw_bn_running_update_multi(hipStream_t, const BnRunJob*, int, int, const void*, float);
-int pw_bn_train_fused(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, size_t, int, const float*, int, const float*, const float*, float*, float*,
+int pw_bn_train_fused(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, int, const float*, const float*, float*, float*,
                       long long*, float, float, float*, int);
 int pw_zero_multi(hipStream_t, const ZeroJob*, int, void*);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
@@ -123,7 +123,7 @@ struct Net {
     BnRunJob* d_runjobs = nullptr; int n_runjobs = 0; const void* runjobs_key = nullptr;
     unsigned long long wg_tick = 0;
 };
-struct PackJobH { const float* src; bf16_t* dst; int A, T, B, kind; long long n; };
+struct PackJobH { const float* src; elem_t* dst; int A, T, B, kind; long long n; };
 
 size_t act_alloc(Net& n, size_t bytes) { size_t o = n.act_bytes; n.act_bytes = align_up(o + bytes); return o; }
 size_t wp_alloc(Net& n, size_t bytes) { size_t o = n.wpack_bytes; n.wpack_bytes = align_up(o + bytes); return o; }
@@ -240,15 +240,15 @@ Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
 
 struct Pool {
     char* base; size_t off[6]; bool used[6] = {false, false, false, false, false, false};
-    bf16_t* get() { for (int i = 0; i < 6; ++i) if (!used[i]) { used[i] = true; return (bf16_t*)(base + off[i]); } return nullptr; }
+    elem_t* get() { for (int i = 0; i < 6; ++i) if (!used[i]) { used[i] = true; return (elem_t*)(base + off[i]); } return nullptr; }
     void put(const void* p) { for (int i = 0; i < 6; ++i) if ((char*)p == base + off[i]) used[i] = false; }
 };
 
 int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* params, char* wpack, bool with_bwd) {
     const float* w = (const float*)params[c.w_idx];
     const ConvGeom& g = c.g;
-    bf16_t* wf = (bf16_t*)(wpack + c.wf_off);
-    bf16_t* wb = (bf16_t*)(wpack + c.wb_off);
+    elem_t* wf = (elem_t*)(wpack + c.wf_off);
+    elem_t* wb = (elem_t*)(wpack + c.wb_off);
     const int T = g.KH * g.KW;
     if (n.f32) {
         if (g.smallc())
@@ -273,7 +273,7 @@ int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* pa
 }
 
 int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, void* const* buffers, const char* wpack,
-                char* act, char* ws, int training, float momentum, const bf16_t* res, int relu) {
+                char* act, char* ws, int training, float momentum, const elem_t* res, int relu) {
     const bool upd = n.update_running != 0;
     ConvEpilogue e;
     float* slab = (float*)(ws + n.ws_slab);
@@ -283,12 +283,12 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     e.stats = training ? slab : nullptr;
     e.f32 = n.f32;
     const void* wptr = (n.f32 && !c.g.smallc() && !c.g.transposed) ? params[c.w_idx] : (const void*)(wpack + c.wf_off);
-    CK(conv_fprop(s, c.g, (const bf16_t*)(act + c.in_off), (const bf16_t*)wptr, act + c.y_off, e));
+    CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
     if (training && !n.f32) {
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
-        const int took = pw_bn_train_fused(s, (const bf16_t*)(act + c.y_off), res, (bf16_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
+        const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
                                            beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
                                            upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu);
         if (took < 0) return took;
@@ -302,7 +302,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
     if (n.f32)
         return pw_bn_apply_f32(s, (const float*)(act + c.y_off), (const float*)res, (float*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
-    return pw_bn_apply(s, (const bf16_t*)(act + c.y_off), res, (bf16_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
+    return pw_bn_apply(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
 }
 
 }  // namespace
@@ -337,8 +337,8 @@ void add_pack_jobs(const Net& n, const ConvL& c, const void* const* params, char
     if (g.smallc()) return;                       // stem: strided gather, launched separately
     const float* w = (const float*)params[c.w_idx];
     const int T = g.KH * g.KW;
-    bf16_t* wf = (bf16_t*)(wpack + c.wf_off);
-    bf16_t* wb = (bf16_t*)(wpack + c.wb_off);
+    elem_t* wf = (elem_t*)(wpack + c.wf_off);
+    elem_t* wb = (elem_t*)(wpack + c.wb_off);
     if (!g.transposed) {
         jobs.push_back(PackJobH{w, wf, 0, 0, 0, 0, (long long)g.Co * T * g.Ci});
         if (with_bwd) jobs.push_back(PackJobH{w, wb, g.Co, T, g.Ci, 1, 0});
@@ -356,7 +356,7 @@ int build_pack_table(Net& n, Net::PackTab& tab, const void* const* params, char*
         if (b.has_ds) add_pack_jobs(n, b.cd, params, wpack, with_bwd, jobs);
     }
     for (int i = 0; i < 3; ++i) add_pack_jobs(n, n.up[i], params, wpack, with_bwd, jobs);
-    jobs.push_back(PackJobH{(const float*)params[n.head.w_idx], (bf16_t*)(wpack + n.head.wf_off), 0, 0, 0, 0, (long long)n.K * 256});
+    jobs.push_back(PackJobH{(const float*)params[n.head.w_idx], (elem_t*)(wpack + n.head.wf_off), 0, 0, 0, 0, (long long)n.K * 256});
     std::vector<int> bj, bs;
     for (size_t j = 0; j < jobs.size(); ++j) {
         const PackJobH& q = jobs[j];
@@ -388,7 +388,7 @@ int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wp
         CK(pack_conv(s, n, n.stem, params, wpack, false));
         CK(pw_pack_multi(s, tab.jobs, tab.blk_job, tab.blk_sub, tab.nblocks));
         if (with_bwd)   // head dgrad pack [256][1][64]: wb[ci][k] = w[k][ci], zero for k >= K
-            CK(pw_pack_strided(s, (const float*)params[n.head.w_idx], (bf16_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
+            CK(pw_pack_strided(s, (const float*)params[n.head.w_idx], (elem_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
         return UDAPOSE_OK;
     }
     CK(pack_conv(s, n, n.stem, params, wpack, false));
@@ -401,9 +401,9 @@ int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wp
     for (int i = 0; i < 3; ++i) CK(pack_conv(s, n, n.up[i], params, wpack, with_bwd));
     const float* hw = (const float*)params[n.head.w_idx];
     if (n.f32) return UDAPOSE_OK;      // the head reads its fp32 master directly
-    CK(pw_cast_f32_bf16(s, hw, (bf16_t*)(wpack + n.head.wf_off), (size_t)n.K * 256));
+    CK(pw_cast_f32_bf16(s, hw, (elem_t*)(wpack + n.head.wf_off), (size_t)n.K * 256));
     if (with_bwd)   // [256][1][64]: wb[ci][k] = w[k][ci], zero for k >= K
-        CK(pw_pack_strided(s, hw, (bf16_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
+        CK(pw_pack_strided(s, hw, (elem_t*)(wpack + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
     return UDAPOSE_OK;
 }
 
@@ -416,21 +416,21 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     char* act = (char*)act_;
     char* ws = (char*)ws_;
     if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
-    else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (bf16_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
+    else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (elem_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
     if (n.f32)
         CK(pw_maxpool3x3s2_fwd_f32(s, (const float*)(act + n.stem_bn.z_off), (float*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
                                    n.Hs, n.Ws, 64));
     else
-        CK(pw_maxpool3x3s2_fwd(s, (const bf16_t*)(act + n.stem_bn.z_off), (bf16_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
+        CK(pw_maxpool3x3s2_fwd(s, (const elem_t*)(act + n.stem_bn.z_off), (elem_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
                                n.Hs, n.Ws, 64));
     for (auto& b : n.blocks) {
         CK(conv_bn_fwd(s, n, b.c1, b.b1, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
         CK(conv_bn_fwd(s, n, b.c2, b.b2, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
-        const bf16_t* res = (const bf16_t*)(act + b.in_off);
+        const elem_t* res = (const elem_t*)(act + b.in_off);
         if (b.has_ds) {
             CK(conv_bn_fwd(s, n, b.cd, b.bd, params, buffers, wpack, act, ws, training, momentum, nullptr, 0));
-            res = (const bf16_t*)(act + b.zd_off);
+            res = (const elem_t*)(act + b.zd_off);
         }
         CK(conv_bn_fwd(s, n, b.c3, b.b3, params, buffers, wpack, act, ws, training, momentum, res, 1));
     }
@@ -440,7 +440,7 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     e.out_f32 = 1;
     e.f32 = n.f32;
     const void* hwp = n.f32 ? params[n.head.w_idx] : (const void*)(wpack + n.head.wf_off);
-    CK(conv_fprop(s, n.head.g, (const bf16_t*)(act + n.head.in_off), (const bf16_t*)hwp, act + n.head_out_off, e));
+    CK(conv_fprop(s, n.head.g, (const elem_t*)(act + n.head.in_off), (const elem_t*)hwp, act + n.head_out_off, e));
     return pw_nhwc_to_nchw_f32(s, act + n.head_out_off, 1, out_nchw, n.N, n.K, n.Hout * n.Wout, n.K, nullptr, nullptr);
 }
 
@@ -450,19 +450,19 @@ namespace {
 // pre:  the dgrad that produced dz already applied this BN's mask and left the partial sums in pre->slab (dz is g)
 // next: the BN that consumes dx; this layer's dgrad masks dx for it and reduces its sums (filled by bn_stat_of)
 int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, const char* wpack, char* act, char* ws,
-                void* const* grads, float beta, Pool& pool, const void* dz, int dz_f32, bf16_t* gout, int relu, const bf16_t* dx_res,
-                bf16_t** dx_out, bool need_dx, int dx_f32, bool grouped_wgrad, const DgradBnStat* pre = nullptr, DgradBnStat* next = nullptr) {
+                void* const* grads, float beta, Pool& pool, const void* dz, int dz_f32, elem_t* gout, int relu, const elem_t* dx_res,
+                elem_t** dx_out, bool need_dx, int dx_f32, bool grouped_wgrad, const DgradBnStat* pre = nullptr, DgradBnStat* next = nullptr) {
     float* slab = (float*)(ws + n.ws_slab);
     float* coef = (float*)(ws + n.ws_coef) + 4096;
     const float* save = (const float*)(act + b.save_off);
-    bf16_t* dy = (bf16_t*)(ws + c.dy_off);
+    elem_t* dy = (elem_t*)(ws + c.dy_off);
     if (pre)
-        CK(pw_bn_bwd_pre(s, dz, dz_f32, (const bf16_t*)(act + c.y_off), dy, b.npix, b.C, (const float*)params[b.g_idx], save, save + b.C, pre->slab,
+        CK(pw_bn_bwd_pre(s, dz, dz_f32, (const elem_t*)(act + c.y_off), dy, b.npix, b.C, (const float*)params[b.g_idx], save, save + b.C, pre->slab,
                          pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta));
     else
-        CK(pw_bn_bwd(s, dz, dz_f32, (const bf16_t*)(act + b.z_off), (const bf16_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx],
+        CK(pw_bn_bwd(s, dz, dz_f32, (const elem_t*)(act + b.z_off), (const elem_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx],
                      save, save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx]));
-    const bf16_t* xin = (const bf16_t*)(act + c.in_off);
+    const elem_t* xin = (const elem_t*)(act + c.in_off);
     if (c.g.smallc() && grouped_wgrad && g_wgrad_group_stem) {
         // (the stem's weight gradient joins the grouped launch in its row-tap form, run_wg_group)
     } else if (c.g.smallc()) {
@@ -474,9 +474,9 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         CK(conv_wgrad(s, c.g, dy, xin, (float*)grads[c.w_idx], beta != 0.f, -1));
     }
     if (need_dx) {
-        bf16_t* dx = pool.get();
+        elem_t* dx = pool.get();
         if (!dx) return UDAPOSE_ERR_ARG;
-        CK(conv_dgrad(s, c.g, dy, (const bf16_t*)(wpack + c.wb_off), dx, dx_res, dx_f32, next));
+        CK(conv_dgrad(s, c.g, dy, (const elem_t*)(wpack + c.wb_off), dx, dx_res, dx_f32, next));
         *dx_out = dx;
     }
     return UDAPOSE_OK;
@@ -486,8 +486,8 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
 DgradBnStat bn_stat_of(const Net& n, const ConvL& c, const BnL& b, const void* const* params, char* act, char* ws, int relu) {
     DgradBnStat st;
     const float* save = (const float*)(act + b.save_off);
-    st.y = (const bf16_t*)(act + c.y_off);
-    st.z = relu == 1 ? (const bf16_t*)(act + b.z_off) : nullptr;
+    st.y = (const elem_t*)(act + c.y_off);
+    st.z = relu == 1 ? (const elem_t*)(act + b.z_off) : nullptr;
     st.mean = save; st.invstd = save + b.C;
     st.gamma = (const float*)params[b.g_idx]; st.beta = (const float*)params[b.b_idx];
     st.slab = (float*)(ws + n.ws_slabf);
@@ -515,7 +515,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         // byte offsets from the workspace / activation arena / gradient bases in place of pointers (see wgrad_dma_group_kernel)
         const ptrdiff_t drel = (const char*)grads[w_idx] - (const char*)grads[0];
         G.rel.push_back({w_idx, drel});
-        CK(conv_wgrad_params(g, (const bf16_t*)dy_off, (const bf16_t*)in_off, (float*)drel, rows_valid, &p, &fl));
+        CK(conv_wgrad_params(g, (const elem_t*)dy_off, (const elem_t*)in_off, (float*)drel, rows_valid, &p, &fl));
         const int t = wgrad_group_plan(p, beta != 0.f, g_wgrad_stages);
         if (t < 0) return UDAPOSE_ERR_UNSUPPORTED;
         const int prob = (int)tab[t].size();
@@ -545,7 +545,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         // 8192 stages), unpacked into the real [Co][KH][KW][3] gradient after the launch
         WgParams p;
         double fl = 0.0;
-        CK(conv_wgrad_params(n.stem.g, (const bf16_t*)n.stem.dy_off, (const bf16_t*)n.stem.in_off, (float*)n.ws_dwtmp, -2, &p, &fl));
+        CK(conv_wgrad_params(n.stem.g, (const elem_t*)n.stem.dy_off, (const elem_t*)n.stem.in_off, (float*)n.ws_dwtmp, -2, &p, &fl));
         p.flags |= WG_FLAG_DW_WS;
         const int t = wgrad_group_plan(p, 1, g_wgrad_stages);      // (accumulate = 1: atomics into the zeroed scratch)
         if (t != 1) return UDAPOSE_ERR_UNSUPPORTED;
@@ -671,17 +671,17 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     const bool grouped = g_wgrad_group != 0;
     const int HWo = n.Hout * n.Wout;
     // head
-    bf16_t* dyh = (bf16_t*)(ws + n.ws_dyhead);
+    elem_t* dyh = (elem_t*)(ws + n.ws_dyhead);
     CK(pw_nchw_f32_to_nhwc_bf16(s, dout_nchw, dyh, n.N, n.K, HWo, 64));
     CK(pw_plane_sum(s, dout_nchw, (float*)grads[n.head.bias_idx], n.N, n.K, HWo, beta));
     ConvGeom hg = n.head.g;
     hg.Co = 64;   // dy is channel-padded to 64 (one 64-wide K step)
     float* tmp = (float*)(ws + n.ws_dwtmp);
     if (!grouped) {
-        CK(conv_wgrad(s, hg, dyh, (const bf16_t*)(act + n.head.in_off), tmp, 0, n.K));
+        CK(conv_wgrad(s, hg, dyh, (const elem_t*)(act + n.head.in_off), tmp, 0, n.K));
         CK(pw_unpack_strided(s, tmp, (float*)grads[n.head.w_idx], n.K, 1, 1, 1, 256, 256, 256, 0, 0, 1, beta));
     }
-    bf16_t* dz = pool.get();
+    elem_t* dz = pool.get();
     // Gradients entering the BatchNorm backward of the three deconv layers are kept in fp32: close to the loss the BN
     // projection (g - mean(g) - xhat*mean(g*xhat)) cancels ~90 % of g, so bf16 rounding of g is amplified ~10x in dy
     // (measured against the backward of the bf16-storage emulation: 2.4 % / 8 % / 14 % relative error per layer with
@@ -694,10 +694,10 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     DgradBnStat cur, nxt;
     bool have = false;
     if (fused) { cur = bn_stat_of(n, n.up[2], n.up_bn[2], params, act, ws, 2); have = true; }
-    CK(conv_dgrad(s, hg, dyh, (const bf16_t*)(wpack + n.head.wb_off), dz, nullptr, 1, have ? &cur : nullptr));
+    CK(conv_dgrad(s, hg, dyh, (const elem_t*)(wpack + n.head.wb_off), dz, nullptr, 1, have ? &cur : nullptr));
     // deconv stack
     for (int i = 2; i >= 0; --i) {
-        bf16_t* dx = nullptr;
+        elem_t* dx = nullptr;
         if (fused) {
             if (i > 0) nxt = bn_stat_of(n, n.up[i - 1], n.up_bn[i - 1], params, act, ws, 2);
             else nxt = bn_stat_of(n, n.blocks.back().c3, n.blocks.back().b3, params, act, ws, 1);
@@ -713,7 +713,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         Block& b = n.blocks[bi];
         // bn3 (+ReLU of the block output): g = masked dz feeds the skip branch (written in place unless the producing dgrad
         // already masked it)
-        bf16_t *dz2 = nullptr, *dz1 = nullptr, *dxd = nullptr, *dxin = nullptr;
+        elem_t *dz2 = nullptr, *dz1 = nullptr, *dxd = nullptr, *dxin = nullptr;
         if (fused) nxt = bn_stat_of(n, b.c2, b.b2, params, act, ws, 2);
         CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, 0, dz, 1, nullptr, &dz2, true, 0, grouped, have ? &cur : nullptr,
                        fused ? &nxt : nullptr));
@@ -722,7 +722,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
                        have ? &cur : nullptr, fused ? &nxt : nullptr));
         if (fused) cur = nxt;
         pool.put(dz2);
-        const bf16_t* skip = dz;
+        const elem_t* skip = dz;
         if (b.has_ds) {
             // the downsample BN shares g with bn3 (already masked): its own reduce / apply, no ReLU
             CK(conv_bn_bwd(s, n, b.cd, b.bd, params, wpack, act, ws, grads, beta, pool, dz, 0, nullptr, 0, nullptr, &dxd, true, 0, grouped));
@@ -739,10 +739,10 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         dz = dxin;
     }
     // stem: maxpool -> bn/relu -> conv (no input gradient)
-    bf16_t* dzs = pool.get();
+    elem_t* dzs = pool.get();
     CK(pw_maxpool3x3s2_bwd(s, dz, (const unsigned char*)(act + n.poolidx_off), dzs, n.N, n.Hs, n.Ws, 64));
     pool.put(dz);
-    bf16_t* none = nullptr;
+    elem_t* none = nullptr;
     CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 2, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
     if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta));

@@ -56,7 +56,11 @@ __global__ void ema_k(MtTable t, float alpha, float one_minus_alpha) {
 // The step counter ticks on the device; lr and grad_scale are READ from it by the sweep, so that an lr scheduler
 // (MultiStepLR in the reference, train_human.py:143,202) or a loss-scale change reaches a captured step through a
 // 8-byte host-to-device copy instead of being frozen into the graph as kernel arguments.
+// state[5] = found_inf (set by grad_check_k: a non-finite gradient under loss scaling): the step is skipped whole - no
+// tick, no update - exactly as GradScaler.step() skips optimizer.step() (train_human.py:286,437); state[6] = loss scale S,
+// state[7] = growth tracker, state[4] = grad_scale = 1/S (scaler_update_k).
 __global__ void adam_tick_k(float* __restrict__ state, float beta1, float beta2) {
+    if (state[5] != 0.f) return;
     const double t = (double)state[0] + 1.0;
     state[0] = (float)t;
     state[1] = (float)(1.0 - pow((double)beta1, t));
@@ -66,7 +70,10 @@ __global__ void adam_tick_k(float* __restrict__ state, float beta1, float beta2)
 // torch.optim.Adam (no amsgrad, no weight decay unless wd != 0): operands a=param b=grad c=exp_avg d=exp_avg_sq
 __global__ void adam_k(MtTable t, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
                        const float* __restrict__ dev_state) {
-    if (dev_state) { bc1 = dev_state[1]; bc2_sqrt = dev_state[2]; lr = dev_state[3]; gscale = dev_state[4]; }
+    if (dev_state) {
+        if (dev_state[5] != 0.f) return;            // inf / nan gradients: skip the step (GradScaler semantics)
+        bc1 = dev_state[1]; bc2_sqrt = dev_state[2]; lr = dev_state[3]; gscale = dev_state[4];
+    }
     const int ti = t.blk_tensor[blockIdx.x];
     const long long off = t.blk_off[blockIdx.x];
     float* p = (float*)t.a[ti];
@@ -89,11 +96,14 @@ __global__ void adam_k(MtTable t, float lr, float beta1, float beta2, float eps,
 }
 
 // torch.optim.SGD(momentum, nesterov, weight_decay): a=param b=grad c=momentum buffer
-__global__ void sgd_tick_k(float* __restrict__ state) { state[0] += 1.f; }
+__global__ void sgd_tick_k(float* __restrict__ state) { if (state[5] == 0.f) state[0] += 1.f; }
 __global__ void sgd_k(MtTable t, float lr, float momentum, float wd, int nesterov, int first_step, float gscale,
                       const float* __restrict__ dev_state) {
     // (first_step: torch initialises the momentum buffer with the first gradient)
-    if (dev_state) { first_step = dev_state[0] == 1.f; lr = dev_state[3]; gscale = dev_state[4]; }
+    if (dev_state) {
+        if (dev_state[5] != 0.f) return;
+        first_step = dev_state[0] == 1.f; lr = dev_state[3]; gscale = dev_state[4];
+    }
     const int ti = t.blk_tensor[blockIdx.x];
     const long long off = t.blk_off[blockIdx.x];
     float* p = (float*)t.a[ti];
@@ -109,9 +119,46 @@ __global__ void sgd_k(MtTable t, float lr, float momentum, float wd, int nestero
         p[i] -= lr * gr;
     }
 }
+// ---- dynamic loss scaling (torch.cuda.amp.GradScaler, train_human.py:260,285-287,324,436-440) on the device
+// found_inf: operand b = the gradient tensors; any non-finite value raises state[5] (every writer stores the same 1.0f)
+__global__ void grad_check_k(MtTable t, float* __restrict__ state) {
+    const int ti = t.blk_tensor[blockIdx.x];
+    const long long off = t.blk_off[blockIdx.x];
+    const float* g = (const float*)t.b[ti];
+    const long long n = t.sizes[ti];
+    const long long end = off + CHUNK < n ? off + CHUNK : n;
+    bool bad = false;
+    for (long long i = off + threadIdx.x; i < end; i += TPB) {
+        const float v = g[i];
+        bad = bad || !(fabsf(v) <= 3.4028234e38f);        // inf or nan
+    }
+    if (bad) state[5] = 1.f;
+}
+// GradScaler.update(): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and scale *= growth every `interval`
+// clean steps.  Re-arms found_inf and refreshes grad_scale = 1 / scale for the next step's sweep.
+__global__ void scaler_update_k(float* __restrict__ state, float growth, float backoff, float interval) {
+    float scale = state[6], tr = state[7];
+    if (state[5] != 0.f) { scale *= backoff; tr = 0.f; }
+    else { tr += 1.f; if (tr >= interval) { scale *= growth; tr = 0.f; } }
+    state[6] = scale; state[7] = tr; state[5] = 0.f;
+    state[4] = 1.f / scale;
+}
 }  // namespace
 
 int opt_chunk() { return CHUNK; }
+int opt_grad_check(hipStream_t s, const long long* g, const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks,
+                   float* dev_state) {
+    if (!dev_state) return UDAPOSE_ERR_ARG;
+    MtTable t{nullptr, g, nullptr, nullptr, sizes, blk_tensor, blk_off};
+    if (nblocks <= 0) return UDAPOSE_OK;
+    hipLaunchKernelGGL(grad_check_k, dim3(nblocks), dim3(TPB), 0, s, t, dev_state);
+    return udapose_check_launch();
+}
+int opt_scaler_update(hipStream_t s, float* dev_state, float growth, float backoff, int interval) {
+    if (!dev_state || interval < 1) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(scaler_update_k, dim3(1), dim3(1), 0, s, dev_state, growth, backoff, (float)interval);
+    return udapose_check_launch();
+}
 
 int opt_ema(hipStream_t s, const long long* tgt, const long long* src, const long long* sizes, const int* blk_tensor, const long long* blk_off,
             int nblocks, float alpha, float one_minus_alpha) {

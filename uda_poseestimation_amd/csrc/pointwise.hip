@@ -12,8 +12,8 @@ inline int nblk(size_t n, int per = TPB) { return (int)((n + per - 1) / per); }
 // ------------------------------------------------------------------ layout conversion
 // 8 consecutive activation values <-> fp32 registers, for bf16 or fp32 storage
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
-template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) {
-    const bf16x8 v = *(const bf16x8*)p;
+template <> __device__ __forceinline__ void ld8<elem_t>(const elem_t* p, float (&o)[8]) {
+    const elem8 v = *(const elem8*)p;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
 }
@@ -23,11 +23,11 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o
     for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
 }
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
-template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-    bf16x8 o;
+template <> __device__ __forceinline__ void st8<elem_t>(elem_t* p, const float (&v)[8]) {
+    elem8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *(bf16x8*)p = o;
+    for (int e = 0; e < 8; ++e) o[e] = (elem_t)v[e];
+    *(elem8*)p = o;
 }
 template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
     *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
@@ -69,11 +69,11 @@ __global__ void nhwc_to_nchw_f32_k(const T* __restrict__ src, float* __restrict_
 }
 
 // ------------------------------------------------------------------ weight packing (fp32 master -> bf16 GEMM layouts)
-__global__ void cast_f32_bf16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8) {
+__global__ void cast_f32_bf16_k(const float* __restrict__ src, elem_t* __restrict__ dst, size_t n8) {
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
         const f32x4 a = *(const f32x4*)(src + i * 8), b = *(const f32x4*)(src + i * 8 + 4);
-        bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
-        *(bf16x8*)(dst + i * 8) = o;
+        elem8 o = {(elem_t)a[0], (elem_t)a[1], (elem_t)a[2], (elem_t)a[3], (elem_t)b[0], (elem_t)b[1], (elem_t)b[2], (elem_t)b[3]};
+        *(elem8*)(dst + i * 8) = o;
     }
 }
 // src [A][T][B] fp32 -> dst [B][T][A] (bf16 or fp32) (32x32 LDS-tiled transpose per tap); grid = (B/32, A/32, T)
@@ -94,7 +94,7 @@ __global__ void transpose_cast_k(const float* __restrict__ src, D* __restrict__ 
 }
 // One launch packs every weight of a network: a job is either a contiguous cast (T == 0: n elements) or a per-tap
 // transpose [A][T][B] fp32 -> [B][T][A] bf16; block b works on job blk_job[b], sub-block blk_sub[b].
-struct PackJob { const float* src; bf16_t* dst; int A, T, B, kind; long long n; };
+struct PackJob { const float* src; elem_t* dst; int A, T, B, kind; long long n; };
 __global__ void pack_multi_k(const PackJob* __restrict__ jobs, const int* __restrict__ blk_job, const int* __restrict__ blk_sub) {
     __shared__ float tile[32][33];
     const PackJob j = jobs[blk_job[blockIdx.x]];
@@ -103,8 +103,8 @@ __global__ void pack_multi_k(const PackJob* __restrict__ jobs, const int* __rest
         const long long base = (long long)sub * 8192;           // 8192 elements per block
         for (long long i = base + threadIdx.x * 8; i < base + 8192 && i < j.n; i += TPB * 8) {
             const f32x4 a = *(const f32x4*)(j.src + i), b = *(const f32x4*)(j.src + i + 4);
-            bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
-            *(bf16x8*)(j.dst + i) = o;
+            elem8 o = {(elem_t)a[0], (elem_t)a[1], (elem_t)a[2], (elem_t)a[3], (elem_t)b[0], (elem_t)b[1], (elem_t)b[2], (elem_t)b[3]};
+            *(elem8*)(j.dst + i) = o;
         }
         return;
     }
@@ -119,7 +119,7 @@ __global__ void pack_multi_k(const PackJob* __restrict__ jobs, const int* __rest
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int b = b0 + r, a = a0 + tx;
-        if (a < j.A && b < j.B) j.dst[((size_t)b * j.T + t) * j.A + a] = (bf16_t)tile[tx][r];
+        if (a < j.A && b < j.B) j.dst[((size_t)b * j.T + t) * j.A + a] = (elem_t)tile[tx][r];
     }
 }
 
@@ -283,8 +283,8 @@ __global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T
 // 8 consecutive gradient values as fp32 (the gradient entering a BN backward may be kept in fp32 near the loss, where
 // g - mean(g) - xhat*mean(g*xhat) cancels most of g and bf16 rounding of g would dominate the result)
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]);
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) {
-    const bf16x8 v = *(const bf16x8*)p;
+template <> __device__ __forceinline__ void load8<elem_t>(const elem_t* p, float (&o)[8]) {
+    const elem8 v = *(const elem8*)p;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
 }
@@ -297,7 +297,7 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 // Backward reduce: per-channel sum(g) and sum(g*xhat), g = dz * (z>0) when relu.  Partial slab [blocks][2][C].
 // Requires C/8 to be a power of two <= 256 (thread's channel group is loop-invariant).
 template <typename DZ>
-__global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+__global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const elem_t* __restrict__ z, const elem_t* __restrict__ y,
                                 size_t npix, int C, const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                 float* __restrict__ slab, int pix_per_block, const float* __restrict__ gamma, const float* __restrict__ beta) {
     __shared__ float red[TPB][17];
@@ -318,9 +318,9 @@ __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const bf16_t* __restr
         const size_t off = p * C + c0;
         float d[8];
         load8<DZ>(dz + off, d);
-        const bf16x8 yy = *(const bf16x8*)(y + off);
-        bf16x8 zz = {};
-        if (relu == 1) zz = *(const bf16x8*)(z + off);
+        const elem8 yy = *(const elem8*)(y + off);
+        elem8 zz = {};
+        if (relu == 1) zz = *(const elem8*)(z + off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float gv = d[e];
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_k(const float* __restri
 }
 // dy = ca*(g - cb - xhat*cc); optionally also write g (masked dz) for the skip branch
 template <typename DZ>
-__global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
-                               bf16_t* __restrict__ dy, bf16_t* __restrict__ gout, size_t n8, int C, const float* __restrict__ mean,
+__global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const elem_t* __restrict__ z, const elem_t* __restrict__ y,
+                               elem_t* __restrict__ dy, elem_t* __restrict__ gout, size_t n8, int C, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ coef, int relu, const float* __restrict__ gamma,
                                const float* __restrict__ beta) {
     const int G = C >> 3;
@@ -374,9 +374,9 @@ __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restri
         const int c0 = (int)(i % G) * 8;
         float d[8];
         load8<DZ>(dz + i * 8, d);
-        const bf16x8 yy = *(const bf16x8*)(y + i * 8);
-        bf16x8 zz = {};
-        if (relu == 1) zz = *(const bf16x8*)(z + i * 8);
+        const elem8 yy = *(const elem8*)(y + i * 8);
+        elem8 zz = {};
+        if (relu == 1) zz = *(const elem8*)(z + i * 8);
         // per-channel coefficients as 16-byte loads (8 consecutive channels)
         float mu[8], is[8], ca[8], cb[8], cc[8], sc[8], sh[8];
         load8<float>(mean + c0, mu);
@@ -394,18 +394,18 @@ __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restri
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
         }
-        bf16x8 o, go;
+        elem8 o, go;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float gv = d[e];
             if (relu == 1 && !((float)zz[e] > 0.f)) gv = 0.f;
             if (relu == 2 && !((float)yy[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
             const float xh = ((float)yy[e] - mu[e]) * is[e];
-            o[e] = (bf16_t)(ca[e] * (gv - cb[e] - xh * cc[e]));
-            go[e] = (bf16_t)gv;
+            o[e] = (elem_t)(ca[e] * (gv - cb[e] - xh * cc[e]));
+            go[e] = (elem_t)gv;
         }
-        *(bf16x8*)(dy + i * 8) = o;
-        if (gout) *(bf16x8*)(gout + i * 8) = go;
+        *(elem8*)(dy + i * 8) = o;
+        if (gout) *(elem8*)(gout + i * 8) = go;
     }
 }
 
@@ -414,7 +414,7 @@ __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const bf16_t* __restri
 // epilogue's partial-statistics slab ([rows][2][C], rows <= 128 since the igemm adds its wave rows itself: <= 64 KB of
 // L2-resident data, read as 16-byte vectors) in fp64 with a fixed order and derives scale / shift exactly as bn_finalize_k
 // does; the sp == 0 work-groups also write the saved statistics and the running-statistics update.  Then it streams its pixels.
-__global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const bf16_t* __restrict__ y, const bf16_t* __restrict__ res, bf16_t* __restrict__ z,
+__global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const elem_t* __restrict__ y, const elem_t* __restrict__ res, elem_t* __restrict__ z,
                                                         size_t npix, int C, const float* __restrict__ slab, int rows, double count,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -478,18 +478,18 @@ __global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const bf16_t* __restrict
     for (size_t p = p0 + prow; p < p1; p += 32) {
         const size_t off = p * C + c0;
         float v[8], o[8];
-        ld8<bf16_t>(y + off, v);
+        ld8<elem_t>(y + off, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = v[e] * sc[e] + sh[e];
         if (res) {
             float r8[8];
-            ld8<bf16_t>(res + off, r8);
+            ld8<elem_t>(res + off, r8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += r8[e];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (relu && o[e] < 0.f) ? 0.f : o[e];
-        st8<bf16_t>(z + off, o);
+        st8<elem_t>(z + off, o);
     }
 }
 
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const bf16_t* __restrict
 // itself (fp64, fixed order) before streaming: the separate finalize launch (6-7 us on the critical path of every layer)
 // is gone, at the price of a <= 32 KB L2-resident prelude per work-group.
 template <typename DZ>
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce_chunk_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_chunk_k(const DZ* __restrict__ dz, const elem_t* __restrict__ z, const elem_t* __restrict__ y,
                                                              size_t npix, int C, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int relu, float* __restrict__ slab, int P,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta) {
@@ -526,9 +526,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_chunk_k(const DZ* __restric
         const size_t off = p * C + c0;
         float d[8];
         load8<DZ>(dz + off, d);
-        const bf16x8 yy = *(const bf16x8*)(y + off);
-        bf16x8 zz = {};
-        if (relu == 1) zz = *(const bf16x8*)(z + off);
+        const elem8 yy = *(const elem8*)(y + off);
+        elem8 zz = {};
+        if (relu == 1) zz = *(const elem8*)(z + off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float gv = d[e];
@@ -549,8 +549,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_chunk_k(const DZ* __restric
     }
 }
 template <typename DZ>
-__global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict__ dz, const bf16_t* __restrict__ z, const bf16_t* __restrict__ y,
-                                                            bf16_t* __restrict__ dy, bf16_t* __restrict__ gout, size_t npix, int C,
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict__ dz, const elem_t* __restrict__ z, const elem_t* __restrict__ y,
+                                                            elem_t* __restrict__ dy, elem_t* __restrict__ gout, size_t npix, int C,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ slab, int P, float* __restrict__ dgamma,
@@ -600,21 +600,21 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict
         const size_t off = p * C + c0;
         float d[8];
         load8<DZ>(dz + off, d);
-        const bf16x8 yy = *(const bf16x8*)(y + off);
-        bf16x8 zz = {};
-        if (relu == 1) zz = *(const bf16x8*)(z + off);
-        bf16x8 o, go;
+        const elem8 yy = *(const elem8*)(y + off);
+        elem8 zz = {};
+        if (relu == 1) zz = *(const elem8*)(z + off);
+        elem8 o, go;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float gv = d[e];
             if (relu == 1 && !((float)zz[e] > 0.f)) gv = 0.f;
             if (relu == 2 && !((float)yy[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
             const float xh = ((float)yy[e] - mu[e]) * is[e];
-            o[e] = (bf16_t)(ca[e] * (gv - cb[e] - xh * cc[e]));
-            go[e] = (bf16_t)gv;
+            o[e] = (elem_t)(ca[e] * (gv - cb[e] - xh * cc[e]));
+            go[e] = (elem_t)gv;
         }
-        *(bf16x8*)(dy + off) = o;
-        if (gout) *(bf16x8*)(gout + off) = go;
+        *(elem8*)(dy + off) = o;
+        if (gout) *(elem8*)(gout + off) = go;
     }
 }
 
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict
 // keeps gridDim.x * TPB a multiple of C/8 (bn_apply_grid), so a thread's 8 channels never change and its 40 coefficients are
 // loaded once instead of per 16-byte access; no integer division in the loop.
 template <typename DZ>
-__global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_k(const DZ* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ dy, size_t n8,
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_k(const DZ* __restrict__ g, const elem_t* __restrict__ y, elem_t* __restrict__ dy, size_t n8,
                                                           int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ coef) {
     const int G = C >> 3;
@@ -636,14 +636,14 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_k(const DZ* __restrict__
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
         float d[8];
         load8<DZ>(g + i * 8, d);
-        const bf16x8 yy = *(const bf16x8*)(y + i * 8);
-        bf16x8 o;
+        const elem8 yy = *(const elem8*)(y + i * 8);
+        elem8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float xh = ((float)yy[e] - mu[e]) * is[e];
-            o[e] = (bf16_t)(ca[e] * (d[e] - cb[e] - xh * cc[e]));
+            o[e] = (elem_t)(ca[e] * (d[e] - cb[e] - xh * cc[e]));
         }
-        *(bf16x8*)(dy + i * 8) = o;
+        *(elem8*)(dy + i * 8) = o;
     }
 }
 
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_k(const DZ* __restrict__
 // dgrad launch.  Work-group = 64 channels x one pixel range, grid (C/64, S): prelude = fp64 column sums of the work-group's 64
 // channels (rows <= 128: <= 64 KB of L2-resident data read as 16-byte vectors, fixed order), then dy = ca*(g - cb - xhat*cc).
 template <typename DZ>
-__global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_chunk_k(const DZ* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_chunk_k(const DZ* __restrict__ g, const elem_t* __restrict__ y, elem_t* __restrict__ dy,
                                                                 size_t npix, int C, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ slab, int rows, int P, float* __restrict__ dgamma,
@@ -712,14 +712,14 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_chunk_k(const DZ* __rest
         const size_t off = p * C + c0;
         float d[8];
         load8<DZ>(g + off, d);
-        const bf16x8 yy = *(const bf16x8*)(y + off);
-        bf16x8 o;
+        const elem8 yy = *(const elem8*)(y + off);
+        elem8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float xh = ((float)yy[e] - mu[e]) * is[e];
-            o[e] = (bf16_t)(ca[e] * (d[e] - cb[e] - xh * cc[e]));
+            o[e] = (elem_t)(ca[e] * (d[e] - cb[e] - xh * cc[e]));
         }
-        *(bf16x8*)(dy + off) = o;
+        *(elem8*)(dy + off) = o;
     }
 }
 
@@ -767,7 +767,7 @@ __global__ void maxpool3x3s2_fwd_k(const T* __restrict__ x, T* __restrict__ y, u
     }
 }
 // gather-style backward (no atomics): each input pixel checks the <=4 windows that contain it
-__global__ void maxpool3x3s2_bwd_k(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ idx, bf16_t* __restrict__ dx, int N,
+__global__ void maxpool3x3s2_bwd_k(const elem_t* __restrict__ dy, const unsigned char* __restrict__ idx, elem_t* __restrict__ dx, int N,
                                    int H, int W, int C, int Ho, int Wo) {
     const int G = C >> 3;
     const size_t total = (size_t)N * H * W * G;
@@ -788,16 +788,16 @@ __global__ void maxpool3x3s2_bwd_k(const bf16_t* __restrict__ dy, const unsigned
                 if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
                 const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8;
                 const unsigned long long pk = *(const unsigned long long*)(idx + o);
-                const bf16x8 d = *(const bf16x8*)(dy + o);
+                const elem8 d = *(const elem8*)(dy + o);
                 const unsigned tap = (unsigned)(kh * 3 + kw);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (((pk >> (8 * e)) & 0xFF) == tap) acc[e] += (float)d[e];
             }
-        bf16x8 o8;
+        elem8 o8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)acc[e];
-        *(bf16x8*)(dx + i * 8) = o8;
+        for (int e = 0; e < 8; ++e) o8[e] = (elem_t)acc[e];
+        *(elem8*)(dx + i * 8) = o8;
     }
 }
 // 2x2 stride 2 ceil-mode (VGG encoder, inference only)
@@ -874,9 +874,9 @@ inline int grid_for(size_t items) {
 }  // namespace
 
 // ------------------------------------------------------------------ host launchers (internal C++ API; C-ABI wrappers in capi.hip)
-int pw_nchw_f32_to_nhwc_bf16(hipStream_t s, const float* src, bf16_t* dst, int N, int C, int HW, int Cp) {
+int pw_nchw_f32_to_nhwc_bf16(hipStream_t s, const float* src, elem_t* dst, int N, int C, int HW, int Cp) {
     if (Cp % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(nchw_f32_to_nhwc_k<bf16_t>, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, dst, N, C, HW, Cp);
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_k<elem_t>, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, dst, N, C, HW, Cp);
     return udapose_check_launch();
 }
 int pw_nchw_f32_to_nhwc_f32(hipStream_t s, const float* src, float* dst, int N, int C, int HW, int Cp) {
@@ -888,16 +888,16 @@ int pw_nhwc_to_nchw_f32(hipStream_t s, const void* src, int src_is_f32, float* d
     if (src_is_f32)
         hipLaunchKernelGGL(nhwc_to_nchw_f32_k<float>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const float*)src, dst, N, C, HW, Cs, lo, hi);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_f32_k<bf16_t>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const bf16_t*)src, dst, N, C, HW, Cs, lo, hi);
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_k<elem_t>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const elem_t*)src, dst, N, C, HW, Cs, lo, hi);
     return udapose_check_launch();
 }
-int pw_cast_f32_bf16(hipStream_t s, const float* src, bf16_t* dst, size_t n) {
+int pw_cast_f32_bf16(hipStream_t s, const float* src, elem_t* dst, size_t n) {
     if (n % 8) return UDAPOSE_ERR_ARG;
     hipLaunchKernelGGL(cast_f32_bf16_k, dim3(grid_for(n / 8)), dim3(TPB), 0, s, src, dst, n / 8);
     return udapose_check_launch();
 }
-int pw_transpose_cast(hipStream_t s, const float* src, bf16_t* dst, int A, int T, int B) {
-    hipLaunchKernelGGL(transpose_cast_k<bf16_t>, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
+int pw_transpose_cast(hipStream_t s, const float* src, elem_t* dst, int A, int T, int B) {
+    hipLaunchKernelGGL(transpose_cast_k<elem_t>, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
     return udapose_check_launch();
 }
 int pw_transpose_f32(hipStream_t s, const float* src, float* dst, int A, int T, int B) {
@@ -909,8 +909,8 @@ int pw_pack_multi(hipStream_t s, const void* jobs, const int* blk_job, const int
     hipLaunchKernelGGL(pack_multi_k, dim3(nblocks), dim3(TPB), 0, s, (const PackJob*)jobs, blk_job, blk_sub);
     return udapose_check_launch();
 }
-int pw_pack_strided(hipStream_t s, const float* src, bf16_t* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
-    hipLaunchKernelGGL(pack_strided_k<bf16_t>, dim3(grid_for((size_t)A * KH * KWp * Bp)), dim3(TPB), 0, s, src, dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
+int pw_pack_strided(hipStream_t s, const float* src, elem_t* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
+    hipLaunchKernelGGL(pack_strided_k<elem_t>, dim3(grid_for((size_t)A * KH * KWp * Bp)), dim3(TPB), 0, s, src, dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
     return udapose_check_launch();
 }
 int pw_pack_strided_f32(hipStream_t s, const float* src, float* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
@@ -929,7 +929,7 @@ int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double cou
 }
 // finalize + apply in one launch where the chunked form applies; returns 1 when it took the layer, 0 when the caller must use
 // pw_bn_finalize + pw_bn_apply, < 0 on error
-int pw_bn_train_fused(hipStream_t s, const bf16_t* y, const bf16_t* res, bf16_t* z, size_t npix, int C, const float* slab, int rows,
+int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, size_t npix, int C, const float* slab, int rows,
                       const float* gamma, const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* save,
                       int relu) {
     // layer3 / layer4 / the first deconv (<= 8 K pixels, <= 128 slab rows): measured -0.1 ms per step; with the 32 K-pixel
@@ -998,9 +998,9 @@ static int bn_apply_grid(size_t n8, int C) {
     }
     return g;
 }
-int pw_bn_apply(hipStream_t s, const bf16_t* y, const bf16_t* res, bf16_t* z, size_t n, int C, const float* scale, const float* shift, int relu) {
+int pw_bn_apply(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, size_t n, int C, const float* scale, const float* shift, int relu) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(bn_apply_k<bf16_t>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    hipLaunchKernelGGL(bn_apply_k<elem_t>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
     return udapose_check_launch();
 }
 int pw_bn_apply_f32(hipStream_t s, const float* y, const float* res, float* z, size_t n, int C, const float* scale, const float* shift, int relu) {
@@ -1016,7 +1016,7 @@ int pw_bn_bwd_rows(size_t npix) {
     // upper bound used to size the scratch slab; the launch picks rows = min(1024, ceil(npix / pixels-per-iteration))
     return (int)(npix < 1024 ? (npix < 1 ? 1 : npix) : 1024);
 }
-int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, const bf16_t* y, bf16_t* dy, bf16_t* gout, size_t npix, int C,
+int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const elem_t* z, const elem_t* y, elem_t* dy, elem_t* gout, size_t npix, int C,
               const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
               float beta_acc, const float* beta) {
     if (relu == 2 && !beta) return UDAPOSE_ERR_ARG;
@@ -1038,8 +1038,8 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, con
             hipLaunchKernelGGL(bn_bwd_apply_chunk_k<float>, grid, dim3(TPB), 0, s, (const float*)dz, z, y, dy, gout, npix, C, mean, invstd, relu, gamma,
                                beta, slab, P, dgamma, dbeta, beta_acc);
         } else {
-            hipLaunchKernelGGL(bn_bwd_reduce_chunk_k<bf16_t>, grid, dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, P, gamma, beta);
-            hipLaunchKernelGGL(bn_bwd_apply_chunk_k<bf16_t>, grid, dim3(TPB), 0, s, (const bf16_t*)dz, z, y, dy, gout, npix, C, mean, invstd, relu, gamma,
+            hipLaunchKernelGGL(bn_bwd_reduce_chunk_k<elem_t>, grid, dim3(TPB), 0, s, (const elem_t*)dz, z, y, npix, C, mean, invstd, relu, slab, P, gamma, beta);
+            hipLaunchKernelGGL(bn_bwd_apply_chunk_k<elem_t>, grid, dim3(TPB), 0, s, (const elem_t*)dz, z, y, dy, gout, npix, C, mean, invstd, relu, gamma,
                                beta, slab, P, dgamma, dbeta, beta_acc);
         }
         return udapose_check_launch();
@@ -1052,19 +1052,19 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const bf16_t* z, con
     if (dz_is_f32)
         hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(TPB), 0, s, (const float*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb, gamma, beta);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb, gamma, beta);
+        hipLaunchKernelGGL(bn_bwd_reduce_k<elem_t>, dim3(rows), dim3(TPB), 0, s, (const elem_t*)dz, z, y, npix, C, mean, invstd, relu, slab, ppb, gamma, beta);
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
     if (dz_is_f32)
         hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)dz, z, y, dy, gout, npix * G, C, mean, invstd,
                            coef, relu, gamma, beta);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)dz, z, y, dy, gout, npix * G, C, mean,
+        hipLaunchKernelGGL(bn_bwd_apply_k<elem_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const elem_t*)dz, z, y, dy, gout, npix * G, C, mean,
                            invstd, coef, relu, gamma, beta);
     return udapose_check_launch();
 }
 // BN backward after a dgrad that already masked dz and reduced it (DgradBnStat): slab[rows][2][C] -> dgamma / dbeta and
 // dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  One launch for the wide, small-spatial layers, finalize + apply otherwise.
-int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const bf16_t* y, bf16_t* dy, size_t npix, int C, const float* gamma, const float* mean,
+int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, elem_t* dy, size_t npix, int C, const float* gamma, const float* mean,
                   const float* invstd, const float* slab, int rows, float* coef, float* dgamma, float* dbeta, float beta_acc) {
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
@@ -1081,7 +1081,7 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const bf16_t* y, b
             hipLaunchKernelGGL(bn_bwd_apply_pre_chunk_k<float>, grid, dim3(TPB), 0, s, (const float*)g, y, dy, npix, C, mean, invstd, gamma, slab, rows, P,
                                dgamma, dbeta, beta_acc);
         else
-            hipLaunchKernelGGL(bn_bwd_apply_pre_chunk_k<bf16_t>, grid, dim3(TPB), 0, s, (const bf16_t*)g, y, dy, npix, C, mean, invstd, gamma, slab, rows, P,
+            hipLaunchKernelGGL(bn_bwd_apply_pre_chunk_k<elem_t>, grid, dim3(TPB), 0, s, (const elem_t*)g, y, dy, npix, C, mean, invstd, gamma, slab, rows, P,
                                dgamma, dbeta, beta_acc);
         return udapose_check_launch();
     }
@@ -1089,23 +1089,23 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const bf16_t* y, b
     static const int legacy = getenv("UDAPOSE_BN_BWD_PRE_LEGACY") ? atoi(getenv("UDAPOSE_BN_BWD_PRE_LEGACY")) : 0;    // A/B hook
     if (legacy) {
         if (g_is_f32)
-            hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)g, (const bf16_t*)nullptr, y, dy, (bf16_t*)nullptr,
+            hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)g, (const elem_t*)nullptr, y, dy, (elem_t*)nullptr,
                                npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
         else
-            hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const bf16_t*)g, (const bf16_t*)nullptr, y, dy,
-                               (bf16_t*)nullptr, npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
+            hipLaunchKernelGGL(bn_bwd_apply_k<elem_t>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const elem_t*)g, (const elem_t*)nullptr, y, dy,
+                               (elem_t*)nullptr, npix * G, C, mean, invstd, coef, 0, gamma, (const float*)nullptr);
         return udapose_check_launch();
     }
     const int grid = bn_apply_grid(npix * G, C);
     if (g_is_f32)
         hipLaunchKernelGGL(bn_bwd_apply_pre_k<float>, dim3(grid), dim3(TPB), 0, s, (const float*)g, y, dy, npix * G, C, mean, invstd, coef);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_pre_k<bf16_t>, dim3(grid), dim3(TPB), 0, s, (const bf16_t*)g, y, dy, npix * G, C, mean, invstd, coef);
+        hipLaunchKernelGGL(bn_bwd_apply_pre_k<elem_t>, dim3(grid), dim3(TPB), 0, s, (const elem_t*)g, y, dy, npix * G, C, mean, invstd, coef);
     return udapose_check_launch();
 }
-int pw_maxpool3x3s2_fwd(hipStream_t s, const bf16_t* x, bf16_t* y, unsigned char* idx, int N, int H, int W, int C) {
+int pw_maxpool3x3s2_fwd(hipStream_t s, const elem_t* x, elem_t* y, unsigned char* idx, int N, int H, int W, int C) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_fwd_k<bf16_t>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_k<elem_t>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_fwd_f32(hipStream_t s, const float* x, float* y, unsigned char* idx, int N, int H, int W, int C) {
@@ -1113,14 +1113,14 @@ int pw_maxpool3x3s2_fwd_f32(hipStream_t s, const float* x, float* y, unsigned ch
     hipLaunchKernelGGL(maxpool3x3s2_fwd_k<float>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
     return udapose_check_launch();
 }
-int pw_maxpool3x3s2_bwd(hipStream_t s, const bf16_t* dy, const unsigned char* idx, bf16_t* dx, int N, int H, int W, int C) {
+int pw_maxpool3x3s2_bwd(hipStream_t s, const elem_t* dy, const unsigned char* idx, elem_t* dx, int N, int H, int W, int C) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3x3s2_bwd_k, dim3(grid_for((size_t)N * H * W * (C / 8))), dim3(TPB), 0, s, dy, idx, dx, N, H, W, C, Ho, Wo);
     return udapose_check_launch();
 }
-int pw_maxpool2x2_ceil(hipStream_t s, const bf16_t* x, bf16_t* y, int N, int H, int W, int C) {
+int pw_maxpool2x2_ceil(hipStream_t s, const elem_t* x, elem_t* y, int N, int H, int W, int C) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    hipLaunchKernelGGL(maxpool2x2_ceil_k<bf16_t>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool2x2_ceil_k<elem_t>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, N, H, W, C, Ho, Wo);
     return udapose_check_launch();
 }
 int pw_maxpool2x2_ceil_f32(hipStream_t s, const float* x, float* y, int N, int H, int W, int C) {

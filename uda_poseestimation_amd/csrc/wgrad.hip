@@ -135,13 +135,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
         if (ms + 1 < ms1) issue_loads(ms + 1);
         const char* P = smem + buf * (C::P_BYTES + C::Q_BYTES);
         const char* Q = P + C::P_BYTES;
-        bf16x8 af[MT], bfr[NT];
+        elem8 af[MT], bfr[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int colb = (wr * TR + i * 16 + 4 * pp) * 2;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, P + trow * C::PSTR + colb));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, P + (16 + trow) * C::PSTR + colb));
-            union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+            union { struct { s16x4 a, b; } s; elem8 v; } u;
             u.s.a = lo; u.s.b = hi;
             af[i] = u.v;
         }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
             const int colb = (wc * TC + j * 16 + 4 * pp) * 2;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, Q + trow * C::QSTR + colb));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, Q + (16 + trow) * C::QSTR + colb));
-            union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+            union { struct { s16x4 a, b; } s; elem8 v; } u;
             u.s.a = lo; u.s.b = hi;
             bfr[j] = u.v;
         }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = UDAPOSE_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
         if (ms + 1 < ms1) store_lds(buf ^ 1);
         __syncthreads();
     }
@@ -234,10 +234,10 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
     // scalar copies of the fields used below (gp may live in global memory: read it once, up front, into SGPRs)
     struct {
-        const bf16_t* dy; const bf16_t* x; float* dw; const IgTap* taps;
+        const elem_t* dy; const elem_t* x; float* dw; const IgTap* taps;
         int Hi, Wi, Ci, Ho, Wo, Co, Hg, Wg, s, os, M, wtaps, flags, ksplit, c_tiles, rows_valid, kw;
         FastDiv div_hw, div_w;
-    } p = {(const bf16_t*)((uintptr_t)gp.dy + dy_base), (const bf16_t*)((uintptr_t)gp.x + x_base), (float*)((uintptr_t)gp.dw + ((gp.flags & WG_FLAG_DW_WS) ? dy_base : dw_base)), gp.taps, gp.Hi, gp.Wi, gp.Ci, gp.Ho, gp.Wo, gp.Co, gp.Hg, gp.Wg, gp.s, gp.os, gp.M, gp.wtaps, gp.flags, gp.ksplit,
+    } p = {(const elem_t*)((uintptr_t)gp.dy + dy_base), (const elem_t*)((uintptr_t)gp.x + x_base), (float*)((uintptr_t)gp.dw + ((gp.flags & WG_FLAG_DW_WS) ? dy_base : dw_base)), gp.taps, gp.Hi, gp.Wi, gp.Ci, gp.Ho, gp.Wo, gp.Co, gp.Hg, gp.Wg, gp.s, gp.os, gp.M, gp.wtaps, gp.flags, gp.ksplit,
            gp.c_tiles, gp.rows_valid, gp.kw, gp.div_hw, gp.div_w};
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
@@ -378,11 +378,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
         const char* Q = P + C::P_BYTES;
 #pragma unroll
         for (int kk = 0; kk < PX / 32; ++kk) {
-            bf16x8 af[MT], bfr[NT];
+            elem8 af[MT], bfr[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int col = wr * TR + i * 16 + 4 * pp;           // first of this lane's 4 columns
-                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+                union { struct { s16x4 a, b; } s; elem8 v; } u;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = 32 * kk + 16 * h + 4 * g + qq;
@@ -395,7 +395,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int col = wc * TC + j * 16 + 4 * pp;
-                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+                union { struct { s16x4 a, b; } s; elem8 v; } u;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = 32 * kk + 16 * h + 4 * g + qq;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = UDAPOSE_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
         }
     }
 

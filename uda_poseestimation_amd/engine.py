@@ -66,13 +66,22 @@ def gather_activates(act):
 class MeanTeacherTrainer:
     def __init__(self, student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=2, image_size=256,
                  heatmap_size=64, use_sgd=False, style_net=None, recover=None, s2t_freq=0.5, t2s_freq=0.5, s2t_alpha=(0.0, 1.0),
-                 t2s_alpha=(0.0, 1.0), rng=None, occlude_rate=-1.0, occlude_thresh=0.9, occlude_size=10, image_px=None):
+                 t2s_alpha=(0.0, 1.0), rng=None, occlude_rate=-1.0, occlude_thresh=0.9, occlude_size=10, image_px=None, precision=None,
+                 loss_scale_init=65536.0, loss_scale_interval=2000):
         self.student, self.teacher = student, teacher
         self.criterion, self.con_criterion = JointsMSELoss(), ConsLoss()
+        # precision: None keeps what the two networks are set to; 'fp16' = the reference's autocast dtype for the student
+        # (train_human.py:280,414) with GradScaler-style dynamic loss scaling kept on the device (optim.py); here the teacher
+        # runs in the same precision (the reference runs it in fp32 outside autocast: teacher.precision = 'fp32' selects that)
+        if precision is not None:
+            student.precision = precision
+            teacher.precision = precision
+        scaled = getattr(student, "precision", "bf16") == "fp16"
+        sc = dict(dynamic_loss_scale=True, init_scale=loss_scale_init, growth_interval=loss_scale_interval) if scaled else {}
         if use_sgd:
-            self.stu_optimizer = fused_optim.FusedSGD(student.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, nesterov=True)
+            self.stu_optimizer = fused_optim.FusedSGD(student.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, nesterov=True, **sc)
         else:
-            self.stu_optimizer = fused_optim.FusedAdam(student.parameters(), lr=lr)
+            self.stu_optimizer = fused_optim.FusedAdam(student.parameters(), lr=lr, **sc)
         self.tea_optimizer = mt.OldWeightEMA(teacher, student, alpha=teacher_alpha)   # ctor copies student -> teacher
         self.sync = GradSync(student)
         self.lambda_c, self.mask_ratio, self.sigma = lambda_c, mask_ratio, sigma
@@ -96,7 +105,7 @@ class MeanTeacherTrainer:
             x_s = self.style_net(x_s, x_t, a, clamp=self.recover)[2]
         y_s = self.student(x_s)
         loss = self.criterion(y_s, label_s, weight_s)
-        loss.backward()
+        self.stu_optimizer.scale_loss(loss).backward()          # (scaler.scale(loss).backward(), train_human.py:285; identity in bf16)
         self.sync()
         self.stu_optimizer.step()
         return {"loss_all": loss.detach(), "loss_s": loss.detach(), "y_s": y_s.detach()}
@@ -188,7 +197,7 @@ class MeanTeacherTrainer:
             y_t_tea_rect = mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
         loss_c = self.con_criterion(st["y_t_stu_recon"], y_t_tea_rect, tea_mask=tea_mask)
         loss_all = loss_s + self.lambda_c * loss_c
-        loss_all.backward()
+        self.stu_optimizer.scale_loss(loss_all).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
         student.finish_grads()              # adds the second pass's gradient buffer (no-op when both ran on one stream)

@@ -54,23 +54,25 @@ class Upsampling(nn.Sequential):
 class _NetHandle:
     """One executor plan (fixed N,H,W) plus its device work areas."""
 
-    def __init__(self, layers, K, N, H, W, device, fp32=False):
+    def __init__(self, layers, K, N, H, W, device, precision='bf16'):
+        # the library build whose element type is this plan's storage / MFMA type ('fp32' plans live in the bf16 build)
+        L = self.L = lib('fp16' if precision == 'fp16' else 'bf16')
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
-        check(lib().udapose_net_create(arr, K, N, H, W, int(fp32), C.byref(h)), "net_create")
+        check(L.udapose_net_create(arr, K, N, H, W, int(precision == 'fp32'), C.byref(h)), "net_create")
         self.h = h
-        self.n_params = lib().udapose_net_num_params(h)
-        self.n_buffers = lib().udapose_net_num_buffers(h)
-        self.numel = [lib().udapose_net_param_numel(h, i) for i in range(self.n_params)]
-        self.act_bytes = lib().udapose_net_act_bytes(h)
+        self.n_params = L.udapose_net_num_params(h)
+        self.n_buffers = L.udapose_net_num_buffers(h)
+        self.numel = [L.udapose_net_param_numel(h, i) for i in range(self.n_params)]
+        self.act_bytes = L.udapose_net_act_bytes(h)
         shp = (C.c_int * 4)()
-        lib().udapose_net_out_shape(h, shp)
+        L.udapose_net_out_shape(h, shp)
         self.out_shape = tuple(shp)
-        self.ws = torch.empty(lib().udapose_net_ws_bytes(h), dtype=torch.uint8, device=device)
-        self.wpack = torch.empty(lib().udapose_net_wpack_bytes(h), dtype=torch.uint8, device=device)
+        self.ws = torch.empty(L.udapose_net_ws_bytes(h), dtype=torch.uint8, device=device)
+        self.wpack = torch.empty(L.udapose_net_wpack_bytes(h), dtype=torch.uint8, device=device)
         self.wpack_version = None
         self.act_nograd = None
-        self._fin = weakref.finalize(self, lib().udapose_net_destroy, h)
+        self._fin = weakref.finalize(self, L.udapose_net_destroy, h)
 
 
 class _PoseNetFn(torch.autograd.Function):
@@ -109,8 +111,11 @@ class PoseResNet(nn.Module):
             raise NotImplementedError("the MI355X executor implements the reference configuration: 3 x deconv(256, k=4), no bias")
         self.num_keypoints = num_keypoints
         self.bn_momentum = 0.1
-        # 'bf16': bf16 MFMA compute, fp32 accumulation (training and inference).  'fp32': exact fp32 MFMA, forward only -
-        # the precision the reference uses for the teacher and validate() (no autocast there); ~16x slower.
+        # 'bf16': bf16 storage + MFMA, fp32 accumulation (training and inference; BASELINE.json's benched precision).
+        # 'fp16': fp16 storage + MFMA (v_mfma_f32_16x16x32_f16), fp32 accumulation - the reference's autocast dtype
+        #         (train_human.py:280,414); gradients need loss scaling (GradScaler, or optim.FusedAdam(dynamic_loss_scale=True)).
+        # 'fp32': exact fp32 MFMA, forward only - the precision the reference uses for the teacher and validate()
+        #         (no autocast there); ~16x slower.
         self.precision = 'bf16'
         self._handles = {}
         self._ptr_cache = None
@@ -182,13 +187,12 @@ class PoseResNet(nn.Module):
         N, Cc, H, W = x.shape
         if Cc != 3:
             raise ValueError("PoseResNet expects [N,3,H,W] input")
-        fp32 = self.precision == 'fp32'
-        if self.precision not in ('bf16', 'fp32'):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
-        key = (N, H, W, x.device.index, fp32)
+        if self.precision not in ('bf16', 'fp16', 'fp32'):
+            raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
+        key = (N, H, W, x.device.index, self.precision)
         hd = self._handles.get(key)
         if hd is None:
-            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, fp32)
+            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, self.precision)
             params = list(self.parameters())
             assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
             for i, p in enumerate(params):
@@ -220,12 +224,12 @@ class PoseResNet(nn.Module):
             same = tok is not None and cap_tok is tok
             if same and (cap_bwd or not need_bwd):
                 return
-            check(lib().udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
+            check(hd.L.udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
             hd._cap = (tok, bool(need_bwd) or (same and cap_bwd))
             hd.wpack_version = None       # what a replay leaves in the pack is unknown to the host-side cache
             return
         if hd.wpack_version != (version, need_bwd) and hd.wpack_version != (version, True):
-            check(lib().udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
+            check(hd.L.udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
             hd.wpack_version = (version, need_bwd)
 
     def _run_forward(self, x, save, defer_bn=False):
@@ -250,7 +254,7 @@ class PoseResNet(nn.Module):
             act, ws = hd.act_nograd, hd.ws
         out = torch.empty(hd.out_shape, dtype=torch.float32, device=x.device)
         defer = bool(defer_bn) and self.training
-        check(lib().udapose_net_forward(hd.h, s, ptr(x), pa, ba, ptr(hd.wpack), ptr(act), ptr(ws), ptr(out),
+        check(hd.L.udapose_net_forward(hd.h, s, ptr(x), pa, ba, ptr(hd.wpack), ptr(act), ptr(ws), ptr(out),
                                         int(self.training) | (2 if defer else 0), float(self.bn_momentum)), "net_forward")
         if defer:
             self._deferred_bn.append((hd, act))
@@ -261,7 +265,7 @@ class PoseResNet(nn.Module):
         `forward_deferred_bn` (the caller has already made this stream wait for those forwards)."""
         pa, ba, params = self._pointers()
         for hd, act in self._deferred_bn:
-            check(lib().udapose_net_apply_running(hd.h, _hip.stream(), ptr(act), ba, float(self.bn_momentum)), "net_apply_running")
+            check(hd.L.udapose_net_apply_running(hd.h, _hip.stream(), ptr(act), ba, float(self.bn_momentum)), "net_apply_running")
         self._deferred_bn = []
 
     def finish_grads(self):
@@ -310,7 +314,7 @@ class PoseResNet(nn.Module):
                 self._grad_ptrs2 = (C.c_void_p * len(arr))(*arr)
             gptrs = self._grad_ptrs2
         dout = dout.contiguous().float()
-        check(lib().udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
+        check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not
         # zeros: SGD's weight decay and Adam must skip it exactly as torch.optim skips parameters without .grad)
         nograd = self._no_grad_ids()

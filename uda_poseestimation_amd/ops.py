@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _hip
-from ._hip import ConvDesc, check, lib, ptr, require_cuda, stream
+from ._hip import ConvDesc, check, lib, lib_for, ptr, require_cuda, stream
 
 EPI_RELU, EPI_OUT_F32, EPI_F32 = 1, 2, 4
 
@@ -27,48 +27,49 @@ def kwp(d):
     return (d.KW + 7) // 8 * 8 if d.Ci == 8 else d.KW
 
 
-def pack_weight(w, d, direction="fwd"):
-    """fp32 torch-layout weight ([Co,Ci,KH,KW]; transposed: [Ci,Co,KH,KW]) -> packed bf16 for fprop or dgrad."""
+def pack_weight(w, d, direction="fwd", dtype=torch.bfloat16):
+    """fp32 torch-layout weight ([Co,Ci,KH,KW]; transposed: [Ci,Co,KH,KW]) -> packed bf16 (or fp16) for fprop or dgrad."""
     require_cuda(w)
+    L = lib("fp16" if dtype == torch.float16 else "bf16")
     T = d.KH * d.KW
     wc = w.detach().float().contiguous(memory_format=torch.channels_last)   # physical [A][KH][KW][B]
     flat = wc.permute(0, 2, 3, 1)                                           # logical [A,KH,KW,B], contiguous
     A, B = flat.shape[0], flat.shape[3]
     if d.Ci == 8:
         assert direction == "fwd" and not d.transposed
-        out = torch.empty(d.Co, d.KH, kwp(d), 8, dtype=torch.bfloat16, device=w.device)
-        check(lib().udapose_pack_strided(stream(), ptr(flat), ptr(out), d.Co, d.KH, kwp(d), d.KW, 8, B, d.KH * d.KW * B, d.KW * B, B, 1), "pack")
+        out = torch.empty(d.Co, d.KH, kwp(d), 8, dtype=dtype, device=w.device)
+        check(L.udapose_pack_strided(stream(), ptr(flat), ptr(out), d.Co, d.KH, kwp(d), d.KW, 8, B, d.KH * d.KW * B, d.KW * B, B, 1), "pack")
         return out
     direct = (direction == "fwd") != bool(d.transposed)
     if direct:
-        out = torch.empty(A, T, B, dtype=torch.bfloat16, device=w.device)
-        check(lib().udapose_cast_f32_bf16(stream(), ptr(flat), ptr(out), flat.numel()), "cast")
+        out = torch.empty(A, T, B, dtype=dtype, device=w.device)
+        check(L.udapose_cast_f32_bf16(stream(), ptr(flat), ptr(out), flat.numel()), "cast")
     else:
-        out = torch.empty(B, T, A, dtype=torch.bfloat16, device=w.device)
-        check(lib().udapose_transpose_cast(stream(), ptr(flat), ptr(out), A, T, B), "transpose_cast")
+        out = torch.empty(B, T, A, dtype=dtype, device=w.device)
+        check(L.udapose_transpose_cast(stream(), ptr(flat), ptr(out), A, T, B), "transpose_cast")
     return out
 
 
 def conv2d_fwd(x, w_fwd, d, res=None, bias=None, relu=False, out_f32=False, want_stats=False):
     require_cuda(x, w_fwd)
     f32 = x.dtype == torch.float32          # exact fp32 path: w_fwd must be fp32 [Co][taps][Ci] too
-    assert x.dtype in (torch.bfloat16, torch.float32) and w_fwd.dtype == x.dtype and x.is_contiguous()
+    assert x.dtype in (torch.bfloat16, torch.float16, torch.float32) and w_fwd.dtype == x.dtype and x.is_contiguous()
     assert tuple(x.shape) == (d.N, d.Hi, d.Wi, d.Ci)
     ho, wo = conv_out_hw(d)
-    y = torch.empty(d.N, ho, wo, d.Co, dtype=torch.float32 if (out_f32 or f32) else torch.bfloat16, device=x.device)
+    y = torch.empty(d.N, ho, wo, d.Co, dtype=torch.float32 if (out_f32 or f32) else x.dtype, device=x.device)
     stats = None
     if want_stats:
         rows = lib().udapose_conv_stat_rows(C.byref(d))
         stats = torch.empty(rows, 2, d.Co, dtype=torch.float32, device=x.device)
     flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_F32 if f32 else 0)
-    check(lib().udapose_conv2d_fwd(stream(), C.byref(d), ptr(x), ptr(w_fwd), ptr(y), ptr(res), ptr(bias), ptr(stats), flags), "conv2d_fwd")
+    check(lib_for(x).udapose_conv2d_fwd(stream(), C.byref(d), ptr(x), ptr(w_fwd), ptr(y), ptr(res), ptr(bias), ptr(stats), flags), "conv2d_fwd")
     return (y, stats) if want_stats else y
 
 
 def conv2d_bwd_data(dy, w_bwd, d, res=None, out_f32=False):
     require_cuda(dy, w_bwd)
-    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dy.device)
-    check(lib().udapose_conv2d_bwd_data(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res), int(out_f32)), "conv2d_bwd_data")
+    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.float32 if out_f32 else dy.dtype, device=dy.device)
+    check(lib_for(dy).udapose_conv2d_bwd_data(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res), int(out_f32)), "conv2d_bwd_data")
     return dx
 
 
@@ -76,14 +77,14 @@ def conv2d_bwd_data_bn(dy, w_bwd, d, bn_y, bn_mean, bn_invstd, bn_z=None, bn_gam
     """dgrad whose output feeds a training-mode BatchNorm (+ReLU) backward: returns (g, slab) with g = dz * relu-mask and
     slab[rows][2][Ci] the per-m-tile partial sums of g and g * xhat (udapose_conv2d_bwd_data_bn)."""
     require_cuda(dy, w_bwd, bn_y, bn_mean, bn_invstd)
-    assert tuple(bn_y.shape) == (d.N, d.Hi, d.Wi, d.Ci) and bn_y.dtype == torch.bfloat16 and bn_y.is_contiguous()
+    assert tuple(bn_y.shape) == (d.N, d.Hi, d.Wi, d.Ci) and bn_y.dtype == dy.dtype and bn_y.is_contiguous()
     assert bn_z is not None or (bn_gamma is not None and bn_beta is not None)
-    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dy.device)
+    dx = torch.empty(d.N, d.Hi, d.Wi, d.Ci, dtype=torch.float32 if out_f32 else dy.dtype, device=dy.device)
     rows = lib().udapose_conv_bwd_stat_rows(C.byref(d))
     if rows < 1:
         raise RuntimeError(f"conv_bwd_stat_rows: {rows}")
     slab = torch.empty(rows, 2, d.Ci, dtype=torch.float32, device=dy.device)
-    check(lib().udapose_conv2d_bwd_data_bn(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res), int(out_f32), ptr(bn_y), ptr(bn_z),
+    check(lib_for(dy).udapose_conv2d_bwd_data_bn(stream(), C.byref(d), ptr(dy), ptr(w_bwd), ptr(dx), ptr(res), int(out_f32), ptr(bn_y), ptr(bn_z),
                                            ptr(bn_mean), ptr(bn_invstd), ptr(bn_gamma), ptr(bn_beta), ptr(slab)), "conv2d_bwd_data_bn")
     return dx, slab
 
@@ -95,16 +96,17 @@ def conv2d_bwd_weight(dy, x, d, dw=None):
     acc = dw is not None
     if dw is None:
         dw = torch.empty(shape, dtype=torch.float32, device=x.device)
-    check(lib().udapose_conv2d_bwd_weight(stream(), C.byref(d), ptr(dy), ptr(x), ptr(dw), int(acc)), "conv2d_bwd_weight")
+    check(lib_for(x).udapose_conv2d_bwd_weight(stream(), C.byref(d), ptr(dy), ptr(x), ptr(dw), int(acc)), "conv2d_bwd_weight")
     return dw
 
 
-def to_nhwc_bf16(x_nchw, cpad=None):
+def to_nhwc_bf16(x_nchw, cpad=None, dtype=torch.bfloat16):
+    """NCHW fp32 -> NHWC in the 16-bit element type (bf16 by default; torch.float16 uses the fp16 build)."""
     require_cuda(x_nchw)
     N, Cc, H, W = x_nchw.shape
     cpad = cpad or (Cc + 7) // 8 * 8
-    out = torch.empty(N, H, W, cpad, dtype=torch.bfloat16, device=x_nchw.device)
-    check(lib().udapose_nchw_f32_to_nhwc_bf16(stream(), ptr(x_nchw.float().contiguous()), ptr(out), N, Cc, H * W, cpad), "to_nhwc")
+    out = torch.empty(N, H, W, cpad, dtype=dtype, device=x_nchw.device)
+    check(lib_for(out).udapose_nchw_f32_to_nhwc_bf16(stream(), ptr(x_nchw.float().contiguous()), ptr(out), N, Cc, H * W, cpad), "to_nhwc")
     return out
 
 
@@ -123,7 +125,7 @@ def to_nchw_f32(x_nhwc, channels=None, lo=None, hi=None):
     N, H, W, Cs = x_nhwc.shape
     Cc = channels or Cs
     out = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x_nhwc.device)
-    check(lib().udapose_nhwc_to_nchw_f32(stream(), ptr(x_nhwc), int(x_nhwc.dtype == torch.float32), ptr(out), N, Cc, H * W, Cs, ptr(lo), ptr(hi)),
+    check(lib_for(x_nhwc).udapose_nhwc_to_nchw_f32(stream(), ptr(x_nhwc), int(x_nhwc.dtype == torch.float32), ptr(out), N, Cc, H * W, Cs, ptr(lo), ptr(hi)),
           "to_nchw")
     return out
 
@@ -136,7 +138,7 @@ def bn_train_fwd(y, stats, gamma, beta, running_mean, running_var, nbt, momentum
     check(lib().udapose_bn_finalize(stream(), ptr(stats), stats.shape[0], C_, count, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                     ptr(nbt), momentum, eps, ptr(scale), ptr(shift), ptr(mean), ptr(invstd)), "bn_finalize")
     z = torch.empty_like(y)
-    check(lib().udapose_bn_apply(stream(), ptr(y), ptr(res), ptr(z), y.numel(), C_, ptr(scale), ptr(shift), int(relu)), "bn_apply")
+    check(lib_for(y).udapose_bn_apply(stream(), ptr(y), ptr(res), ptr(z), y.numel(), C_, ptr(scale), ptr(shift), int(relu)), "bn_apply")
     return z, mean, invstd
 
 
@@ -152,7 +154,7 @@ def bn_bwd(dz, z, y, gamma, mean, invstd, relu=True, want_g=False, beta=None):
     dbeta = torch.empty(C_, dtype=torch.float32, device=dev)
     dy = torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
-    check(lib().udapose_bn_bwd(stream(), ptr(dz), int(dz.dtype == torch.float32), ptr(z), ptr(y), ptr(dy), ptr(g), npix, C_, ptr(gamma), ptr(mean),
+    check(lib_for(y).udapose_bn_bwd(stream(), ptr(dz), int(dz.dtype == torch.float32), ptr(z), ptr(y), ptr(dy), ptr(g), npix, C_, ptr(gamma), ptr(mean),
                                ptr(invstd), int(relu),
                                ptr(slab), ptr(coef), ptr(dgamma), ptr(dbeta), 0.0, ptr(beta)), "bn_bwd")
     return dy, dgamma, dbeta, g
@@ -167,7 +169,7 @@ def bn_bwd_pre(g, y, gamma, mean, invstd, slab):
     dgamma = torch.empty(C_, dtype=torch.float32, device=dev)
     dbeta = torch.empty(C_, dtype=torch.float32, device=dev)
     dy = torch.empty_like(y)
-    check(lib().udapose_bn_bwd_pre(stream(), ptr(g), int(g.dtype == torch.float32), ptr(y), ptr(dy), npix, C_, ptr(gamma), ptr(mean), ptr(invstd),
+    check(lib_for(y).udapose_bn_bwd_pre(stream(), ptr(g), int(g.dtype == torch.float32), ptr(y), ptr(dy), npix, C_, ptr(gamma), ptr(mean), ptr(invstd),
                                    ptr(slab), slab.shape[0], ptr(coef), ptr(dgamma), ptr(dbeta), 0.0), "bn_bwd_pre")
     return dy, dgamma, dbeta
 
@@ -175,23 +177,23 @@ def bn_bwd_pre(g, y, gamma, mean, invstd, slab):
 def maxpool3x3s2_fwd(x):
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    y = torch.empty(N, Ho, Wo, C_, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(N, Ho, Wo, C_, dtype=x.dtype, device=x.device)
     idx = torch.empty(N, Ho, Wo, C_, dtype=torch.uint8, device=x.device)
-    check(lib().udapose_maxpool3x3s2_fwd(stream(), ptr(x), ptr(y), ptr(idx), N, H, W, C_), "maxpool_fwd")
+    check(lib_for(x).udapose_maxpool3x3s2_fwd(stream(), ptr(x), ptr(y), ptr(idx), N, H, W, C_), "maxpool_fwd")
     return y, idx
 
 
 def maxpool3x3s2_bwd(dy, idx, H, W):
     N, _, _, C_ = dy.shape
-    dx = torch.empty(N, H, W, C_, dtype=torch.bfloat16, device=dy.device)
-    check(lib().udapose_maxpool3x3s2_bwd(stream(), ptr(dy), ptr(idx), ptr(dx), N, H, W, C_), "maxpool_bwd")
+    dx = torch.empty(N, H, W, C_, dtype=dy.dtype, device=dy.device)
+    check(lib_for(dy).udapose_maxpool3x3s2_bwd(stream(), ptr(dy), ptr(idx), ptr(dx), N, H, W, C_), "maxpool_bwd")
     return dx
 
 
 def maxpool2x2_ceil(x):
     N, H, W, C_ = x.shape
     y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C_, dtype=x.dtype, device=x.device)
-    fn = lib().udapose_maxpool2x2_ceil_f32 if x.dtype == torch.float32 else lib().udapose_maxpool2x2_ceil
+    fn = lib().udapose_maxpool2x2_ceil_f32 if x.dtype == torch.float32 else lib_for(x).udapose_maxpool2x2_ceil
     check(fn(stream(), ptr(x), ptr(y), N, H, W, C_), "maxpool2x2")
     return y
 
@@ -199,10 +201,11 @@ def maxpool2x2_ceil(x):
 def adain(content, style, alpha=1.0, eps=1e-5, want_stats=False, stats_only=False):
     """NHWC bf16 or fp32 (both operands alike).  stats_only: no output tensor, [N,C,4] = (mean_c, std_c, mean_s, std_s)."""
     N, H, W, C_ = content.shape
-    assert content.dtype == style.dtype and content.dtype in (torch.bfloat16, torch.float32) and style.shape[0] == N and style.shape[3] == C_
+    assert content.dtype == style.dtype and content.dtype in (torch.bfloat16, torch.float16, torch.float32)
+    assert style.shape[0] == N and style.shape[3] == C_
     out = None if stats_only else torch.empty_like(content)
     st = torch.empty(N, C_, 4, dtype=torch.float32, device=content.device) if (want_stats or stats_only) else None
-    fn = lib().udapose_adain_f32 if content.dtype == torch.float32 else lib().udapose_adain
+    fn = lib().udapose_adain_f32 if content.dtype == torch.float32 else lib_for(content).udapose_adain
     check(fn(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps, float(alpha), ptr(st)), "adain")
     if stats_only:
         return st

@@ -8,6 +8,12 @@ parameter group (`udapose_adam_multi`'s dev_state).  `sync_hyper()` uploads lr /
 layout (device tables and state tensors are kept on the optimizer object, not in param_groups) with `step` read back from
 the device counter; checkpoints written by torch.optim.Adam / SGD load (per-parameter `step` entries are folded into the
 group counter).
+
+Loss scaling for the fp16 precision (`dynamic_loss_scale=True`) is torch.cuda.amp.GradScaler's algorithm
+(train_human.py:260,285-287) kept entirely on the device: `scale_loss(loss)` multiplies by the device-resident scale,
+`step()` = found-inf sweep over the gradients -> Adam / SGD sweep that un-scales (and is skipped whole, counter included,
+when an inf / nan was found) -> scale update (x backoff on overflow, x growth after `growth_interval` clean steps).
+No host read-back, so the whole thing is hipGraph-capturable.
 """
 import torch
 
@@ -19,10 +25,14 @@ from .utils import _MultiTensorTable, _bump_versions
 class _FusedBase(torch.optim.Optimizer):
     _state_names = ()
 
-    def __init__(self, params, defaults):
+    def __init__(self, params, defaults, scaler=None):
         super().__init__(params, defaults)
         self._tables = {}        # group index -> _MultiTensorTable (raw device pointers: never serialised)
         self._dev = {}           # group index -> (device state tensor [8], uploaded (lr, grad_scale))
+        # dynamic loss scaling (GradScaler's defaults: 65536, x2 every 2000 clean steps, x0.5 on overflow), or None
+        self._scaler = scaler
+        if scaler is not None and len(self.param_groups) != 1:
+            raise ValueError("dynamic loss scaling needs a single parameter group (one device-resident scaler state)")
 
     # ------------------------------------------------------------------ tables / device state
     def _gather(self, gi, group):
@@ -55,10 +65,39 @@ class _FusedBase(torch.optim.Optimizer):
         ent = self._dev.get(gi)
         if ent is None or ent[0].device != device:
             hyper = (float(group["lr"]), float(group.get("grad_scale", 1.0)))
-            ds = torch.tensor([float(group.get("step", 0)), 0.0, 0.0, hyper[0], hyper[1], 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+            scale, tracker = 0.0, 0.0
+            if self._scaler is not None:
+                scale = float(group.get("loss_scale", self._scaler["init_scale"]))
+                tracker = float(group.get("growth_tracker", 0))
+                hyper = (hyper[0], 1.0 / scale)
+            ds = torch.tensor([float(group.get("step", 0)), 0.0, 0.0, hyper[0], hyper[1], 0.0, scale, tracker], dtype=torch.float32, device=device)
             ent = [ds, hyper]
             self._dev[gi] = ent
         return ent
+
+    # ------------------------------------------------------------------ loss scaling (fp16)
+    def loss_scale(self):
+        """The current loss scale as a 0-d DEVICE tensor (1.0 without dynamic scaling); no host synchronisation."""
+        if self._scaler is None:
+            return None
+        p0 = self.param_groups[0]["params"][0]
+        return self._dev_state(0, self.param_groups[0], p0.device)[0][6]
+
+    def scale_loss(self, loss):
+        """loss * scale (GradScaler.scale); identity without dynamic scaling."""
+        sc = self.loss_scale()
+        return loss if sc is None else loss * sc
+
+    def _pre_sweep(self, t, ent):
+        if self._scaler is not None:
+            check(lib().udapose_grad_scaler_check(_hip.stream(), ptr(t.ptrs[1]), ptr(t.sizes), ptr(t.blk_t), ptr(t.blk_o), t.nblocks, ptr(ent[0])),
+                  "grad_scaler_check")
+
+    def _post_sweep(self, ent):
+        if self._scaler is not None:
+            sc = self._scaler
+            check(lib().udapose_grad_scaler_update(_hip.stream(), ptr(ent[0]), float(sc["growth_factor"]), float(sc["backoff_factor"]),
+                                                   int(sc["growth_interval"])), "grad_scaler_update")
 
     def sync_hyper(self):
         """Upload lr / grad_scale of every group whose host value changed since the last upload (stream-ordered 8-byte copy;
@@ -66,6 +105,11 @@ class _FusedBase(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             ent = self._dev.get(gi)
             if ent is None:
+                continue
+            if self._scaler is not None:           # grad_scale = 1 / loss scale is owned by the device-side scaler
+                if float(group["lr"]) != ent[1][0]:
+                    ent[0][3:4].copy_(torch.tensor([float(group["lr"])], dtype=torch.float32), non_blocking=True)
+                    ent[1] = (float(group["lr"]), ent[1][1])
                 continue
             hyper = (float(group["lr"]), float(group.get("grad_scale", 1.0)))
             if hyper != ent[1]:
@@ -77,7 +121,10 @@ class _FusedBase(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             ent = self._dev.get(gi)
             if ent is not None:
-                group["step"] = int(round(float(ent[0][0].item())))       # replays tick the device counter only
+                host = ent[0].tolist()
+                group["step"] = int(round(host[0]))                       # replays tick the device counter only
+                if self._scaler is not None:
+                    group["loss_scale"], group["growth_tracker"] = float(host[6]), int(round(host[7]))
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
@@ -94,8 +141,11 @@ class _FusedBase(torch.optim.Optimizer):
 class FusedAdam(_FusedBase):
     _state_names = ("exp_avg", "exp_avg_sq")
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale, step=0))
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, dynamic_loss_scale=False,
+                 init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        scaler = dict(init_scale=init_scale, growth_factor=growth_factor, backoff_factor=backoff_factor,
+                      growth_interval=growth_interval) if dynamic_loss_scale else None
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale, step=0), scaler)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -111,10 +161,12 @@ class FusedAdam(_FusedBase):
             b1, b2 = group["betas"]
             if not capturing:
                 self.sync_hyper()
+            self._pre_sweep(t, ent)
             check(lib().udapose_adam_multi(_hip.stream(), ptr(t.ptrs[0]), ptr(t.ptrs[1]), ptr(t.ptrs[2]), ptr(t.ptrs[3]), ptr(t.sizes), ptr(t.blk_t),
                                            ptr(t.blk_o), t.nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                            float(group["weight_decay"]), int(group["step"]), float(group.get("grad_scale", 1.0)), ptr(ent[0])),
                   "adam_multi")
+            self._post_sweep(ent)
             _bump_versions(ps)
         return loss
 
@@ -122,8 +174,12 @@ class FusedAdam(_FusedBase):
 class FusedSGD(_FusedBase):
     _state_names = ("momentum_buffer",)
 
-    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0, nesterov=False, grad_scale=1.0):
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, grad_scale=grad_scale, step=0))
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0, nesterov=False, grad_scale=1.0, dynamic_loss_scale=False,
+                 init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        scaler = dict(init_scale=init_scale, growth_factor=growth_factor, backoff_factor=backoff_factor,
+                      growth_interval=growth_interval) if dynamic_loss_scale else None
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, grad_scale=grad_scale, step=0),
+                         scaler)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -138,9 +194,11 @@ class FusedSGD(_FusedBase):
             group["step"] = group.get("step", 0) + 1
             if not capturing:
                 self.sync_hyper()
+            self._pre_sweep(t, ent)
             check(lib().udapose_sgd_multi(_hip.stream(), ptr(t.ptrs[0]), ptr(t.ptrs[1]), ptr(t.ptrs[2]), ptr(t.sizes), ptr(t.blk_t), ptr(t.blk_o),
                                           t.nblocks, float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]),
                                           int(group["nesterov"]), int(group["step"] == 1), float(group.get("grad_scale", 1.0)), ptr(ent[0])),
                   "sgd_multi")
+            self._post_sweep(ent)
             _bump_versions(ps)
         return loss
