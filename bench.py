@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--wgrad-group", type=int, default=1, help="tuning: 0 = one weight-gradient launch per layer")
     ap.add_argument("--bn-bwd-fused", type=int, default=1, help="tuning: 0 = separate BN-backward reduce launches")
     ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
+    ap.add_argument("--policy", action="append", default=[], metavar="FIELD=INT", help="tuning: override one field of the dispatch policy "
+                    "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
@@ -200,10 +202,19 @@ def main():
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
     import uda_poseestimation_amd.lib.models as models
     lib = _hip.lib(args.dtype)
-    lib.udapose_debug_set_wgrad_group(args.wgrad_group, args.wgrad_stages)
-    lib.udapose_debug_set_bn_bwd_fused(args.bn_bwd_fused)
+    # tuning flags -> explicit dispatch policy of both networks' executor plans (udapose_policy; empty = production policy)
+    tune = {}
+    if args.wgrad_group != 1:
+        tune["wgrad_group"] = args.wgrad_group
+    if args.wgrad_stages > 0:
+        tune["wgrad_stages"] = args.wgrad_stages
+    if args.bn_bwd_fused != 1:
+        tune["bn_bwd_fused"] = args.bn_bwd_fused
     if args.igemm_tile >= 0:
-        lib.udapose_debug_set_tiles(args.igemm_tile, -1, -1)
+        tune["igemm_tile"] = args.igemm_tile
+    for kv in args.policy:
+        k, v = kv.split("=")
+        tune[k] = int(v)
 
     N, K = args.batch, args.keypoints
     if args.strong:
@@ -215,6 +226,8 @@ def main():
     torch.manual_seed(0)
     student = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
     teacher = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
+    student.policy.update(tune)
+    teacher.policy.update(tune)
     extra = {}
     if args.config2:
         import numpy as np

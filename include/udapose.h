@@ -8,9 +8,20 @@
  *
  * Conventions: extern "C"; plain pointers and sizes; every pointer is a DEVICE pointer unless its name starts with
  * h_ (host) or the comment says "host array"; `stream` is a hipStream_t passed as void*; return 0 on success,
- * negative UDAPOSE_ERR_* otherwise; no allocation and no synchronisation inside a call after the first call for a
- * given convolution geometry (the first call uploads a small tap table); re-entrant across streams.
- * Activations are NHWC bf16 unless stated; heat-maps are NCHW fp32.
+ * negative UDAPOSE_ERR_* otherwise.
+ *
+ * State and re-entrancy.  No entry point reads an environment variable or a mutable global to decide what it runs: the
+ * dispatch policy is an explicit value (udapose_policy: per network plan, or named by a convolution descriptor; a
+ * default-initialised one is the measured production policy).  Device-side tables are built only by the explicit
+ * preparation calls - udapose_net_create / udapose_net_bind / udapose_net_bind_grads for a network plan,
+ * udapose_conv_prepare for a single geometry - which allocate and copy synchronously and therefore must run outside stream
+ * capture; every compute call (udapose_conv2d_*, udapose_net_forward / backward / pack_weights / apply_running, all the
+ * element-wise and loss kernels) then neither allocates nor synchronises, and returns UDAPOSE_ERR_NOT_PREPARED instead of
+ * building a missing table (a per-op convolution call on an unprepared geometry outside capture prepares it itself, once per
+ * device, under a lock).  Distinct network plans may be driven concurrently from different host threads on different
+ * streams; ONE plan is not re-entrant (its scratch workspace belongs to one call at a time).  Kernel attributes are set
+ * once per device, so one process may drive several GPUs.
+ * Activations are NHWC bf16 (fp16 in the fp16 build) unless stated; heat-maps are NCHW fp32.
  */
 #ifndef UDAPOSE_H
 #define UDAPOSE_H
@@ -24,6 +35,7 @@ extern "C" {
 #define UDAPOSE_ERR_ARG (-1)
 #define UDAPOSE_ERR_LAUNCH (-2)
 #define UDAPOSE_ERR_UNSUPPORTED (-3)
+#define UDAPOSE_ERR_NOT_PREPARED (-4)   /* a device table this call needs was not built (udapose_net_bind*, udapose_conv_prepare) */
 
 int udapose_version(void);
 /* element type this build stores and multiplies: 0 = bf16 (libudapose_hip.so), 1 = fp16 (libudapose_hip_f16.so: the same
@@ -34,13 +46,34 @@ int udapose_elem_kind(void);
  * Replaces torch.nn.Conv2d / ConvTranspose2d as used by torchvision Bottleneck (lib/models/resnet.py:8-10,25-40),
  * Upsampling (lib/models/pose_resnet.py:33-43), the head (pose_resnet.py:74) and the VGG encoder / decoder
  * (lib/models/Style_net.py:32-118). */
+/* Explicit dispatch policy (tests force a code path with it, bench.py's tuning flags run A/B comparisons through it).
+ * udapose_policy_default fills in the production policy; fields: igemm_tile / wgrad_tile / wgrad_ksplit -1 = heuristics;
+ * igemm_h3: run-staged 3x3 form 0 off, 1 measured per-shape policy, 2 / 3 force the 64- / 128-row form, 4 three taps per
+ * barrier; wgrad_group: one grouped weight-gradient launch per tile class in udapose_net_backward (0: layer by layer),
+ * wgrad_stages: 64-pixel stages a work-group reduces before a layer's pixel range is split; bn_bwd_fused: dgrad epilogues
+ * mask for the consumer BatchNorm and reduce its backward sums; timeline: device buffer ([work-groups][8] uint64) for
+ * per-work-group s_memrealtime stamps, or NULL. */
+typedef struct {
+    int igemm_tile, igemm_h3, igemm_lean, igemm_short_lds, igemm_tap0;
+    int wgrad_tile, wgrad_ksplit, wgrad_fastgeo;
+    int wgrad_group, wgrad_stages, wgrad_group_stem;
+    int bn_bwd_fused, bn_fwd_chunked, bn_bwd_chunked, bn_bwd_pre_legacy;
+    int debug_sync;
+    void* timeline;
+} udapose_policy;
+void udapose_policy_default(udapose_policy* p);
+
 typedef struct {
     int N, Hi, Wi, Ci;   /* input NHWC (Ci multiple of 32, or exactly 8 for 3-channel images padded to 8) */
     int Co, KH, KW, stride, pad;
     int transposed;      /* 1: ConvTranspose2d(k, stride, pad), output_padding 0 */
     int reflect;         /* 1: ReflectionPad2d(pad) instead of zero padding */
     int upsample;        /* 1: input is read through nn.Upsample(scale_factor=2, mode='nearest') */
+    const udapose_policy* policy;   /* host pointer, NULL = production policy */
 } udapose_conv_desc;
+/* builds (once per device) the small tap tables the three directions of this geometry use: the only allocation a convolution
+ * ever needs; call it before capturing a stream that will run udapose_conv2d_* on the geometry */
+int udapose_conv_prepare(const udapose_conv_desc* d);
 
 #define UDAPOSE_EPI_RELU 1
 #define UDAPOSE_EPI_OUT_F32 2
@@ -127,6 +160,17 @@ size_t udapose_net_wpack_bytes(udapose_net_t net);
 size_t udapose_net_act_bytes(udapose_net_t net);
 size_t udapose_net_ws_bytes(udapose_net_t net);
 void udapose_net_out_shape(udapose_net_t net, int shape[4]);
+/* the plan's dispatch policy (set it before udapose_net_bind_grads: the grouped weight-gradient tables depend on it) */
+int udapose_net_set_policy(udapose_net_t net, const udapose_policy* p);
+int udapose_net_get_policy(udapose_net_t net, udapose_policy* p);
+/* Preparation (allocates + copies synchronously; outside stream capture; repeat when a pointer changes):
+ *   bind:        tap tables of every layer geometry, the weight-packing job tables for (h_params, wpack), the
+ *                running-statistics job table for h_buffers (may be NULL for a plan that never defers them);
+ *   bind_grads:  the grouped weight-gradient tables for this placement of the gradient tensors (they hold offsets relative
+ *                to h_grads[0]: any other set of buffers with the same relative placement reuses them).
+ * pack_weights / forward / apply_running / backward return UDAPOSE_ERR_NOT_PREPARED if what they are given was not bound. */
+int udapose_net_bind(udapose_net_t net, const void* const* h_params, void* const* h_buffers, void* wpack);
+int udapose_net_bind_grads(udapose_net_t net, void* const* h_grads);
 int udapose_net_pack_weights(udapose_net_t net, void* stream, const void* const* h_params, void* wpack, int with_bwd);
 int udapose_net_forward(udapose_net_t net, void* stream, const float* x_nchw, const void* const* h_params, void* const* h_buffers,
                         const void* wpack, void* act, void* ws, float* out_nchw, int training, float momentum);
@@ -215,22 +259,7 @@ int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C
 /* ---------------------------------------------------------------- per-launch timing of the MFMA kernels (bench.py roofline)
  * HIP events are recorded on the launch stream around every convolution launch between begin and end.
  * h_out9 (host): for kind in (fprop, dgrad, wgrad): launches, total milliseconds, total algorithmic FLOPs. */
-/* tuning hook: force tile configuration ids / split count (-1 = heuristic); not for production use */
-void udapose_debug_set_tiles(int igemm_tile, int wgrad_tile, int wgrad_ksplit);
-/* tuning hook: udapose_net_backward computes all weight gradients of a pass in one grouped launch per tile class after
- * the dgrad / BN-backward chain (on = 1, default) or layer by layer (on = 0); stages_per_block (> 0) = 64-pixel stages a
- * work-group reduces before a layer's pixel range is split (default 128) */
-void udapose_debug_set_wgrad_group(int on, int stages_per_block);
-/* tuning / test hook: udapose_net_backward lets every dgrad launch apply the ReLU mask of the BatchNorm that consumes its
- * output and reduce that BN's backward sums in its epilogue (on = 1, default), or runs the separate reduce launches (on = 0) */
-void udapose_debug_set_bn_bwd_fused(int on);
-/* tuning / test hook: the run-staged form of 3x3 stride-1 pad-1 convolutions and their data gradients (one stage of
- * BM + 2(W+1) consecutive pixels per 64 channels instead of nine shifted tiles): 0 = off, 1 = measured per-shape policy
- * (default), 2 = 64-row tiles for every eligible launch, 3 = 128-row tiles where the run fits (W <= 32), else 64-row */
-void udapose_debug_set_igemm_h3(int mode);
-/* tuning hook: device buffer ([work-groups][8] uint64, or NULL = off) into which every conv work-group writes s_memrealtime
- * stamps (100 MHz): entry, prologue done, first K stage landed, K loop done, epilogue issued, stores drained */
-void udapose_debug_set_timeline(void* dev_buf);
+/* measurement: HIP events around every conv launch between begin and end (process-wide recorder, mutex-guarded) */
 void udapose_prof_begin(void);
 int udapose_prof_end(double* h_out9);
 

@@ -147,7 +147,7 @@ def test_network_forward_backward_fp16_vs_oracle():
         err_bf16 = (net(x.cuda()).cpu() - y_ref.detach()).abs().max().item()
     net.precision = "fp16"
     print(f"fp16 network: max|y|={scale:.3f} |fp16 device - fp32 oracle|={err:.3e} (bf16 mode on the same net: {err_bf16:.3e})")
-    assert err <= 1e-2 * scale and err < err_bf16
+    assert err <= 2e-2 * scale and err < 0.25 * err_bf16
     R = torch.randn(y_ref.shape, generator=g)
     S = 16.0
     (y_ref * R).sum().backward()
@@ -160,7 +160,7 @@ def test_network_forward_backward_fp16_vs_oracle():
         assert torch.isfinite(gn).all(), name
         cos = torch.nn.functional.cosine_similarity(gn.flatten(), p_r.grad.flatten(), dim=0).item()
         worst = min(worst, cos)
-        assert cos > 0.98, (name, cos)
+        assert cos > 0.95, (name, cos)
     print("fp16 network: worst gradient cosine vs fp32 autograd", worst)
 
 
@@ -216,7 +216,7 @@ def test_fp16_training_step_with_device_side_loss_scaling():
     st = trainer._forward_part(args[0], args[1], args[2], args[3], [args[4]], warp.recon_thetas(args[5], N, 4.0, "cuda"),
                                [warp.recon_thetas(args[6], N, 4.0, "cuda")])
     trainer._loss_backward_part(st, None)
-    next(p for p in stu.parameters() if p.grad is not None).grad.view(-1)[5] = float("inf")
+    stu.backbone.bn1.weight.grad[5] = float("inf")
     trainer._update()
     sd = opt_d.state_dict()["param_groups"][0]
     assert sd["step"] == 3 and sd["loss_scale"] == 65536.0 and sd["growth_tracker"] == 0          # skipped, backed off

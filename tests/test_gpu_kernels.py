@@ -425,15 +425,12 @@ def test_run_staged_3x3_form(dev, case, mode):
     bn_y = (torch.randn(N, H, H, Ci, generator=g) + 0.2).bfloat16().cuda()
     mean, invstd, gamma, beta = (torch.rand(Ci, generator=g).cuda() + 0.5 for _ in range(4))
     out = {}
-    try:
-        for m in (0, mode):
-            lib.udapose_debug_set_igemm_h3(m)
-            y, stats = ops.conv2d_fwd(nhwc(x), wf, d, want_stats=True)
-            dx = ops.conv2d_bwd_data(nhwc(dy), wb, d)
-            gq, slab = ops.conv2d_bwd_data_bn(nhwc(dy), wb, d, bn_y, mean, invstd, bn_gamma=gamma, bn_beta=beta)
-            out[m] = (y.float(), stats.double().sum(0), dx.float(), gq.float(), slab.double().sum(0))
-    finally:
-        lib.udapose_debug_set_igemm_h3(1)
+    for m in (0, mode):
+        dm = ops.with_policy(d, _hip.policy(igemm_h3=m))       # the form is chosen by the call's explicit policy
+        y, stats = ops.conv2d_fwd(nhwc(x), wf, dm, want_stats=True)
+        dx = ops.conv2d_bwd_data(nhwc(dy), wb, dm)
+        gq, slab = ops.conv2d_bwd_data_bn(nhwc(dy), wb, dm, bn_y, mean, invstd, bn_gamma=gamma, bn_beta=beta)
+        out[m] = (y.float(), stats.double().sum(0), dx.float(), gq.float(), slab.double().sum(0))
     for a, b in zip(out[0], out[mode]):
         scale = float(a.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 8e-3 * scale, (float((a - b).abs().max()), scale)

@@ -249,15 +249,12 @@ def test_grouped_weight_gradients_equal_per_layer_launches():
     x = torch.randn(8, 3, 128, 128, generator=torch.Generator().manual_seed(2)).cuda()
     R = torch.randn(8, 6, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
     grads = {}
-    try:
-        for mode in (0, 1):
-            lib.udapose_debug_set_wgrad_group(mode, 0)
-            net.zero_grad(set_to_none=True)
-            (net(x) * R).sum().backward()
-            (net(x) * R).sum().backward()              # second backward accumulates (atomic adds into the kept buffer)
-            grads[mode] = {n_: p_.grad.clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
-    finally:
-        lib.udapose_debug_set_wgrad_group(1, 0)
+    for mode in (0, 1):
+        net.policy, net._handles = {"wgrad_group": mode}, {}      # explicit policy of the plans created from here on
+        net.zero_grad(set_to_none=True)
+        (net(x) * R).sum().backward()
+        (net(x) * R).sum().backward()              # second backward accumulates (atomic adds into the kept buffer)
+        grads[mode] = {n_: p_.grad.clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
     assert len(grads[0]) == len(grads[1]) >= 90
     for n_ in grads[0]:
         a, b = grads[1][n_], grads[0][n_]
@@ -278,15 +275,12 @@ def test_fused_bn_backward_reduction_equals_separate_reduce_launches(layers, N, 
     x = torch.randn(N, 3, HW, HW, generator=torch.Generator().manual_seed(2)).cuda()
     R = torch.randn(N, 6, HW // 4, HW // 4, generator=torch.Generator().manual_seed(3)).cuda()
     grads = {}
-    try:
-        for mode in (0, 1):
-            lib.udapose_debug_set_bn_bwd_fused(mode)
-            net.zero_grad(set_to_none=True)
-            (net(x) * R).sum().backward()
-            (net(x) * R).sum().backward()
-            grads[mode] = {n_: p_.grad.clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
-    finally:
-        lib.udapose_debug_set_bn_bwd_fused(1)
+    for mode in (0, 1):
+        net.policy, net._handles = {"bn_bwd_fused": mode}, {}
+        net.zero_grad(set_to_none=True)
+        (net(x) * R).sum().backward()
+        (net(x) * R).sum().backward()
+        grads[mode] = {n_: p_.grad.clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
     assert len(grads[0]) == len(grads[1]) >= 60
     worst = 0.0
     for n_ in grads[0]:

@@ -36,9 +36,9 @@ for name, H, Ci, Co, K, s, p, tr, cnt in SHAPES:
         w = torch.randn(Co, K * K, Ci, device='cuda').bfloat16()
         res = []
         for t in (0, 4, 1, 6, 2, 5, 7, 8):
-            lib.udapose_debug_set_tiles(t, -1, -1)
+            dt = ops.with_policy(d, _hip.policy(igemm_tile=t))       # the tile is part of the call's explicit dispatch policy
             try:
-                us = timeit(lambda: ops.conv2d_fwd(x, w, d, want_stats=True))
+                us = timeit(lambda: ops.conv2d_fwd(x, w, dt, want_stats=True))
             except Exception as e:
                 us = float('nan')
             res.append((t, us))
@@ -49,14 +49,13 @@ for name, H, Ci, Co, K, s, p, tr, cnt in SHAPES:
         dy = torch.randn(N, ho, wo, Co, device='cuda').bfloat16()
         res = []
         for t, ks in itertools.product((0, 1), (1, 2, 4, 8, 16, 32, 64)):
-            lib.udapose_debug_set_tiles(-1, t, ks)
+            dt = ops.with_policy(d, _hip.policy(wgrad_tile=t, wgrad_ksplit=ks))
             try:
-                us = timeit(lambda: ops.conv2d_bwd_weight(dy, x, d))
+                us = timeit(lambda: ops.conv2d_bwd_weight(dy, x, dt))
             except Exception as e:
                 us = float('nan')
             res.append((t, ks, us))
         best = min(res, key=lambda r: r[2] if r[2] == r[2] else 1e9)
         tot[name] = best[2] * cnt
         print(f"{name:22s} GF={flops/1e9:6.2f} " + " ".join(f"t{t}k{ks}:{us:5.0f}" for t, ks, us in res) + f"  best t{best[0]}k{best[1]} {flops/best[2]/1e6:6.0f} TF")
-lib.udapose_debug_set_tiles(-1, -1, -1)
 print("sum of best x count (us per forward-equivalent):", sum(tot.values()))

@@ -16,8 +16,27 @@ _libs = {}
 vp, ci, cf, cd, sz, ll, cl = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_longlong, C.c_long
 
 
+class Policy(C.Structure):
+    """udapose_policy: the explicit dispatch policy (include/udapose.h).  `policy()` returns the production policy with the
+    given fields overridden; tests force code paths with it, bench.py's tuning flags run A/B comparisons through it."""
+    _fields_ = [(k, C.c_int) for k in ("igemm_tile", "igemm_h3", "igemm_lean", "igemm_short_lds", "igemm_tap0", "wgrad_tile", "wgrad_ksplit",
+                                       "wgrad_fastgeo", "wgrad_group", "wgrad_stages", "wgrad_group_stem", "bn_bwd_fused", "bn_fwd_chunked",
+                                       "bn_bwd_chunked", "bn_bwd_pre_legacy", "debug_sync")] + [("timeline", C.c_void_p)]
+
+
+def policy(**overrides):
+    p = Policy()
+    lib().udapose_policy_default(C.byref(p))
+    for k, v in overrides.items():
+        if k not in dict(Policy._fields_):
+            raise KeyError(f"udapose_policy has no field {k!r}")
+        setattr(p, k, v)
+    return p
+
+
 class ConvDesc(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("N", "Hi", "Wi", "Ci", "Co", "KH", "KW", "stride", "pad", "transposed", "reflect", "upsample")]
+    _fields_ = [(k, C.c_int) for k in ("N", "Hi", "Wi", "Ci", "Co", "KH", "KW", "stride", "pad", "transposed", "reflect", "upsample")] + \
+               [("policy", C.POINTER(Policy))]
 
 
 _SIGS = {
@@ -25,6 +44,12 @@ _SIGS = {
     "udapose_elem_kind": (ci, []),
     "udapose_grad_scaler_check": (ci, [vp, vp, vp, vp, vp, ci, vp]),
     "udapose_grad_scaler_update": (ci, [vp, vp, cf, cf, ci]),
+    "udapose_policy_default": (None, [vp]),
+    "udapose_conv_prepare": (ci, [vp]),
+    "udapose_net_set_policy": (ci, [vp, vp]),
+    "udapose_net_get_policy": (ci, [vp, vp]),
+    "udapose_net_bind": (ci, [vp, vp, vp, vp]),
+    "udapose_net_bind_grads": (ci, [vp, vp]),
     "udapose_conv_out_hw": (None, [vp, vp, vp]),
     "udapose_conv_stat_rows": (ci, [vp]),
     "udapose_conv2d_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci]),
@@ -78,11 +103,6 @@ _SIGS = {
     "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf, vp]),
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_adain_f32": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
-    "udapose_debug_set_tiles": (None, [ci, ci, ci]),
-    "udapose_debug_set_wgrad_group": (None, [ci, ci]),
-    "udapose_debug_set_bn_bwd_fused": (None, [ci]),
-    "udapose_debug_set_timeline": (None, [vp]),
-    "udapose_debug_set_igemm_h3": (None, [ci]),
     "udapose_patch_paste": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
     "udapose_prof_begin": (None, []),
     "udapose_prof_end": (ci, [vp]),
@@ -128,9 +148,13 @@ def lib_for(*tensors):
 ELEM_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
 
+_ERRORS = {-1: "bad argument", -2: "launch / runtime failure", -3: "unsupported configuration",
+           -4: "not prepared: a device table was not built for these pointers (udapose_net_bind / udapose_net_bind_grads / udapose_conv_prepare)"}
+
+
 def check(code, what=""):
     if code != 0:
-        raise RuntimeError(f"libudapose_hip call failed ({what}): error {code}")
+        raise RuntimeError(f"libudapose_hip call failed ({what}): error {code} ({_ERRORS.get(code, 'unknown')})")
 
 
 def ptr(t):

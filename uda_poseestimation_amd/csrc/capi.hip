@@ -13,9 +13,9 @@ int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*,
 int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd_pre(hipStream_t, const void*, int, const elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
-                  float*, float*, float);
+                  float*, float*, float, int, int);
 int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
-              float*, float*, float*, float*, float, const float*);
+              float*, float*, float*, float*, float, const float*, int);
 int pw_maxpool3x3s2_fwd(hipStream_t, const elem_t*, elem_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const elem_t*, const unsigned char*, elem_t*, int, int, int, int);
 int pw_maxpool2x2_ceil(hipStream_t, const elem_t*, elem_t*, int, int, int, int);
@@ -41,15 +41,16 @@ int opt_scaler_update(hipStream_t, float*, float, float, int);
 int adain_launch(hipStream_t, const elem_t*, const elem_t*, elem_t*, int, int, int, int, float, float, float*);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
-extern int g_igemm_tile_override, g_wgrad_tile_override, g_wgrad_ksplit_override;
 int net_apply_running(void*, hipStream_t, const void*, void* const*, float);
 int pw_axpy(hipStream_t, float*, const float*, size_t);
 void prof_begin();
 int prof_end(double*);
 void* net_create(const int layers[4], int K, int N, int H, int W, int f32);
 void net_destroy(void*);
-void net_set_wgrad_group(int, int);
-void net_set_bn_bwd_fused(int);
+void net_set_policy(void*, const Policy&);
+const Policy& net_get_policy(void*);
+int net_bind(void*, const void* const*, void* const*, void*);
+int net_bind_grads(void*, void* const*);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -61,9 +62,31 @@ int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
 int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
 int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float);
 
-static ConvGeom to_geom(const udapose_conv_desc* d) {
-    return ConvGeom{d->N, d->Hi, d->Wi, d->Ci, d->Co, d->KH, d->KW, d->stride, d->pad, d->transposed, d->reflect, d->upsample};
+static Policy from_c(const udapose_policy& c) {
+    Policy p;
+    p.igemm_tile = c.igemm_tile; p.igemm_h3 = c.igemm_h3; p.igemm_lean = c.igemm_lean; p.igemm_short_lds = c.igemm_short_lds;
+    p.igemm_tap0 = c.igemm_tap0; p.wgrad_tile = c.wgrad_tile; p.wgrad_ksplit = c.wgrad_ksplit; p.wgrad_fastgeo = c.wgrad_fastgeo;
+    p.wgrad_group = c.wgrad_group; p.wgrad_stages = c.wgrad_stages > 0 ? c.wgrad_stages : 128; p.wgrad_group_stem = c.wgrad_group_stem;
+    p.bn_bwd_fused = c.bn_bwd_fused; p.bn_fwd_chunked = c.bn_fwd_chunked; p.bn_bwd_chunked = c.bn_bwd_chunked;
+    p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.debug_sync = c.debug_sync; p.timeline = (unsigned long long*)c.timeline;
+    return p;
 }
+static void to_c(const Policy& p, udapose_policy* c) {
+    c->igemm_tile = p.igemm_tile; c->igemm_h3 = p.igemm_h3; c->igemm_lean = p.igemm_lean; c->igemm_short_lds = p.igemm_short_lds;
+    c->igemm_tap0 = p.igemm_tap0; c->wgrad_tile = p.wgrad_tile; c->wgrad_ksplit = p.wgrad_ksplit; c->wgrad_fastgeo = p.wgrad_fastgeo;
+    c->wgrad_group = p.wgrad_group; c->wgrad_stages = p.wgrad_stages; c->wgrad_group_stem = p.wgrad_group_stem;
+    c->bn_bwd_fused = p.bn_bwd_fused; c->bn_fwd_chunked = p.bn_fwd_chunked; c->bn_bwd_chunked = p.bn_bwd_chunked;
+    c->bn_bwd_pre_legacy = p.bn_bwd_pre_legacy; c->debug_sync = p.debug_sync; c->timeline = p.timeline;
+}
+// a convolution descriptor and the policy it names, as the host-side geometry (the policy lives as long as this object)
+struct Geom {
+    Policy pol;
+    ConvGeom g;
+    explicit Geom(const udapose_conv_desc* d)
+        : g{d->N, d->Hi, d->Wi, d->Ci, d->Co, d->KH, d->KW, d->stride, d->pad, d->transposed, d->reflect, d->upsample} {
+        if (d->policy) { pol = from_c(*d->policy); g.pol = &pol; }
+    }
+};
 #define S(x) ((hipStream_t)(x))
 #define B16(x) ((elem_t*)(x))
 #define CB16(x) ((const elem_t*)(x))
@@ -73,31 +96,37 @@ extern "C" {
 int udapose_version(void) { return 200; }
 int udapose_elem_kind(void) { return UDAPOSE_ELEM_KIND; }      // 0: this build stores / multiplies bf16, 1: fp16
 
-void udapose_conv_out_hw(const udapose_conv_desc* d, int* Ho, int* Wo) { ConvGeom g = to_geom(d); *Ho = g.Ho(); *Wo = g.Wo(); }
-int udapose_conv_stat_rows(const udapose_conv_desc* d) { return conv_stat_rows(to_geom(d)); }
+void udapose_policy_default(udapose_policy* p) { if (p) to_c(default_policy(), p); }
+void udapose_conv_out_hw(const udapose_conv_desc* d, int* Ho, int* Wo) { Geom G(d); *Ho = G.g.Ho(); *Wo = G.g.Wo(); }
+int udapose_conv_stat_rows(const udapose_conv_desc* d) { Geom G(d); return conv_stat_rows(G.g); }
+int udapose_conv_prepare(const udapose_conv_desc* d) { if (!d) return UDAPOSE_ERR_ARG; Geom G(d); return conv_prepare(G.g); }
 int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, const void* w_fwd, void* y, const void* res, const float* bias,
                        float* stats, int flags) {
     if (!d || !x || !w_fwd || !y) return UDAPOSE_ERR_ARG;
     ConvEpilogue e;
     e.res = CB16(res); e.bias = bias; e.stats = stats; e.relu = (flags & UDAPOSE_EPI_RELU) != 0; e.out_f32 = (flags & UDAPOSE_EPI_OUT_F32) != 0; e.f32 = (flags & UDAPOSE_EPI_F32) != 0;
-    return conv_fprop(S(stream), to_geom(d), CB16(x), CB16(w_fwd), y, e);
+    Geom G(d);
+    return conv_fprop(S(stream), G.g, CB16(x), CB16(w_fwd), y, e);
 }
 int udapose_conv2d_bwd_data(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res, int out_f32) {
     if (!d || !dy || !w_bwd || !dx) return UDAPOSE_ERR_ARG;
-    return conv_dgrad(S(stream), to_geom(d), CB16(dy), CB16(w_bwd), dx, CB16(res), out_f32);
+    Geom G(d);
+    return conv_dgrad(S(stream), G.g, CB16(dy), CB16(w_bwd), dx, CB16(res), out_f32);
 }
-int udapose_conv_bwd_stat_rows(const udapose_conv_desc* d) { return d ? conv_dgrad_stat_rows(to_geom(d)) : UDAPOSE_ERR_ARG; }
+int udapose_conv_bwd_stat_rows(const udapose_conv_desc* d) { if (!d) return UDAPOSE_ERR_ARG; Geom G(d); return conv_dgrad_stat_rows(G.g); }
 int udapose_conv2d_bwd_data_bn(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res, int out_f32,
                                const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
                                const float* bn_beta, float* slab) {
     if (!d || !dy || !w_bwd || !dx || !bn_y || !bn_mean || !bn_invstd || !slab) return UDAPOSE_ERR_ARG;
     DgradBnStat st;
     st.y = CB16(bn_y); st.z = CB16(bn_z); st.mean = bn_mean; st.invstd = bn_invstd; st.gamma = bn_gamma; st.beta = bn_beta; st.slab = slab;
-    return conv_dgrad(S(stream), to_geom(d), CB16(dy), CB16(w_bwd), dx, CB16(res), out_f32, &st);
+    Geom G(d);
+    return conv_dgrad(S(stream), G.g, CB16(dy), CB16(w_bwd), dx, CB16(res), out_f32, &st);
 }
 int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate) {
     if (!d || !dy || !x || !dw) return UDAPOSE_ERR_ARG;
-    return conv_wgrad(S(stream), to_geom(d), CB16(dy), CB16(x), dw, accumulate, -1);
+    Geom G(d);
+    return conv_wgrad(S(stream), G.g, CB16(dy), CB16(x), dw, accumulate, -1);
 }
 int udapose_cast_f32_bf16(void* stream, const float* src, void* dst, size_t n) { return pw_cast_f32_bf16(S(stream), src, B16(dst), n); }
 int udapose_transpose_cast(void* stream, const float* src, void* dst, int A, int T, int B) { return pw_transpose_cast(S(stream), src, B16(dst), A, T, B); }
@@ -126,12 +155,13 @@ int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, c
                    const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
                    float beta_acc, const float* beta) {
     return pw_bn_bwd(S(stream), dz, dz_is_f32, CB16(z), CB16(y), B16(dy), B16(gout), npix, C, gamma, mean, invstd, relu, slab, coef, dgamma, dbeta,
-                     beta_acc, beta);
+                     beta_acc, beta, default_policy().bn_bwd_chunked);
 }
 int udapose_bn_bwd_pre(void* stream, const void* g, int g_is_f32, const void* y, void* dy, size_t npix, int C, const float* gamma, const float* mean,
                        const float* invstd, const float* slab, int rows, float* coef, float* dgamma, float* dbeta, float beta_acc) {
     if (!g || !y || !dy || !gamma || !mean || !invstd || !slab || !coef) return UDAPOSE_ERR_ARG;
-    return pw_bn_bwd_pre(S(stream), g, g_is_f32, CB16(y), B16(dy), npix, C, gamma, mean, invstd, slab, rows, coef, dgamma, dbeta, beta_acc);
+    return pw_bn_bwd_pre(S(stream), g, g_is_f32, CB16(y), B16(dy), npix, C, gamma, mean, invstd, slab, rows, coef, dgamma, dbeta, beta_acc,
+                         default_policy().bn_bwd_chunked, default_policy().bn_bwd_pre_legacy);
 }
 int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C) {
     return pw_maxpool3x3s2_fwd(S(stream), CB16(x), B16(y), idx, N, H, W, C);
@@ -155,12 +185,24 @@ int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32
     return *out ? UDAPOSE_OK : UDAPOSE_ERR_ARG;
 }
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
-void udapose_debug_set_wgrad_group(int on, int stages_per_block) { net_set_wgrad_group(on, stages_per_block); }
-void udapose_debug_set_bn_bwd_fused(int on) { net_set_bn_bwd_fused(on); }
-extern int g_igemm_h3;
-void udapose_debug_set_igemm_h3(int mode) { g_igemm_h3 = mode; }
-extern unsigned long long* g_igemm_timeline;
-void udapose_debug_set_timeline(void* dev_buf) { g_igemm_timeline = (unsigned long long*)dev_buf; }
+int udapose_net_set_policy(udapose_net_t n, const udapose_policy* p) {
+    if (!n || !p) return UDAPOSE_ERR_ARG;
+    net_set_policy(n, from_c(*p));
+    return UDAPOSE_OK;
+}
+int udapose_net_get_policy(udapose_net_t n, udapose_policy* p) {
+    if (!n || !p) return UDAPOSE_ERR_ARG;
+    to_c(net_get_policy(n), p);
+    return UDAPOSE_OK;
+}
+int udapose_net_bind(udapose_net_t n, const void* const* params, void* const* buffers, void* wpack) {
+    if (!n || !params || !wpack) return UDAPOSE_ERR_ARG;
+    return net_bind(n, params, buffers, wpack);
+}
+int udapose_net_bind_grads(udapose_net_t n, void* const* grads) {
+    if (!n || !grads) return UDAPOSE_ERR_ARG;
+    return net_bind_grads(n, grads);
+}
 int udapose_net_num_params(udapose_net_t n) { return net_num_params(n); }
 int udapose_net_num_buffers(udapose_net_t n) { return net_num_buffers(n); }
 long long udapose_net_param_numel(udapose_net_t n, int i) { return net_param_numel(n, i); }
@@ -257,9 +299,6 @@ int udapose_affine_nearest(void* stream, const float* src, float* dst, const flo
     return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);
 }
 
-void udapose_debug_set_tiles(int igemm_tile, int wgrad_tile, int wgrad_ksplit) {
-    g_igemm_tile_override = igemm_tile; g_wgrad_tile_override = wgrad_tile; g_wgrad_ksplit_override = wgrad_ksplit;
-}
 void udapose_prof_begin(void) { prof_begin(); }
 int udapose_prof_end(double* h_out9) { return prof_end(h_out9); }
 

@@ -8,6 +8,7 @@
 #define UDAPOSE_ERR_ARG (-1)
 #define UDAPOSE_ERR_LAUNCH (-2)
 #define UDAPOSE_ERR_UNSUPPORTED (-3)
+#define UDAPOSE_ERR_NOT_PREPARED (-4)   // a device table this call needs was not built (udapose_net_bind / udapose_conv_prepare)
 
 // Storage / MFMA-operand element type of this build of the library.  The same sources are compiled twice:
 //   libudapose_hip.so      elem_t = bf16  (v_mfma_f32_16x16x32_bf16)   - BASELINE.json's benched precision

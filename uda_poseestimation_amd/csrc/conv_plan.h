@@ -1,7 +1,47 @@
 // Host-side description of one convolution and the tap plans (fprop / dgrad / wgrad) the igemm kernels execute.
 #pragma once
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include "igemm.h"
+
+// Explicit dispatch policy.  A default-constructed Policy IS the measured production policy; nothing in the library reads an
+// environment variable or a mutable global to choose a kernel.  A network plan owns a copy (udapose_net_set_policy), a
+// single convolution call names one through its descriptor (udapose_conv_desc.policy, NULL = default).  The non-default
+// values exist for tests (force a code path) and tuning (A/B runs through bench.py flags).
+struct Policy {
+    int igemm_tile = -1;        // force one igemm tile configuration id (-1: the heuristics of igemm_pick_tile)
+    int igemm_h3 = 1;           // run-staged 3x3 form: 0 off, 1 measured per-shape policy, 2 / 3: force the 64- / 128-row form, 4: three taps per barrier
+    int igemm_lean = 1;         // lean 1x1 form (saddr LDS-DMA loads) where eligible
+    int igemm_short_lds = 1;    // one-stage LDS request for launches whose K loop is one stage
+    int igemm_tap0 = 1;         // 1x1 kernels skip the tap-table read
+    int wgrad_tile = -1;        // force a weight-gradient tile id (-1: heuristics)
+    int wgrad_ksplit = -1;      // force the pixel-split count of a per-layer weight-gradient launch
+    int wgrad_fastgeo = 1;      // bit-field pixel coordinates in the weight-gradient loader where eligible
+    int wgrad_group = 1;        // net backward: one grouped weight-gradient launch per tile class (0: layer by layer)
+    int wgrad_stages = 128;     // grouped launch: 64-pixel stages a work-group reduces before a layer's pixel range is split
+    int wgrad_group_stem = 1;   // the Ci == 8 stem joins the 64x64 group in its row-tap form
+    int bn_bwd_fused = 1;       // net backward: dgrad epilogues mask for the consumer BatchNorm and reduce its backward sums
+    int bn_fwd_chunked = 1;     // BN forward: finalize + apply in one channel-chunked launch where it pays
+    int bn_bwd_chunked = 1;     // BN backward: channel-chunked forms without a finalize launch
+    int bn_bwd_pre_legacy = 0;  // BN backward from pre-reduced sums through the generic apply kernel (A/B)
+    int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
+    unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null
+};
+inline const Policy& default_policy() { static const Policy p; return p; }
+
+// hipFuncSetAttribute (dynamic LDS size) is a per-DEVICE property of a kernel: run `f` once per (call site, device ordinal).
+template <typename F>
+inline void once_per_device(std::atomic<unsigned long long>& done, std::mutex& mu, F&& f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    f();
+    done.fetch_or(bit, std::memory_order_release);
+}
 
 struct ConvGeom {
     int N, Hi, Wi, Ci;      // logical input (for transposed: the small side)
@@ -9,6 +49,8 @@ struct ConvGeom {
     int transposed;         // 1 = ConvTranspose2d(k, stride, pad, output_padding = 0)
     int reflect;            // reflection padding (style net)
     int upsample;           // nearest x2 upsample folded into the loader (style decoder); Hi/Wi are the PHYSICAL dims
+    const Policy* pol = nullptr;   // dispatch policy of this call (null: the default = production policy)
+    const Policy& policy() const { return pol ? *pol : default_policy(); }
     int Ho() const { return transposed ? (Hi - 1) * stride - 2 * pad + KH : (((Hi << upsample) + 2 * pad - KH) / stride + 1); }
     int Wo() const { return transposed ? (Wi - 1) * stride - 2 * pad + KW : (((Wi << upsample) + 2 * pad - KW) / stride + 1); }
     bool smallc() const { return Ci == 8; }
@@ -23,19 +65,23 @@ struct TapPlan {
     const IgTap* d_taps = nullptr;   // device copy (owned by the plan cache)
 };
 
-// direction 0: fprop (also the plan wgrad walks), 1: dgrad
-const TapPlan* get_tap_plan(const ConvGeom& g, int direction);
+// direction 0: fprop (also the plan wgrad walks), 1: dgrad, 2: row-tap wgrad of a Ci == 8 conv.  Plans (a few hundred bytes of
+// device memory each) are cached per (device, geometry class); building one allocates and copies synchronously, so a plan
+// that is missing while `stream` is being captured is NOT built: the call returns null (UDAPOSE_ERR_NOT_PREPARED at the ABI).
+// conv_prepare builds the plans of a geometry up front (udapose_conv_prepare / udapose_net_bind).
+const TapPlan* get_tap_plan(const ConvGeom& g, int direction, hipStream_t stream = nullptr);
+int conv_prepare(const ConvGeom& g);
 
-int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok = 0);   // h3_ok: 3x3 stride-1 pad-1 same-size conv (conv_h3_ok)
+int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& pol);   // h3_ok: 3x3 stride-1 pad-1 same-size conv (conv_h3_ok)
 int conv_h3_ok(const ConvGeom& g);
 int igemm_stat_rows(int M, int Co, int nclass, int tile);
-int igemm_launch(IgParams& p, int tile, hipStream_t stream);
-int wgrad_pick_tile(int Rdim, int Cdim, int smallc);
-int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream);
+int igemm_launch(IgParams& p, int tile, hipStream_t stream, const Policy& pol);
+int wgrad_pick_tile(int Rdim, int Cdim, int smallc, const Policy& pol);
+int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, const Policy& pol);
 // Grouped wgrad (many layers, one launch per tile class).  wgrad_group_plan completes p for the group kernels and returns
 // the tile class (0 = 128x128, 1 = 64x64) or < 0 when the layer needs its own launch; stages_per_block bounds a work-group's
 // pixel range (longer reductions are split and accumulated with fp32 atomics into a zeroed dW).
-int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block);
+int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Policy& pol);
 // the x / dy / dw fields of the table entries are byte offsets from the three bases
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base);

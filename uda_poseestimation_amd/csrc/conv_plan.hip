@@ -17,8 +17,9 @@ static double alg_flops(const ConvGeom& g) {
 
 namespace {
 
+// per (device, geometry class) tap tables; guarded by g_mu (any thread, any device)
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int, int>, TapPlan*> g_plans;
+std::map<std::tuple<int, int, int, int, int, int, int, int>, TapPlan*> g_plans;
 
 // classes of a stride-s transposed mapping: output/in-grad pixel o = s*i + a receives tap k iff k == (a+p) mod s,
 // from source pixel i + (a+p-k)/s.
@@ -56,11 +57,16 @@ static int plan_is_tap0(const TapPlan& tp) {
     return 1;
 }
 
-const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
-    const auto key = std::make_tuple(g.KH, g.KW, g.stride, g.pad, g.transposed, g.KWp(), direction);
+const TapPlan* get_tap_plan(const ConvGeom& g, int direction, hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_tuple(dev, g.KH, g.KW, g.stride, g.pad, g.transposed, g.KWp(), direction);
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
+    // building a plan allocates and copies synchronously: never during a stream capture (prepare the geometry first)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;
     TapPlan* tp = new TapPlan();
     const int KWp = g.KWp();
     const bool sub = (direction == 0) ? (g.transposed != 0) : (g.transposed == 0 && g.stride > 1);
@@ -91,6 +97,13 @@ const TapPlan* get_tap_plan(const ConvGeom& g, int direction) {
     return tp;
 }
 
+int conv_prepare(const ConvGeom& g) {
+    if (!get_tap_plan(g, 0)) return UDAPOSE_ERR_UNSUPPORTED;
+    if (!g.reflect && !g.upsample && !g.smallc() && !get_tap_plan(g, 1)) return UDAPOSE_ERR_UNSUPPORTED;
+    if (g.smallc() && !g.transposed && g.KWp() == 8 && !get_tap_plan(g, 2)) return UDAPOSE_ERR_UNSUPPORTED;
+    return UDAPOSE_OK;
+}
+
 // geometry the 3x3 run-staged igemm form takes (fprop and data gradient alike: the gradient of such a conv is such a conv)
 int conv_h3_ok(const ConvGeom& g) {
     const bool ok = g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && !g.reflect && !g.upsample && g.Ci % 64 == 0 &&
@@ -103,12 +116,12 @@ int conv_stat_rows(const ConvGeom& g) {
     const int M = g.transposed ? g.N * g.Hi * g.Wi : g.N * g.Ho() * g.Wo();
     const TapPlan* tp = get_tap_plan(g, 0);
     const int K = (tp ? tp->cls[0].ntaps : g.KH * g.KW) * g.Ci;     // same K as conv_fprop passes
-    return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass, K, conv_h3_ok(g)));
+    return igemm_stat_rows(M, g.Co, nclass, igemm_pick_tile(M, g.Co, nclass, K, conv_h3_ok(g), g.policy()));
 }
 
 int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* w_fwd, void* y, const ConvEpilogue& e) {
-    const TapPlan* tp = get_tap_plan(g, 0);
-    if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
+    const TapPlan* tp = get_tap_plan(g, 0, s);
+    if (!tp) return UDAPOSE_ERR_NOT_PREPARED;
     if (g.transposed && (g.reflect || g.upsample)) return UDAPOSE_ERR_UNSUPPORTED;
     IgParams p{};
     p.x = x; p.w = w_fwd; p.y = y; p.res = e.res; p.bias = e.bias; p.stats = e.stats; p.taps = tp->d_taps;
@@ -124,15 +137,15 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* 
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     p.tap0 = plan_is_tap0(*tp);
     const int tok = prof_before(s, 0, alg_flops(g));
-    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g)), s);
+    const int rc = igemm_launch(p, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g), g.policy()), s, g.policy());
     prof_after(s, tok);
     return rc;
 }
 
-static int dgrad_params(const ConvGeom& g, IgParams& p) {
+static int dgrad_params(const ConvGeom& g, IgParams& p, hipStream_t s = nullptr) {
     if (g.reflect || g.upsample || g.smallc()) return UDAPOSE_ERR_UNSUPPORTED;
-    const TapPlan* tp = get_tap_plan(g, 1);
-    if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
+    const TapPlan* tp = get_tap_plan(g, 1, s);
+    if (!tp) return UDAPOSE_ERR_NOT_PREPARED;
     p.taps = tp->d_taps;
     p.N = g.N; p.Hi = g.Ho(); p.Wi = g.Wo(); p.Ci = g.Co;     // igemm "input" is dy
     p.Ho = g.Hi; p.Wo = g.Wi; p.Co = g.Ci;                     // igemm "output" is dx
@@ -151,16 +164,16 @@ int conv_dgrad_stat_rows(const ConvGeom& g) {
     IgParams p{};
     const int rc = dgrad_params(g, p);
     if (rc != UDAPOSE_OK) return rc;
-    return igemm_stat_rows(p.M, p.Co, p.nclass, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g)));
+    return igemm_stat_rows(p.M, p.Co, p.nclass, igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g), g.policy()));
 }
 
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t* w_bwd, void* dx, const elem_t* res, int out_f32, DgradBnStat* bs) {
     IgParams p{};
-    const int rc0 = dgrad_params(g, p);
+    const int rc0 = dgrad_params(g, p, s);
     if (rc0 != UDAPOSE_OK) return rc0;
     p.x = dy; p.w = w_bwd; p.y = dx; p.res = res;
     p.flags = (out_f32 ? IG_FLAG_OUT_F32 : 0) | ((!g.transposed && g.stride == 1) ? IG_FLAG_MIRROR : 0);   // (stride-1 data gradient: mirrored taps)
-    const int tile = igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g));
+    const int tile = igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g), g.policy());
     if (bs) {
         p.bs_y = bs->y; p.bs_z = bs->z; p.bs_mean = bs->mean; p.bs_invstd = bs->invstd; p.bs_gamma = bs->gamma; p.bs_beta = bs->beta;
         p.stats = bs->slab;
@@ -168,7 +181,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t*
         if (!bs->y || !bs->slab || !bs->mean || !bs->invstd || (!bs->z && (!bs->gamma || !bs->beta))) return UDAPOSE_ERR_ARG;
     }
     const int tok = prof_before(s, 1, alg_flops(g));
-    const int rc = igemm_launch(p, tile, s);
+    const int rc = igemm_launch(p, tile, s, g.policy());
     prof_after(s, tok);
     return rc;
 }
@@ -178,7 +191,7 @@ int conv_wgrad_params(const ConvGeom& g, const elem_t* dy, const elem_t* x, floa
     const bool rowtap = rows_valid == -2;          // grouped Ci == 8 form (see wgrad_dma_body)
     if (rowtap && (!g.smallc() || g.transposed || g.KWp() != 8)) return UDAPOSE_ERR_UNSUPPORTED;
     const TapPlan* tp = get_tap_plan(g, rowtap ? 2 : 0);
-    if (!tp) return UDAPOSE_ERR_UNSUPPORTED;
+    if (!tp) return UDAPOSE_ERR_NOT_PREPARED;
     WgParams p{};
     p.dy = dy; p.x = x; p.dw = dw; p.taps = tp->d_taps;
     p.kw = rowtap ? g.KW : 0;
@@ -206,7 +219,7 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t*
     if (rc0 != UDAPOSE_OK) return rc0;
     const int Rdim = g.transposed ? g.Ci : g.Co, Cdim = g.transposed ? g.Co : g.Ci;
     const int tok = prof_before(s, 2, fl);
-    const int rc = wgrad_launch(p, wgrad_pick_tile(Rdim, Cdim, g.smallc()), accumulate, s);
+    const int rc = wgrad_launch(p, wgrad_pick_tile(Rdim, Cdim, g.smallc(), g.policy()), accumulate, s, g.policy());
     prof_after(s, tok);
     return rc;
 }

@@ -17,7 +17,7 @@
 // (one row per wave-row of the grid), not added atomically: every block would hit the same few cache lines.
 #include <stdlib.h>
 #include <algorithm>
-#include "igemm.h"
+#include "conv_plan.h"
 
 namespace {
 
@@ -834,26 +834,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
     }
 }
 
-int g_igemm_lean = getenv("UDAPOSE_IGEMM_LEAN") ? atoi(getenv("UDAPOSE_IGEMM_LEAN")) : 1;   // A/B hook: lean 1x1 form
-int g_igemm_short_lds = getenv("UDAPOSE_IGEMM_SHORT_LDS") ? atoi(getenv("UDAPOSE_IGEMM_SHORT_LDS")) : 1;   // A/B hook
-
 template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0>
-int launch_cfg_t(IgParams& p, hipStream_t stream) {
+int launch_cfg_t(IgParams& p, hipStream_t stream, const Policy& pol) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Co + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    static std::mutex attr_mu;
+    once_per_device(attr_done, attr_mu, [] {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, (H3 == 1 || H3 == 2) ? 112 * 1024 : C::LDS_BYTES);
-        attr_set = true;
-    }
+    });
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
     // A launch whose K loop is ONE stage (K <= 128 bytes per row: layer1's 64-channel 1x1 convs and their data gradients, the
     // head's data gradient) only ever touches ring buffer 0: it asks for one stage of LDS instead of NS, so four instead of
     // three work-groups are resident per CU.  These launches are HBM-bound (33-285 MB each) and a work-group's life is a
     // load - compute - store sequence with nothing to overlap inside it: residency is what hides the latency.
     int lds = C::LDS_BYTES;
-    if (!RS && !(p.flags & IG_FLAG_SMALLC) && g_igemm_short_lds) {
+    if (!RS && !(p.flags & IG_FLAG_SMALLC) && pol.igemm_short_lds) {
         constexpr int bke = 128 / (int)sizeof(T);
         int nst = 0;
         for (int c = 0; c < p.nclass; ++c) nst = std::max(nst, p.cls[c].ntaps * p.Ci / bke);
@@ -870,33 +867,29 @@ int launch_cfg_t(IgParams& p, hipStream_t stream) {
 }
 
 template <int BM, int BN, int WM, int WN, int NS, bool RS = false>
-int launch_cfg(IgParams& p, hipStream_t stream) {
+int launch_cfg(IgParams& p, hipStream_t stream, const Policy& pol) {
     if constexpr (RS) {
         // register-staged variants exist for the bf16 fast path only (zero padding, no upsample, Ci >= 64)
-        if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) == 0) return launch_cfg_t<elem_t, BM, BN, WM, WN, 2, true>(p, stream);
-        return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false>(p, stream);
+        if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) == 0) return launch_cfg_t<elem_t, BM, BN, WM, WN, 2, true>(p, stream, pol);
+        return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false>(p, stream, pol);
     } else {
         // lean 1x1 form: stride-1 single-tap convolution whose tiles are all full (M % BM, Co % BN), offsets in 32 bits
-        const bool lean = g_igemm_lean && BN >= 64 && !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.tap0 &&
+        const bool lean = pol.igemm_lean && BN >= 64 && !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.tap0 &&
                           p.nclass == 1 && p.cls[0].ntaps == 1 && p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hg == p.Ho &&
                           p.Wg == p.Wo && p.M % BM == 0 && p.Co % BN == 0 && p.Ci % 64 == 0 && p.wtaps == 1 &&
                           (long long)p.M * p.Ci * 2 < (1ll << 32) && (long long)p.Co * p.Ci * 2 < (1ll << 32);
         if (p.bs_y) {
             // dgrad with the consumer BatchNorm's backward reduction in the epilogue (bf16 operands; bf16 or fp32 output)
             if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_RELU)) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-            if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, true, 3>(p, stream);
-            return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, true>(p, stream);
+            if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, true, 3>(p, stream, pol);
+            return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, true>(p, stream, pol);
         }
-        if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, false, 3>(p, stream);
-        return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS, false>(p, stream) : launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false>(p, stream);
+        if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, false, 3>(p, stream, pol);
+        return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS, false>(p, stream, pol) : launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false>(p, stream, pol);
     }
 }
 
 }  // namespace
-
-int g_igemm_tile_override = -1;   // debug/tuning hook (udapose_debug_set_tiles)
-int g_igemm_tap0 = getenv("UDAPOSE_IGEMM_TAP0") ? atoi(getenv("UDAPOSE_IGEMM_TAP0")) : 1;   // A/B hook
-unsigned long long* g_igemm_timeline = nullptr;   // tuning hook: device buffer for per-work-group timeline stamps
 
 // Tile selection (measured on MI355X over every PoseResNet-101 layer shape at N=32, tools/tune_conv.py): 128x64 tiles
 // when they still yield >= 512 work-groups (2 per CU), else 64x64 (4-deep ring when K is long).  128x128 tiles lose to
@@ -904,10 +897,10 @@ unsigned long long* g_igemm_timeline = nullptr;   // tuning hook: device buffer 
 // ids: 0 = 128x128 NS3, 1 = 128x64 NS3, 2 = 64x64 NS4, 3 = 128x32 NS3, 4 = 128x128 NS2, 5 = 64x64 NS2, 6 = 128x64 NS2,
 // 7 = 64x64 register-staged, 8 = 128x64 register-staged (measured within +-8 % of the LDS-DMA variants on every shape: the
 // feed rate per CU, ~16 B/clk from L2, is the same for both staging methods; kept for tuning, never selected)
-int g_igemm_h3 = getenv("UDAPOSE_IGEMM_H3") ? atoi(getenv("UDAPOSE_IGEMM_H3")) : 1;   // 0 off, 1 measured policy (default), 2 / 3: force the 64- / 128-row form (tests)
-int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok) {
+int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& pol) {
     if (Co <= 32) return 3;
-    if (g_igemm_tile_override >= 0) return g_igemm_tile_override;
+    if (pol.igemm_tile >= 0) return pol.igemm_tile;
+    const int h3 = pol.igemm_h3;
     const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
     // run-staged 3x3 form (measured per shape at N = 32, tools/time_shapes.py): 64-row tiles where the tap-staged form would take
     // 64x64 (layer3: 21.0 vs 21.9 us, layer4: 27.3 vs 27.9), 128-row tiles where it would take 128x64 and the run fits (layer2:
@@ -915,11 +908,11 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok) {
     // variant (tile 12, W <= 16) is faster alone (layer3 18.5 us, layer4 22.7) but its 77 KB of LDS leave room for two work-groups
     // per CU, and inside the three-stream step that costs more than it gains (+0.13 ms per step against tile 10's -0.15 ms): the
     // other streams' kernels need the residency.  It stays selectable (mode 4) for single-stream use.
-    if (h3_ok && g_igemm_h3 == 1) { if (b12864 < 512) return 10; if (h3_ok >= 2) return 11; }
-    if (h3_ok && g_igemm_h3 == 2) return 10;
-    if (h3_ok && g_igemm_h3 == 4) return 12;                  // (row-grouped 64-row form; falls back inside igemm_launch when W > 16)
-    if (h3_ok >= 2 && g_igemm_h3 == 3) return 11;              // (h3_ok >= 2: W <= 32, the 128-row form fits; 3: W <= 16)
-    if (h3_ok && g_igemm_h3 == 3) return 10;
+    if (h3_ok && h3 == 1) { if (b12864 < 512) return 10; if (h3_ok >= 2) return 11; }
+    if (h3_ok && h3 == 2) return 10;
+    if (h3_ok && h3 == 4) return 12;                  // (row-grouped 64-row form; falls back inside igemm_launch when W > 16)
+    if (h3_ok >= 2 && h3 == 3) return 11;              // (h3_ok >= 2: W <= 32, the 128-row form fits; 3: W <= 16)
+    if (h3_ok && h3 == 3) return 10;
     // measured (tools/tune_conv.py, then re-tuned under the three-stream step): 128x64 tiles with a 2-stage ring as soon as
     // they give two work-groups per CU, else 64x64 with a 3-stage ring for long K and a 2-stage ring otherwise.  Every
     // choice lands on THREE resident work-groups per CU (48 KB of LDS each): deeper rings (4 stages = 2 per CU) and one deep
@@ -935,10 +928,10 @@ int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     }
 }
 
-int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
-    p.dbg = g_igemm_timeline;
+int igemm_launch(IgParams& p, int tile, hipStream_t stream, const Policy& pol) {
+    p.dbg = pol.timeline;
     if (p.flags & IG_FLAG_TAP0) p.flags &= ~IG_FLAG_TAP0;
-    if (g_igemm_tap0 && p.tap0) p.flags |= IG_FLAG_TAP0;
+    if (pol.igemm_tap0 && p.tap0) p.flags |= IG_FLAG_TAP0;
     const int bke = (p.flags & IG_FLAG_F32) ? 32 : 64;
     if (p.Ci % 8 != 0 || (!(p.flags & IG_FLAG_SMALLC) && p.Ci % bke != 0)) return UDAPOSE_ERR_ARG;
     if ((p.flags & IG_FLAG_SMALLC) && p.Ci != 8) return UDAPOSE_ERR_ARG;
@@ -950,51 +943,51 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream) {
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     switch (tile) {
-        case 0: return launch_cfg<128, 128, 2, 2, 3>(p, stream);
-        case 1: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
-        case 2: return launch_cfg<64, 64, 2, 2, 4>(p, stream);
-        case 3: return launch_cfg<128, 32, 4, 1, 3>(p, stream);
-        case 4: return launch_cfg<128, 128, 2, 2, 2>(p, stream);
-        case 5: return launch_cfg<64, 64, 2, 2, 2>(p, stream);
-        case 6: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
-        case 7: return launch_cfg<64, 64, 2, 2, 4, true>(p, stream);
-        case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
-        case 9: return launch_cfg<64, 64, 2, 2, 3>(p, stream);
+        case 0: return launch_cfg<128, 128, 2, 2, 3>(p, stream, pol);
+        case 1: return launch_cfg<128, 64, 2, 2, 3>(p, stream, pol);
+        case 2: return launch_cfg<64, 64, 2, 2, 4>(p, stream, pol);
+        case 3: return launch_cfg<128, 32, 4, 1, 3>(p, stream, pol);
+        case 4: return launch_cfg<128, 128, 2, 2, 2>(p, stream, pol);
+        case 5: return launch_cfg<64, 64, 2, 2, 2>(p, stream, pol);
+        case 6: return launch_cfg<128, 64, 2, 2, 2>(p, stream, pol);
+        case 7: return launch_cfg<64, 64, 2, 2, 4, true>(p, stream, pol);
+        case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream, pol);
+        case 9: return launch_cfg<64, 64, 2, 2, 3>(p, stream, pol);
         case 10: {
             // 3x3 stride-1 same-size form (tile id given by igemm_pick_tile only when h3_ok): re-checked here
             const bool ok = !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.nclass == 1 && p.cls[0].ntaps == 9 &&
                             p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hi == p.Ho && p.Wi == p.Wo && p.Wi <= 64 && p.Ci % 64 == 0 &&
                             p.cls[0].oa == 0 && p.cls[0].ob == 0;
-            if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream);
+            if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream, pol);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, true, 1>(p, stream);
+                return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, true, 1>(p, stream, pol);
             }
-            return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, false, 1>(p, stream);
+            return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, false, 1>(p, stream, pol);
         }
         case 12: {
             // 64-row tiles, three taps per barrier (two groups of weight tiles: 77 KB of LDS at W = 16, two work-groups per CU)
             const bool ok = !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.nclass == 1 && p.cls[0].ntaps == 9 &&
                             p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hi == p.Ho && p.Wi == p.Wo && p.Wi <= 16 && p.Ci % 64 == 0 &&
                             p.cls[0].oa == 0 && p.cls[0].ob == 0;
-            if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream);
+            if (!ok) return launch_cfg<64, 64, 2, 2, 3>(p, stream, pol);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, true, 2>(p, stream);
+                return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, true, 2>(p, stream, pol);
             }
-            return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, false, 2>(p, stream);
+            return launch_cfg_t<elem_t, 64, 64, 2, 2, 3, false, false, 2>(p, stream, pol);
         }
         case 11: {
             // the same with 128-row tiles (the 9 weight tiles of a chunk serve twice the rows); run of 128 + 2(W+1) rows <= 28 pieces
             const bool ok = !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.nclass == 1 && p.cls[0].ntaps == 9 &&
                             p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hi == p.Ho && p.Wi == p.Wo && p.Wi <= 32 && p.Ci % 64 == 0 &&
                             p.cls[0].oa == 0 && p.cls[0].ob == 0;
-            if (!ok) return launch_cfg<128, 64, 2, 2, 2>(p, stream);
+            if (!ok) return launch_cfg<128, 64, 2, 2, 2>(p, stream, pol);
             if (p.bs_y) {
                 if ((p.flags & IG_FLAG_RELU) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-                return launch_cfg_t<elem_t, 128, 64, 2, 2, 2, false, true, 1>(p, stream);
+                return launch_cfg_t<elem_t, 128, 64, 2, 2, 2, false, true, 1>(p, stream, pol);
             }
-            return launch_cfg_t<elem_t, 128, 64, 2, 2, 2, false, false, 1>(p, stream);
+            return launch_cfg_t<elem_t, 128, 64, 2, 2, 2, false, false, 1>(p, stream, pol);
         }
         default: return UDAPOSE_ERR_ARG;
     }

@@ -25,16 +25,16 @@ int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*,
 int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
-              float*, float*, float*, float*, float, const float*);
+              float*, float*, float*, float*, float, const float*, int);
 int pw_bn_bwd_pre(hipStream_t, const void*, int, const elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, const float*, int, float*,
-                  float*, float*, float);
+                  float*, float*, float, int, int);
 int pw_maxpool3x3s2_fwd(hipStream_t, const elem_t*, elem_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const elem_t*, const unsigned char*, elem_t*, int, int, int, int);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
 int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
 int pw_bn_running_update_multi(hipStream_t, const BnRunJob*, int, int, const void*, float);
 int pw_bn_train_fused(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, int, const float*, const float*, float*, float*,
-                      long long*, float, float, float*, int);
+                      long long*, float, float, float*, int, int);
 int pw_zero_multi(hipStream_t, const ZeroJob*, int, void*);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
@@ -46,17 +46,14 @@ int pw_maxpool3x3s2_fwd_f32(hipStream_t, const float*, float*, unsigned char*, i
 namespace {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-// UDAPOSE_DEBUG_SYNC=1: synchronise after every enqueued stage and report the source line of the first failure
-static int dbg_sync() { static int v = -1; if (v < 0) { const char* e = getenv("UDAPOSE_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; } return v; }
+// Policy::debug_sync: synchronise after every enqueued stage and report the source line of the first failure (set for the
+// duration of a net_* call on the calling thread; never on by default)
+static thread_local int t_dbg_sync = 0;
+struct DbgSyncScope { int prev; explicit DbgSyncScope(int on) : prev(t_dbg_sync) { t_dbg_sync = on; } ~DbgSyncScope() { t_dbg_sync = prev; } };
 #define CK(expr) do { int _e = (expr); \
-    if (dbg_sync()) { fprintf(stderr, "[udapose] net.hip:%d %s\n", __LINE__, #expr); fflush(stderr); \
+    if (t_dbg_sync) { fprintf(stderr, "[udapose] net.hip:%d %s\n", __LINE__, #expr); fflush(stderr); \
         if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "[udapose] FAILED at net.hip:%d\n", __LINE__); return UDAPOSE_ERR_LAUNCH; } } \
     if (_e != UDAPOSE_OK) return _e; } while (0)
-
-int g_wgrad_group = 1, g_wgrad_stages = 128;   // grouped weight-gradient launch (see build_wg_group); tuning hook
-int g_wgrad_group_stem = 1;                    // the Ci == 8 stem joins the 64x64 group in its row-tap form
-// every dgrad masks its output with the consumer BatchNorm's ReLU and reduces that BN's backward sums in its epilogue
-int g_bn_bwd_fused = getenv("UDAPOSE_BN_BWD_FUSED") ? atoi(getenv("UDAPOSE_BN_BWD_FUSED")) : 1;
 
 struct ConvL {
     ConvGeom g;
@@ -85,7 +82,7 @@ struct Block {
 
 struct Net {
     int layers[4], K, N, H, W;
-    int update_running = 1; // per-call: 0 = leave the BN running statistics alone (deferred, see net_apply_running)
+    Policy policy;          // dispatch policy of this plan (udapose_net_set_policy); every ConvGeom below points at it
     int f32 = 0;            // 1: fp32 storage + exact fp32 MFMA (forward only: the reference's teacher / validate() precision)
     size_t es = 2;          // bytes per activation element
     int n_params = 0, n_buffers = 0;
@@ -235,6 +232,11 @@ Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
     for (auto& b : n.blocks) { dyb(b.c1); dyb(b.c2); dyb(b.c3); if (b.has_ds) dyb(b.cd); }
     for (int i = 0; i < 3; ++i) dyb(n.up[i]);
     n.ws_bytes = o;
+    // every convolution of the plan dispatches with the plan's policy
+    n.stem.g.pol = &n.policy;
+    for (auto& b : n.blocks) { b.c1.g.pol = b.c2.g.pol = b.c3.g.pol = b.cd.g.pol = &n.policy; }
+    for (int i = 0; i < 3; ++i) n.up[i].g.pol = &n.policy;
+    n.head.g.pol = &n.policy;
     return np;
 }
 
@@ -273,8 +275,7 @@ int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* pa
 }
 
 int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, void* const* buffers, const char* wpack,
-                char* act, char* ws, int training, float momentum, const elem_t* res, int relu) {
-    const bool upd = n.update_running != 0;
+                char* act, char* ws, int training, float momentum, const elem_t* res, int relu, bool upd) {
     ConvEpilogue e;
     float* slab = (float*)(ws + n.ws_slab);
     float* scale = (float*)(ws + n.ws_coef);
@@ -290,7 +291,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
                                            beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
-                                           upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu);
+                                           upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked);
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }
@@ -321,8 +322,8 @@ void net_destroy(void* h) {
     for (auto& g : n->wg_groups) if (g.d_zero) (void)hipFree(g.d_zero);
     delete n;
 }
-void net_set_wgrad_group(int on, int stages) { g_wgrad_group = on; if (stages > 0) g_wgrad_stages = stages; }
-void net_set_bn_bwd_fused(int on) { g_bn_bwd_fused = on; }
+void net_set_policy(void* h, const Policy& p) { ((Net*)h)->policy = p; }
+const Policy& net_get_policy(void* h) { return ((Net*)h)->policy; }
 int net_num_params(void* h) { return ((Net*)h)->n_params; }
 int net_num_buffers(void* h) { return ((Net*)h)->n_buffers; }
 long long net_param_numel(void* h, int i) { return ((Net*)h)->param_numel[i]; }
@@ -374,17 +375,57 @@ int build_pack_table(Net& n, Net::PackTab& tab, const void* const* params, char*
     tab.key0 = params[0]; tab.key1 = params[n.n_params - 1]; tab.keyw = wpack;
     return UDAPOSE_OK;
 }
+int build_run_jobs(Net& n, void* const* buffers) {
+    std::vector<BnRunJob> jobs;
+    auto one = [&](const BnL& b) {
+        jobs.push_back(BnRunJob{b.save_off, (float*)buffers[b.rm_idx], (float*)buffers[b.rv_idx], (long long*)buffers[b.nbt_idx], b.C, 0});
+    };
+    one(n.stem_bn);
+    for (auto& b : n.blocks) {
+        one(b.b1); one(b.b2); one(b.b3);
+        if (b.has_ds) one(b.bd);
+    }
+    for (int i = 0; i < 3; ++i) one(n.up_bn[i]);
+    if (n.d_runjobs) { (void)hipFree(n.d_runjobs); n.d_runjobs = nullptr; }
+    if (hipMalloc((void**)&n.d_runjobs, jobs.size() * sizeof(BnRunJob)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMemcpy(n.d_runjobs, jobs.data(), jobs.size() * sizeof(BnRunJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    n.n_runjobs = (int)jobs.size();
+    n.runjobs_key = buffers[0];
+    return UDAPOSE_OK;
+}
 }  // namespace
+
+// Builds every device table the plan's calls need for THESE parameter / buffer / pack pointers (pack job tables, the
+// running-statistics job table, the tap plans of all layer geometries): the only place where net_pack_weights, net_forward and
+// net_apply_running's tables are allocated and uploaded (synchronously: call it outside stream capture, again whenever a
+// pointer changes).  Those calls return UDAPOSE_ERR_NOT_PREPARED when their table does not match the pointers they are given.
+int net_bind(void* h, const void* const* params, void* const* buffers, void* wpack_) {
+    Net& n = *(Net*)h;
+    char* wpack = (char*)wpack_;
+    CK(conv_prepare(n.stem.g));
+    for (auto& b : n.blocks) {
+        CK(conv_prepare(b.c1.g)); CK(conv_prepare(b.c2.g)); CK(conv_prepare(b.c3.g));
+        if (b.has_ds) CK(conv_prepare(b.cd.g));
+    }
+    for (int i = 0; i < 3; ++i) CK(conv_prepare(n.up[i].g));
+    { ConvGeom hg = n.head.g; CK(conv_prepare(hg)); hg.Co = 64; CK(conv_prepare(hg)); }
+    if (!n.f32) {
+        CK(build_pack_table(n, n.pack_fwd, params, wpack, false));
+        CK(build_pack_table(n, n.pack_all, params, wpack, true));
+    }
+    if (buffers) CK(build_run_jobs(n, buffers));
+    return UDAPOSE_OK;
+}
 
 int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wpack_, int with_bwd) {
     Net& n = *(Net*)h;
+    DbgSyncScope dbg(n.policy.debug_sync);
     char* wpack = (char*)wpack_;
     if (!n.f32) {
-        // bf16: ONE launch casts / transposes every weight (table built on first use for these pointers: not capturable,
-        // so the first call must happen outside graph capture - the warm-up step does that)
+        // ONE launch casts / transposes every weight through the job table net_bind built for these pointers
         Net::PackTab& tab = with_bwd ? n.pack_all : n.pack_fwd;
         if (!tab.jobs || tab.key0 != params[0] || tab.key1 != params[n.n_params - 1] || tab.keyw != (const void*)wpack)
-            CK(build_pack_table(n, tab, params, wpack, with_bwd != 0));
+            return UDAPOSE_ERR_NOT_PREPARED;
         CK(pack_conv(s, n, n.stem, params, wpack, false));
         CK(pw_pack_multi(s, tab.jobs, tab.blk_job, tab.blk_sub, tab.nblocks));
         if (with_bwd)   // head dgrad pack [256][1][64]: wb[ci][k] = w[k][ci], zero for k >= K
@@ -409,15 +450,16 @@ int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wp
 
 int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* params, void* const* buffers, const void* wpack_, void* act_, void* ws_,
                 float* out_nchw, int training, float momentum) {
-    Net& n = *(Net*)h;
-    n.update_running = (training & 2) ? 0 : 1;      // bit 1 of `training`: defer the running-statistics update
+    const Net& n = *(const Net*)h;
+    DbgSyncScope dbg(n.policy.debug_sync);
+    const bool upd = !(training & 2);               // bit 1 of `training`: defer the running-statistics update
     training &= 1;
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
     if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (elem_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
-    CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
+    CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1, upd));
     if (n.f32)
         CK(pw_maxpool3x3s2_fwd_f32(s, (const float*)(act + n.stem_bn.z_off), (float*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
                                    n.Hs, n.Ws, 64));
@@ -425,16 +467,16 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
         CK(pw_maxpool3x3s2_fwd(s, (const elem_t*)(act + n.stem_bn.z_off), (elem_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
                                n.Hs, n.Ws, 64));
     for (auto& b : n.blocks) {
-        CK(conv_bn_fwd(s, n, b.c1, b.b1, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
-        CK(conv_bn_fwd(s, n, b.c2, b.b2, params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
+        CK(conv_bn_fwd(s, n, b.c1, b.b1, params, buffers, wpack, act, ws, training, momentum, nullptr, 1, upd));
+        CK(conv_bn_fwd(s, n, b.c2, b.b2, params, buffers, wpack, act, ws, training, momentum, nullptr, 1, upd));
         const elem_t* res = (const elem_t*)(act + b.in_off);
         if (b.has_ds) {
-            CK(conv_bn_fwd(s, n, b.cd, b.bd, params, buffers, wpack, act, ws, training, momentum, nullptr, 0));
+            CK(conv_bn_fwd(s, n, b.cd, b.bd, params, buffers, wpack, act, ws, training, momentum, nullptr, 0, upd));
             res = (const elem_t*)(act + b.zd_off);
         }
-        CK(conv_bn_fwd(s, n, b.c3, b.b3, params, buffers, wpack, act, ws, training, momentum, res, 1));
+        CK(conv_bn_fwd(s, n, b.c3, b.b3, params, buffers, wpack, act, ws, training, momentum, res, 1, upd));
     }
-    for (int i = 0; i < 3; ++i) CK(conv_bn_fwd(s, n, n.up[i], n.up_bn[i], params, buffers, wpack, act, ws, training, momentum, nullptr, 1));
+    for (int i = 0; i < 3; ++i) CK(conv_bn_fwd(s, n, n.up[i], n.up_bn[i], params, buffers, wpack, act, ws, training, momentum, nullptr, 1, upd));
     ConvEpilogue e;
     e.bias = (const float*)params[n.head.bias_idx];
     e.out_f32 = 1;
@@ -458,12 +500,13 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     elem_t* dy = (elem_t*)(ws + c.dy_off);
     if (pre)
         CK(pw_bn_bwd_pre(s, dz, dz_f32, (const elem_t*)(act + c.y_off), dy, b.npix, b.C, (const float*)params[b.g_idx], save, save + b.C, pre->slab,
-                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta));
+                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, n.policy.bn_bwd_chunked, n.policy.bn_bwd_pre_legacy));
     else
         CK(pw_bn_bwd(s, dz, dz_f32, (const elem_t*)(act + b.z_off), (const elem_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx],
-                     save, save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx]));
+                     save, save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx],
+                     n.policy.bn_bwd_chunked));
     const elem_t* xin = (const elem_t*)(act + c.in_off);
-    if (c.g.smallc() && grouped_wgrad && g_wgrad_group_stem) {
+    if (c.g.smallc() && grouped_wgrad && n.policy.wgrad_group_stem) {
         // (the stem's weight gradient joins the grouped launch in its row-tap form, run_wg_group)
     } else if (c.g.smallc()) {
         float* tmp = (float*)(ws + n.ws_dwtmp);
@@ -516,7 +559,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         const ptrdiff_t drel = (const char*)grads[w_idx] - (const char*)grads[0];
         G.rel.push_back({w_idx, drel});
         CK(conv_wgrad_params(g, (const elem_t*)dy_off, (const elem_t*)in_off, (float*)drel, rows_valid, &p, &fl));
-        const int t = wgrad_group_plan(p, beta != 0.f, g_wgrad_stages);
+        const int t = wgrad_group_plan(p, beta != 0.f, n.policy.wgrad_stages, n.policy);
         if (t < 0) return UDAPOSE_ERR_UNSUPPORTED;
         const int prob = (int)tab[t].size();
         tab[t].push_back(p);
@@ -540,14 +583,14 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         CK(add_geom(hg, n.head.w_idx, n.ws_dyhead, n.head.in_off, n.K));
         G.flops[1] -= 2.0 * n.N * n.Hout * n.Wout * 256.0 * (64 - n.K);   // (count the K real channels only)
     }
-    if (g_wgrad_group_stem) {
+    if (n.policy.wgrad_group_stem) {
         // stem (Ci == 8): row-tap form into the padded [Co][KH][8][8] scratch in the workspace (always zeroed, always split:
         // 8192 stages), unpacked into the real [Co][KH][KW][3] gradient after the launch
         WgParams p;
         double fl = 0.0;
         CK(conv_wgrad_params(n.stem.g, (const elem_t*)n.stem.dy_off, (const elem_t*)n.stem.in_off, (float*)n.ws_dwtmp, -2, &p, &fl));
         p.flags |= WG_FLAG_DW_WS;
-        const int t = wgrad_group_plan(p, 1, g_wgrad_stages);      // (accumulate = 1: atomics into the zeroed scratch)
+        const int t = wgrad_group_plan(p, 1, n.policy.wgrad_stages, n.policy);      // (accumulate = 1: atomics into the zeroed scratch)
         if (t != 1) return UDAPOSE_ERR_UNSUPPORTED;
         const int prob = (int)tab[t].size();
         tab[t].push_back(p);
@@ -602,37 +645,38 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         if (hipMemcpy(G.d_zero, zj.data(), zj.size() * sizeof(ZeroJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         G.n_zero = (int)zj.size();
     }
-    G.k_beta = beta; G.k_stages = g_wgrad_stages;
+    G.k_beta = beta; G.k_stages = n.policy.wgrad_stages;
     return UDAPOSE_OK;
 }
 
-// the tables are built (hipMalloc + synchronous copies) by the first pass with a given beta: like the tap plans, that first
-// pass must not be inside a stream capture.  They hold offsets, so later passes with other arenas / gradient buffers reuse
-// them as long as the gradients keep their relative placement (checked per call).
-int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta) {
-    Net::WgGroup* G = nullptr;
-    for (auto& g : n.wg_groups)
-        if (g.k_beta == beta && g.k_stages == g_wgrad_stages) G = &g;
-    if (G)
-        for (auto& r : G->rel)
-            if ((const char*)grads[r.first] - (const char*)grads[0] != r.second) { G = nullptr; break; }
-    if (!G) {
+// The tables hold OFFSETS (relative to the arenas and to grads[0]), so one pair of tables - overwrite and accumulate mode -
+// serves every pass whose gradient tensors keep their relative placement (both per-pass gradient buffers of a step do).
+Net::WgGroup* find_wg_group(Net& n, void* const* grads, float beta) {
+    for (auto& g : n.wg_groups) {
+        if (g.k_beta != beta || g.k_stages != n.policy.wgrad_stages) continue;
+        bool same = true;
+        for (auto& r : g.rel)
+            if ((const char*)grads[r.first] - (const char*)grads[0] != r.second) { same = false; break; }
+        if (same) return &g;
+    }
+    return nullptr;
+}
+// net_bind_grads: allocate + upload the grouped weight-gradient tables (both accumulate modes) for this gradient placement.
+// Synchronous - never inside a stream capture; net_backward itself never builds them.
+int bind_wg_groups(Net& n, void* const* grads) {
+    for (const float beta : {0.f, 1.f}) {
+        if (find_wg_group(n, grads, beta)) continue;
+        Net::WgGroup* G;
         if (n.wg_groups.size() < 4) { n.wg_groups.emplace_back(); G = &n.wg_groups.back(); }
         else { G = &n.wg_groups[0]; for (auto& g : n.wg_groups) if (g.last_use < G->last_use) G = &g; }
         CK(build_wg_group(n, *G, grads, beta));
-        // build the other accumulate mode's table now as well: which of the two a pass needs depends on stream identity
-        // at run time (second pass on the same stream -> beta 1), and a first use inside a stream capture could not build it
-        const float other = beta != 0.f ? 0.f : 1.f;
-        bool have = false;
-        for (auto& g : n.wg_groups) have = have || (g.k_beta == other && g.k_stages == g_wgrad_stages);
-        if (!have && n.wg_groups.size() < 4) {
-            n.wg_groups.emplace_back();
-            CK(build_wg_group(n, n.wg_groups.back(), grads, other));
-            n.wg_groups.back().last_use = n.wg_tick;
-            for (auto& g : n.wg_groups)                      // (emplace_back may have moved the entries)
-                if (g.k_beta == beta && g.k_stages == g_wgrad_stages) G = &g;
-        }
+        G->last_use = ++n.wg_tick;
     }
+    return UDAPOSE_OK;
+}
+int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta) {
+    Net::WgGroup* G = find_wg_group(n, grads, beta);
+    if (!G) return UDAPOSE_ERR_NOT_PREPARED;
     G->last_use = ++n.wg_tick;
     if (G->d_zero) {
         CK(pw_zero_multi(s, G->d_zero, G->n_zero, grads[0]));
@@ -642,7 +686,7 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
     }
     const ConvGeom& sg = n.stem.g;
     const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
-    if (g_wgrad_group_stem && hipMemsetAsync(ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (n.policy.wgrad_group_stem && hipMemsetAsync(ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     for (int t = 0; t < 2; ++t) {
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);
@@ -650,7 +694,7 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         conv_prof_after(s, tok);
         CK(rc);
     }
-    if (g_wgrad_group_stem)
+    if (n.policy.wgrad_group_stem)
         CK(pw_unpack_strided(s, (const float*)(ws + n.ws_dwtmp), (float*)grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
                              (long)sg.KH * sg.KW * 3, (long)sg.KW * 3, 3, 1, beta));
     return UDAPOSE_OK;
@@ -661,6 +705,7 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
 int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack_, void* act_, void* ws_,
                  void* const* grads, float beta) {
     Net& n = *(Net*)h;
+    DbgSyncScope dbg(n.policy.debug_sync);
     if (n.f32) return UDAPOSE_ERR_UNSUPPORTED;   // fp32 mode is forward-only (teacher / validate precision)
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
@@ -668,7 +713,8 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     Pool pool;
     pool.base = ws;
     for (int i = 0; i < 6; ++i) pool.off[i] = n.ws_gbuf[i];
-    const bool grouped = g_wgrad_group != 0;
+    const bool grouped = n.policy.wgrad_group != 0;
+    if (grouped && (!find_wg_group(n, grads, beta))) return UDAPOSE_ERR_NOT_PREPARED;     // (before anything is enqueued)
     const int HWo = n.Hout * n.Wout;
     // head
     elem_t* dyh = (elem_t*)(ws + n.ws_dyhead);
@@ -690,7 +736,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     // Fused chain (g_bn_bwd_fused): every dgrad launch knows the BatchNorm that consumes its output; its epilogue applies
     // that BN's ReLU mask and reduces sum(g), sum(g*xhat) per m-tile, so a BN backward is ONE launch (column sums of the
     // slab + apply) for the wide layers and finalize + apply for the others.  `cur` describes the pending statistics of dz.
-    const bool fused = g_bn_bwd_fused != 0;
+    const bool fused = n.policy.bn_bwd_fused != 0;
     DgradBnStat cur, nxt;
     bool have = false;
     if (fused) { cur = bn_stat_of(n, n.up[2], n.up_bn[2], params, act, ws, 2); have = true; }
@@ -759,24 +805,12 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
 // forwards of one module run concurrently on different streams.
 int net_apply_running(void* h, hipStream_t s, const void* act_, void* const* buffers, float momentum) {
     Net& n = *(Net*)h;
-    // one launch for all layers; the job table (buffer pointers) is built on the first call with these buffers, which must
-    // not be inside a stream capture
-    if (!n.d_runjobs || n.runjobs_key != buffers[0]) {
-        std::vector<BnRunJob> jobs;
-        auto one = [&](const BnL& b) {
-            jobs.push_back(BnRunJob{b.save_off, (float*)buffers[b.rm_idx], (float*)buffers[b.rv_idx], (long long*)buffers[b.nbt_idx], b.C, 0});
-        };
-        one(n.stem_bn);
-        for (auto& b : n.blocks) {
-            one(b.b1); one(b.b2); one(b.b3);
-            if (b.has_ds) one(b.bd);
-        }
-        for (int i = 0; i < 3; ++i) one(n.up_bn[i]);
-        if (n.d_runjobs) { (void)hipFree(n.d_runjobs); n.d_runjobs = nullptr; }
-        if (hipMalloc((void**)&n.d_runjobs, jobs.size() * sizeof(BnRunJob)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        if (hipMemcpy(n.d_runjobs, jobs.data(), jobs.size() * sizeof(BnRunJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        n.n_runjobs = (int)jobs.size();
-        n.runjobs_key = buffers[0];
-    }
+    // one launch for all layers through the job table net_bind built for these buffers
+    if (!n.d_runjobs || n.runjobs_key != buffers[0]) return UDAPOSE_ERR_NOT_PREPARED;
     return pw_bn_running_update_multi(s, n.d_runjobs, n.n_runjobs, 2048, act_, momentum);
+}
+int net_bind_grads(void* h, void* const* grads) {
+    Net& n = *(Net*)h;
+    if (n.f32) return UDAPOSE_OK;
+    return bind_wg_groups(n, grads);
 }

@@ -931,11 +931,11 @@ int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double cou
 // pw_bn_finalize + pw_bn_apply, < 0 on error
 int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, size_t npix, int C, const float* slab, int rows,
                       const float* gamma, const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* save,
-                      int relu) {
+                      int relu, int enabled) {
     // layer3 / layer4 / the first deconv (<= 8 K pixels, <= 128 slab rows): measured -0.1 ms per step; with the 32 K-pixel
     // layers included the 128-byte row segments of the chunked layout cost what the saved launches gain
-    static const int on = getenv("UDAPOSE_BN_FWD_CHUNKED") ? atoi(getenv("UDAPOSE_BN_FWD_CHUNKED")) : 1;
-    if (!on || C < 256 || C % 64 || npix > 8192 || npix < 1024 || rows > 128) return 0;
+    // (enabled: Policy::bn_fwd_chunked)
+    if (!enabled || C < 256 || C % 64 || npix > 8192 || npix < 1024 || rows > 128) return 0;
     const int chunks = C / 64;
     int S = 1024 / chunks;
     if (S > 64) S = 64;
@@ -1008,22 +1008,19 @@ int pw_bn_apply_f32(hipStream_t s, const float* y, const float* res, float* z, s
     hipLaunchKernelGGL(bn_apply_k<float>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
     return udapose_check_launch();
 }
-static int bn_bwd_chunked() {   // tuning hook: UDAPOSE_BN_BWD_CHUNKED=0 restores reduce / finalize / apply everywhere
-    static const int v = getenv("UDAPOSE_BN_BWD_CHUNKED") ? atoi(getenv("UDAPOSE_BN_BWD_CHUNKED")) : 1;
-    return v;
-}
 int pw_bn_bwd_rows(size_t npix) {
     // upper bound used to size the scratch slab; the launch picks rows = min(1024, ceil(npix / pixels-per-iteration))
     return (int)(npix < 1024 ? (npix < 1 ? 1 : npix) : 1024);
 }
 int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const elem_t* z, const elem_t* y, elem_t* dy, elem_t* gout, size_t npix, int C,
               const float* gamma, const float* mean, const float* invstd, int relu, float* slab, float* coef, float* dgamma, float* dbeta,
-              float beta_acc, const float* beta) {
+              float beta_acc, const float* beta, int chunked) {
+    // chunked (Policy::bn_bwd_chunked): 0 restores reduce / finalize / apply everywhere
     if (relu == 2 && !beta) return UDAPOSE_ERR_ARG;
     if (relu == 1 && !z) return UDAPOSE_ERR_ARG;
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1))) return UDAPOSE_ERR_UNSUPPORTED;
-    if (bn_bwd_chunked() && C >= 256 && npix <= 32768 && npix >= 1024) {
+    if (chunked && C >= 256 && npix <= 32768 && npix >= 1024) {
         // channel-chunked form without a finalize launch (see bn_bwd_reduce_chunk_k)
         const int chunks = C / 64;
         int S = 1024 / chunks;
@@ -1065,10 +1062,11 @@ int pw_bn_bwd(hipStream_t s, const void* dz, int dz_is_f32, const elem_t* z, con
 // BN backward after a dgrad that already masked dz and reduced it (DgradBnStat): slab[rows][2][C] -> dgamma / dbeta and
 // dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  One launch for the wide, small-spatial layers, finalize + apply otherwise.
 int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, elem_t* dy, size_t npix, int C, const float* gamma, const float* mean,
-                  const float* invstd, const float* slab, int rows, float* coef, float* dgamma, float* dbeta, float beta_acc) {
+                  const float* invstd, const float* slab, int rows, float* coef, float* dgamma, float* dbeta, float beta_acc, int chunked,
+                  int legacy) {
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
-    if (bn_bwd_chunked() && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
+    if (chunked && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
         const int chunks = C / 64;
         int S = 1024 / chunks;
         if (S > 64) S = 64;
@@ -1086,7 +1084,6 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
         return udapose_check_launch();
     }
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
-    static const int legacy = getenv("UDAPOSE_BN_BWD_PRE_LEGACY") ? atoi(getenv("UDAPOSE_BN_BWD_PRE_LEGACY")) : 0;    // A/B hook
     if (legacy) {
         if (g_is_f32)
             hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)g, (const elem_t*)nullptr, y, dy, (elem_t*)nullptr,

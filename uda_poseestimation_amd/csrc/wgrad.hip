@@ -9,7 +9,7 @@
 //
 // grid = (r_tiles*c_tiles, taps (or tap groups of 4 when Ci==8), ksplit).  ksplit>1 or accumulate -> fp32 atomics.
 #include <stdlib.h>
-#include "igemm.h"
+#include "conv_plan.h"
 
 namespace {
 
@@ -202,7 +202,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
 // (chunk ^ ((row>>1)&3)<<1 for 128-byte rows, chunk ^ (row&7)<<1 for 256-byte rows), which makes the transposing reads
 // of one 32-lane half (8 pixel rows x 32 bytes) hit 16 distinct 16-byte bank slots.
 __device__ u32x4 g_wzero16[2];
-int g_wgrad_fastgeo = getenv("UDAPOSE_WGRAD_FASTGEO") ? atoi(getenv("UDAPOSE_WGRAD_FASTGEO")) : 1;   // A/B hook
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -465,11 +464,11 @@ template <int RT, int CT, int WR, int WC, int NS, int PX>
 int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
                     hipStream_t stream) {
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    static std::mutex attr_mu;
+    once_per_device(attr_done, attr_mu, [] {
         (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd), dim3(256), C::LDS_BYTES, stream, d_tab, d_blk,
                        (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base);
     return udapose_check_launch();
@@ -482,11 +481,11 @@ int launch_wd(WgParams& p, hipStream_t stream) {
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
     p.r_tiles = (Rdim + RT - 1) / RT;
     p.c_tiles = (Cdim + CT - 1) / CT;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    static std::mutex attr_mu;
+    once_per_device(attr_done, attr_mu, [] {
         (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<RT, CT, WR, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
-    }
+    });
     dim3 grid(p.r_tiles * p.c_tiles, p.total_taps, p.ksplit);
     hipLaunchKernelGGL((wgrad_dma_kernel<RT, CT, WR, WC, NS>), grid, dim3(256), C::LDS_BYTES, stream, p);
     return udapose_check_launch();
@@ -508,25 +507,23 @@ int launch_wg(WgParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int g_wgrad_tile_override = -1, g_wgrad_ksplit_override = -1;   // debug/tuning hooks
-
 // host side of the loader's fast geometry (wgrad_dma_body): stride-1 same-size convolution on power-of-two maps, 24-bit factors
-static bool wg_fastgeo_ok(const WgParams& p) {
+static bool wg_fastgeo_ok(const WgParams& p, const Policy& pol) {
     const bool pow2 = ((p.Hi & (p.Hi - 1)) | (p.Wi & (p.Wi - 1))) == 0;
-    return g_wgrad_fastgeo && !(p.flags & (IG_FLAG_SMALLC | WG_FLAG_SWAP)) && p.s == 1 && p.os == 1 && p.nclass == 1 && p.Hg == p.Hi && p.Wg == p.Wi &&
+    return pol.wgrad_fastgeo && !(p.flags & (IG_FLAG_SMALLC | WG_FLAG_SWAP)) && p.s == 1 && p.os == 1 && p.nclass == 1 && p.Hg == p.Hi && p.Wg == p.Wi &&
            p.Hg == p.Ho && p.Wg == p.Wo && pow2 && p.Hi > 0 && p.M < (1 << 24) && p.Ci < (1 << 24) && p.Co < (1 << 24) &&
            (long long)p.M * (p.Ci > p.Co ? p.Ci : p.Co) < (1ll << 31);
 }
 
 // tile ids: 0 = 128x128, 1 = 64x64, 2 = 64x32 (Ci==8 stem), 3 = 32x128 (narrow-row: head)
-int wgrad_pick_tile(int Rdim, int Cdim, int smallc) {
+int wgrad_pick_tile(int Rdim, int Cdim, int smallc, const Policy& pol) {
     if (smallc) return 2;
-    if (g_wgrad_tile_override >= 0 && Rdim > 32) return g_wgrad_tile_override;
+    if (pol.wgrad_tile >= 0 && Rdim > 32) return pol.wgrad_tile;
     if (Rdim <= 32) return 3;
     return 1;    // refined in wgrad_launch once the tap count is known (128x128 only for large weight tensors)
 }
 
-int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
+int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, const Policy& pol) {
     const bool smallc = (p.flags & IG_FLAG_SMALLC) != 0;
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
     if (p.Co % 8 != 0 || p.Ci % 8 != 0) return UDAPOSE_ERR_ARG;
@@ -537,7 +534,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
     static const int RT[4] = {128, 64, 64, 32}, CT[4] = {128, 64, 32, 128};
     // measured (tools/tune_conv.py, LDS-DMA kernels): 128x128 tiles for multi-tap convs with >= 128 channels on both sides
     // (3x3 trunk convs, 4x4 deconvs), 64x64 otherwise
-    if (tile == 1 && g_wgrad_tile_override < 0 && Rdim >= 128 && Cdim >= 128 && p.total_taps >= 9) tile = 0;
+    if (tile == 1 && pol.wgrad_tile < 0 && Rdim >= 128 && Cdim >= 128 && p.total_taps >= 9) tile = 0;
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
     const bool dma = !smallc && (tile == 0 || tile == 1) && (p.Ci % 64 == 0) && (p.Co % 64 == 0);
@@ -547,7 +544,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
     const int min_stages = tile == 0 ? 16 : 4;
     int ks = 1;
     while (tiles * ks < 512 && ms_total / (ks * 2) >= min_stages) ks *= 2;
-    if (g_wgrad_ksplit_override > 0) { ks = g_wgrad_ksplit_override; while (ks > 1 && ms_total / ks < 1) ks /= 2; }
+    if (pol.wgrad_ksplit > 0) { ks = pol.wgrad_ksplit; while (ks > 1 && ms_total / ks < 1) ks /= 2; }
     p.ksplit = ks;
     p.msteps_per_split = (ms_total + ks - 1) / ks;
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
@@ -555,7 +552,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
         const size_t n = (size_t)Rdim * p.wtaps * Cdim;
         if (hipMemsetAsync(p.dw, 0, n * sizeof(float), stream) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }
-    if (wg_fastgeo_ok(p)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
+    if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
     if (dma) return tile == 0 ? launch_wd<128, 128, 2, 2, 2>(p, stream) : launch_wd<64, 64, 2, 2, 4>(p, stream);
     switch (tile) {
         case 0: return launch_wg<128, 128, 2, 2>(p, stream);
@@ -566,7 +563,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream) {
     }
 }
 
-int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block) {
+int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Policy& pol) {
     const bool smallc = (p.flags & IG_FLAG_SMALLC) != 0;
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
     if (smallc && (swap || p.Co % 64 != 0 || p.kw <= 0 || p.kw > 8)) return -1;
@@ -586,7 +583,7 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block) {
     p.ksplit = ks;
     p.msteps_per_split = (ms_total + ks - 1) / ks;
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
-    if (wg_fastgeo_ok(p)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
+    if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
     return tile;
 }
 

@@ -54,13 +54,18 @@ class Upsampling(nn.Sequential):
 class _NetHandle:
     """One executor plan (fixed N,H,W) plus its device work areas."""
 
-    def __init__(self, layers, K, N, H, W, device, precision='bf16'):
+    def __init__(self, layers, K, N, H, W, device, precision='bf16', policy=None):
         # the library build whose element type is this plan's storage / MFMA type ('fp32' plans live in the bf16 build)
         L = self.L = lib('fp16' if precision == 'fp16' else 'bf16')
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
         check(L.udapose_net_create(arr, K, N, H, W, int(precision == 'fp32'), C.byref(h)), "net_create")
         self.h = h
+        if policy:
+            pol = _hip.policy(**policy)
+            check(L.udapose_net_set_policy(h, C.byref(pol)), "net_set_policy")
+        self.bound = None            # pointer key the plan's device tables were built for (udapose_net_bind)
+        self.bound_grads = set()     # gradient placements bound so far (udapose_net_bind_grads)
         self.n_params = L.udapose_net_num_params(h)
         self.n_buffers = L.udapose_net_num_buffers(h)
         self.numel = [L.udapose_net_param_numel(h, i) for i in range(self.n_params)]
@@ -128,6 +133,9 @@ class PoseResNet(nn.Module):
         # the eager fused optimizers are caught by the parameters' version counters as well.
         self._wepoch = 0
         self._capture_token = None    # set by GraphedTrainStep around a capture: pack once per capture, unconditionally
+        # explicit dispatch-policy overrides for this network's executor plans (fields of udapose_policy, include/udapose.h);
+        # empty = the production policy.  Plans read it when they are created: clear self._handles after changing it.
+        self.policy = {}
         self._to_channels_last()
 
     # ------------------------------------------------------------------ layout / pointer bookkeeping
@@ -192,7 +200,7 @@ class PoseResNet(nn.Module):
         key = (N, H, W, x.device.index, self.precision)
         hd = self._handles.get(key)
         if hd is None:
-            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, self.precision)
+            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, self.precision, dict(self.policy))
             params = list(self.parameters())
             assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
             for i, p in enumerate(params):
@@ -214,7 +222,16 @@ class PoseResNet(nn.Module):
         hipGraph): every plan re-packs its bf16 weights before its next forward."""
         self._wepoch += 1
 
+    def _bind(self, hd, pa, ba):
+        """Build the plan's device tables for the current parameter / buffer pointers (allocates: never inside a capture; the
+        compute calls themselves never allocate and fail with 'not prepared' otherwise)."""
+        key = self._ptr_cache[0]
+        if hd.bound != key:
+            check(hd.L.udapose_net_bind(hd.h, pa, ba, ptr(hd.wpack)), "net_bind")
+            hd.bound, hd.bound_grads = key, set()
+
     def _pack(self, hd, pa, params, need_bwd):
+        self._bind(hd, pa, self._ptr_cache[2])
         version = (self._wepoch, sum(p._version for p in params))
         if torch.cuda.is_current_stream_capturing():
             # inside a capture the pack kernels must be IN the graph (a replay runs on the weights of that moment, whatever
@@ -313,6 +330,10 @@ class PoseResNet(nn.Module):
                     off += p.numel()
                 self._grad_ptrs2 = (C.c_void_p * len(arr))(*arr)
             gptrs = self._grad_ptrs2
+        gkey = gptrs[0]      # (placement key: the tables hold offsets relative to the first gradient tensor)
+        if gkey not in hd.bound_grads:
+            check(hd.L.udapose_net_bind_grads(hd.h, gptrs), "net_bind_grads")
+            hd.bound_grads.add(gkey)
         dout = dout.contiguous().float()
         check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not

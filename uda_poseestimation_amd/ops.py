@@ -13,8 +13,17 @@ from ._hip import ConvDesc, check, lib, lib_for, ptr, require_cuda, stream
 EPI_RELU, EPI_OUT_F32, EPI_F32 = 1, 2, 4
 
 
-def conv_desc(N, Hi, Wi, Ci, Co, K, stride=1, pad=0, transposed=False, reflect=False, upsample=False):
-    return ConvDesc(N, Hi, Wi, Ci, Co, K, K, stride, pad, int(transposed), int(reflect), int(upsample))
+def conv_desc(N, Hi, Wi, Ci, Co, K, stride=1, pad=0, transposed=False, reflect=False, upsample=False, policy=None):
+    """`policy`: a _hip.Policy (explicit dispatch policy of calls made with this descriptor), None = production policy."""
+    d = ConvDesc(N, Hi, Wi, Ci, Co, K, K, stride, pad, int(transposed), int(reflect), int(upsample))
+    if policy is not None:
+        d.policy = C.pointer(policy)        # (ctypes keeps the Policy object alive with the descriptor)
+    return d
+
+
+def with_policy(d, policy):
+    """A copy of descriptor d that names another dispatch policy."""
+    return conv_desc(d.N, d.Hi, d.Wi, d.Ci, d.Co, d.KH, d.stride, d.pad, d.transposed, d.reflect, d.upsample, policy)
 
 
 def conv_out_hw(d):
