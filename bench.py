@@ -340,7 +340,7 @@ def main():
                                                     (f", K={K}, {args.dtype} (BASELINE.json configs[4] shape and dtype on one GPU; NOT the metric)"
                                                      if (S, K, args.arch, args.dtype) == (384, 18, "pose_resnet101", "fp16") else f", K={K}, {args.dtype}"))),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
-            "loss": loss, "launch": "eager" if args.eager else ("3 hipGraphs around the two RCCL collectives" if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
+            "loss": loss, "launch": "eager" if args.eager else (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,

@@ -181,6 +181,14 @@ int udapose_net_apply_running(udapose_net_t net, void* stream, const void* act, 
 int udapose_axpy_f32(void* stream, float* y, const float* x, size_t n);
 int udapose_net_backward(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
                          void* act, void* ws, void* const* h_grads, float beta);
+/* The same backward in two calls, cut after the first block of layer3, for a data-parallel step that overlaps the gradient
+ * all-reduce with the backward (replaces nn.DataParallel's reduce, train_human.py:145-148,436): part 1 = head, deconvs,
+ * layer4, layer3 and the weight gradients of those layers - a contiguous suffix of .parameters() starting at
+ * udapose_net_grad_split_param(), final when part 1 has run; part 2 = layer2, layer1, stem and theirs, continuing from the
+ * gradient part 1 left in `ws` (same act / ws / grads / beta as part 1; dout is ignored). */
+int udapose_net_backward_part(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
+                              void* act, void* ws, void* const* h_grads, float beta, int part);
+long long udapose_net_grad_split_param(udapose_net_t net);
 
 /* ---------------------------------------------------------------- heat-map losses and decode (fp32 NCHW rows [R=B*K][HW]) */
 /* JointsMSELoss (lib/models/loss.py:39-49): rows[r] = 0.5*w[r]*mean_hw((p-g)^2); mean_out = mean_r rows (reduction='mean') */

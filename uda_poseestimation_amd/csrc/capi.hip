@@ -51,6 +51,7 @@ void net_set_policy(void*, const Policy&);
 const Policy& net_get_policy(void*);
 int net_bind(void*, const void* const*, void* const*, void*);
 int net_bind_grads(void*, void* const*);
+long long net_grad_split_param(void*);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -60,7 +61,7 @@ size_t net_ws_bytes(void*);
 void net_out_shape(void*, int*);
 int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
 int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
-int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float);
+int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int);
 
 static Policy from_c(const udapose_policy& c) {
     Policy p;
@@ -223,8 +224,14 @@ int udapose_net_apply_running(udapose_net_t n, void* stream, const void* act, vo
 int udapose_axpy_f32(void* stream, float* y, const float* x, size_t n) { return pw_axpy(S(stream), y, x, n); }
 int udapose_net_backward(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act, void* ws,
                          void* const* grads, float beta) {
-    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta);
+    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, 0);
 }
+int udapose_net_backward_part(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act,
+                              void* ws, void* const* grads, float beta, int part) {
+    if (part != 1 && part != 2) return UDAPOSE_ERR_ARG;
+    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part);
+}
+long long udapose_net_grad_split_param(udapose_net_t n) { return net_grad_split_param(n); }
 
 int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out) {
     return hm_sqdiff_rows(S(stream), pred, gt, w, nullptr, R, HW, 0.5f, rows, mean_out, nullptr, nullptr, 1);

@@ -82,6 +82,7 @@ struct Block {
 
 struct Net {
     int layers[4], K, N, H, W;
+    int split_dz_idx = -1;  // pool buffer holding the gradient that net_backward part 1 hands to part 2 (a function of the plan)
     Policy policy;          // dispatch policy of this plan (udapose_net_set_policy); every ConvGeom below points at it
     int f32 = 0;            // 1: fp32 storage + exact fp32 MFMA (forward only: the reference's teacher / validate() precision)
     size_t es = 2;          // bytes per activation element
@@ -107,7 +108,7 @@ struct Net {
     PackTab pack_fwd, pack_all;
     // grouped weight-gradient launch of one backward pass: device tables, rebuilt when the buffers change
     struct WgGroup {
-        float k_beta = -1.f; int k_stages = 0;
+        float k_beta = -1.f; int k_stages = 0; int k_part = 0;     // part: 0 all layers, 1 upper (head..layer3), 2 lower (layer2..stem)
         std::vector<std::pair<int, ptrdiff_t>> rel;      // (parameter index, byte offset of its gradient from grads[0]) the table assumes
         WgParams* d_tab[2] = {nullptr, nullptr}; WgGroupBlk* d_blk[2] = {nullptr, nullptr}; int per_xcd[2] = {0, 0};
         double flops[2] = {0.0, 0.0};
@@ -544,7 +545,13 @@ DgradBnStat bn_stat_of(const Net& n, const ConvL& c, const BnL& b, const void* c
 // launch over ALL layers has thousands of tiles: most layers reduce all their pixels inside one work-group (plain stores,
 // deterministic, no memset), take 128x128 tiles, and only the large-image layers are still split.
 
-int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
+// first block of layer3: the backward of a data-parallel step is cut there (net_backward part 1 / part 2), because the
+// gradients of everything above it - 94 % of the parameters - are complete at that point and their all-reduce can run under
+// the rest of the backward
+inline int split_block(const Net& n) { return n.layers[0] + n.layers[1]; }
+
+int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int part) {
+    const bool upper = part != 2, lower = part != 1;
     std::vector<WgParams> tab[2];
     struct Unit { int prob, z, nblk; long load; };
     std::vector<Unit> units[2];
@@ -577,13 +584,13 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         return UDAPOSE_OK;
     };
     auto add = [&](const ConvL& c) -> int { return add_geom(c.g, c.w_idx, c.dy_off, c.in_off, -1); };
-    {   // head: dy is channel-padded to 64, only the K real rows of dW exist
+    if (upper) {   // head: dy is channel-padded to 64, only the K real rows of dW exist
         ConvGeom hg = n.head.g;
         hg.Co = 64;
         CK(add_geom(hg, n.head.w_idx, n.ws_dyhead, n.head.in_off, n.K));
         G.flops[1] -= 2.0 * n.N * n.Hout * n.Wout * 256.0 * (64 - n.K);   // (count the K real channels only)
     }
-    if (n.policy.wgrad_group_stem) {
+    if (lower && n.policy.wgrad_group_stem) {
         // stem (Ci == 8): row-tap form into the padded [Co][KH][8][8] scratch in the workspace (always zeroed, always split:
         // 8192 stages), unpacked into the real [Co][KH][KW][3] gradient after the launch
         WgParams p;
@@ -602,8 +609,9 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
             if (st > 0) units[t].push_back(Unit{prob, z, nblk, (long)nblk * (st + 4)});
         }
     }
-    for (int i = 2; i >= 0; --i) CK(add(n.up[i]));
+    if (upper) for (int i = 2; i >= 0; --i) CK(add(n.up[i]));
     for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
+        if (bi >= split_block(n) ? !upper : !lower) continue;
         Block& b = n.blocks[bi];
         CK(add(b.c3)); CK(add(b.c2));
         if (b.has_ds) CK(add(b.cd));
@@ -645,15 +653,15 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta) {
         if (hipMemcpy(G.d_zero, zj.data(), zj.size() * sizeof(ZeroJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         G.n_zero = (int)zj.size();
     }
-    G.k_beta = beta; G.k_stages = n.policy.wgrad_stages;
+    G.k_beta = beta; G.k_stages = n.policy.wgrad_stages; G.k_part = part;
     return UDAPOSE_OK;
 }
 
 // The tables hold OFFSETS (relative to the arenas and to grads[0]), so one pair of tables - overwrite and accumulate mode -
 // serves every pass whose gradient tensors keep their relative placement (both per-pass gradient buffers of a step do).
-Net::WgGroup* find_wg_group(Net& n, void* const* grads, float beta) {
+Net::WgGroup* find_wg_group(Net& n, void* const* grads, float beta, int part) {
     for (auto& g : n.wg_groups) {
-        if (g.k_beta != beta || g.k_stages != n.policy.wgrad_stages) continue;
+        if (g.k_beta != beta || g.k_stages != n.policy.wgrad_stages || g.k_part != part) continue;
         bool same = true;
         for (auto& r : g.rel)
             if ((const char*)grads[r.first] - (const char*)grads[0] != r.second) { same = false; break; }
@@ -664,19 +672,22 @@ Net::WgGroup* find_wg_group(Net& n, void* const* grads, float beta) {
 // net_bind_grads: allocate + upload the grouped weight-gradient tables (both accumulate modes) for this gradient placement.
 // Synchronous - never inside a stream capture; net_backward itself never builds them.
 int bind_wg_groups(Net& n, void* const* grads) {
-    for (const float beta : {0.f, 1.f}) {
-        if (find_wg_group(n, grads, beta)) continue;
-        Net::WgGroup* G;
-        if (n.wg_groups.size() < 4) { n.wg_groups.emplace_back(); G = &n.wg_groups.back(); }
-        else { G = &n.wg_groups[0]; for (auto& g : n.wg_groups) if (g.last_use < G->last_use) G = &g; }
-        CK(build_wg_group(n, *G, grads, beta));
-        G->last_use = ++n.wg_tick;
-    }
+    n.wg_groups.reserve(12);          // (pointers into the vector stay valid: 3 parts x 2 accumulate modes x 2 placements)
+    for (const int part : {0, 1, 2})
+        for (const float beta : {0.f, 1.f}) {
+            if (find_wg_group(n, grads, beta, part)) continue;
+            Net::WgGroup* G;
+            if (n.wg_groups.size() < 12) { n.wg_groups.emplace_back(); G = &n.wg_groups.back(); }
+            else { G = &n.wg_groups[0]; for (auto& g : n.wg_groups) if (g.last_use < G->last_use) G = &g; }
+            CK(build_wg_group(n, *G, grads, beta, part));
+            G->last_use = ++n.wg_tick;
+        }
     return UDAPOSE_OK;
 }
-int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta) {
-    Net::WgGroup* G = find_wg_group(n, grads, beta);
+int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta, int part) {
+    Net::WgGroup* G = find_wg_group(n, grads, beta, part);
     if (!G) return UDAPOSE_ERR_NOT_PREPARED;
+    const bool with_stem = part != 1 && n.policy.wgrad_group_stem;
     G->last_use = ++n.wg_tick;
     if (G->d_zero) {
         CK(pw_zero_multi(s, G->d_zero, G->n_zero, grads[0]));
@@ -686,7 +697,7 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
     }
     const ConvGeom& sg = n.stem.g;
     const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
-    if (n.policy.wgrad_group_stem && hipMemsetAsync(ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (with_stem && hipMemsetAsync(ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     for (int t = 0; t < 2; ++t) {
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);
@@ -694,7 +705,7 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         conv_prof_after(s, tok);
         CK(rc);
     }
-    if (n.policy.wgrad_group_stem)
+    if (with_stem)
         CK(pw_unpack_strided(s, (const float*)(ws + n.ws_dwtmp), (float*)grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
                              (long)sg.KH * sg.KW * 3, (long)sg.KW * 3, 3, 1, beta));
     return UDAPOSE_OK;
@@ -702,9 +713,16 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
 }  // namespace
 
 // grads[i] (fp32, same physical layout as params[i]) = beta*grads[i] + d loss / d params[i]; beta in {0,1}
+// part 0: the whole backward (one grouped weight-gradient launch per tile class at its end).
+// part 1 / part 2: the same backward cut after the first block of layer3 (split_block): part 1 = head, deconvs, layer4, layer3
+// and THEIR weight gradients - 94 % of the parameters, a contiguous suffix of the flat gradient buffer, final when part 1 ends;
+// part 2 = layer2, layer1, stem and theirs, continuing from the gradient part 1 left in the workspace.  Data parallel:
+// the all-reduce of the suffix runs under part 2 (engine.py).  The two parts together enqueue exactly the kernels of part 0
+// except that the weight gradients are two grouped launches per tile class instead of one.
 int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack_, void* act_, void* ws_,
-                 void* const* grads, float beta) {
+                 void* const* grads, float beta, int part) {
     Net& n = *(Net*)h;
+    if (part < 0 || part > 2) return UDAPOSE_ERR_ARG;
     DbgSyncScope dbg(n.policy.debug_sync);
     if (n.f32) return UDAPOSE_ERR_UNSUPPORTED;   // fp32 mode is forward-only (teacher / validate precision)
     const char* wpack = (const char*)wpack_;
@@ -714,8 +732,14 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     pool.base = ws;
     for (int i = 0; i < 6; ++i) pool.off[i] = n.ws_gbuf[i];
     const bool grouped = n.policy.wgrad_group != 0;
-    if (grouped && (!find_wg_group(n, grads, beta))) return UDAPOSE_ERR_NOT_PREPARED;     // (before anything is enqueued)
+    if (grouped && (!find_wg_group(n, grads, beta, part))) return UDAPOSE_ERR_NOT_PREPARED;     // (before anything is enqueued)
     const int HWo = n.Hout * n.Wout;
+    const int split = split_block(n);
+    const bool fused = n.policy.bn_bwd_fused != 0;
+    DgradBnStat cur, nxt;
+    bool have = false;
+    elem_t* dz = nullptr;
+    if (part != 2) {
     // head
     elem_t* dyh = (elem_t*)(ws + n.ws_dyhead);
     CK(pw_nchw_f32_to_nhwc_bf16(s, dout_nchw, dyh, n.N, n.K, HWo, 64));
@@ -727,7 +751,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         CK(conv_wgrad(s, hg, dyh, (const elem_t*)(act + n.head.in_off), tmp, 0, n.K));
         CK(pw_unpack_strided(s, tmp, (float*)grads[n.head.w_idx], n.K, 1, 1, 1, 256, 256, 256, 0, 0, 1, beta));
     }
-    elem_t* dz = pool.get();
+    dz = pool.get();
     // Gradients entering the BatchNorm backward of the three deconv layers are kept in fp32: close to the loss the BN
     // projection (g - mean(g) - xhat*mean(g*xhat)) cancels ~90 % of g, so bf16 rounding of g is amplified ~10x in dy
     // (measured against the backward of the bf16-storage emulation: 2.4 % / 8 % / 14 % relative error per layer with
@@ -736,9 +760,6 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     // Fused chain (g_bn_bwd_fused): every dgrad launch knows the BatchNorm that consumes its output; its epilogue applies
     // that BN's ReLU mask and reduces sum(g), sum(g*xhat) per m-tile, so a BN backward is ONE launch (column sums of the
     // slab + apply) for the wide layers and finalize + apply for the others.  `cur` describes the pending statistics of dz.
-    const bool fused = n.policy.bn_bwd_fused != 0;
-    DgradBnStat cur, nxt;
-    bool have = false;
     if (fused) { cur = bn_stat_of(n, n.up[2], n.up_bn[2], params, act, ws, 2); have = true; }
     CK(conv_dgrad(s, hg, dyh, (const elem_t*)(wpack + n.head.wb_off), dz, nullptr, 1, have ? &cur : nullptr));
     // deconv stack
@@ -754,8 +775,21 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         pool.put(dz);
         dz = dx;
     }
+    } else {
+        // part 2 resumes where part 1 stopped: the gradient entering block split-1 sits in the pool buffer part 1 ended on
+        // (the buffer sequence is a function of the plan alone), masked for that block's bn3 with its sums in the slab
+        if (split < 1 || split >= (int)n.blocks.size() || n.split_dz_idx < 0) return UDAPOSE_ERR_ARG;
+        pool.used[n.split_dz_idx] = true;
+        dz = (elem_t*)(ws + pool.off[n.split_dz_idx]);
+        if (fused) {
+            cur = bn_stat_of(n, n.blocks[split - 1].c3, n.blocks[split - 1].b3, params, act, ws, 1);
+            cur.rows = conv_dgrad_stat_rows(n.blocks[split].c1.g);
+            have = true;
+        }
+    }
     // bottlenecks, last to first
-    for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
+    const int bi_hi = part == 2 ? split - 1 : (int)n.blocks.size() - 1, bi_lo = part == 1 ? split : 0;
+    for (int bi = bi_hi; bi >= bi_lo; --bi) {
         Block& b = n.blocks[bi];
         // bn3 (+ReLU of the block output): g = masked dz feeds the skip branch (written in place unless the producing dgrad
         // already masked it)
@@ -784,6 +818,11 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         pool.put(dz);
         dz = dxin;
     }
+    if (part == 1) {
+        for (int i = 0; i < 6; ++i) if ((char*)dz == ws + pool.off[i]) n.split_dz_idx = i;      // (the same value on every pass)
+        if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta, 1));
+        return UDAPOSE_OK;
+    }
     // stem: maxpool -> bn/relu -> conv (no input gradient)
     elem_t* dzs = pool.get();
     CK(pw_maxpool3x3s2_bwd(s, dz, (const unsigned char*)(act + n.poolidx_off), dzs, n.N, n.Hs, n.Ws, 64));
@@ -791,7 +830,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     elem_t* none = nullptr;
     CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 2, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
-    if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta));
+    if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta, part));
     // backbone.fc is not part of the forward: zero gradient when overwriting
     if (beta == 0.f) {
         if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
@@ -813,4 +852,12 @@ int net_bind_grads(void* h, void* const* grads) {
     Net& n = *(Net*)h;
     if (n.f32) return UDAPOSE_OK;
     return bind_wg_groups(n, grads);
+}
+// index (in .parameters() order) of the first parameter whose gradient is final when net_backward part 1 has run: the first
+// parameter of layer3's first block.  Everything from there on (layer3, layer4, fc, upsampling, head) is part 1's.
+long long net_grad_split_param(void* h) {
+    Net& n = *(Net*)h;
+    const int split = split_block(n);
+    if (split < 1 || split >= (int)n.blocks.size()) return -1;
+    return n.blocks[split].c1.w_idx;
 }

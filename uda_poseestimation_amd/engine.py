@@ -35,23 +35,55 @@ def _dist_on():
 
 
 class GradSync:
-    """All-reduce (mean) of the student's flat fp32 gradient buffer: ONE collective per step over RCCL/xGMI.
-    (The PoseResNet executor writes every parameter gradient into views of a single buffer.)"""
+    """All-reduce (mean) of the student's flat fp32 gradient buffer over RCCL/xGMI.  (The PoseResNet executor writes every
+    parameter gradient into views of a single buffer.)  Either ONE collective per step (`sync()`), or two buckets so that
+    the first - the suffix holding layer3 / layer4 / upsampling / head, 94 % of the bytes, final when backward part 1 has
+    run - travels under backward part 2: `start_upper()` right after part 1, `finish()` after part 2."""
 
     def __init__(self, model):
         self.model = model
+        self._work = None
+
+    def _flat(self):
+        flat = getattr(self.model, "_flat_grad", None)
+        if flat is None:
+            raise RuntimeError("GradSync: model has no flat gradient buffer yet (run backward first)")
+        return flat
+
+    @staticmethod
+    def _reduce(t, async_op=False):
+        if dist.get_backend() == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)   # RCCL averages in the collective: no second sweep
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)          # gloo (CPU tests, shared-GPU test) has no AVG
+        if not async_op:
+            t.mul_(1.0 / dist.get_world_size())
+        return w
 
     def __call__(self):
         if not _dist_on():
             return
-        flat = getattr(self.model, "_flat_grad", None)
-        if flat is None:
-            raise RuntimeError("GradSync: model has no flat gradient buffer yet (run backward first)")
-        if dist.get_backend() == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG)      # RCCL averages in the collective: no second sweep over 212 MB
-        else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)      # gloo (CPU tests, shared-GPU test) has no AVG
-            flat.mul_(1.0 / dist.get_world_size())
+        self._reduce(self._flat())
+
+    def start_upper(self):
+        """Launch the all-reduce of the gradient suffix on the communicator's own stream (it waits for what is enqueued on the
+        current stream - backward part 1 and the sum of the two passes - and then runs beside whatever comes next)."""
+        if not _dist_on():
+            return
+        flat = self._flat()
+        self._upper = flat[self.model.grad_split_offset():]
+        self._work = self._reduce(self._upper, async_op=True)
+
+    def finish(self):
+        """All-reduce the prefix (layer2 / layer1 / stem: 6 % of the bytes), then join the suffix's collective."""
+        if not _dist_on():
+            return
+        flat = self._flat()
+        self._reduce(flat[:self.model.grad_split_offset()])
+        if self._work is not None:
+            self._work.wait()                        # the current stream waits for the suffix's collective
+            if dist.get_backend() != "nccl":
+                self._upper.mul_(1.0 / dist.get_world_size())
+            self._work = None
 
 
 def gather_activates(act):
@@ -95,6 +127,9 @@ class MeanTeacherTrainer:
         self.occlude_rate, self.occlude_thresh, self.occlude_size = occlude_rate, occlude_thresh, occlude_size
         self.image_px = image_px if image_px is not None else image_size
         self._aug_stu = None
+        # data parallel: cut the backward after layer3 and all-reduce the finished 94 % of the gradient under the rest of it
+        # (None: whenever a process group is active and the network has the layer3 boundary)
+        self.overlap_allreduce = None
 
     # ------------------------------------------------------------------ train_human.py:262-302
     def pretrain_step(self, x_s, label_s, weight_s, x_t=None):
@@ -105,8 +140,13 @@ class MeanTeacherTrainer:
             x_s = self.style_net(x_s, x_t, a, clamp=self.recover)[2]
         y_s = self.student(x_s)
         loss = self.criterion(y_s, label_s, weight_s)
+        overlap = self._overlap()
+        self.student.split_backward = overlap
         self.stu_optimizer.scale_loss(loss).backward()          # (scaler.scale(loss).backward(), train_human.py:285; identity in bf16)
-        self.sync()
+        self.student.split_backward = False
+        if overlap:
+            self.sync.start_upper()
+        self._sync_grads()
         self.stu_optimizer.step()
         return {"loss_all": loss.detach(), "loss_s": loss.detach(), "y_s": y_s.detach()}
 
@@ -120,7 +160,7 @@ class MeanTeacherTrainer:
         self._aug_stu = aug_param_stu
         thetas_tea = [warp.recon_thetas(ap, n, self.ratio, dev) for ap in aug_params_tea]
         out = self._forward_backward(x_s, label_s, weight_s, x_t_stu, list(x_t_teas), theta_stu, thetas_tea)
-        self.sync()
+        self._sync_grads()
         self._update()
         if with_accuracy:
             _, avg_acc, cnt, _ = kd.accuracy(out["y_s"], label_s)
@@ -186,10 +226,42 @@ class MeanTeacherTrainer:
         return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
                 "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu}
 
+    def _overlap(self):
+        on = self.overlap_allreduce
+        if on is None:
+            on = _dist_on()
+        return bool(on) and hasattr(self.student, "finish_backward")
+
+    def _sync_grads(self):
+        """What sits between backward and the optimizer: nothing on one rank; with overlap, backward part 2 under the first
+        bucket's all-reduce, then the second bucket; otherwise one all-reduce of the whole buffer."""
+        if self._overlap() and self.student._pending_lower:
+            self._backward_lower()
+            self.sync.finish()
+        else:
+            self.sync()
+
+    def _backward_lower(self, st=None):
+        student = self.student
+        main = torch.cuda.current_stream()
+        streams = {id(p[5]): p[5] for p in student._pending_lower}
+        for stv in streams.values():
+            if stv is not main:
+                stv.wait_stream(main)              # (fork: inside a capture the side stream joins the graph here)
+        student.finish_backward()
+        for stv in streams.values():
+            if stv is not main:
+                main.wait_stream(stv)
+        student.finish_grads(part=2)
+
     def _loss_backward_part(self, st, gathered_activates):
-        """Losses and backward from the forward state; `gathered_activates` = all ranks' confidences (None on one rank)."""
+        """Losses and backward from the forward state; `gathered_activates` = all ranks' confidences (None on one rank).
+        With overlap (data parallel) this is backward PART 1 of both passes, the sum of their gradient suffixes and the launch
+        of that suffix's all-reduce; _sync_grads() runs part 2 and the rest."""
         student = self.student
         main, s_stu = st["main"], st["s_stu"]
+        overlap = self._overlap()
+        student.split_backward = overlap
         loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
@@ -200,7 +272,13 @@ class MeanTeacherTrainer:
         self.stu_optimizer.scale_loss(loss_all).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
-        student.finish_grads()              # adds the second pass's gradient buffer (no-op when both ran on one stream)
+        student.split_backward = False
+        if overlap:
+            student.finish_grads(part=1)    # the suffix of both passes is final: sum it ...
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync.start_upper()     # ... and send it off (a captured step issues the collective between its graphs)
+        else:
+            student.finish_grads()          # adds the second pass's gradient buffer (no-op when both ran on one stream)
         return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": st["y_s"].detach()}
 
     def _forward_backward(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
@@ -253,6 +331,9 @@ def validate(batches, model, criterion=None):
 class GraphedTrainStep:
     """The mean-teacher step captured into two hipGraphs (forward/backward, then Adam+EMA) around the eager gradient
     all-reduce: ~2500 kernel launches per step are replayed by two graph launches, which removes the host launch gaps.
+    Data parallel: four graphs - forwards | losses + backward part 1 | backward part 2 | Adam + EMA - with the confidence
+    all-gather after the first, the all-reduce of the finished gradient suffix launched after the second (it runs on the
+    communicator's stream under the third) and the small prefix all-reduce after the third.
     Inputs are copied into static device tensors before each replay; the re-warp matrices are computed on the host from
     the batch's aug_param tuples exactly as in the eager step.  Style transfer / occlusion draw host random numbers per
     step and therefore stay on the eager path."""
@@ -276,7 +357,7 @@ class GraphedTrainStep:
             for _ in range(warmup):     # fills the tap-plan / table caches and reaches allocator steady state
                 trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
                                           [st["theta_tea"]])
-                trainer.sync()
+                trainer._sync_grads()
                 trainer._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -292,10 +373,16 @@ class GraphedTrainStep:
         self.g_fb, self.g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # other threads (the RCCL watchdog of torch.distributed) may touch the runtime while this thread captures
         mode = "thread_local" if _dist_on() else "global"
+        # overlap: the backward is cut after layer3 (two graph segments) and the finished gradient suffix is all-reduced on
+        # the communicator's stream while the second segment replays
+        self.overlap = trainer._overlap()
+        self.g_lb2 = None
         if not self.split:
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
                 self.out = trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
                                                      [st["theta_tea"]])
+                if trainer.student._pending_lower:      # (overlap forced on one rank: both backward parts in the one graph)
+                    trainer._backward_lower()
         else:
             self.g_lb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
@@ -305,7 +392,15 @@ class GraphedTrainStep:
             self.gathered = g0.clone() if g0 is not None else self.fwd_state["activates"].reshape(-1).clone()
             with torch.cuda.graph(self.g_lb, pool=self.g_fb.pool(), capture_error_mode=mode):
                 self.out = trainer._loss_backward_part(self.fwd_state, self.gathered)
-        trainer.sync()
+            if self.overlap:
+                trainer.sync.start_upper()
+                self.g_lb2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_lb2, pool=self.g_fb.pool(), capture_error_mode=mode):
+                    trainer._backward_lower()
+        if self.g_lb2 is not None:
+            trainer.sync.finish()
+        else:
+            trainer.sync()
         with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode):
             trainer._update()
         for m in (trainer.student, trainer.teacher):
@@ -365,7 +460,12 @@ class GraphedTrainStep:
             g = gather_activates(self.fwd_state["activates"])
             self.gathered.copy_(g if g is not None else self.fwd_state["activates"].reshape(-1))
             self.g_lb.replay()
-        self.t.sync()
+        if self.g_lb2 is not None:
+            self.t.sync.start_upper()            # suffix (94 %) on the communicator's stream ...
+            self.g_lb2.replay()                  # ... under backward part 2
+            self.t.sync.finish()
+        else:
+            self.t.sync()
         self.t.stu_optimizer.sync_hyper()        # lr scheduler / loss scale -> device state read by the captured sweep
         self.g_up.replay()
         # the replayed Adam / EMA kernels changed both networks' parameters behind torch's back: every executor plan (other

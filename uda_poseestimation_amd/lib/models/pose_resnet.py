@@ -136,6 +136,11 @@ class PoseResNet(nn.Module):
         # explicit dispatch-policy overrides for this network's executor plans (fields of udapose_policy, include/udapose.h);
         # empty = the production policy.  Plans read it when they are created: clear self._handles after changing it.
         self.policy = {}
+        # Data parallel: cut every backward after the first block of layer3 (udapose_net_backward_part).  backward() then runs
+        # part 1 only - after it the gradients of layer3 / layer4 / upsampling / head (a contiguous suffix of the flat buffer,
+        # 94 % of it) are final - and finish_backward() runs part 2; the caller all-reduces the suffix in between, under part 2.
+        self.split_backward = False
+        self._pending_lower = []
         self._to_channels_last()
 
     # ------------------------------------------------------------------ layout / pointer bookkeeping
@@ -155,6 +160,8 @@ class PoseResNet(nn.Module):
         self._grad_state = None
         self._deferred_bn = []
         self._handles = {}
+        self._pending_lower = []
+        self._split_off = None
         return r
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -285,13 +292,44 @@ class PoseResNet(nn.Module):
             check(hd.L.udapose_net_apply_running(hd.h, _hip.stream(), ptr(act), ba, float(self.bn_momentum)), "net_apply_running")
         self._deferred_bn = []
 
-    def finish_grads(self):
+    def finish_grads(self, part=0):
         """Sum the second per-pass gradient buffer into p.grad's buffer (only needed when two backward passes ran on
-        different streams; the caller has already made the current stream wait for both)."""
+        different streams; the caller has already made the current stream wait for both).  part 1 / 2: only the suffix /
+        prefix of the flat buffer that backward part 1 / part 2 produced (split_backward)."""
         st = self._grad_state
         if st is not None and st[1]:
-            check(lib().udapose_axpy_f32(_hip.stream(), ptr(self._flat_grad), ptr(self._flat_grad2), self._flat_grad.numel()), "axpy")
-        self._grad_state = None
+            n, off = self._flat_grad.numel(), (self.grad_split_offset() if part else 0)
+            lo, cnt = (0, n) if part == 0 else ((off, n - off) if part == 1 else (0, off))
+            check(lib().udapose_axpy_f32(_hip.stream(), self._flat_grad.data_ptr() + 4 * lo, self._flat_grad2.data_ptr() + 4 * lo, cnt), "axpy")
+        if part != 1:
+            self._grad_state = None
+
+    def grad_split_offset(self):
+        """Element offset into the flat gradient buffer where backward part 1's gradients start (layer3's first parameter)."""
+        off = getattr(self, "_split_off", None)
+        if off is None:
+            hd = next(iter(self._handles.values()))
+            idx = hd.L.udapose_net_grad_split_param(hd.h)
+            params = list(self.parameters())
+            if idx < 0 or idx >= len(params):
+                raise RuntimeError("this network has no layer3 boundary to split the backward at")
+            off = sum(p.numel() for p in params[:idx])
+            if off % 4:
+                raise RuntimeError("gradient split offset is not 16-byte aligned")
+            self._split_off = off
+        return off
+
+    def finish_backward(self):
+        """Run part 2 (layer2, layer1, stem and their weight gradients) of every backward that ran with split_backward, each
+        on the stream its part 1 ran on."""
+        pending, self._pending_lower = self._pending_lower, []
+        pa, ba, params = self._pointers()
+        for hd, act, ws, gptrs, beta, stream in pending:
+            with torch.cuda.stream(stream):
+                check(hd.L.udapose_net_backward_part(hd.h, stream.cuda_stream, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 2),
+                      "net_backward part 2")
+                act.record_stream(stream)
+                ws.record_stream(stream)
 
     def _run_backward(self, dout, act, hd, ws):
         pa, ba, params = self._pointers()
@@ -335,7 +373,12 @@ class PoseResNet(nn.Module):
             check(hd.L.udapose_net_bind_grads(hd.h, gptrs), "net_bind_grads")
             hd.bound_grads.add(gkey)
         dout = dout.contiguous().float()
-        check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
+        if self.split_backward:
+            check(hd.L.udapose_net_backward_part(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 1),
+                  "net_backward part 1")
+            self._pending_lower.append((hd, act, ws, gptrs, beta, cur))       # (keeps the arenas alive until part 2 has run)
+        else:
+            check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not
         # zeros: SGD's weight decay and Adam must skip it exactly as torch.optim skips parameters without .grad)
         nograd = self._no_grad_ids()
