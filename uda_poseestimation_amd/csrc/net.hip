@@ -821,6 +821,10 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     if (part == 1) {
         for (int i = 0; i < 6; ++i) if ((char*)dz == ws + pool.off[i]) n.split_dz_idx = i;      // (the same value on every pass)
         if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta, 1));
+        if (beta == 0.f) {       // backbone.fc lies in part 1's suffix of the gradient buffer (not part of forward: zero)
+            if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+            if (hipMemsetAsync(grads[n.fc_b_idx], 0, (size_t)1000 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        }
         return UDAPOSE_OK;
     }
     // stem: maxpool -> bn/relu -> conv (no input gradient)
@@ -832,7 +836,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     pool.put(dzs);
     if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta, part));
     // backbone.fc is not part of the forward: zero gradient when overwriting
-    if (beta == 0.f) {
+    if (beta == 0.f && part == 0) {
         if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         if (hipMemsetAsync(grads[n.fc_b_idx], 0, (size_t)1000 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }

@@ -130,6 +130,10 @@ class MeanTeacherTrainer:
         # data parallel: cut the backward after layer3 and all-reduce the finished 94 % of the gradient under the rest of it
         # (None: whenever a process group is active and the network has the layer3 boundary)
         self.overlap_allreduce = None
+        # The source-domain loss needs nothing from the teacher / target branches (train_human.py:425): its backward can start
+        # as soon as student(x_s) is done, beside the other two branches' forwards, instead of after the join.  Same sums
+        # (loss_all.backward() = loss_s.backward() + lambda_c * loss_c.backward()), another interleaving of the three streams.
+        self.early_source_backward = False
 
     # ------------------------------------------------------------------ train_human.py:262-302
     def pretrain_step(self, x_s, label_s, weight_s, x_t=None):
@@ -206,6 +210,10 @@ class MeanTeacherTrainer:
                 y_t_stu = student.forward_deferred_bn(x_t_stu)     # separate forwards: separate BN statistics per domain
                 y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
             y_s = student(x_s)
+            loss_s_early = None
+            if self.early_source_backward and torch.is_grad_enabled() and not self._overlap():
+                loss_s_early = self.criterion(y_s, label_s, weight_s)
+                self.stu_optimizer.scale_loss(loss_s_early).backward()      # on `main`, while the other branches still run forward
             main.wait_stream(s_stu)
             student.apply_deferred_bn()
             for t in (y_t_stu, y_t_stu_recon):
@@ -224,7 +232,8 @@ class MeanTeacherTrainer:
         with torch.no_grad():
             activates = mt.heatmap_activations(y_t_tea_recon)    # BEFORE rectify (train_human.py:427)
         return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
-                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu}
+                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu,
+                "loss_s": (loss_s_early if not occl else None)}
 
     def _overlap(self):
         on = self.overlap_allreduce
@@ -262,13 +271,14 @@ class MeanTeacherTrainer:
         main, s_stu = st["main"], st["s_stu"]
         overlap = self._overlap()
         student.split_backward = overlap
-        loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
+        early = st.get("loss_s") is not None
+        loss_s = st["loss_s"] if early else self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
             tea_mask, _, _ = mt.confidence_mask(st["y_t_tea_recon"], self.mask_ratio, None, gathered_activates, st["activates"])
             y_t_tea_rect = mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
         loss_c = self.con_criterion(st["y_t_stu_recon"], y_t_tea_rect, tea_mask=tea_mask)
-        loss_all = loss_s + self.lambda_c * loss_c
+        loss_all = loss_s.detach() + self.lambda_c * loss_c if early else loss_s + self.lambda_c * loss_c
         self.stu_optimizer.scale_loss(loss_all).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
