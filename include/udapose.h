@@ -238,6 +238,21 @@ int udapose_sgd_multi(void* stream, const long long* p, const long long* g, cons
                       const int* blk_tensor, const long long* blk_off, int nblocks, float lr, float momentum, float weight_decay,
                       int nesterov, int first_step, float grad_scale, float* dev_state);
 
+/* The whole tail of a mean-teacher step in ONE sweep over the parameters: torch.optim.Adam.step on the student
+ * (train_human.py:437), OldWeightEMA.step into the teacher (utils.py:21-25, train_human.py:438) and the element-type weight
+ * packs that the next forwards of both networks' plans need (what udapose_net_pack_weights would re-read the masters for):
+ * 46 bytes per parameter instead of 58, four launches fewer.  Arithmetic identical to udapose_adam_multi followed by
+ * udapose_ema_multi (bit for bit); parameters by index in .parameters() order (host arrays of device pointers); exp_avg /
+ * exp_avg_sq entries are NULL for parameters without gradient (backbone.fc: EMA only).  bind_update builds the device job
+ * table (allocates: outside capture; again when a pointer changes); dev_state as for udapose_adam_multi; do_adam = 0: EMA
+ * and packs only. */
+int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* const* h_params_s, void* const* h_grads,
+                            void* const* h_exp_avg, void* const* h_exp_avg_sq, void* const* h_params_t, void* wpack_s, void* wpack_t);
+int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* h_params_s, void* const* h_grads,
+                             void* const* h_exp_avg, void* const* h_params_t, void* wpack_s, void* wpack_t, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha,
+                             float one_minus_alpha, int do_adam);
+
 /* Dynamic loss scaling = torch.cuda.amp.GradScaler (train_human.py:260,285-287,324,436-440) on the device, for the fp16 build.
  * dev_state is the optimizer's 8-float state: [5] = found_inf, [6] = loss scale S, [7] = growth tracker, [4] = 1/S.
  * check: raises found_inf if any gradient is inf / nan (then adam_multi / sgd_multi skip the step, counter included);

@@ -295,3 +295,56 @@ def test_backward_in_two_parts_equals_whole_backward():
         num = sum(float(((a - b_) ** 2).sum()) for a, b_ in zip(ps, ref_p))
         den = sum(float(((b_ - c) ** 2).sum()) for b_, c in zip(ref_p, p0))
         assert (num / den) ** 0.5 < 0.2, (mode, (num / den) ** 0.5)
+
+
+def test_fused_optimizer_tail_is_bit_identical_to_adam_then_ema_then_pack():
+    """udapose_net_fused_update (Adam + EMA + the weight packs of both plans in one sweep) against the separate launches on
+    IDENTICAL gradients and state: parameters, both moments, the teacher and every byte of both pack buffers are equal; a
+    second step (moments no longer zero, step counter 2) as well; parameters without gradient (backbone.fc) get the EMA only."""
+    from uda_poseestimation_amd import optim as fo
+    from uda_poseestimation_amd.utils import OldWeightEMA
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    x = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    R = torch.randn(2, 16, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def build():
+        torch.manual_seed(3)
+        s_ = pr._pose_resnet("t", 16, pr.Bottleneck_default, [2, 1, 1, 1], False, False).cuda()
+        torch.manual_seed(4)
+        t_ = pr._pose_resnet("t", 16, pr.Bottleneck_default, [2, 1, 1, 1], False, False).cuda()
+        opt = fo.FusedAdam(s_.parameters(), lr=1e-3, weight_decay=1e-2)
+        ema = OldWeightEMA(t_, s_, alpha=0.9)
+        with torch.no_grad():                       # teacher != student, so that the EMA is visible
+            for p in t_.parameters():
+                p.mul_(1.01)
+        return s_, t_, opt, ema
+
+    (sa, ta, oa, ea), (sb, tb, ob, eb) = build(), build()
+    for step in range(2):
+        # one backward on A; B gets a bit-copy of A's gradients (weight-gradient atomics make two backwards differ in the last bits)
+        sa.zero_grad(set_to_none=True); sb.zero_grad(set_to_none=True)
+        (sa(x) * R).sum().backward()
+        (sb(x) * R).sum().backward()
+        with torch.no_grad():
+            ta(x); tb(x)
+        sb._flat_grad.copy_(sa._flat_grad)
+        oa.step(); ea.step()
+        assert ob.fused_tail_step(sb, tb, eb) is True
+        hd_a, hd_b, ht_a, ht_b = sa._last_hd, sb._last_hd, ta._last_hd, tb._last_hd
+        sa.prepare(x)                               # A re-packs from its masters the ordinary way
+        with torch.no_grad():
+            ta.prepare(x)
+        for (n, pa), (_, pb) in zip(sa.named_parameters(), sb.named_parameters()):
+            assert torch.equal(pa.detach(), pb.detach()), (step, n)
+            if pa.grad is not None:
+                assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]) and torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+        for (n, pa), (_, pb) in zip(ta.named_parameters(), tb.named_parameters()):
+            assert torch.equal(pa.detach(), pb.detach()), (step, "teacher", n)
+        assert torch.equal(hd_a.wpack, hd_b.wpack), "student packs differ"
+        # the teacher plan holds forward packs only: compare through a forward (eval-free: same batch statistics)
+        with torch.no_grad():
+            assert torch.equal(ta(x), tb(x))
+        assert hd_b.wpack_version == (sb.version_key(), True) and ht_b.wpack_version == (tb.version_key(), False)
+    assert oa.state_dict()["param_groups"][0]["step"] == ob.state_dict()["param_groups"][0]["step"] == 2
+    fc = sb.backbone.fc.weight
+    assert fc.grad is None and fc not in ob.state

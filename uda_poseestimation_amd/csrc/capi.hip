@@ -52,6 +52,9 @@ const Policy& net_get_policy(void*);
 int net_bind(void*, const void* const*, void* const*, void*);
 int net_bind_grads(void*, void* const*);
 long long net_grad_split_param(void*);
+int net_bind_update(void*, void*, void* const*, void* const*, void* const*, void* const*, void* const*, void*, void*);
+int net_fused_update(void*, void*, hipStream_t, void* const*, void* const*, void* const*, void* const*, void*, void*, float, float, float, float, float,
+                     int, float, float*, float, float, int);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -232,6 +235,19 @@ int udapose_net_backward_part(udapose_net_t n, void* stream, const float* dout, 
     return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part);
 }
 long long udapose_net_grad_split_param(udapose_net_t n) { return net_grad_split_param(n); }
+int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* const* params_s, void* const* grads, void* const* exp_avg,
+                            void* const* exp_avg_sq, void* const* params_t, void* wpack_s, void* wpack_t) {
+    if (!student || !teacher || !params_s || !grads || !exp_avg || !exp_avg_sq || !params_t || !wpack_s || !wpack_t) return UDAPOSE_ERR_ARG;
+    return net_bind_update(student, teacher, params_s, grads, exp_avg, exp_avg_sq, params_t, wpack_s, wpack_t);
+}
+int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* params_s, void* const* grads,
+                             void* const* exp_avg, void* const* params_t, void* wpack_s, void* wpack_t, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha, float one_minus_alpha,
+                             int do_adam) {
+    if (!student || !teacher) return UDAPOSE_ERR_ARG;
+    return net_fused_update(student, teacher, S(stream), params_s, grads, exp_avg, params_t, wpack_s, wpack_t, lr, beta1, beta2, eps, weight_decay,
+                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam);
+}
 
 int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out) {
     return hm_sqdiff_rows(S(stream), pred, gt, w, nullptr, R, HW, 0.5f, rows, mean_out, nullptr, nullptr, 1);

@@ -38,6 +38,10 @@ int pw_bn_train_fused(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t
 int pw_zero_multi(hipStream_t, const ZeroJob*, int, void*);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
+size_t opt_tail_job_bytes();
+int opt_chunk();
+void opt_tail_job_fill(void*, float*, const float*, float*, float*, float*, void*, void*, void*, void*, int, int, int, int, long long);
+int opt_tail(hipStream_t, const void*, const int*, const int*, int, float, float, float, float, float, int, float, float*, float, float, int);
 int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
 int pw_pack_strided_f32(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long);
 int pw_bn_apply_f32(hipStream_t, const float*, const float*, float*, size_t, int, const float*, const float*, int);
@@ -117,6 +121,11 @@ struct Net {
         unsigned long long last_use = 0;
     };
     std::vector<WgGroup> wg_groups;
+    // fused optimizer tail (Adam + EMA + weight packs of student and teacher in one sweep): device job table
+    struct UpdTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0;
+                    const void* k_ps = nullptr; const void* k_pt = nullptr; const void* k_g = nullptr; const void* k_m = nullptr;
+                    const void* k_ws = nullptr; const void* k_wt = nullptr; };
+    UpdTab upd;
     // batched deferred running-statistics update: device job table, rebuilt when the buffer pointers change
     BnRunJob* d_runjobs = nullptr; int n_runjobs = 0; const void* runjobs_key = nullptr;
     unsigned long long wg_tick = 0;
@@ -318,6 +327,7 @@ void net_destroy(void* h) {
     Net* n = (Net*)h;
     if (!n) return;
     if (n->d_runjobs) (void)hipFree(n->d_runjobs);
+    if (n->upd.jobs) { (void)hipFree(n->upd.jobs); (void)hipFree(n->upd.blk_job); (void)hipFree(n->upd.blk_sub); }
     for (auto& g : n->wg_groups)
         for (int t = 0; t < 2; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
     for (auto& g : n->wg_groups) if (g.d_zero) (void)hipFree(g.d_zero);
@@ -864,4 +874,84 @@ long long net_grad_split_param(void* h) {
     const int split = split_block(n);
     if (split < 1 || split >= (int)n.blocks.size()) return -1;
     return n.blocks[split].c1.w_idx;
+}
+
+// ---- fused optimizer tail: Adam on the student, EMA into the teacher, and the element-type weight packs of BOTH networks'
+// plans in one sweep (optim.hip opt_tail_k).  hs / ht: the student's and the teacher's plans (same architecture).
+// h_m / h_v: host arrays of the Adam moments per parameter index, NULL entries for parameters without gradient (backbone.fc:
+// EMA only).  bind builds the device job table (allocates: outside capture); the update itself only launches.
+int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grads, void* const* h_m, void* const* h_v, void* const* params_t,
+                    void* wpack_s_, void* wpack_t_) {
+    Net& n = *(Net*)hs;
+    const Net& nt = *(const Net*)ht;
+    if (n.f32 || nt.f32 || n.n_params != nt.n_params || n.wpack_bytes != nt.wpack_bytes) return UDAPOSE_ERR_UNSUPPORTED;
+    char* ws_ = (char*)wpack_s_;
+    char* wt_ = (char*)wpack_t_;
+    const size_t jb = opt_tail_job_bytes();
+    std::vector<char> jobs;
+    std::vector<int> bj, bs;
+    std::vector<char> covered(n.n_params, 0);
+    auto push = [&](int idx, void* sd, void* td, void* sx, void* tx, int A, int T, int B) -> int {
+        const long long numel = n.param_numel[idx];
+        const int adam = (h_m[idx] && h_v[idx] && grads[idx]) ? 1 : 0;
+        if (A) {
+            const uintptr_t al = (uintptr_t)params_s[idx] | (uintptr_t)params_t[idx] | (adam ? ((uintptr_t)grads[idx] | (uintptr_t)h_m[idx] | (uintptr_t)h_v[idx]) : 0);
+            if ((al & 15) || (A & 63) || (B & 63) || (long long)A * T * B != numel) return UDAPOSE_ERR_UNSUPPORTED;
+        }
+        jobs.resize(jobs.size() + jb);
+        opt_tail_job_fill(jobs.data() + jobs.size() - jb, (float*)params_s[idx], (const float*)grads[idx], (float*)h_m[idx], (float*)h_v[idx],
+                          (float*)params_t[idx], sd, td, sx, tx, A, T, B, adam, numel);
+        const int j = (int)(jobs.size() / jb) - 1;
+        const long nb = A ? (long)(A / 64) * (B / 64) * T : (long)((numel + opt_chunk() - 1) / opt_chunk());
+        for (long k = 0; k < nb; ++k) { bj.push_back(j); bs.push_back((int)k); }
+        covered[idx] = 1;
+        return UDAPOSE_OK;
+    };
+    auto conv = [&](const ConvL& c) -> int {
+        const ConvGeom& g = c.g;
+        const int T = g.KH * g.KW;
+        if (g.smallc()) return push(c.w_idx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);     // stem: packed by its own strided launch
+        if (!g.transposed)   // master [Co][T][Ci]: fprop pack = cast, dgrad pack = per-tap transpose; the teacher needs the fprop pack
+            return push(c.w_idx, ws_ + c.wf_off, wt_ + c.wf_off, ws_ + c.wb_off, nullptr, g.Co, T, g.Ci);
+        // ConvTranspose2d master [Ci][T][Co]: dgrad pack = cast, fprop pack = per-tap transpose
+        return push(c.w_idx, ws_ + c.wb_off, nullptr, ws_ + c.wf_off, wt_ + c.wf_off, g.Ci, T, g.Co);
+    };
+    CK(conv(n.stem));
+    for (auto& b : n.blocks) {
+        CK(conv(b.c1)); CK(conv(b.c2)); CK(conv(b.c3));
+        if (b.has_ds) CK(conv(b.cd));
+    }
+    for (int i = 0; i < 3; ++i) CK(conv(n.up[i]));
+    CK(push(n.head.w_idx, ws_ + n.head.wf_off, wt_ + n.head.wf_off, nullptr, nullptr, 0, 0, 0));      // [K][256]: the fprop pack is a cast
+    for (int i = 0; i < n.n_params; ++i)
+        if (!covered[i]) CK(push(i, nullptr, nullptr, nullptr, nullptr, 0, 0, 0));                   // BN vectors, head bias, backbone.fc
+    Net::UpdTab& u = n.upd;
+    if (u.jobs) { (void)hipFree(u.jobs); (void)hipFree(u.blk_job); (void)hipFree(u.blk_sub); u.jobs = nullptr; }
+    if (hipMalloc(&u.jobs, jobs.size()) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMalloc((void**)&u.blk_job, bj.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMalloc((void**)&u.blk_sub, bs.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMemcpy(u.jobs, jobs.data(), jobs.size(), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMemcpy(u.blk_job, bj.data(), bj.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (hipMemcpy(u.blk_sub, bs.data(), bs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    u.nblocks = (int)bj.size();
+    u.k_ps = params_s[0]; u.k_pt = params_t[0]; u.k_g = grads[0]; u.k_m = h_m[0]; u.k_ws = wpack_s_; u.k_wt = wpack_t_;
+    return UDAPOSE_OK;
+}
+
+int net_fused_update(void* hs, void* ht, hipStream_t s, void* const* params_s, void* const* grads, void* const* h_m, void* const* params_t,
+                     void* wpack_s_, void* wpack_t_, float lr, float beta1, float beta2, float eps, float wd, int step, float gscale,
+                     float* dev_state, float alpha, float oma, int do_adam) {
+    Net& n = *(Net*)hs;
+    const Net& nt = *(const Net*)ht;
+    DbgSyncScope dbg(n.policy.debug_sync);
+    const Net::UpdTab& u = n.upd;
+    if (!u.jobs || u.k_ps != params_s[0] || u.k_pt != params_t[0] || u.k_g != grads[0] || u.k_m != h_m[0] || u.k_ws != wpack_s_ || u.k_wt != wpack_t_)
+        return UDAPOSE_ERR_NOT_PREPARED;
+    CK(opt_tail(s, u.jobs, u.blk_job, u.blk_sub, u.nblocks, lr, beta1, beta2, eps, wd, step, gscale, dev_state, alpha, oma, do_adam));
+    // the two packs that are not a cast or a per-tap transpose of a whole tensor: the stem's 3 -> 8 channel gather (both
+    // networks) and the head's zero-padded dgrad pack (student)
+    CK(pack_conv(s, n, n.stem, (const void* const*)params_s, (char*)wpack_s_, false));
+    CK(pack_conv(s, nt, nt.stem, (const void* const*)params_t, (char*)wpack_t_, false));
+    CK(pw_pack_strided(s, (const float*)params_s[n.head.w_idx], (elem_t*)((char*)wpack_s_ + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
+    return UDAPOSE_OK;
 }

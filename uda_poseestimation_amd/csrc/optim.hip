@@ -143,9 +143,116 @@ __global__ void scaler_update_k(float* __restrict__ state, float growth, float b
     state[6] = scale; state[7] = tr; state[5] = 0.f;
     state[4] = 1.f / scale;
 }
+// ---- fused optimizer tail -------------------------------------------------------------------------------------------------
+// After the backward a step has nothing left but sweeps over the 55 M parameters, one after the other on one stream: Adam
+// (28 B / parameter), the EMA teacher update (12 B), and - at the start of the next step - the element-type weight packs of
+// both networks, which re-read the fp32 masters (3 x 6 B).  One kernel does all of it while every value is in registers:
+// read p, g, m, v and the teacher; write p, m, v, the teacher and the packs: 46 B / parameter instead of 58.
+// The arithmetic is adam_k's and ema_k's, expression for expression (this file is compiled without FMA contraction), so the
+// parameters, moments and teacher come out bit-identical to the separate launches and the packs are casts of those values.
+// Linear jobs (BatchNorm vectors, biases, stem / head / fc weights): 4096-element chunks, optional same-layout packs.
+// Tiled jobs (conv / deconv weights [A][T][B], A and B multiples of 64): one 64 x 64 tile of one tap per block; the
+// same-layout pack is written from registers, the transposed pack [B][T][A] goes through an LDS tile.
+struct TailJob {
+    float* p; const float* g; float* m; float* v; float* t;   // student parameter, gradient, moments, teacher parameter
+    elem_t* sd; elem_t* td; elem_t* sx; elem_t* tx;             // packs: student / teacher same-layout, student / teacher transposed
+    int A, T, B, adam;                                          // A == 0: linear job; adam == 0: no gradient (EMA + packs only)
+    long long n;
+};
+
+struct TailHyper { float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, gscale, alpha, oma; int do_adam; };
+
+__device__ __forceinline__ void tail1(const TailHyper& h, bool adam, float& pv, float gr, float& mi, float& vi, float& tv) {
+    if (adam) {
+        gr *= h.gscale;
+        if (h.wd != 0.f) gr += h.wd * pv;
+        mi = mi * h.beta1 + (1.f - h.beta1) * gr;
+        vi = vi * h.beta2 + (1.f - h.beta2) * gr * gr;
+        pv = pv - (h.lr / h.bc1) * (mi / (sqrtf(vi) / h.bc2_sqrt + h.eps));
+    }
+    tv = ema1(tv, pv, h.alpha, h.oma);
+}
+
+__global__ __launch_bounds__(TPB) void opt_tail_k(const TailJob* __restrict__ jobs, const int* __restrict__ blk_job, const int* __restrict__ blk_sub,
+                                                  TailHyper h, const float* __restrict__ dev_state) {
+    __shared__ elem_t ts[64][66], tt[64][66];
+    if (dev_state) {
+        h.bc1 = dev_state[1]; h.bc2_sqrt = dev_state[2]; h.lr = dev_state[3]; h.gscale = dev_state[4];
+        if (dev_state[5] != 0.f) h.do_adam = 0;          // inf / nan gradients: the optimizer step is skipped, the EMA is not
+    }
+    const TailJob j = jobs[blk_job[blockIdx.x]];
+    const int sub = blk_sub[blockIdx.x];
+    const bool adam = j.adam && h.do_adam;
+    if (j.A == 0) {
+        const long long off = (long long)sub * CHUNK;
+        const long long end = off + CHUNK < j.n ? off + CHUNK : j.n;
+        for (long long i = off + threadIdx.x; i < end; i += TPB) {
+            float pv = j.p[i], tv = j.t[i], mi = 0.f, vi = 0.f;
+            if (adam) { mi = j.m[i]; vi = j.v[i]; }
+            tail1(h, adam, pv, adam ? j.g[i] : 0.f, mi, vi, tv);
+            if (adam) { j.p[i] = pv; j.m[i] = mi; j.v[i] = vi; }
+            j.t[i] = tv;
+            if (j.sd) j.sd[i] = (elem_t)pv;
+            if (j.td) j.td[i] = (elem_t)tv;
+        }
+        return;
+    }
+    const int tb = j.B >> 6;
+    const int t = sub % j.T, tile = sub / j.T;
+    const int a0 = (tile / tb) << 6, b0 = (tile % tb) << 6;
+    const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) << 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = r + 16 * i;
+        const size_t idx = ((size_t)(a0 + a) * j.T + t) * j.B + b0 + c4;
+        f32x4 pv = *(const f32x4*)(j.p + idx), tv = *(const f32x4*)(j.t + idx);
+        f32x4 mi = {0.f, 0.f, 0.f, 0.f}, vi = mi, gr = mi;
+        if (adam) { mi = *(const f32x4*)(j.m + idx); vi = *(const f32x4*)(j.v + idx); gr = *(const f32x4*)(j.g + idx); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float p1 = pv[e], m1 = mi[e], v1 = vi[e], t1 = tv[e];
+            tail1(h, adam, p1, gr[e], m1, v1, t1);
+            pv[e] = p1; mi[e] = m1; vi[e] = v1; tv[e] = t1;
+        }
+        if (adam) { *(f32x4*)(j.p + idx) = pv; *(f32x4*)(j.m + idx) = mi; *(f32x4*)(j.v + idx) = vi; }
+        *(f32x4*)(j.t + idx) = tv;
+        const elem4 ps = {(elem_t)pv[0], (elem_t)pv[1], (elem_t)pv[2], (elem_t)pv[3]};
+        const elem4 pt = {(elem_t)tv[0], (elem_t)tv[1], (elem_t)tv[2], (elem_t)tv[3]};
+        if (j.sd) *(elem4*)(j.sd + idx) = ps;
+        if (j.td) *(elem4*)(j.td + idx) = pt;
+        if (j.sx) { ts[a][c4] = ps[0]; ts[a][c4 + 1] = ps[1]; ts[a][c4 + 2] = ps[2]; ts[a][c4 + 3] = ps[3]; }
+        if (j.tx) { tt[a][c4] = pt[0]; tt[a][c4 + 1] = pt[1]; tt[a][c4 + 2] = pt[2]; tt[a][c4 + 3] = pt[3]; }
+    }
+    if (!j.sx && !j.tx) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = r + 16 * i;
+        const size_t idx = ((size_t)(b0 + b) * j.T + t) * j.A + a0 + c4;       // transposed pack [B][T][A]
+        if (j.sx) { const elem4 o = {ts[c4][b], ts[c4 + 1][b], ts[c4 + 2][b], ts[c4 + 3][b]}; *(elem4*)(j.sx + idx) = o; }
+        if (j.tx) { const elem4 o = {tt[c4][b], tt[c4 + 1][b], tt[c4 + 2][b], tt[c4 + 3][b]}; *(elem4*)(j.tx + idx) = o; }
+    }
+}
 }  // namespace
 
 int opt_chunk() { return CHUNK; }
+size_t opt_tail_job_bytes() { return sizeof(TailJob); }
+// host-side filler of one table entry (net.hip builds the table: it knows the pack offsets)
+void opt_tail_job_fill(void* dst, float* p, const float* g, float* m, float* v, float* t, void* sd, void* td, void* sx, void* tx, int A, int T, int B,
+                       int adam, long long n) {
+    TailJob j{p, g, m, v, t, (elem_t*)sd, (elem_t*)td, (elem_t*)sx, (elem_t*)tx, A, T, B, adam, n};
+    *(TailJob*)dst = j;
+}
+int opt_tail(hipStream_t s, const void* d_jobs, const int* blk_job, const int* blk_sub, int nblocks, float lr, float beta1, float beta2, float eps,
+             float wd, int step, float gscale, float* dev_state, float alpha, float oma, int do_adam) {
+    if (nblocks <= 0) return UDAPOSE_OK;
+    double bc1 = 1.0, bc2 = 1.0;
+    if (dev_state) { if (do_adam) hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(1), 0, s, dev_state, beta1, beta2); }
+    else { bc1 = 1.0 - pow((double)beta1, (double)step); bc2 = 1.0 - pow((double)beta2, (double)step); }
+    TailHyper h{lr, beta1, beta2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, alpha, oma, do_adam};
+    hipLaunchKernelGGL(opt_tail_k, dim3(nblocks), dim3(TPB), 0, s, (const TailJob*)d_jobs, blk_job, blk_sub, h, dev_state);
+    return udapose_check_launch();
+}
 int opt_grad_check(hipStream_t s, const long long* g, const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks,
                    float* dev_state) {
     if (!dev_state) return UDAPOSE_ERR_ARG;

@@ -130,10 +130,8 @@ class MeanTeacherTrainer:
         # data parallel: cut the backward after layer3 and all-reduce the finished 94 % of the gradient under the rest of it
         # (None: whenever a process group is active and the network has the layer3 boundary)
         self.overlap_allreduce = None
-        # The source-domain loss needs nothing from the teacher / target branches (train_human.py:425): its backward can start
-        # as soon as student(x_s) is done, beside the other two branches' forwards, instead of after the join.  Same sums
-        # (loss_all.backward() = loss_s.backward() + lambda_c * loss_c.backward()), another interleaving of the three streams.
-        self.early_source_backward = False
+        self.fuse_tail = True               # Adam + EMA + weight packs in one sweep (optim.FusedAdam.fused_tail_step)
+        self.fused_last = False
 
     # ------------------------------------------------------------------ train_human.py:262-302
     def pretrain_step(self, x_s, label_s, weight_s, x_t=None):
@@ -210,10 +208,6 @@ class MeanTeacherTrainer:
                 y_t_stu = student.forward_deferred_bn(x_t_stu)     # separate forwards: separate BN statistics per domain
                 y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
             y_s = student(x_s)
-            loss_s_early = None
-            if self.early_source_backward and torch.is_grad_enabled() and not self._overlap():
-                loss_s_early = self.criterion(y_s, label_s, weight_s)
-                self.stu_optimizer.scale_loss(loss_s_early).backward()      # on `main`, while the other branches still run forward
             main.wait_stream(s_stu)
             student.apply_deferred_bn()
             for t in (y_t_stu, y_t_stu_recon):
@@ -232,8 +226,7 @@ class MeanTeacherTrainer:
         with torch.no_grad():
             activates = mt.heatmap_activations(y_t_tea_recon)    # BEFORE rectify (train_human.py:427)
         return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
-                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu,
-                "loss_s": (loss_s_early if not occl else None)}
+                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu}
 
     def _overlap(self):
         on = self.overlap_allreduce
@@ -271,14 +264,13 @@ class MeanTeacherTrainer:
         main, s_stu = st["main"], st["s_stu"]
         overlap = self._overlap()
         student.split_backward = overlap
-        early = st.get("loss_s") is not None
-        loss_s = st["loss_s"] if early else self.criterion(st["y_s"], st["label_s"], st["weight_s"])
+        loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
             tea_mask, _, _ = mt.confidence_mask(st["y_t_tea_recon"], self.mask_ratio, None, gathered_activates, st["activates"])
             y_t_tea_rect = mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
         loss_c = self.con_criterion(st["y_t_stu_recon"], y_t_tea_rect, tea_mask=tea_mask)
-        loss_all = loss_s.detach() + self.lambda_c * loss_c if early else loss_s + self.lambda_c * loss_c
+        loss_all = loss_s + self.lambda_c * loss_c
         self.stu_optimizer.scale_loss(loss_all).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
@@ -296,8 +288,12 @@ class MeanTeacherTrainer:
         return self._loss_backward_part(st, gather_activates(st["activates"]))
 
     def _update(self):
-        self.stu_optimizer.step()
-        self.tea_optimizer.step()           # EMA after the optimizer step (train_human.py:437-438)
+        # Adam, the EMA and the next forwards' weight packs of both networks in ONE sweep when the layout allows ...
+        fuse = self.fuse_tail and hasattr(self.stu_optimizer, "fused_tail_step")
+        self.fused_last = bool(fuse and self.stu_optimizer.fused_tail_step(self.student, self.teacher, self.tea_optimizer))
+        if not self.fused_last:
+            self.stu_optimizer.step()
+            self.tea_optimizer.step()       # EMA after the optimizer step (train_human.py:437-438)
 
 
 def validate(batches, model, criterion=None):
@@ -416,6 +412,11 @@ class GraphedTrainStep:
         for m in (trainer.student, trainer.teacher):
             m._capture_token = None
             m.weights_changed()
+        self._fused_tail = bool(trainer.fused_last)
+        self._maintained = [(trainer.student, trainer.student._last_hd, True), (trainer.teacher, trainer.teacher._last_hd, False)]
+        if self._fused_tail:
+            for m, hd, bwd in self._maintained:
+                m.packs_refreshed(hd, bwd)
         torch.cuda.synchronize()
 
     def _frozen_hyper(self):
@@ -465,6 +466,14 @@ class GraphedTrainStep:
             changed = [a[0] for a, b in zip(self._frozen_hyper(), self._frozen) if a != b]
             raise RuntimeError(f"GraphedTrainStep: {changed} changed after capture; these are baked into the captured launches - "
                                "build a new GraphedTrainStep (lr and grad_scale may change freely)")
+        if self._fused_tail:
+            # the captured step relies on the packs its own previous update left: if anything else touched the weights since
+            # (an eager optimizer, load_state_dict), re-pack eagerly first
+            for m, hd, bwd in self._maintained:
+                if hd.wpack_version is None or hd.wpack_version[0] != m.version_key():
+                    hd.wpack_version = None
+                    with torch.enable_grad() if bwd else torch.no_grad():
+                        m.prepare(self.static["x_s"])
         self.g_fb.replay()
         if self.split:
             g = gather_activates(self.fwd_state["activates"])
@@ -482,4 +491,7 @@ class GraphedTrainStep:
         # batch sizes, validate(), fp32 mode) must re-pack its bf16 weights before its next forward
         self.t.student.weights_changed()
         self.t.teacher.weights_changed()
+        if self._fused_tail:
+            for m, hd, bwd in self._maintained:          # ... whose own packs the captured update has just rewritten
+                m.packs_refreshed(hd, bwd)
         return self.out

@@ -229,6 +229,15 @@ class PoseResNet(nn.Module):
         hipGraph): every plan re-packs its bf16 weights before its next forward."""
         self._wepoch += 1
 
+    def version_key(self):
+        """What the weight packs of a plan are valid for: the weights epoch and the parameters' version counters."""
+        return (self._wepoch, sum(p._version for p in self.parameters()))
+
+    def packs_refreshed(self, hd, with_bwd):
+        """A kernel outside _pack (the fused optimizer tail) has just rewritten hd's packs from the current parameters."""
+        hd.wpack_version = (self.version_key(), bool(with_bwd))
+        hd.maintained = True
+
     def _bind(self, hd, pa, ba):
         """Build the plan's device tables for the current parameter / buffer pointers (allocates: never inside a capture; the
         compute calls themselves never allocate and fail with 'not prepared' otherwise)."""
@@ -248,6 +257,10 @@ class PoseResNet(nn.Module):
             same = tok is not None and cap_tok is tok
             if same and (cap_bwd or not need_bwd):
                 return
+            if tok is not None and getattr(hd, "maintained", False) and hd.wpack_version in ((version, need_bwd), (version, True)):
+                # the captured step ends with the fused optimizer tail, which rewrites this plan's packs: they are valid now and
+                # after every replay (GraphedTrainStep.step re-packs eagerly if anything else touched the weights in between)
+                return
             check(hd.L.udapose_net_pack_weights(hd.h, _hip.stream(), pa, ptr(hd.wpack), int(need_bwd)), "net_pack_weights")
             hd._cap = (tok, bool(need_bwd) or (same and cap_bwd))
             hd.wpack_version = None       # what a replay leaves in the pack is unknown to the host-side cache
@@ -262,6 +275,7 @@ class PoseResNet(nn.Module):
             x = x.float()
         x = x.contiguous()
         hd = self._handle(x)
+        self._last_hd = hd            # the plan of the most recent forward (the fused optimizer tail keeps ITS packs fresh)
         if save and self.precision == 'fp32':
             raise RuntimeError("precision='fp32' is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
         pa, ba, params = self._pointers()

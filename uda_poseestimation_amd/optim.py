@@ -171,6 +171,63 @@ class FusedAdam(_FusedBase):
         return loss
 
 
+    # ------------------------------------------------------------------ fused tail: Adam + EMA + weight packs in one sweep
+    def fused_tail_step(self, student, teacher, ema):
+        """One launch for torch.optim.Adam.step on the student, OldWeightEMA.step into the teacher and the weight packs of the
+        two executor plans their last forwards used (udapose_net_fused_update).  Returns False - nothing done - when the
+        layout is not the one the kernel serves (then step() and ema.step() apply)."""
+        import ctypes as C
+        if len(self.param_groups) != 1:
+            return False
+        group = self.param_groups[0]
+        ps = list(student.parameters())
+        hd_s, hd_t = getattr(student, "_last_hd", None), getattr(teacher, "_last_hd", None)
+        if hd_s is None or hd_t is None or hd_s.L is not hd_t.L or student.precision == "fp32" or teacher.precision != student.precision:
+            return False
+        if len(group["params"]) != len(ps) or any(a is not b for a, b in zip(group["params"], ps)):
+            return False
+        if len(ema.source_params) != len(ps) or any(a is not b for a, b in zip(ema.source_params, ps)):
+            return False
+        got = self._gather(0, group)
+        if got is None:
+            return False
+        with_grad, tab = got
+        ent = self._dev_state(0, group, ps[0].device)
+        tps = ema.target_params
+        key = (ps[0].data_ptr(), tps[0].data_ptr(), with_grad[0].grad.data_ptr(), self.state[with_grad[0]]["exp_avg"].data_ptr(),
+               hd_s.wpack.data_ptr(), hd_t.wpack.data_ptr(), len(with_grad))
+        cache = getattr(self, "_tail", None)
+        if cache is None or cache[0] != key:
+            n = len(ps)
+            arr = lambda vals: (C.c_void_p * n)(*vals)
+            st = [self.state[p] if p.grad is not None else None for p in ps]
+            cache = (key, arr([p.data_ptr() for p in ps]), arr([p.grad.data_ptr() if p.grad is not None else None for p in ps]),
+                     arr([s_["exp_avg"].data_ptr() if s_ else None for s_ in st]), arr([s_["exp_avg_sq"].data_ptr() if s_ else None for s_ in st]),
+                     arr([p.data_ptr() for p in tps]))
+            rc = hd_s.L.udapose_net_bind_update(hd_s.h, hd_t.h, cache[1], cache[2], cache[3], cache[4], cache[5], ptr(hd_s.wpack), ptr(hd_t.wpack))
+            if rc == -3:        # unsupported layout (unaligned tensors, channel counts that are not multiples of 64)
+                self._tail = None
+                return False
+            check(rc, "net_bind_update")
+            self._tail = cache
+        _, pa_s, ga, ma, va, pa_t = cache
+        group["step"] = group.get("step", 0) + 1
+        b1, b2 = group["betas"]
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        self._pre_sweep(tab, ent)
+        check(hd_s.L.udapose_net_fused_update(hd_s.h, hd_t.h, _hip.stream(), pa_s, ga, ma, pa_t, ptr(hd_s.wpack), ptr(hd_t.wpack), float(group["lr"]),
+                                              float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(group["step"]),
+                                              float(group.get("grad_scale", 1.0)), ptr(ent[0]), float(ema.alpha), float(1.0 - ema.alpha), 1),
+              "net_fused_update")
+        self._post_sweep(ent)
+        _bump_versions(ps)
+        _bump_versions(tps)
+        student.packs_refreshed(hd_s, True)
+        teacher.packs_refreshed(hd_t, False)
+        return True
+
+
 class FusedSGD(_FusedBase):
     _state_names = ("momentum_buffer",)
 
