@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
     ap.add_argument("--policy", action="append", default=[], metavar="FIELD=INT", help="tuning: override one field of the dispatch policy "
                     "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
+    ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
@@ -242,6 +243,8 @@ def main():
         args.eager = True
     trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
                                  heatmap_size=S // 4, precision=args.dtype, **extra)
+    if args.no_fuse_tail:
+        trainer.fuse_tail = False
     b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=rank)   # one shard per rank
     g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 
