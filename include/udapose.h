@@ -282,6 +282,23 @@ int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C
 /* ---------------------------------------------------------------- per-launch timing of the MFMA kernels (bench.py roofline)
  * HIP events are recorded on the launch stream around every convolution launch between begin and end.
  * h_out9 (host): for kind in (fprop, dgrad, wgrad): launches, total milliseconds, total algorithmic FLOPs. */
+/* ---------------------------------------------------------------- device-side data pipeline of the target views (the work
+ * of the reference's DataLoader workers for the `_mt` datasets, lib/datasets/human36m_mt.py:76-161): images are uint8 NHWC
+ * [N][H][W][3] as PIL arrays are; results are bit-exact with PIL's own arithmetic.
+ * aug_affine_u8: torchvision F.affine on a PIL image = Image.transform(AFFINE, NEAREST) (lib/transforms/keypoint_detection.py:138):
+ *   coef [N][6] int64 = PIL's 16.16 fixed-point coefficients (FIX(a0), FIX(a1), FIX(a2 + a0/2 + a1/2), FIX(a3), FIX(a4),
+ *   FIX(a5 + a3/2 + a4/2)) of the inverse affine matrix (a0..a5), prepared on the host in double.
+ * aug_color_op: one PIL.ImageEnhance step per image, in place (ColorJitter, train_human.py:68): op[n] 0 none, 1 brightness,
+ *   2 contrast, 3 saturation; factor[n]; mean_scratch [N] int (the contrast step's rounded L mean).
+ * aug_to_tensor: ToTensor + Normalize -> NCHW fp32.
+ * gaussian_labels: generate_target (lib/datasets/util.py:12-70): kp [R][2] double pixels, vis [R] -> target [R][Hh][Wh],
+ *   weight [R]; patch = the (2*rad+1)^2 Gaussian built by the caller as the reference builds it. */
+int udapose_aug_affine_u8(void* stream, const unsigned char* src, unsigned char* dst, const long long* coef, int N, int H, int W);
+int udapose_aug_color_op(void* stream, unsigned char* img, const int* op, const float* factor, int* mean_scratch, int N, int HW);
+int udapose_aug_to_tensor(void* stream, const unsigned char* img, float* out, int N, int HW, const float* mean3, const float* std3);
+int udapose_gaussian_labels(void* stream, const double* kp, const float* vis, float* target, float* weight, int R, int Hh, int Wh,
+                            double stride_x, double stride_y, const float* patch, int rad);
+
 /* measurement: HIP events around every conv launch between begin and end (process-wide recorder, mutex-guarded) */
 void udapose_prof_begin(void);
 int udapose_prof_end(double* h_out9);

@@ -1,0 +1,85 @@
+"""GPU data pipeline of the target views (uda_poseestimation_amd/data_gpu.py, csrc/augment.hip) against the CPU oracle
+(oracle/transforms_ref.py = PIL's own arithmetic + the reference's key-point / label code): warped and colour-jittered
+uint8 images bit-exact, normalised tensors bit-exact, Gaussian label maps bit-exact, aug_param = the inverse augmentation,
+and the collated 8-tuple drives a mean-teacher step (the aug_param contract of SURVEY.md Appendix D)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_views_bit_exact_with_pil_oracle():
+    from oracle import transforms_ref as R
+    from oracle.mean_teacher_ref import generate_target_ref
+    from uda_poseestimation_amd import data_gpu as D
+    rs = np.random.RandomState(0)
+    N, S, K = 6, 128, 16
+    base = rs.randint(0, 256, (N, S, S, 3)).astype(np.uint8)
+    base[1, 40:60, 30:90] = 250; base[2] = (base[2] // 3)            # some structure / a dark image (contrast mean matters)
+    kps = rs.uniform(-10, S + 10, (N, K, 2))                         # some key points outside the image: weight 0
+    pipe = D.TargetViewPipeline(image_size=S, heatmap_size=S // 4, sigma=2, rng=random.Random(3))
+    cfg = D.ViewConfig(rotation=60, color=0.25)
+    params = [cfg.draw_affine(random.Random(10 + i), (S, S)) for i in range(N)]
+    jit = [cfg.draw_jitter(random.Random(20 + i)) for i in range(N)]
+    jit[0] = ([2, 1, 3], [1.25, 0.75, 1.1]); jit[1] = ([3, 2, 1], [0.8, 1.2, 1.25])      # every order position of the contrast step
+    x, kp_t, aug, target, weight = pipe.view(torch.from_numpy(base).cuda(), kps, cfg, params=params, jitter=jit)
+    assert x.shape == (N, 3, S, S) and target.shape == (N, K, S // 4, S // 4) and weight.shape == (N, K, 1)
+    for i in range(N):
+        w_ref, k_ref, aug_ref = R.affine_view_ref(base[i], kps[i], *params[i])
+        j_ref = R.color_jitter_ref(w_ref, *jit[i])
+        t_ref = R.to_tensor_normalize_ref(j_ref, D.IMAGENET_MEAN, D.IMAGENET_STD)
+        assert torch.equal(x[i].cpu(), t_ref), f"view {i}: image differs from PIL"
+        np.testing.assert_allclose(kp_t[i], k_ref, rtol=0, atol=1e-12)
+        assert float(aug[0][i]) == aug_ref[0] and int(aug[1][0][i]) == aug_ref[1][0] and int(aug[1][1][i]) == aug_ref[1][1]
+        assert float(aug[2][0][i]) == aug_ref[2][0] and float(aug[3][i]) == aug_ref[3]
+        lt, lw = generate_target_ref(k_ref, np.ones((K, 1), np.float32), (S // 4, S // 4), 2, (S, S))
+        assert np.array_equal(target[i].cpu().numpy(), lt) and np.array_equal(weight[i].cpu().numpy(), lw)
+    assert (weight == 0).any() and (weight == 1).any()
+    # the separate steps on their own: warp only / jitter only
+    w_only = pipe.warp_images(torch.from_numpy(base).cuda(), params).cpu().numpy()
+    for i in range(N):
+        assert np.array_equal(w_only[i], R.affine_view_ref(base[i], kps[i], *params[i])[0])
+    j_only = pipe.jitter_(torch.from_numpy(base).cuda().clone(), [j[0] for j in jit], [j[1] for j in jit]).cpu().numpy()
+    for i in range(N):
+        assert np.array_equal(j_only[i], R.color_jitter_ref(base[i], *jit[i]))
+
+
+def test_pipeline_batch_feeds_a_training_step():
+    """The collated 8-tuple has the layout the loop reads (train_human.py:330-345, Appendix D) and its aug_param really is
+    the inverse of the image warp: re-warping the labels of the augmented view with aug_param recovers the original labels
+    around every key point that stayed inside the image."""
+    from uda_poseestimation_amd import data_gpu as D, synthetic, warp
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    rs = np.random.RandomState(1)
+    N, S, K = 4, 128, 16
+    base = torch.from_numpy(rs.randint(0, 256, (N, S, S, 3)).astype(np.uint8)).cuda()
+    kps = rs.uniform(30, S - 30, (N, K, 2))
+    pipe = D.TargetViewPipeline(image_size=S, heatmap_size=S // 4, sigma=2, k=1, student=D.ViewConfig(rotation=60), teacher=D.ViewConfig(rotation=60),
+                                rng=random.Random(7))
+    x_t_stu, t_stu, w_stu, meta_stu, x_t_teas, ts_tea, ws_tea, metas_tea = pipe(base, kps)
+    assert x_t_stu.shape == (N, 3, S, S) and len(x_t_teas) == 1 and set(meta_stu) >= {"aug_param_stu", "target_ori", "target_weight_ori"}
+    # inverse property on the label maps
+    recon = warp.recon_heatmaps(t_stu, meta_stu["aug_param_stu"], ratio=4.0)
+    ori = meta_stu["target_ori"]
+    hits = total = 0
+    for n in range(N):
+        for k in range(K):
+            if float(w_stu[n, k]) > 0.5:
+                total += 1
+                py, px = divmod(int(ori[n, k].argmax()), S // 4)
+                qy, qx = divmod(int(recon[n, k].argmax()), S // 4)
+                hits += abs(py - qy) <= 1 and abs(px - qx) <= 1 and float(recon[n, k].max()) > 0.5
+    assert total >= 30 and hits >= 0.9 * total, (hits, total)
+    # ... and the batch drives the step
+    torch.manual_seed(0)
+    stu = pr._pose_resnet("t", K, pr.Bottleneck_default, [1, 1, 1, 1], False, False).cuda()
+    tea = pr._pose_resnet("t", K, pr.Bottleneck_default, [1, 1, 1, 1], False, False).cuda()
+    trainer = MeanTeacherTrainer(stu, tea, image_size=S, heatmap_size=S // 4)
+    src = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=2)
+    out = trainer.train_step(src["x_s"].cuda(), src["label_s"].cuda(), src["weight_s"].cuda(), x_t_stu, x_t_teas, meta_stu["aug_param_stu"],
+                             [m["aug_param_tea"] for m in metas_tea])
+    assert torch.isfinite(out["loss_all"]) and float(out["loss_c"]) > 0

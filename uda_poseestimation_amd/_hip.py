@@ -108,6 +108,10 @@ _SIGS = {
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_adain_f32": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_patch_paste": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
+    "udapose_aug_affine_u8": (ci, [vp, vp, vp, vp, ci, ci, ci]),
+    "udapose_aug_color_op": (ci, [vp, vp, vp, vp, vp, ci, ci]),
+    "udapose_aug_to_tensor": (ci, [vp, vp, vp, ci, ci, vp, vp]),
+    "udapose_gaussian_labels": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cd, cd, vp, ci]),
     "udapose_prof_begin": (None, []),
     "udapose_prof_end": (ci, [vp]),
     "udapose_affine_nearest": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci]),

@@ -1,0 +1,144 @@
+// Device-side data pipeline of the mean-teacher target views: what the reference's DataLoader workers
+// do per sample with PIL / torchvision (lib/transforms/keypoint_detection.py:137-167,365-453 RandomAffineRotation -> F.affine
+// on a PIL image, ColorJitter = PIL.ImageEnhance brightness / contrast / saturation in a random order, ToTensor, Normalize;
+// lib/datasets/util.py:12-70 generate_target) for a whole batch on the GPU, bit-exact with PIL's own integer arithmetic:
+//   * Image.transform(AFFINE, NEAREST) steps 16.16 fixed-point source coordinates (libImaging affine_fixed): reproduced with
+//     the same FIX()ed coefficients (computed on the host in double, like PIL) and arithmetic shifts;
+//   * ImageEnhance = Image.blend(degenerate, image, factor): float32  d + f * (v - d), clipped to [0, 255], TRUNCATED to uint8;
+//     degenerate = black (brightness), the rounded mean of the L image (contrast), the L image (saturation);
+//     L = (R*19595 + G*38470 + B*7471 + 0x8000) >> 16.
+// All kernels are byte / float sweeps (HBM-bound, 196 KB per 256x256 image); images are uint8 NHWC as PIL arrays are.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+// dst[n][y][x][:] = src[n][yin][xin][:] with (xin, yin) = ((a2 + x*a0 + y*a1) >> 16, (a5 + x*a3 + y*a4) >> 16), zero outside
+__global__ void aug_affine_u8_k(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, const long long* __restrict__ coef, int H, int W) {
+    const int n = blockIdx.y;
+    const long long* c = coef + (size_t)n * 6;
+    const long long a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3], a4 = c[4], a5 = c[5];
+    const unsigned char* s = src + (size_t)n * H * W * 3;
+    unsigned char* d = dst + (size_t)n * H * W * 3;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < H * W; i += gridDim.x * TPB) {
+        const int y = i / W, x = i - y * W;
+        const long long xin = (a2 + (long long)x * a0 + (long long)y * a1) >> 16;
+        const long long yin = (a5 + (long long)x * a3 + (long long)y * a4) >> 16;
+        unsigned char r = 0, g = 0, b = 0;
+        if (xin >= 0 && xin < W && yin >= 0 && yin < H) {
+            const unsigned char* p = s + ((size_t)yin * W + xin) * 3;
+            r = p[0]; g = p[1]; b = p[2];
+        }
+        d[(size_t)i * 3] = r; d[(size_t)i * 3 + 1] = g; d[(size_t)i * 3 + 2] = b;
+    }
+}
+
+__device__ __forceinline__ int lum(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+// mean[n] = int(sum(L) / HW + 0.5) of image n (ImageStat.Stat(img.convert("L")).mean[0] rounded as ImageEnhance.Contrast does);
+// computed only where this launch's op for the image is "contrast" (op[n] == 2): one block per image
+__global__ void aug_gray_mean_k(const unsigned char* __restrict__ img, const int* __restrict__ op, int HW, int* __restrict__ mean) {
+    __shared__ unsigned long long red[TPB / 64];
+    const int n = blockIdx.x;
+    if (op[n] != 2) return;
+    const unsigned char* p = img + (size_t)n * HW * 3;
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < HW; i += TPB) s += (unsigned long long)lum(p[(size_t)i * 3], p[(size_t)i * 3 + 1], p[(size_t)i * 3 + 2]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < TPB / 64; ++i) t += red[i];
+        // int(t / HW + 0.5) with t / HW in double exactly as ImageStat computes it (sum / count), then truncation
+        mean[n] = (int)((double)t / (double)HW + 0.5);
+    }
+}
+
+__device__ __forceinline__ unsigned char blend1(float d, float v, float f) {
+    const float t = d + f * (v - d);
+    return t <= 0.f ? 0 : (t >= 255.f ? 255 : (unsigned char)t);
+}
+
+// one ImageEnhance step per image, in place: op 0 none, 1 brightness, 2 contrast, 3 saturation (Color)
+__global__ void aug_color_op_k(unsigned char* __restrict__ img, const int* __restrict__ op, const float* __restrict__ factor,
+                               const int* __restrict__ mean, int HW) {
+    const int n = blockIdx.y, o = op[n];
+    if (o == 0) return;
+    const float f = factor[n];
+    const float dm = o == 2 ? (float)mean[n] : 0.f;
+    unsigned char* p = img + (size_t)n * HW * 3;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
+        const int r = p[(size_t)i * 3], g = p[(size_t)i * 3 + 1], b = p[(size_t)i * 3 + 2];
+        const float d = o == 3 ? (float)lum(r, g, b) : dm;
+        p[(size_t)i * 3] = blend1(d, (float)r, f);
+        p[(size_t)i * 3 + 1] = blend1(d, (float)g, f);
+        p[(size_t)i * 3 + 2] = blend1(d, (float)b, f);
+    }
+}
+
+// ToTensor + Normalize: out[n][c][i] = (img[n][i][c] / 255 - mean[c]) / std[c], float32 operations in torch's order
+__global__ void aug_to_tensor_k(const unsigned char* __restrict__ img, float* __restrict__ out, int HW, const float* __restrict__ mean3,
+                                const float* __restrict__ std3) {
+    const int n = blockIdx.y;
+    const unsigned char* p = img + (size_t)n * HW * 3;
+    float* o = out + (size_t)n * 3 * HW;
+    const float m0 = mean3[0], m1 = mean3[1], m2 = mean3[2], s0 = std3[0], s1 = std3[1], s2 = std3[2];
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
+        o[i] = ((float)p[(size_t)i * 3] / 255.f - m0) / s0;
+        o[HW + i] = ((float)p[(size_t)i * 3 + 1] / 255.f - m1) / s1;
+        o[2 * HW + i] = ((float)p[(size_t)i * 3 + 2] / 255.f - m2) / s2;
+    }
+}
+
+// generate_target (lib/datasets/util.py:12-70): one block per (sample, joint) row; kp [R][2] double (x, y) in image pixels,
+// vis [R]; centre mu = int(kp / stride + 0.5) (truncation, like Python's int()); weight = vis, 0 when the centre is outside the
+// map; the (2*rad+1)^2 patch (built on the host exactly as the reference builds it) is copied where weight > 0.5.
+__global__ void gaussian_labels_k(const double* __restrict__ kp, const float* __restrict__ vis, float* __restrict__ target, float* __restrict__ weight,
+                                  int Hh, int Wh, double stride_x, double stride_y, const float* __restrict__ patch, int rad) {
+    const size_t r = blockIdx.x;
+    const int mx = (int)(kp[r * 2] / stride_x + 0.5), my = (int)(kp[r * 2 + 1] / stride_y + 0.5);
+    float w = vis[r];
+    const bool outside = mx >= Wh || my >= Hh || mx < 0 || my < 0;
+    if (outside) w = 0.f;
+    if (threadIdx.x == 0) weight[r] = w;
+    const bool draw = !outside && w > 0.5f;
+    const int size = 2 * rad + 1;
+    float* t = target + r * (size_t)Hh * Wh;
+    for (int i = threadIdx.x; i < Hh * Wh; i += TPB) {
+        const int y = i / Wh, x = i - y * Wh;
+        const int gx = x - (mx - rad), gy = y - (my - rad);
+        t[i] = (draw && gx >= 0 && gx < size && gy >= 0 && gy < size) ? patch[gy * size + gx] : 0.f;
+    }
+}
+}  // namespace
+
+int aug_affine_u8(hipStream_t s, const unsigned char* src, unsigned char* dst, const long long* coef, int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return UDAPOSE_ERR_ARG;
+    int gx = (H * W + TPB - 1) / TPB;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(aug_affine_u8_k, dim3(gx, N), dim3(TPB), 0, s, src, dst, coef, H, W);
+    return udapose_check_launch();
+}
+int aug_color_op(hipStream_t s, unsigned char* img, const int* op, const float* factor, int* mean_scratch, int N, int HW) {
+    if (N <= 0 || HW <= 0) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(aug_gray_mean_k, dim3(N), dim3(TPB), 0, s, img, op, HW, mean_scratch);
+    int gx = (HW + TPB - 1) / TPB;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(aug_color_op_k, dim3(gx, N), dim3(TPB), 0, s, img, op, factor, mean_scratch, HW);
+    return udapose_check_launch();
+}
+int aug_to_tensor(hipStream_t s, const unsigned char* img, float* out, int N, int HW, const float* mean3, const float* std3) {
+    if (N <= 0 || HW <= 0) return UDAPOSE_ERR_ARG;
+    int gx = (HW + TPB - 1) / TPB;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(aug_to_tensor_k, dim3(gx, N), dim3(TPB), 0, s, img, out, HW, mean3, std3);
+    return udapose_check_launch();
+}
+int aug_gaussian_labels(hipStream_t s, const double* kp, const float* vis, float* target, float* weight, int R, int Hh, int Wh, double stride_x,
+                        double stride_y, const float* patch, int rad) {
+    if (R <= 0 || Hh <= 0 || Wh <= 0 || rad < 0 || !patch) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(gaussian_labels_k, dim3(R), dim3(TPB), 0, s, kp, vis, target, weight, Hh, Wh, stride_x, stride_y, patch, rad);
+    return udapose_check_launch();
+}

@@ -39,6 +39,10 @@ int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, c
 int opt_grad_check(hipStream_t, const long long*, const long long*, const int*, const long long*, int, float*);
 int opt_scaler_update(hipStream_t, float*, float, float, int);
 int adain_launch(hipStream_t, const elem_t*, const elem_t*, elem_t*, int, int, int, int, float, float, float*);
+int aug_affine_u8(hipStream_t, const unsigned char*, unsigned char*, const long long*, int, int, int);
+int aug_color_op(hipStream_t, unsigned char*, const int*, const float*, int*, int, int);
+int aug_to_tensor(hipStream_t, const unsigned char*, float*, int, int, const float*, const float*);
+int aug_gaussian_labels(hipStream_t, const double*, const float*, float*, float*, int, int, int, double, double, const float*, int);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
 int net_apply_running(void*, hipStream_t, const void*, void* const*, float);
@@ -322,6 +326,23 @@ int udapose_affine_nearest(void* stream, const float* src, float* dst, const flo
     return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);
 }
 
+int udapose_aug_affine_u8(void* stream, const unsigned char* src, unsigned char* dst, const long long* coef, int N, int H, int W) {
+    if (!src || !dst || !coef) return UDAPOSE_ERR_ARG;
+    return aug_affine_u8(S(stream), src, dst, coef, N, H, W);
+}
+int udapose_aug_color_op(void* stream, unsigned char* img, const int* op, const float* factor, int* mean_scratch, int N, int HW) {
+    if (!img || !op || !factor || !mean_scratch) return UDAPOSE_ERR_ARG;
+    return aug_color_op(S(stream), img, op, factor, mean_scratch, N, HW);
+}
+int udapose_aug_to_tensor(void* stream, const unsigned char* img, float* out, int N, int HW, const float* mean3, const float* std3) {
+    if (!img || !out || !mean3 || !std3) return UDAPOSE_ERR_ARG;
+    return aug_to_tensor(S(stream), img, out, N, HW, mean3, std3);
+}
+int udapose_gaussian_labels(void* stream, const double* kp, const float* vis, float* target, float* weight, int R, int Hh, int Wh,
+                            double stride_x, double stride_y, const float* patch, int rad) {
+    if (!kp || !vis || !target || !weight) return UDAPOSE_ERR_ARG;
+    return aug_gaussian_labels(S(stream), kp, vis, target, weight, R, Hh, Wh, stride_x, stride_y, patch, rad);
+}
 void udapose_prof_begin(void) { prof_begin(); }
 int udapose_prof_end(double* h_out9) { return prof_end(h_out9); }
 

@@ -1,0 +1,216 @@
+"""GPU data pipeline of the mean-teacher target views.
+
+The reference feeds its loop from DataLoader workers (`--workers 1` by default, train_human.py:591) that run, per sample and
+per view, PIL / torchvision transforms on the host (train_human.py:63-78, lib/datasets/human36m_mt.py:76-161):
+
+    base crop (RandomResizedCrop, host)                                       -> image [H,W,3] uint8, keypoint2d [K,2]
+    student view:  RandomAffineRotation -> ColorJitter -> GaussianBlur(high=0) -> ToTensor -> Normalize, generate_target
+    teacher views: the same with the teacher's ranges, k times
+
+At ~1900 img/s that loader cannot keep up.  Here everything after the base crop runs on the device for the whole batch:
+the affine warp, the colour jitter, the tensor conversion and normalisation, and the Gaussian label maps are HIP kernels
+(csrc/augment.hip) that reproduce PIL's integer arithmetic bit for bit; the random parameters (a few floats per sample) and
+the key-point algebra (K x 2 per sample) are drawn / computed on the host exactly as lib/transforms/keypoint_detection.py
+does, including the `aug_param` tuple that the loop consumes (inverse augmentation, :139).  The result has the collated
+8-tuple layout of Appendix D / `default_collate`, ready for MeanTeacherTrainer.train_step or GraphedTrainStep.prefetch.
+
+GaussianBlur is the identity with the reference's default `--blur_* 0` (radius U(0, 0)); a non-zero radius is not implemented.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import check, lib, ptr
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def inverse_affine_matrix_pil(center, angle, translate, scale, shear):
+    """torchvision `_get_inverse_affine_matrix` as `F.affine` calls it for a PIL image: centre = (w/2, h/2), angle / shear in
+    degrees, translation in pixels -> the 6 coefficients handed to Image.transform(AFFINE)."""
+    rot = math.radians(angle)
+    sx, sy = math.radians(shear[0]), math.radians(shear[1])
+    cx, cy = center
+    tx, ty = translate
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    m = [d / scale, -b / scale, 0.0, -c / scale, a / scale, 0.0]
+    m[2] += m[0] * (-cx - tx) + m[1] * (-cy - ty)
+    m[5] += m[3] * (-cx - tx) + m[4] * (-cy - ty)
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def pil_fixed_coefficients(m):
+    """PIL's 16.16 fixed-point form of an affine matrix (libImaging affine_fixed): FIX(v) = floor(v * 65536 + 0.5), with the
+    half-pixel offset of the first sample folded into the two constants."""
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    return [fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5)]
+
+
+def transform_keypoints(kp, angle, shear_x, shear_y, trans_x, trans_y, scale, width, height):
+    """The key-point side of `affine` (lib/transforms/keypoint_detection.py:141-165): rotate / shear / scale about the image
+    centre, then translate."""
+    ang, sx, sy = np.deg2rad(angle), np.deg2rad(shear_x), np.deg2rad(shear_y)
+    a = np.cos(ang - sy) / np.cos(sy)
+    b = (-np.cos(ang - sy) * np.tan(sx) / np.cos(sy) - np.sin(ang))
+    c = np.sin(ang - sy) / np.cos(sy)
+    d = (-np.sin(ang - sy) * np.tan(sx) / np.cos(sy) + np.cos(ang))
+    rot = np.array([[scale * a, scale * b], [scale * c, scale * d]])
+    kp = np.copy(kp).astype(np.float64)
+    kp[:, 0] -= width / 2
+    kp[:, 1] -= height / 2
+    kp = np.matmul(rot, kp.T).T
+    kp[:, 0] += width / 2 + trans_x
+    kp[:, 1] += height / 2 + trans_y
+    return kp
+
+
+class ViewConfig:
+    """Ranges of one view's augmentation = the reference's `--rotation_* --shear_* --translate_* --scale_* --color_*` flags
+    (train_human.py:535-557)."""
+
+    def __init__(self, rotation=180, shear=(-30, 30), translate=(0.05, 0.05), scale=(0.6, 1.3), color=0.25):
+        self.degrees = (-rotation, rotation) if isinstance(rotation, (int, float)) else tuple(rotation)
+        self.shear = (-shear, shear) if isinstance(shear, (int, float)) else tuple(shear)
+        self.translate = (translate, translate) if isinstance(translate, (int, float)) else tuple(translate)
+        self.scale = (scale, scale) if isinstance(scale, (int, float)) else tuple(scale)
+        self.color = float(color)
+
+    def draw_affine(self, rng, img_size):
+        """RandomAffineRotation.get_params (lib/transforms/keypoint_detection.py:396-412), same draws in the same order from
+        `rng` (the reference uses the global `random` module)."""
+        angle = rng.uniform(self.degrees[0], self.degrees[1])
+        shear_x, shear_y = rng.uniform(self.shear[0], self.shear[1]), 0.0
+        if len(self.shear) == 4:
+            shear_y = rng.uniform(self.shear[2], self.shear[3])
+        max_dx, max_dy = float(self.translate[0] * img_size[0]), float(self.translate[1] * img_size[1])
+        trans_x = int(round(rng.uniform(-max_dx, max_dx)))
+        trans_y = int(round(rng.uniform(-max_dy, max_dy)))
+        scale = rng.uniform(self.scale[0], self.scale[1])
+        return angle, shear_x, shear_y, trans_x, trans_y, scale
+
+    def draw_jitter(self, rng):
+        """ColorJitter(brightness=c, contrast=c, saturation=c): a random order of the three steps and one factor U(1-c, 1+c)
+        each.  (torchvision draws these from torch's RNG in a version-dependent way; any order / factors are valid samples of
+        the same distribution.)  -> ([op codes], [factors]) with op 1 brightness, 2 contrast, 3 saturation."""
+        ops = [1, 2, 3]
+        rng.shuffle(ops)
+        c = self.color
+        return ops, [rng.uniform(max(0.0, 1 - c), 1 + c) for _ in ops]
+
+
+class TargetViewPipeline:
+    """Batched device pipeline for the `_mt` datasets' student / teacher views."""
+
+    def __init__(self, image_size=256, heatmap_size=64, sigma=2, k=1, student=None, teacher=None, mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                 rng=None):
+        self.image_size, self.heatmap_size, self.sigma, self.k = int(image_size), int(heatmap_size), sigma, int(k)
+        self.stu, self.tea = student or ViewConfig(), teacher or ViewConfig()
+        self.mean, self.std = tuple(mean), tuple(std)
+        self.rng = rng if rng is not None else random
+        self._dev = {}
+
+    # ------------------------------------------------------------------ device constants
+    def _consts(self, device):
+        c = self._dev.get(device)
+        if c is None:
+            tmp = self.sigma * 3
+            size = 2 * tmp + 1
+            if float(size) != int(size):
+                raise NotImplementedError("label patch needs an integer 3*sigma")
+            x = np.arange(0, size, 1, np.float32)
+            y = x[:, np.newaxis]
+            x0 = y0 = size // 2
+            g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * self.sigma ** 2)).astype(np.float32)      # util.py:48-53
+            c = dict(mean=torch.tensor(self.mean, dtype=torch.float32, device=device), std=torch.tensor(self.std, dtype=torch.float32, device=device),
+                     patch=torch.from_numpy(np.ascontiguousarray(g)).to(device), rad=int(tmp))
+            self._dev[device] = c
+        return c
+
+    # ------------------------------------------------------------------ building blocks (each = one kernel family)
+    def warp_images(self, base_u8, params):
+        """F.affine on the whole batch: base_u8 [N,H,W,3] uint8 CUDA, params = list of (angle, shear_x, shear_y, tx, ty, scale)."""
+        _hip.require_cuda(base_u8)
+        N, H, W, C3 = base_u8.shape
+        assert C3 == 3 and base_u8.dtype == torch.uint8 and base_u8.is_contiguous()
+        coef = [pil_fixed_coefficients(inverse_affine_matrix_pil((W * 0.5, H * 0.5), a, (tx, ty), sc, (shx, shy)))
+                for (a, shx, shy, tx, ty, sc) in params]
+        cdev = torch.tensor(coef, dtype=torch.int64).to(base_u8.device, non_blocking=True)
+        out = torch.empty_like(base_u8)
+        check(lib().udapose_aug_affine_u8(_hip.stream(), ptr(base_u8), ptr(out), ptr(cdev), N, H, W), "aug_affine_u8")
+        return out
+
+    def jitter_(self, img_u8, ops, factors):
+        """ColorJitter in place: ops / factors = per-sample lists of three op codes / factors (applied in list order)."""
+        N, H, W, _ = img_u8.shape
+        dev = img_u8.device
+        op_t = torch.tensor(ops, dtype=torch.int32).t().contiguous().to(dev, non_blocking=True)          # [3][N]
+        f_t = torch.tensor(factors, dtype=torch.float32).t().contiguous().to(dev, non_blocking=True)
+        scratch = torch.empty(N, dtype=torch.int32, device=dev)
+        for i in range(op_t.shape[0]):
+            check(lib().udapose_aug_color_op(_hip.stream(), ptr(img_u8), ptr(op_t[i]), ptr(f_t[i]), ptr(scratch), N, H * W), "aug_color_op")
+        return img_u8
+
+    def to_tensor(self, img_u8):
+        N, H, W, _ = img_u8.shape
+        c = self._consts(img_u8.device)
+        out = torch.empty(N, 3, H, W, dtype=torch.float32, device=img_u8.device)
+        check(lib().udapose_aug_to_tensor(_hip.stream(), ptr(img_u8), ptr(out), N, H * W, ptr(c["mean"]), ptr(c["std"])), "aug_to_tensor")
+        return out
+
+    def labels(self, keypoints, visible, device):
+        """generate_target for [N,K,2] key points (numpy float64, image pixels) -> (target [N,K,Hh,Wh], weight [N,K,1]) on device."""
+        c = self._consts(device)
+        N, K, _ = keypoints.shape
+        kp = torch.from_numpy(np.ascontiguousarray(keypoints, dtype=np.float64)).to(device, non_blocking=True)
+        vis = torch.from_numpy(np.ascontiguousarray(visible, dtype=np.float32).reshape(N * K)).to(device, non_blocking=True)
+        Hh = Wh = self.heatmap_size
+        target = torch.empty(N, K, Hh, Wh, dtype=torch.float32, device=device)
+        weight = torch.empty(N, K, 1, dtype=torch.float32, device=device)
+        stride = self.image_size / self.heatmap_size
+        check(lib().udapose_gaussian_labels(_hip.stream(), ptr(kp), ptr(vis), ptr(target), ptr(weight), N * K, Hh, Wh, float(stride), float(stride),
+                                            ptr(c["patch"]), c["rad"]), "gaussian_labels")
+        return target, weight
+
+    # ------------------------------------------------------------------ one view of the whole batch
+    def view(self, base_u8, keypoints, cfg, params=None, jitter=None):
+        """-> (image [N,3,H,W] fp32 normalised, key points [N,K,2], aug_param collated, target, weight)"""
+        N, H, W, _ = base_u8.shape
+        if params is None:
+            params = [cfg.draw_affine(self.rng, (W, H)) for _ in range(N)]
+        if jitter is None:
+            jitter = [cfg.draw_jitter(self.rng) for _ in range(N)]
+        img = self.warp_images(base_u8, params)
+        self.jitter_(img, [j[0] for j in jitter], [j[1] for j in jitter])
+        x = self.to_tensor(img)
+        kp = np.stack([transform_keypoints(keypoints[i], *params[i], W, H) for i in range(N)])
+        # aug_param = the INVERSE augmentation (keypoint_detection.py:139), collated like default_collate does
+        aug = [torch.tensor([-p[0] for p in params], dtype=torch.float64),
+               [torch.tensor([-p[3] for p in params], dtype=torch.int64), torch.tensor([-p[4] for p in params], dtype=torch.int64)],
+               [torch.tensor([-p[1] for p in params], dtype=torch.float64), torch.tensor([-p[2] for p in params], dtype=torch.float64)],
+               torch.tensor([1.0 / p[5] for p in params], dtype=torch.float64)]
+        vis = np.ones((N, keypoints.shape[1], 1), np.float32)
+        target, weight = self.labels(kp, vis, base_u8.device)
+        return x, kp, aug, target, weight
+
+    def __call__(self, base_u8, keypoints):
+        """The collated 8-tuple of the `_mt` datasets (human36m_mt.py:161): (x_t_stu, target_stu, weight_stu, meta_stu, x_t_teas,
+        targets_tea, weights_tea, metas_tea) with the meta fields the loop reads (train_human.py:330-345)."""
+        keypoints = np.asarray(keypoints, dtype=np.float64)
+        x_s, kp_s, aug_s, t_s, w_s = self.view(base_u8, keypoints, self.stu)
+        vis = np.ones((keypoints.shape[0], keypoints.shape[1], 1), np.float32)
+        t_ori, w_ori = self.labels(keypoints, vis, base_u8.device)
+        meta_stu = {"aug_param_stu": aug_s, "keypoint2d_stu": kp_s, "keypoint2d_ori": keypoints, "target_ori": t_ori, "target_weight_ori": w_ori}
+        xs, ts, ws, metas = [], [], [], []
+        for _ in range(self.k):
+            x_t, kp_t, aug_t, t_t, w_t = self.view(base_u8, keypoints, self.tea)
+            xs.append(x_t); ts.append(t_t); ws.append(w_t)
+            metas.append({"aug_param_tea": aug_t, "keypoint2d_tea": kp_t})
+        return x_s, t_s, w_s, meta_stu, xs, ts, ws, metas
