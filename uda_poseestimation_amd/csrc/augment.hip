@@ -10,6 +10,10 @@
 // All kernels are byte / float sweeps (HBM-bound, 196 KB per 256x256 image); images are uint8 NHWC as PIL arrays are.
 #include "common.h"
 
+// no FMA contraction: PIL's blend rounds the product and the sum separately (d + f * (v - d) in C float); a fused
+// multiply-add lands on the other side of an integer for ~1 % of the bytes and the truncation to uint8 then differs
+#pragma clang fp contract(off)
+
 namespace {
 constexpr int TPB = 256;
 
@@ -57,7 +61,9 @@ __global__ void aug_gray_mean_k(const unsigned char* __restrict__ img, const int
 }
 
 __device__ __forceinline__ unsigned char blend1(float d, float v, float f) {
-    const float t = d + f * (v - d);
+    float prod = f * (v - d);
+    asm volatile("" : "+v"(prod));        // (belt and braces: the product is pinned in a register, no contraction can cross this)
+    const float t = d + prod;
     return t <= 0.f ? 0 : (t >= 255.f ? 255 : (unsigned char)t);
 }
 
