@@ -16,5 +16,9 @@ Pinning status:
     torchvision is a third-party dependency that is absent from the reference tree and from this
     image, version unpinned (API usage brackets it to 0.8-0.12).  These two are restated from the
     published algorithm and validated on analytic cases and on the reference's own
-    ``Upsampling``/``PoseResNet`` wrapper code -> **parity unpinned** at that boundary.
+    ``Upsampling``/``PoseResNet`` wrapper code -> **parity unpinned** at that boundary.  For ``tF.affine`` the direction
+    conventions are additionally pinned against the reference's own key-point algebra and against PIL (forward warp by PIL,
+    inverse by the restated three-warp chain): tests/test_oracle_affine.py.
+  * data-pipeline transforms (``F.affine`` on PIL images, ``ColorJitter``): the oracle IS PIL (Pillow is the reference's own
+    dependency for them and is present in this image): oracle/transforms_ref.py.
 """

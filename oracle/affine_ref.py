@@ -1,7 +1,11 @@
 """torchvision.transforms.functional.affine on tensors (nearest, zero fill), CPU oracle (test-only).
 
 torchvision is NOT in the reference tree nor in this image: restated from the published algorithm of
-torchvision 0.8-0.12, validated on analytic cases only -> parity unpinned.
+torchvision 0.8-0.12.  It cannot be run against torchvision itself (-> still "parity unpinned" at
+that boundary); what the reference's OWN code pins is checked in tests/test_oracle_affine.py: identity / translation /
+180-degree / scale cases, the rotation, shear and translation DIRECTIONS against the reference's key-point algebra
+(lib/transforms/keypoint_detection.py:141-165: content and key points move together), and the loop's three-warp inverse
+(train_human.py:366-368) against a forward warp by PIL, the reference's image backend.
 Call sites it stands in for: train_human.py:366-368, 388-390, 412, 421-423.
 """
 import math
