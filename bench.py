@@ -240,11 +240,13 @@ def main():
         hi = torch.tensor([2.2489, 2.4285, 2.64], device=dev)
         extra = dict(style_net=style, recover=(lo, hi), s2t_freq=1.0, t2s_freq=1.0, s2t_alpha=(0.5, 0.5), t2s_alpha=(0.5, 0.5),
                      rng=np.random.RandomState(0), occlude_rate=0.5, occlude_thresh=0.9, occlude_size=10)
-        args.eager = True
     trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
                                  heatmap_size=S // 4, precision=args.dtype, **extra)
     if args.no_fuse_tail:
         trainer.fuse_tail = False
+    # configs[2] captured: the occlusion decisions are taken on the device (four uniform draws per sample, no read-back);
+    # --eager keeps the reference's host draws (one read-back of the confidences per step)
+    trainer.device_occlusion = bool(args.config2 and not args.eager)
     b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=rank)   # one shard per rank
     g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 
@@ -343,7 +345,7 @@ def main():
                                                     (f", K={K}, {args.dtype} (BASELINE.json configs[4] shape and dtype on one GPU; NOT the metric)"
                                                      if (S, K, args.arch, args.dtype) == (384, 18, "pose_resnet101", "fp16") else f", K={K}, {args.dtype}"))),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
-            "loss": loss, "launch": "eager" if args.eager else (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
+            "loss": loss, "launch": "eager" if args.eager else ("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,

@@ -268,6 +268,10 @@ int udapose_adain(void* stream, const void* content, const void* style, void* ou
 /* the same on fp32 NHWC features (the reference's precision); out may be NULL: statistics only (calc_mean_std) */
 int udapose_adain_f32(void* stream, const float* content, const float* style, float* out, int N, int HWc, int HWs, int C, float eps,
                       float alpha, float* stats_out);
+/* the same with the blend factor read from device memory at run time (one float): a launch captured in a hipGraph then follows
+ * the step's draw of alpha.  is_f32 selects the fp32 form (content / style / out are float*), else the library's element type. */
+int udapose_adain_alpha_dev(void* stream, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps,
+                            const float* alpha_dev, float* stats_out, int is_f32);
 
 /* ---------------------------------------------------------------- batched nearest inverse-affine re-warp
  * (torchvision.transforms.functional.affine x3 per sample, train_human.py:366-368,388-390,412,421-423): NCHW fp32;
@@ -278,6 +282,13 @@ int udapose_affine_nearest(void* stream, const float* src, float* dst, const flo
 /* occlusion paste (train_human.py:399-409): for image i of img[n][C][H][W] (fp32) and boxes[i] = (r0,r1,c0,c1,rs,cs):
  * img[i][:, r0:r1, c0:c1] = img[i][:, rs:rs+(r1-r0), cs:cs+(c1-c0)] (source read completely before the write). */
 int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems);
+/* The occlusion DECISIONS (train_human.py:374-410) on the device, so that the step needs no read-back and can be captured:
+ * conf / flat_idx [N][K] from udapose_heatmap_argmax of the teacher's re-warped heat-maps, u [N][4] uniform [0,1) draws (rate
+ * test, key-point choice, patch row / column origin) -> boxes [N][6] for udapose_patch_paste (zero area when not selected) and
+ * apply [N]; udapose_select_rows then keeps the occluded image for the selected samples only: dst[n] = apply[n] ? a[n] : b[n]. */
+int udapose_occlusion_pick(void* stream, const float* conf, const int* flat_idx, const float* u, int N, int K, int w, double ratio,
+                           int image_size, float rate, float thresh, int occlude_size, int* boxes, unsigned char* apply);
+int udapose_select_rows(void* stream, float* dst, const float* a, const float* b, const unsigned char* flag, int N, size_t row_elems);
 
 /* ---------------------------------------------------------------- per-launch timing of the MFMA kernels (bench.py roofline)
  * HIP events are recorded on the launch stream around every convolution launch between begin and end.

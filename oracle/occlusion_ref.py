@@ -35,3 +35,40 @@ def occlude_ref(x_t_stu, y_t_tea_recon, aug_param_stu, ratio, image_size, occlud
             x_t_stu[_b] = affine_nearest_ref(temp, -a, [-tx / ratio, -ty / ratio], 1.0 / sc, [-sx, -sy])
             chosen.append(_b)
     return x_t_stu, chosen
+
+
+class _UniformDraws:
+    """The rng interface occlude_ref uses, fed from four uniform [0,1) numbers of ONE sample: rand() = u0, choice(c) =
+    c[floor(u1 * len(c))], the two randint(m) calls = floor(u2 * m), floor(u3 * m) (float32 products, clamped to m - 1) - the
+    mapping of the device-side decision kernel (udapose_occlusion_pick), whose distribution is the reference's."""
+
+    def __init__(self, u4):
+        self.u = [np.float32(v) for v in u4]
+        self.n_randint = 0
+
+    def rand(self):
+        return float(self.u[0])
+
+    def _pick(self, u, m):
+        return min(int(u * np.float32(m)), m - 1)
+
+    def choice(self, cands):
+        return cands[self._pick(self.u[1], len(cands))]
+
+    def randint(self, m):
+        self.n_randint += 1
+        return self._pick(self.u[1 + self.n_randint], m)
+
+
+def occlude_from_uniforms_ref(x_t_stu, y_t_tea_recon, aug_param_stu, ratio, image_size, occlude_rate, occlude_thresh, occlude_size, u):
+    """occlude_ref sample by sample with the draws taken from u [B,4] instead of a sequential generator."""
+    angle, (tx, ty), (sx, sy), scale = aug_param_stu
+    out, chosen = x_t_stu.clone(), []
+    for b in range(x_t_stu.shape[0]):
+        ap = ([angle[b]], ([tx[b]], [ty[b]]), ([sx[b]], [sy[b]]), [scale[b]])
+        o, c = occlude_ref(x_t_stu[b:b + 1], y_t_tea_recon[b:b + 1], ap, ratio, image_size, occlude_rate, occlude_thresh, occlude_size,
+                           _UniformDraws(u[b].tolist()))
+        out[b] = o[0]
+        if c:
+            chosen.append(b)
+    return out, chosen

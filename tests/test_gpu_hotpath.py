@@ -337,6 +337,52 @@ def test_occlusion_matches_oracle():
     assert c2 == [] or all(np.random.RandomState(1).rand() <= 0.0 for _ in c2)
 
 
+def test_device_side_occlusion_decisions_match_oracle():
+    """The same occlusion with the decisions taken on the device from four uniform draws per sample (no read-back): the selected
+    samples, boxes and patch origins follow the oracle fed with the same draws; unselected samples come back bit-identical."""
+    from oracle.occlusion_ref import occlude_from_uniforms_ref
+    from uda_poseestimation_amd import synthetic, warp
+    g = torch.Generator().manual_seed(8)
+    B, K, S = 12, 16, 128
+    x = synthetic.images(B, S, 5)
+    recon = torch.rand(B, K, S // 4, S // 4, generator=g) * 0.8
+    for b, k, r, c, v in ((0, 3, 10, 12, 0.95), (0, 7, 2, 30, 0.99), (2, 1, 31, 0, 0.97), (4, 15, 0, 0, 1.5), (5, 9, 20, 20, 0.91),
+                          (7, 0, 16, 16, 0.93), (7, 5, 1, 1, 0.92), (7, 11, 30, 30, 0.96), (9, 2, 8, 25, 0.9), (11, 14, 31, 31, 2.0)):
+        recon[b, k, r, c] = v
+    ap = synthetic.aug_params(B, np.random.RandomState(3))
+    u = torch.from_numpy(np.random.RandomState(5).rand(B, 4).astype(np.float32))
+    u[7, 0] = 0.0; u[7, 1] = 0.999999; u[11, 0] = 0.1; u[11, 2] = 0.999999; u[11, 3] = 0.0     # edge draws: last candidate, last origin
+    ref, chosen_ref = occlude_from_uniforms_ref(x, recon, ap, 4.0, S, 0.7, 0.9, 10, u)
+    fwd = warp.recon_thetas(ap, B, 4.0, "cuda")
+    back = warp.occlusion_back_thetas(ap, B, 4.0, "cuda")
+    out, apply = warp.occlude_keypoints_device(x.cuda(), recon.cuda(), fwd, back, u.cuda(), 4.0, S, 0.7, 0.9, 10)
+    chosen = [int(i) for i in torch.nonzero(apply.cpu()).flatten()]
+    assert chosen == chosen_ref and len(chosen) >= 3 and len(chosen) < B
+    out = out.cpu()
+    untouched = [b for b in range(B) if b not in chosen]
+    assert torch.equal(out[untouched], x[untouched])
+    mism = (out[chosen] != ref[chosen]).float().mean().item()
+    assert mism < 5e-3, mism
+    # ... and identical to the host-decision path when that is fed the same picks (same warps, same paste)
+    from oracle.occlusion_ref import _UniformDraws
+
+    class _Seq:     # the host path draws sequentially over the qualifying samples: serve each sample's four numbers in turn
+        def __init__(self, u, qualifying):
+            self.it = iter(qualifying); self.u = u; self.cur = None
+        def rand(self):
+            self.cur = _UniformDraws(self.u[next(self.it)].tolist()); return self.cur.rand()
+        def choice(self, c):
+            return self.cur.choice(c)
+        def randint(self, m):
+            return self.cur.randint(m)
+    qualifying = [b for b in range(B) if bool((recon[b].amax(dim=(1, 2)) >= 0.9).any())]
+    host, chosen_h = warp.occlude_keypoints(x.cuda(), recon.cuda(), ap, 4.0, S, 0.7, 0.9, 10, _Seq(u, qualifying))
+    assert chosen_h == chosen and torch.equal(host.cpu(), out)
+    # rate <= -1 / no confident key point: nothing selected
+    out0, apply0 = warp.occlude_keypoints_device(x.cuda(), (recon * 0.1).cuda(), fwd, back, u.cuda(), 4.0, S, 0.7, 0.9, 10)
+    assert int(apply0.sum()) == 0 and torch.equal(out0.cpu(), x)
+
+
 def test_style_and_occlusion_step_runs_config2():
     """BASELINE.json configs[2]: the step with AdaIN s2t/t2s style passes (seeded random VGG/decoder) and occlusion."""
     from seeded import fill_style_weights

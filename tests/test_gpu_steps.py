@@ -348,3 +348,81 @@ def test_fused_optimizer_tail_is_bit_identical_to_adam_then_ema_then_pack():
     assert oa.state_dict()["param_groups"][0]["step"] == ob.state_dict()["param_groups"][0]["step"] == 2
     fc = sb.backbone.fc.weight
     assert fc.grad is None and fc not in ob.state
+
+
+def test_config2_step_with_style_and_occlusion_captured_equals_eager_twin():
+    """BASELINE.json configs[2]'s step (AdaIN style transfer both ways with probability 0.5 each, random alpha;
+    adaptive occlusion) captured - style directions as their own graphs with alpha on the device, the occlusion decisions
+    taken on the device - against an eager twin with the same host draws from identical state, over steps whose decisions
+    differ."""
+    from seeded import fill_style_weights
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    from uda_poseestimation_amd.lib.models import Style_net
+    fill_style_weights(Style_net.vgg, 11)
+    fill_style_weights(Style_net.decoder, 12)
+    Style_net.vgg.cuda(); Style_net.decoder.cuda()
+    net = Style_net.Net(torch.nn.Sequential(*list(Style_net.vgg.children())[:31]), Style_net.decoder).cuda()
+    net.compute_losses = False
+    N, K, S = 4, 16, 128
+    lo = torch.tensor([-2.1179, -2.0357, -1.8044]).cuda()
+    hi = torch.tensor([2.2489, 2.4285, 2.64]).cuda()
+    batches = []
+    for s in (41, 42, 43, 44, 45, 46):
+        b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=s)
+        g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+        batches.append((g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"]))
+    base = _tiny(K, seed=8)
+    nets, trs = [], []
+    for _ in range(2):
+        s_, t_ = _tiny(K, seed=8), _tiny(K, seed=8)
+        s_.load_state_dict(base.state_dict())
+        nets.append((s_.cuda(), t_.cuda()))
+        tr = MeanTeacherTrainer(*nets[-1], lr=1e-4, image_size=S, heatmap_size=S // 4, style_net=net, recover=(lo, hi), s2t_freq=0.5,
+                                t2s_freq=0.5, s2t_alpha=(0.0, 1.0), t2s_alpha=(0.0, 1.0), rng=np.random.RandomState(123),
+                                occlude_rate=0.5, occlude_thresh=-1e9, occlude_size=10)     # (threshold below everything: every sample qualifies)
+        tr.device_occlusion = True
+        trs.append(tr)
+    tr_g, tr_e = trs
+    p0 = [p.detach().clone() for p in nets[0][0].parameters()]
+    with pytest.raises(RuntimeError, match="device_occlusion"):
+        tr_g.device_occlusion = False
+        GraphedTrainStep(tr_g, *batches[0], warmup=1)
+    tr_g.device_occlusion = True
+    gs = GraphedTrainStep(tr_g, *batches[0], warmup=1)        # the warm-up step IS step 1 (on batch 0, with step 1's draws)
+    tr_e.train_step(*batches[0])
+    seen = set()
+    probe = np.random.RandomState(123)                         # replay the draws to know which decisions the steps took
+    for i in range(len(batches)):
+        a = probe.rand() < 0.5
+        if a:
+            probe.uniform(0, 1)
+        b_ = probe.rand() < 0.5
+        if b_:
+            probe.uniform(0, 1)
+        probe.rand(N, 4)
+        seen.add((a, b_))
+    assert len(seen) >= 3, seen                                # styled / unstyled in both directions do occur
+    occl = []
+    for bt in batches[1:]:
+        og = gs.step(*bt)
+        occl.append(int(tr_g.occluded.sum()))
+        oe = tr_e.train_step(*bt)
+        assert int(tr_e.occluded.sum()) == occl[-1]
+        assert torch.isfinite(og["loss_all"])
+        assert abs(float(og["loss_all"]) - float(oe["loss_all"])) <= 2e-3 * abs(float(oe["loss_all"]))
+        assert abs(float(og["loss_c"]) - float(oe["loss_c"])) <= 5e-3 * abs(float(oe["loss_c"])) + 1e-7
+    assert 0 < sum(occl) < N * len(occl)                       # some samples occluded, some not
+    num = den = 0.0
+    for pg, pe, q0 in zip(nets[0][0].parameters(), nets[1][0].parameters(), p0):
+        num += float(((pg.detach() - pe.detach()) ** 2).sum())
+        den += float(((pe.detach() - q0) ** 2).sum())
+    rel = (num / max(den, 1e-30)) ** 0.5
+    print(f"configs[2] captured vs eager twin: relative parameter distance {rel:.3e} after {len(batches)} steps")
+    assert rel < 0.2
+    assert rng_state_equal(tr_g.rng, tr_e.rng)                 # both consumed exactly the same host draws
+
+
+def rng_state_equal(a, b):
+    sa, sb = a.get_state(), b.get_state()
+    return sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]

@@ -107,7 +107,10 @@ _SIGS = {
     "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf, vp]),
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_adain_f32": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
+    "udapose_adain_alpha_dev": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, ci]),
     "udapose_patch_paste": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
+    "udapose_occlusion_pick": (ci, [vp, vp, vp, vp, ci, ci, ci, cd, ci, cf, cf, ci, vp, vp]),
+    "udapose_select_rows": (ci, [vp, vp, vp, vp, vp, ci, sz]),
     "udapose_aug_affine_u8": (ci, [vp, vp, vp, vp, ci, ci, ci]),
     "udapose_aug_color_op": (ci, [vp, vp, vp, vp, vp, ci, ci]),
     "udapose_aug_to_tensor": (ci, [vp, vp, vp, ci, ci, vp, vp]),

@@ -57,7 +57,8 @@ __device__ __forceinline__ void unraw(const Raw8<float>& r, float (&o)[8]) {
 
 template <typename T>
 __global__ __launch_bounds__(ATPB) void adain_k(const T* __restrict__ content, const T* __restrict__ style, T* __restrict__ out, int HWc, int HWs,
-                                                int C, float eps, float alpha, float* __restrict__ stats_out) {
+                                                int C, float eps, float alpha, const float* __restrict__ alpha_dev, float* __restrict__ stats_out) {
+    if (alpha_dev) alpha = *alpha_dev;      // (a captured launch reads the step's blend factor from device memory)
     __shared__ float red[ATPB / 64][8][4][8];   // [wave][cg][stat][e]  16 KiB
     __shared__ float coef[64][2];
     const int slabs = C / 64;
@@ -164,14 +165,14 @@ __global__ __launch_bounds__(ATPB) void adain_k(const T* __restrict__ content, c
 }  // namespace
 
 int adain_launch(hipStream_t s, const elem_t* content, const elem_t* style, elem_t* out, int N, int HWc, int HWs, int C, float eps, float alpha,
-                 float* stats_out) {
+                 const float* alpha_dev, float* stats_out) {
     if (C % 64 || HWc < 2 || HWs < 2) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(adain_k<elem_t>, dim3(N * (C / 64)), dim3(ATPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, stats_out);
+    hipLaunchKernelGGL(adain_k<elem_t>, dim3(N * (C / 64)), dim3(ATPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, alpha_dev, stats_out);
     return udapose_check_launch();
 }
 int adain_launch_f32(hipStream_t s, const float* content, const float* style, float* out, int N, int HWc, int HWs, int C, float eps, float alpha,
-                     float* stats_out) {
+                     const float* alpha_dev, float* stats_out) {
     if (C % 64 || HWc < 2 || HWs < 2) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(adain_k<float>, dim3(N * (C / 64)), dim3(ATPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, stats_out);
+    hipLaunchKernelGGL(adain_k<float>, dim3(N * (C / 64)), dim3(ATPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, alpha_dev, stats_out);
     return udapose_check_launch();
 }

@@ -59,7 +59,68 @@ __global__ void patch_paste_k(float* __restrict__ img, const int* __restrict__ b
         base[((size_t)c * H + r0 + r) * W + c0 + q] = buf[i];
     }
 }
+// The occlusion DECISIONS of train_human.py:374-410 on the device, one thread per sample: which samples (any confidence >=
+// thresh and a uniform draw <= rate), which confident key point, the box around it in image pixels (rows from y, columns from
+// x: the reference's index math) and where the replacement patch comes from.  u[n][0..3] are uniform [0,1) draws supplied by
+// the caller: u0 = the rate test, u1 -> np.random.choice among the confident key points, u2 / u3 -> np.random.randint of the
+// patch origin.  (The reference consumes its draws only for qualifying samples, from an unseeded global generator; drawing
+// all four for every sample gives the same distribution without the read-back that made this step un-capturable.)
+// boxes[n] = {r0, r1, c0, c1, rs, cs} (a zero-area box when the sample is not selected), apply[n] = 0 / 1.
+__global__ void occlusion_pick_k(const float* __restrict__ conf, const int* __restrict__ idx, const float* __restrict__ u, int N, int K, int w,
+                                 double ratio, int image_size, float rate, float thresh, int occ, int* __restrict__ boxes,
+                                 unsigned char* __restrict__ apply) {
+    const int n = blockIdx.x * TPB + threadIdx.x;
+    if (n >= N) return;
+    int count = 0;
+    for (int k = 0; k < K; ++k) count += conf[n * K + k] >= thresh;
+    int* b = boxes + n * 6;
+    if (count == 0 || !(u[n * 4] <= rate)) {
+        for (int i = 0; i < 6; ++i) b[i] = 0;
+        apply[n] = 0;
+        return;
+    }
+    int j = (int)(u[n * 4 + 1] * (float)count);
+    if (j > count - 1) j = count - 1;
+    int c = 0;
+    for (int k = 0; k < K; ++k)
+        if (conf[n * K + k] >= thresh) { if (j == 0) { c = k; break; } --j; }
+    const int flat = idx[n * K + c];
+    const int px = (int)((double)(flat % w) * ratio), py = (int)((double)(flat / w) * ratio);      // (pred_position * ratio).astype(int)
+    const int r0 = max(py - occ, 0), r1 = min(py + occ, image_size);
+    const int c0 = max(px - occ, 0), c1 = min(px + occ, image_size);
+    const int mr = image_size - (r1 - r0) + 1, mc = image_size - (c1 - c0) + 1;
+    int rs = (int)(u[n * 4 + 2] * (float)mr), cs = (int)(u[n * 4 + 3] * (float)mc);
+    if (rs > mr - 1) rs = mr - 1;
+    if (cs > mc - 1) cs = mc - 1;
+    b[0] = r0; b[1] = r1; b[2] = c0; b[3] = c1; b[4] = rs; b[5] = cs;
+    apply[n] = 1;
+}
+
+// dst[n] = flag[n] ? a[n] : b[n] over rows of `row` floats (16-byte vectors): only the selected samples take the occluded image
+__global__ void select_rows_k(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, const unsigned char* __restrict__ flag,
+                              size_t row4, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total4; i += (size_t)gridDim.x * TPB) {
+        const size_t n = i / row4;
+        ((f32x4*)dst)[i] = flag[n] ? ((const f32x4*)a)[i] : ((const f32x4*)b)[i];
+    }
+}
 }  // namespace
+
+int occlusion_pick(hipStream_t s, const float* conf, const int* idx, const float* u, int N, int K, int w, double ratio, int image_size, float rate,
+                   float thresh, int occ, int* boxes, unsigned char* apply) {
+    if (N <= 0 || K <= 0 || w <= 0 || occ < 0) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(occlusion_pick_k, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, conf, idx, u, N, K, w, ratio, image_size, rate, thresh, occ, boxes,
+                       apply);
+    return udapose_check_launch();
+}
+int select_rows(hipStream_t s, float* dst, const float* a, const float* b, const unsigned char* flag, int N, size_t row) {
+    if (N <= 0 || row % 4) return UDAPOSE_ERR_ARG;
+    const size_t total4 = (size_t)N * row / 4;
+    size_t blocks = (total4 + TPB - 1) / TPB;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(select_rows_k, dim3((int)blocks), dim3(TPB), 0, s, dst, a, b, flag, row / 4, total4);
+    return udapose_check_launch();
+}
 
 int patch_paste(hipStream_t s, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems) {
     if (n <= 0) return UDAPOSE_OK;

@@ -26,7 +26,7 @@ int hm_sqdiff_bwd(hipStream_t, const float*, const float*, const float*, const u
 int hm_mask_count(hipStream_t, const unsigned char*, size_t, float*);
 int pw_maxpool2x2_ceil_f32(hipStream_t, const float*, float*, int, int, int, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
-int adain_launch_f32(hipStream_t, const float*, const float*, float*, int, int, int, int, float, float, float*);
+int adain_launch_f32(hipStream_t, const float*, const float*, float*, int, int, int, int, float, float, const float*, float*);
 int hm_argmax_rectify(hipStream_t, const float*, int, int, int, float*, int*, float*, float*, const float*, int);
 int hm_kth_mask(hipStream_t, const float*, const float*, int, int, float*, unsigned char*, const float*, int);
 int hm_pck(hipStream_t, const float*, const float*, int, int, float, float, float, float*, float*);
@@ -38,13 +38,15 @@ int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, c
             int, int, float, float*);
 int opt_grad_check(hipStream_t, const long long*, const long long*, const int*, const long long*, int, float*);
 int opt_scaler_update(hipStream_t, float*, float, float, int);
-int adain_launch(hipStream_t, const elem_t*, const elem_t*, elem_t*, int, int, int, int, float, float, float*);
+int adain_launch(hipStream_t, const elem_t*, const elem_t*, elem_t*, int, int, int, int, float, float, const float*, float*);
 int aug_affine_u8(hipStream_t, const unsigned char*, unsigned char*, const long long*, int, int, int);
 int aug_color_op(hipStream_t, unsigned char*, const int*, const float*, int*, int, int);
 int aug_to_tensor(hipStream_t, const unsigned char*, float*, int, int, const float*, const float*);
 int aug_gaussian_labels(hipStream_t, const double*, const float*, float*, float*, int, int, int, double, double, const float*, int);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
+int occlusion_pick(hipStream_t, const float*, const int*, const float*, int, int, int, double, int, float, float, int, int*, unsigned char*);
+int select_rows(hipStream_t, float*, const float*, const float*, const unsigned char*, int, size_t);
 int net_apply_running(void*, hipStream_t, const void*, void* const*, float);
 int pw_axpy(hipStream_t, float*, const float*, size_t);
 void prof_begin();
@@ -312,15 +314,30 @@ int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, flo
     return opt_scaler_update(S(stream), dev_state, growth, backoff, interval);
 }
 int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha, float* stats_out) {
-    return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, stats_out);
+    return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, nullptr, stats_out);
+}
+int udapose_adain_alpha_dev(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, const float* alpha_dev,
+                            float* stats_out, int is_f32) {
+    if (!alpha_dev) return UDAPOSE_ERR_ARG;
+    if (is_f32) return adain_launch_f32(S(stream), (const float*)c, (const float*)s, (float*)out, N, HWc, HWs, C, eps, 1.f, alpha_dev, stats_out);
+    return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, 1.f, alpha_dev, stats_out);
 }
 int udapose_adain_f32(void* stream, const float* c, const float* s, float* out, int N, int HWc, int HWs, int C, float eps, float alpha,
                       float* stats_out) {
-    return adain_launch_f32(S(stream), c, s, out, N, HWc, HWs, C, eps, alpha, stats_out);
+    return adain_launch_f32(S(stream), c, s, out, N, HWc, HWs, C, eps, alpha, nullptr, stats_out);
 }
 
 int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems) {
     return patch_paste(S(stream), img, boxes, n, C, H, W, max_patch_elems);
+}
+int udapose_occlusion_pick(void* stream, const float* conf, const int* flat_idx, const float* u, int N, int K, int w, double ratio, int image_size,
+                           float rate, float thresh, int occlude_size, int* boxes, unsigned char* apply) {
+    if (!conf || !flat_idx || !u || !boxes || !apply) return UDAPOSE_ERR_ARG;
+    return occlusion_pick(S(stream), conf, flat_idx, u, N, K, w, ratio, image_size, rate, thresh, occlude_size, boxes, apply);
+}
+int udapose_select_rows(void* stream, float* dst, const float* a, const float* b, const unsigned char* flag, int N, size_t row_elems) {
+    if (!dst || !a || !b || !flag) return UDAPOSE_ERR_ARG;
+    return select_rows(S(stream), dst, a, b, flag, N, row_elems);
 }
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage, int backward) {
     return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);

@@ -126,7 +126,11 @@ class MeanTeacherTrainer:
         # adaptive key-point occlusion (train_human.py:374-412); rate <= -1 disables it like `--occlude-rate -1`
         self.occlude_rate, self.occlude_thresh, self.occlude_size = occlude_rate, occlude_thresh, occlude_size
         self.image_px = image_px if image_px is not None else image_size
-        self._aug_stu = None
+        # False: the reference's host draws in its order (rand / choice / randint x 2 per qualifying sample, after one read-back
+        # of the confidences).  True: four uniform draws per sample go to the device and udapose_occlusion_pick takes the
+        # decisions there - same distribution, no read-back, capturable (GraphedTrainStep needs it)
+        self.device_occlusion = False
+        self._occl = None                   # ("host", aug_param_stu) | ("device", theta_back [N,1,6], u [N,4])
         # data parallel: cut the backward after layer3 and all-reduce the finished 94 % of the gradient under the rest of it
         # (None: whenever a process group is active and the network has the layer3 boundary)
         self.overlap_allreduce = None
@@ -159,9 +163,15 @@ class MeanTeacherTrainer:
             x_t_teas, aug_params_tea = [x_t_teas], [aug_params_tea]
         n, dev = x_t_stu.shape[0], x_t_stu.device
         theta_stu = warp.recon_thetas(aug_param_stu, n, self.ratio, dev)
-        self._aug_stu = aug_param_stu
         thetas_tea = [warp.recon_thetas(ap, n, self.ratio, dev) for ap in aug_params_tea]
-        out = self._forward_backward(x_s, label_s, weight_s, x_t_stu, list(x_t_teas), theta_stu, thetas_tea)
+        x_s_in, x_t_teas_in = self._style_part(x_s, list(x_t_teas))
+        self._occl = None
+        if self.occlude_rate > -1:
+            if self.device_occlusion:
+                self._occl = ("device", warp.occlusion_back_thetas(aug_param_stu, n, self.ratio, dev), self.draw_occlusion_uniforms(n, dev))
+            else:
+                self._occl = ("host", aug_param_stu)
+        out = self._forward_backward(x_s_in, label_s, weight_s, x_t_stu, x_t_teas_in, theta_stu, thetas_tea)
         self._sync_grads()
         self._update()
         if with_accuracy:
@@ -169,20 +179,37 @@ class MeanTeacherTrainer:
             out["acc_s"], out["cnt_s"] = avg_acc, cnt
         return out
 
+    def draw_style_decisions(self):
+        """The step's host draws for the style pass, in the reference's order (train_human.py:345-358): rand, [uniform], rand,
+        [uniform] -> (alpha_s2t | None, alpha_t2s | None)."""
+        if self.style_net is None:
+            return None, None
+        a_s2t = self.rng.uniform(*self.s2t_alpha) if self.s2t_freq > self.rng.rand() else None
+        a_t2s = self.rng.uniform(*self.t2s_alpha) if self.t2s_freq > self.rng.rand() else None
+        return a_s2t, a_t2s
+
+    def draw_occlusion_uniforms(self, n, device=None):
+        u = torch.from_numpy(np.asarray(self.rng.rand(n, 4), dtype=np.float32))
+        return u.to(device, non_blocking=True) if device is not None else u
+
+    def _style_part(self, x_s, x_t_teas):
+        """Bidirectional style transfer of the step's inputs (train_human.py:345-358), both from the ORIGINAL images."""
+        a_s2t, a_t2s = self.draw_style_decisions()
+        x_s_ori, x_t_teas_ori = x_s, list(x_t_teas)
+        with torch.no_grad():
+            if a_s2t is not None:
+                x_s = self.style_net(x_s_ori, x_t_teas_ori[0], a_s2t, clamp=self.recover)[2]
+            if a_t2s is not None:
+                x_t_teas = [self.style_net(x_t, x_s_ori, a_t2s, clamp=self.recover)[2] for x_t in x_t_teas_ori]
+        return x_s, x_t_teas
+
     def _forward_part(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
-        """All forwards of the step (device-only, no host reads: capturable in a hipGraph)."""
+        """All forwards of the step after the style pass (no host reads unless the occlusion draws on the host: capturable
+        in a hipGraph)."""
         student, teacher = self.student, self.teacher
         student.train()
         teacher.train()                     # the teacher's BN uses batch statistics too (train_human.py:321)
         self.stu_optimizer.zero_grad()
-        x_s_ori, x_t_teas_ori = x_s, list(x_t_teas)
-        with torch.no_grad():
-            if self.style_net is not None and self.s2t_freq > self.rng.rand():
-                a = self.rng.uniform(*self.s2t_alpha)
-                x_s = self.style_net(x_s, x_t_teas_ori[0], a, clamp=self.recover)[2]
-            if self.style_net is not None and self.t2s_freq > self.rng.rand():
-                a = self.rng.uniform(*self.t2s_alpha)
-                x_t_teas = [self.style_net(x_t, x_s_ori, a, clamp=self.recover)[2] for x_t in x_t_teas]
         # Three independent branches run on three HIP streams and meet at the consistency loss: the teacher branch (forward
         # + re-warp), the student's target-domain forward (+ re-warp) and the student's source-domain forward.  Their kernels
         # interleave on the device (measured: two concurrent fwd+bwd passes take 22.3 ms instead of 28.6 ms back to back).
@@ -193,36 +220,44 @@ class MeanTeacherTrainer:
         if self._side is None or self._side[0].device != x_s.device:
             self._side = (torch.cuda.Stream(device=x_s.device), torch.cuda.Stream(device=x_s.device))
         s_tea, s_stu = self._side if self.concurrent else (main, main)
-        occl = self.occlude_rate > -1 and self._aug_stu is not None
+        occl = self._occl if self.occlude_rate > -1 else None
         student.prepare(x_s)                # bf16 weight packs refreshed on `main` before the branches fork
         with torch.no_grad():
             teacher.prepare(x_t_teas[0])
         s_tea.wait_stream(main)
+        s_stu.wait_stream(main)
         with torch.cuda.stream(s_tea), torch.no_grad():
             y_t_teas = [teacher(x_t) for x_t in x_t_teas]
             recons = [warp.warp_chain(y, th) for y, th in zip(y_t_teas, thetas_tea)]
             y_t_tea_recon = recons[0] if len(recons) == 1 else torch.stack(recons).mean(0)
-        if not occl:
-            s_stu.wait_stream(main)
-            with torch.cuda.stream(s_stu):
-                y_t_stu = student.forward_deferred_bn(x_t_stu)     # separate forwards: separate BN statistics per domain
-                y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
+        if occl is not None:
+            # the occlusion needs the teacher's re-warped heat-maps: the source-domain forward is issued first (it runs under
+            # the teacher's), the target-domain branch waits for the teacher
             y_s = student(x_s)
-            main.wait_stream(s_stu)
-            student.apply_deferred_bn()
-            for t in (y_t_stu, y_t_stu_recon):
-                t.record_stream(main)
+            s_stu.wait_stream(s_tea)
+            for t in y_t_teas + recons + [y_t_tea_recon]:
+                t.record_stream(s_stu)
+        with torch.cuda.stream(s_stu):
+            if occl is not None:
+                with torch.no_grad():
+                    if occl[0] == "device":
+                        x_t_stu, self.occluded = warp.occlude_keypoints_device(x_t_stu, y_t_tea_recon, theta_stu, occl[1], occl[2], self.ratio,
+                                                                               self.image_px, self.occlude_rate, self.occlude_thresh,
+                                                                               self.occlude_size)
+                    else:   # (one small D2H of confidences, as in the reference)
+                        x_t_stu, self.occluded = warp.occlude_keypoints(x_t_stu, y_t_tea_recon, occl[1], self.ratio, self.image_px,
+                                                                        self.occlude_rate, self.occlude_thresh, self.occlude_size, self.rng)
+            y_t_stu = student.forward_deferred_bn(x_t_stu)     # separate forwards: separate BN statistics per domain
+            y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
+        if occl is None:
+            y_s = student(x_s)
+        main.wait_stream(s_stu)
+        student.apply_deferred_bn()         # (x_s first, then x_t_stu: the reference's call order, train_human.py:414-417)
+        for t in (y_t_stu, y_t_stu_recon, x_t_stu):
+            t.record_stream(main)
         main.wait_stream(s_tea)
         for t in y_t_teas + recons + [y_t_tea_recon]:
             t.record_stream(main)
-        if occl:
-            # the occlusion needs the teacher's re-warped heat-maps first (one small D2H of confidences, as in the reference)
-            with torch.no_grad():
-                x_t_stu, _ = warp.occlude_keypoints(x_t_stu, y_t_tea_recon, self._aug_stu, self.ratio, self.image_px, self.occlude_rate,
-                                                   self.occlude_thresh, self.occlude_size, self.rng)
-            y_s = student(x_s)
-            y_t_stu = student(x_t_stu)
-            y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
         with torch.no_grad():
             activates = mt.heatmap_activations(y_t_tea_recon)    # BEFORE rectify (train_human.py:427)
         return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
@@ -341,12 +376,18 @@ class GraphedTrainStep:
     all-gather after the first, the all-reduce of the finished gradient suffix launched after the second (it runs on the
     communicator's stream under the third) and the small prefix all-reduce after the third.
     Inputs are copied into static device tensors before each replay; the re-warp matrices are computed on the host from
-    the batch's aug_param tuples exactly as in the eager step.  Style transfer / occlusion draw host random numbers per
-    step and therefore stay on the eager path."""
+    the batch's aug_param tuples exactly as in the eager step.
+    Style transfer (train_human.py:345-358): each direction is its own small graph (content, style, alpha as a device scalar ->
+    the step's effective input); the host draws the step's decisions in the reference's order and replays the direction(s) it
+    drew, or copies the original images, before the main graph.  Occlusion (train_human.py:374-412): the decisions are taken
+    on the device from four uniform draws per sample (trainer.device_occlusion), inside the main graph."""
 
     def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None):
-        assert trainer.style_net is None and trainer.occlude_rate <= -1, \
-            "the graphed step covers the style-free, occlusion-free configuration (both draw host random numbers per step)"
+        self.styled = trainer.style_net is not None
+        self.occl = trainer.occlude_rate > -1
+        if self.occl and not trainer.device_occlusion:
+            raise RuntimeError("GraphedTrainStep with occlusion needs trainer.device_occlusion = True (the reference's host draws read "
+                               "the confidences back every step, which a captured step cannot do)")
         self.t = trainer
         self._stage, self._have_staged = None, False
         dev = x_s.device
@@ -357,16 +398,41 @@ class GraphedTrainStep:
                        "theta_stu": warp.recon_thetas(aug_param_stu, n, trainer.ratio, dev),
                        "theta_tea": warp.recon_thetas(aug_param_tea, n, trainer.ratio, dev)}
         st = self.static
+        # the main graph reads the step's EFFECTIVE inputs: the originals, or what the style graphs wrote
+        st["x_s_in"] = st["x_s"].clone() if self.styled else st["x_s"]
+        st["x_t_tea_in"] = st["x_t_tea"].clone() if self.styled else st["x_t_tea"]
+        if self.styled:
+            st["alpha_s2t"] = torch.ones(1, dtype=torch.float32, device=dev)
+            st["alpha_t2s"] = torch.ones(1, dtype=torch.float32, device=dev)
+        if self.occl:
+            st["theta_back"] = warp.occlusion_back_thetas(aug_param_stu, n, trainer.ratio, dev)
+            st["u"] = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+            trainer._occl = ("device", st["theta_back"], st["u"])
+        else:
+            trainer._occl = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
+        self.g_style = {}
         with torch.cuda.stream(side):
-            for _ in range(warmup):     # fills the tap-plan / table caches and reaches allocator steady state
-                trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
+            if self.styled:             # (the style net's plans and packs; no model state involved)
+                self._style_pass("s2t")
+                self._style_pass("t2s")
+            for _ in range(warmup):     # REAL steps (same host draws as step()): fill the plan / table caches, allocator steady state
+                self._draw_and_style()
+                trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]], st["theta_stu"],
                                           [st["theta_tea"]])
                 trainer._sync_grads()
                 trainer._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        style_mode = "thread_local" if _dist_on() else "global"
+        if self.styled:
+            for which in ("s2t", "t2s"):
+                g = torch.cuda.CUDAGraph()
+                pool = {} if not self.g_style else {"pool": self.g_style["s2t"].pool()}
+                with torch.cuda.graph(g, capture_error_mode=style_mode, **pool):
+                    self._style_pass(which)
+                self.g_style[which] = g
         # Data parallel: the confidence all-gather sits between the forwards and the losses, the gradient all-reduce between
         # backward and the optimizer; both stay eager, so the step is cut into three graphs around them.
         self.split = _dist_on() if split is None else bool(split)
@@ -385,14 +451,14 @@ class GraphedTrainStep:
         self.g_lb2 = None
         if not self.split:
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
-                self.out = trainer._forward_backward(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]], st["theta_stu"],
-                                                     [st["theta_tea"]])
+                self.out = trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
+                                                     st["theta_stu"], [st["theta_tea"]])
                 if trainer.student._pending_lower:      # (overlap forced on one rank: both backward parts in the one graph)
                     trainer._backward_lower()
         else:
             self.g_lb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
-                self.fwd_state = trainer._forward_part(st["x_s"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea"]],
+                self.fwd_state = trainer._forward_part(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
                                                        st["theta_stu"], [st["theta_tea"]])
             g0 = gather_activates(self.fwd_state["activates"])
             self.gathered = g0.clone() if g0 is not None else self.fwd_state["activates"].reshape(-1).clone()
@@ -419,11 +485,39 @@ class GraphedTrainStep:
                 m.packs_refreshed(hd, bwd)
         torch.cuda.synchronize()
 
+    def _style_pass(self, which):
+        """One direction of the style transfer, from the ORIGINAL images into the main graph's input buffer."""
+        st, t = self.static, self.t
+        with torch.no_grad():
+            if which == "s2t":
+                st["x_s_in"].copy_(t.style_net(st["x_s"], st["x_t_tea"], st["alpha_s2t"], clamp=t.recover)[2])
+            else:
+                st["x_t_tea_in"].copy_(t.style_net(st["x_t_tea"], st["x_s"], st["alpha_t2s"], clamp=t.recover)[2])
+
+    def _draw_and_style(self):
+        """The step's host draws, in the eager step's (= the reference's) order, and what follows from them: each style
+        direction drawn runs (its graph once captured) into the main graph's input buffer, the other keeps the original
+        images; the occlusion's uniform numbers go to the device."""
+        st = self.static
+        if self.styled:
+            for which, a, src in zip(("s2t", "t2s"), self.t.draw_style_decisions(), (("x_s_in", "x_s"), ("x_t_tea_in", "x_t_tea"))):
+                if a is not None:
+                    st["alpha_" + which].fill_(float(a))
+                    if which in self.g_style:
+                        self.g_style[which].replay()
+                    else:
+                        self._style_pass(which)
+                else:
+                    st[src[0]].copy_(st[src[1]], non_blocking=True)
+        if self.occl:
+            st["u"].copy_(self.t.draw_occlusion_uniforms(self.n), non_blocking=True)
+
     def _frozen_hyper(self):
         t = self.t
         opt = t.stu_optimizer
         frozen = [("teacher_alpha", float(t.tea_optimizer.alpha)), ("lambda_c", float(t.lambda_c)), ("mask_ratio", float(t.mask_ratio)),
-                  ("sigma", float(t.sigma)), ("bn_momentum", float(t.student.bn_momentum))]
+                  ("sigma", float(t.sigma)), ("bn_momentum", float(t.student.bn_momentum)), ("occlude_rate", float(t.occlude_rate)),
+                  ("occlude_thresh", float(t.occlude_thresh)), ("occlude_size", int(t.occlude_size))]
         for gi, g in enumerate(opt.param_groups):
             for k in ("betas", "eps", "weight_decay", "momentum", "nesterov"):
                 if k in g:
@@ -460,6 +554,8 @@ class GraphedTrainStep:
                 st[k].copy_(v, non_blocking=True)
         if aug_param_stu is not None:
             st["theta_stu"].copy_(warp.recon_thetas(aug_param_stu, self.n, self.t.ratio), non_blocking=True)
+            if self.occl:
+                st["theta_back"].copy_(warp.occlusion_back_thetas(aug_param_stu, self.n, self.t.ratio), non_blocking=True)
         if aug_param_tea is not None:
             st["theta_tea"].copy_(warp.recon_thetas(aug_param_tea, self.n, self.t.ratio), non_blocking=True)
         if self._frozen_hyper() != self._frozen:
@@ -474,6 +570,7 @@ class GraphedTrainStep:
                     hd.wpack_version = None
                     with torch.enable_grad() if bwd else torch.no_grad():
                         m.prepare(self.static["x_s"])
+        self._draw_and_style()
         self.g_fb.replay()
         if self.split:
             g = gather_activates(self.fwd_state["activates"])

@@ -273,15 +273,17 @@ class Net(nn.Module):
 
     def forward(self, content, style, alpha=1.0, clamp=None):
         """-> (loss_c, loss_s, g_t) (Style_net.py:163-177).  `clamp=(lo[3], hi[3])` fuses the loop's recover clamp
-        (train_human.py:351) into the output conversion (the losses, when computed, see the unclamped g_t like the reference)."""
-        assert 0 <= alpha <= 1
+        (train_human.py:351) into the output conversion (the losses, when computed, see the unclamped g_t like the reference).
+        `alpha` may be a one-element fp32 CUDA tensor: the blend factor is then read on the device when the kernel runs."""
+        if not torch.is_tensor(alpha):
+            assert 0 <= alpha <= 1
         with torch.no_grad():
             if self.compute_losses:
                 sf, style_feats = self._intermediate(self._image_in(style))
             else:
                 sf = self._enc.run(self._image_in(style))
             cf = self._enc.run(self._image_in(content))
-            t = ops.adain(cf, sf, alpha=float(alpha))              # alpha-blend fused (Style_net.py:167-168)
+            t = ops.adain(cf, sf, alpha=alpha if torch.is_tensor(alpha) else float(alpha))              # alpha-blend fused (Style_net.py:167-168)
             g = self._dec.run(t, final_f32=True)                    # [N,H,W,3] fp32
             lo, hi = (None, None) if clamp is None else (clamp[0].float().contiguous(), clamp[1].float().contiguous())
             g_t = ops.to_nchw_f32(g, 3, lo, hi)

@@ -214,8 +214,15 @@ def adain(content, style, alpha=1.0, eps=1e-5, want_stats=False, stats_only=Fals
     assert style.shape[0] == N and style.shape[3] == C_
     out = None if stats_only else torch.empty_like(content)
     st = torch.empty(N, C_, 4, dtype=torch.float32, device=content.device) if (want_stats or stats_only) else None
-    fn = lib().udapose_adain_f32 if content.dtype == torch.float32 else lib_for(content).udapose_adain
-    check(fn(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps, float(alpha), ptr(st)), "adain")
+    f32 = content.dtype == torch.float32
+    if torch.is_tensor(alpha):      # the blend factor as ONE fp32 device scalar: read at run time (captured launches follow it)
+        assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.numel() == 1
+        L = lib() if f32 else lib_for(content)
+        check(L.udapose_adain_alpha_dev(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps,
+                                        ptr(alpha), ptr(st), int(f32)), "adain")
+    else:
+        fn = lib().udapose_adain_f32 if f32 else lib_for(content).udapose_adain
+        check(fn(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps, float(alpha), ptr(st)), "adain")
     if stats_only:
         return st
     return (out, st) if want_stats else out

@@ -174,3 +174,39 @@ def occlude_keypoints(x_t_stu, y_t_tea_recon, aug_param_stu, ratio, image_size, 
     out = x_t_stu.clone()
     out.index_copy_(0, idx, warp_chain(temp, back).to(x_t_stu.dtype))
     return out, sel
+
+
+def occlusion_back_thetas(aug_param_stu, n, ratio, device=None):
+    """[N,1,6]: the warp back of the occlusion path (train_human.py:412): -angle, (-tx/ratio, -ty/ratio), 1/scale, (-shear)."""
+    angle, (tx, ty), (sx, sy), scale = aug_param_stu
+    a_, tx_, ty_, sx_, sy_, sc_ = (_as_list(v, n) for v in (angle, tx, ty, sx, sy, scale))
+    return single_thetas([-v for v in a_], ([-v / ratio for v in tx_], [-v / ratio for v in ty_]), [1.0 / v for v in sc_],
+                         ([-v for v in sx_], [-v for v in sy_]), n, device)
+
+
+def occlude_keypoints_device(x_t_stu, y_t_tea_recon, theta_fwd, theta_back, u, ratio, image_size, occlude_rate, occlude_thresh, occlude_size):
+    """The same occlusion with its DECISIONS taken on the device (udapose_occlusion_pick): no read-back, fixed shapes - the step
+    stays capturable.  theta_fwd = recon_thetas(aug_param_stu), theta_back = occlusion_back_thetas(aug_param_stu), u = [N,4]
+    uniform [0,1) draws (rate test, key-point choice, patch row / column origin).  Every image goes through the warps; only the
+    selected samples keep the result (the others are returned bit-identical).  Returns (images, apply [N] uint8)."""
+    _hip.require_cuda(x_t_stu, y_t_tea_recon, theta_fwd, theta_back, u)
+    B, K, h, w = y_t_tea_recon.shape
+    hm = y_t_tea_recon.detach().float().contiguous()
+    conf = torch.empty(B, K, dtype=torch.float32, device=hm.device)
+    idx = torch.empty(B, K, dtype=torch.int32, device=hm.device)
+    check(lib().udapose_heatmap_argmax(_hip.stream(), ptr(hm), B * K, h, w, ptr(conf), ptr(idx), None, None, None, 0), "heatmap_argmax")
+    boxes = torch.empty(B, 6, dtype=torch.int32, device=hm.device)
+    apply = torch.empty(B, dtype=torch.uint8, device=hm.device)
+    uu = u.detach().float().contiguous()
+    assert tuple(uu.shape) == (B, 4)
+    check(lib().udapose_occlusion_pick(_hip.stream(), ptr(conf), ptr(idx), ptr(uu), B, K, w, float(ratio), int(image_size), float(occlude_rate),
+                                       float(occlude_thresh), int(occlude_size), ptr(boxes), ptr(apply)), "occlusion_pick")
+    x = x_t_stu.detach().float().contiguous()
+    temp = warp_chain(x, theta_fwd).contiguous()
+    C_ = temp.shape[1]
+    check(lib().udapose_patch_paste(_hip.stream(), ptr(temp), ptr(boxes), B, C_, temp.shape[2], temp.shape[3], 4 * occlude_size * occlude_size * C_),
+          "patch_paste")
+    back = warp_chain(temp, theta_back).contiguous()
+    out = torch.empty_like(x)
+    check(lib().udapose_select_rows(_hip.stream(), ptr(out), ptr(back), ptr(x), ptr(apply), B, x[0].numel()), "select_rows")
+    return out.to(x_t_stu.dtype), apply
