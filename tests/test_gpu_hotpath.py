@@ -510,6 +510,26 @@ def test_two_rank_step_on_one_gpu_gloo():
     assert d["rccl_ranks"] == 0                        # (gloo here: the one-GPU box cannot host two RCCL ranks)
 
 
+def test_two_rank_config3_step_style_and_occlusion_captured():
+    """BASELINE.json configs[3] in small (data parallel + style / occlusion was never run, even at two
+    ranks): two ranks sharing cuda:0 over gloo, each with its shard, the style directions and the occlusion decisions inside
+    the captured step, the four data-parallel graphs around the collectives; replicas stay bit-identical."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UDAPOSE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config2", "--steps", "3", "--warmup", "1", "--spinup", "0",
+           "--arch", "pose_resnet50", "--batch", "4", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["replicas_in_sync"] is True
+    assert "style-transfer hipGraphs" in d["launch"] and "4 hipGraphs" in d["launch"]
+    assert d["loss"] == d["loss"] and d["value"] > 0
+
+
 def test_bench_gpus_flag_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher and WORLD_SIZE unset: the parent spawns two fresh rank processes before
     touching the GPU, relays rank 0's ONE JSON line and exits with the children's status (`--gpus` used to be

@@ -130,6 +130,7 @@ class MeanTeacherTrainer:
         # of the confidences).  True: four uniform draws per sample go to the device and udapose_occlusion_pick takes the
         # decisions there - same distribution, no read-back, capturable (GraphedTrainStep needs it)
         self.device_occlusion = False
+        self.occl_rng = self.rng            # generator of the host-side occlusion draws (the reference: the global np.random)
         self._occl = None                   # ("host", aug_param_stu) | ("device", theta_back [N,1,6], u [N,4])
         # data parallel: cut the backward after layer3 and all-reduce the finished 94 % of the gradient under the rest of it
         # (None: whenever a process group is active and the network has the layer3 boundary)
@@ -170,6 +171,10 @@ class MeanTeacherTrainer:
             if self.device_occlusion:
                 self._occl = ("device", warp.occlusion_back_thetas(aug_param_stu, n, self.ratio, dev), self.draw_occlusion_uniforms(n, dev))
             else:
+                if _dist_on() and self.style_net is not None and self.occl_rng is self.rng:
+                    raise RuntimeError("data parallel with style transfer: the host occlusion draws are data dependent in number and "
+                                       "would take the ranks' common style decisions out of step - set trainer.device_occlusion = True "
+                                       "or give the occlusion its own generator (trainer.occl_rng)")
                 self._occl = ("host", aug_param_stu)
         out = self._forward_backward(x_s_in, label_s, weight_s, x_t_stu, x_t_teas_in, theta_stu, thetas_tea)
         self._sync_grads()
@@ -189,7 +194,15 @@ class MeanTeacherTrainer:
         return a_s2t, a_t2s
 
     def draw_occlusion_uniforms(self, n, device=None):
-        u = torch.from_numpy(np.asarray(self.rng.rand(n, 4), dtype=np.float32))
+        """[n,4] uniform numbers for this rank's samples.  Data parallel: every rank draws the GLOBAL batch's numbers and keeps its
+        slice - with equally seeded generators the ranks' host streams stay in step (the style decisions that follow are per
+        step for the whole global batch, as in the reference's single process) and the samples' draws stay independent."""
+        if _dist_on():
+            w, r = dist.get_world_size(), dist.get_rank()
+            u = np.asarray(self.rng.rand(w * n, 4), dtype=np.float32)[r * n:(r + 1) * n]
+        else:
+            u = np.asarray(self.rng.rand(n, 4), dtype=np.float32)
+        u = torch.from_numpy(np.ascontiguousarray(u))
         return u.to(device, non_blocking=True) if device is not None else u
 
     def _style_part(self, x_s, x_t_teas):
@@ -246,7 +259,7 @@ class MeanTeacherTrainer:
                                                                                self.occlude_size)
                     else:   # (one small D2H of confidences, as in the reference)
                         x_t_stu, self.occluded = warp.occlude_keypoints(x_t_stu, y_t_tea_recon, occl[1], self.ratio, self.image_px,
-                                                                        self.occlude_rate, self.occlude_thresh, self.occlude_size, self.rng)
+                                                                        self.occlude_rate, self.occlude_thresh, self.occlude_size, self.occl_rng)
             y_t_stu = student.forward_deferred_bn(x_t_stu)     # separate forwards: separate BN statistics per domain
             y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
         if occl is None:
