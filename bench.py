@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
     ap.add_argument("--policy", action="append", default=[], metavar="FIELD=INT", help="tuning: override one field of the dispatch policy "
                     "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
+    ap.add_argument("--wgrad-side", action="store_true", help="tuning: the upper part's weight gradients on a side stream under the lower "
+                    "part's gradient chain instead of after the whole chain (measured slower: profiles/r2_ab_runs.txt)")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
@@ -229,6 +231,7 @@ def main():
     teacher = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
     student.policy.update(tune)
     teacher.policy.update(tune)
+    student.wgrad_side_stream = bool(args.wgrad_side)
     extra = {}
     if args.config2:
         import numpy as np

@@ -188,6 +188,12 @@ int udapose_net_backward(udapose_net_t net, void* stream, const float* dout_nchw
  * gradient part 1 left in `ws` (same act / ws / grads / beta as part 1; dout is ignored). */
 int udapose_net_backward_part(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
                               void* act, void* ws, void* const* h_grads, float beta, int part);
+/* The same with the two halves of a part separable: phase 0 = the gradient chain of `part` followed by its grouped weight-gradient
+ * launches (= udapose_net_backward_part; part 0 = the whole backward); phase 1 = the chain only; phase 2 = the grouped
+ * weight-gradient launches of `part` only, on ANY stream that has waited for the chain (every layer owns its dy buffer in `ws`):
+ * one device: the weight gradients of part 1 run under the gradient chain of part 2. */
+int udapose_net_backward_phase(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
+                               void* act, void* ws, void* const* h_grads, float beta, int part, int phase);
 long long udapose_net_grad_split_param(udapose_net_t net);
 
 /* ---------------------------------------------------------------- heat-map losses and decode (fp32 NCHW rows [R=B*K][HW]) */

@@ -426,3 +426,27 @@ def test_config2_step_with_style_and_occlusion_captured_equals_eager_twin():
 def rng_state_equal(a, b):
     sa, sb = a.get_state(), b.get_state()
     return sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+
+
+def test_weight_gradients_on_a_side_stream_are_bit_identical_eager_and_captured():
+    """udapose_net_backward_phase: the upper part's grouped weight gradients on a side stream under the lower part's gradient
+    chain (student.wgrad_side_stream, off by default: measured slower) give exactly the in-stream result, eagerly and captured
+    (the side streams join the capture's origin stream: tools/capture_fork_patterns.py)."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=2)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    res = {}
+    for side in (False, True):
+        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=0).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=0).cuda()
+        stu.wgrad_side_stream = side
+        tr = MeanTeacherTrainer(stu, tea, image_size=S, heatmap_size=S // 4)
+        tr.train_step(*args)
+        gs = GraphedTrainStep(tr, *args, warmup=1)
+        for _ in range(3):
+            out = gs.step(*args)
+        assert torch.isfinite(out["loss_all"])
+        res[side] = [p.detach().clone() for p in stu.parameters()]
+    assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))

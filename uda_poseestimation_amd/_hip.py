@@ -88,6 +88,7 @@ _SIGS = {
     "udapose_axpy_f32": (ci, [vp, vp, vp, sz]),
     "udapose_net_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf]),
     "udapose_net_backward_part": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci]),
+    "udapose_net_backward_phase": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]),
     "udapose_net_grad_split_param": (ll, [vp]),
     "udapose_net_bind_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "udapose_net_fused_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, cf, cf, ci]),
@@ -165,6 +166,11 @@ _ERRORS = {-1: "bad argument", -2: "launch / runtime failure", -3: "unsupported 
 
 def check(code, what=""):
     if code != 0:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # (an exception that unwinds a stream capture with forked streams can take the runtime down before it is ever shown)
+            import sys
+            print(f"libudapose_hip call failed inside a stream capture ({what}): error {code} ({_ERRORS.get(code, 'unknown')})",
+                  file=sys.stderr, flush=True)
         raise RuntimeError(f"libudapose_hip call failed ({what}): error {code} ({_ERRORS.get(code, 'unknown')})")
 
 

@@ -70,7 +70,7 @@ size_t net_ws_bytes(void*);
 void net_out_shape(void*, int*);
 int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
 int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
-int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int);
+int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int, int);
 
 static Policy from_c(const udapose_policy& c) {
     Policy p;
@@ -233,12 +233,17 @@ int udapose_net_apply_running(udapose_net_t n, void* stream, const void* act, vo
 int udapose_axpy_f32(void* stream, float* y, const float* x, size_t n) { return pw_axpy(S(stream), y, x, n); }
 int udapose_net_backward(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act, void* ws,
                          void* const* grads, float beta) {
-    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, 0);
+    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, 0, 0);
 }
 int udapose_net_backward_part(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act,
                               void* ws, void* const* grads, float beta, int part) {
     if (part != 1 && part != 2) return UDAPOSE_ERR_ARG;
-    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part);
+    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part, 0);
+}
+int udapose_net_backward_phase(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act,
+                               void* ws, void* const* grads, float beta, int part, int phase) {
+    if (!n) return UDAPOSE_ERR_ARG;
+    return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part, phase);
 }
 long long udapose_net_grad_split_param(udapose_net_t n) { return net_grad_split_param(n); }
 int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* const* params_s, void* const* grads, void* const* exp_avg,

@@ -729,10 +729,18 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
 // part 2 = layer2, layer1, stem and theirs, continuing from the gradient part 1 left in the workspace.  Data parallel:
 // the all-reduce of the suffix runs under part 2 (engine.py).  The two parts together enqueue exactly the kernels of part 0
 // except that the weight gradients are two grouped launches per tile class instead of one.
+// phase 0: the gradient chain, then the grouped weight-gradient launches of this part; 1: the chain only; 2: the grouped launches
+// only (every layer owns its dy buffer in the workspace, so a caller may run them on another stream under the chain of part 2).
 int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack_, void* act_, void* ws_,
-                 void* const* grads, float beta, int part) {
+                 void* const* grads, float beta, int part, int phase) {
     Net& n = *(Net*)h;
-    if (part < 0 || part > 2) return UDAPOSE_ERR_ARG;
+    if (part < 0 || part > 2 || phase < 0 || phase > 2) return UDAPOSE_ERR_ARG;
+    if (phase != 0 && !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
+    if (phase == 2) {
+        if (n.f32) return UDAPOSE_ERR_UNSUPPORTED;
+        DbgSyncScope dbg2(n.policy.debug_sync);
+        return run_wg_group(s, n, (const char*)act_, (char*)ws_, grads, beta, part);
+    }
     DbgSyncScope dbg(n.policy.debug_sync);
     if (n.f32) return UDAPOSE_ERR_UNSUPPORTED;   // fp32 mode is forward-only (teacher / validate precision)
     const char* wpack = (const char*)wpack_;
@@ -830,7 +838,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     }
     if (part == 1) {
         for (int i = 0; i < 6; ++i) if ((char*)dz == ws + pool.off[i]) n.split_dz_idx = i;      // (the same value on every pass)
-        if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta, 1));
+        if (grouped && phase == 0) CK(run_wg_group(s, n, act, ws, grads, beta, 1));
         if (beta == 0.f) {       // backbone.fc lies in part 1's suffix of the gradient buffer (not part of forward: zero)
             if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
             if (hipMemsetAsync(grads[n.fc_b_idx], 0, (size_t)1000 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
@@ -844,7 +852,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     elem_t* none = nullptr;
     CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 2, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
-    if (grouped) CK(run_wg_group(s, n, act, ws, grads, beta, part));
+    if (grouped && phase == 0) CK(run_wg_group(s, n, act, ws, grads, beta, part));
     // backbone.fc is not part of the forward: zero gradient when overwriting
     if (beta == 0.f && part == 0) {
         if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;

@@ -291,7 +291,7 @@ class MeanTeacherTrainer:
         else:
             self.sync()
 
-    def _backward_lower(self, st=None):
+    def _backward_lower(self, grads_part=2):
         student = self.student
         main = torch.cuda.current_stream()
         streams = {id(p[5]): p[5] for p in student._pending_lower}
@@ -302,7 +302,7 @@ class MeanTeacherTrainer:
         for stv in streams.values():
             if stv is not main:
                 main.wait_stream(stv)
-        student.finish_grads(part=2)
+        student.finish_grads(part=grads_part)
 
     def _loss_backward_part(self, st, gathered_activates):
         """Losses and backward from the forward state; `gathered_activates` = all ranks' confidences (None on one rank).
@@ -311,7 +311,9 @@ class MeanTeacherTrainer:
         student = self.student
         main, s_stu = st["main"], st["s_stu"]
         overlap = self._overlap()
-        student.split_backward = overlap
+        # one device: the same cut, used to run the upper part's weight gradients on side streams under the lower part's chains
+        side = (not overlap) and getattr(student, "wgrad_side_stream", False) and hasattr(student, "finish_backward")
+        student.split_backward = True if overlap else ("side" if side else False)
         loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
@@ -327,6 +329,8 @@ class MeanTeacherTrainer:
             student.finish_grads(part=1)    # the suffix of both passes is final: sum it ...
             if not torch.cuda.is_current_stream_capturing():
                 self.sync.start_upper()     # ... and send it off (a captured step issues the collective between its graphs)
+        elif student._pending_lower:
+            self._backward_lower(grads_part=0)      # weight gradients of the upper part on side streams | the lower part
         else:
             student.finish_grads()          # adds the second pass's gradient buffer (no-op when both ran on one stream)
         return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": st["y_s"].detach()}

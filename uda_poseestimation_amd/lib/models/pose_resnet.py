@@ -76,6 +76,8 @@ class _NetHandle:
         self.ws = torch.empty(L.udapose_net_ws_bytes(h), dtype=torch.uint8, device=device)
         self.wpack = torch.empty(L.udapose_net_wpack_bytes(h), dtype=torch.uint8, device=device)
         self.wpack_version = None
+        # (the backward can be cut at layer3's first block, and its weight gradients are grouped launches)
+        self.can_split = L.udapose_net_grad_split_param(h) >= 0 and int((policy or {}).get("wgrad_group", 1)) != 0
         self.act_nograd = None
         self._fin = weakref.finalize(self, L.udapose_net_destroy, h)
 
@@ -136,11 +138,18 @@ class PoseResNet(nn.Module):
         # explicit dispatch-policy overrides for this network's executor plans (fields of udapose_policy, include/udapose.h);
         # empty = the production policy.  Plans read it when they are created: clear self._handles after changing it.
         self.policy = {}
-        # Data parallel: cut every backward after the first block of layer3 (udapose_net_backward_part).  backward() then runs
+        # split_backward = True (data parallel): cut every backward after the first block of layer3 (udapose_net_backward_part).  backward() then runs
         # part 1 only - after it the gradients of layer3 / layer4 / upsampling / head (a contiguous suffix of the flat buffer,
         # 94 % of it) are final - and finish_backward() runs part 2; the caller all-reduces the suffix in between, under part 2.
         self.split_backward = False
         self._pending_lower = []
+        # split_backward = "side" (one device, set by the engine when wgrad_side_stream): backward() runs the gradient chain of
+        # part 1 only; finish_backward() then starts part 1's weight gradients (layer3 ... head: most of the backward's MFMA work,
+        # two long launches) on a side stream and runs part 2 under them.  OFF: measured slower on configs[1] (17.06 vs 16.63 ms per
+        # step, three interleaved A/B runs on one box, profiles/r2_ab_runs.txt) - with three passes already in flight the extra
+        # concurrency costs the memory-bound lower chains more than it hides.
+        self.wgrad_side_stream = False
+        self._wg_side = {}
         self._to_channels_last()
 
     # ------------------------------------------------------------------ layout / pointer bookkeeping
@@ -338,12 +347,28 @@ class PoseResNet(nn.Module):
         on the stream its part 1 ran on."""
         pending, self._pending_lower = self._pending_lower, []
         pa, ba, params = self._pointers()
-        for hd, act, ws, gptrs, beta, stream in pending:
+        joins = []
+        for hd, act, ws, gptrs, beta, stream, side in pending:
+            args = (pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta)
+            if side:
+                # one device: the weight gradients of part 1 (layer3 ... head: two long MFMA-bound launches) on a side stream,
+                # under the gradient chain of part 2 (layer2, layer1, stem: short memory-bound launches)
+                sd = self._side_stream_for(stream, act.device)
+                sd.wait_stream(stream)
+                check(hd.L.udapose_net_backward_phase(hd.h, sd.cuda_stream, None, *args, 1, 2), "net_backward part 1 weight gradients")
+                act.record_stream(sd)
+                ws.record_stream(sd)
+                joins.append((stream, sd))
             with torch.cuda.stream(stream):
-                check(hd.L.udapose_net_backward_part(hd.h, stream.cuda_stream, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 2),
-                      "net_backward part 2")
+                check(hd.L.udapose_net_backward_part(hd.h, stream.cuda_stream, None, *args, 2), "net_backward part 2")
                 act.record_stream(stream)
                 ws.record_stream(stream)
+        # The side streams join the CALLER's stream, not the stream they forked from: inside a stream capture on this ROCm a
+        # stream that waits back on its own fork (a -> b -> a) brings hipStreamEndCapture down (tools/_t_cap.py patterns Q1 / Q5),
+        # while joining the fork into the capture's origin stream is fine (Q2 / Q6).  The caller sums the gradients on this stream.
+        here = torch.cuda.current_stream()
+        for stream, sd in joins:
+            here.wait_stream(sd)
 
     def _run_backward(self, dout, act, hd, ws):
         pa, ba, params = self._pointers()
@@ -387,10 +412,12 @@ class PoseResNet(nn.Module):
             check(hd.L.udapose_net_bind_grads(hd.h, gptrs), "net_bind_grads")
             hd.bound_grads.add(gkey)
         dout = dout.contiguous().float()
-        if self.split_backward:
-            check(hd.L.udapose_net_backward_part(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 1),
+        if self.split_backward and (self.split_backward != "side" or hd.can_split):
+            # "side": the gradient chain of part 1 only - finish_backward() starts its weight gradients on a side stream
+            side = self.split_backward == "side"
+            check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 1, int(side)),
                   "net_backward part 1")
-            self._pending_lower.append((hd, act, ws, gptrs, beta, cur))       # (keeps the arenas alive until part 2 has run)
+            self._pending_lower.append((hd, act, ws, gptrs, beta, cur, side))       # (keeps the arenas alive until part 2 has run)
         else:
             check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not
@@ -399,6 +426,21 @@ class PoseResNet(nn.Module):
         for p, v in zip(params, views):
             if p.requires_grad and id(p) not in nograd:
                 p.grad = v
+
+    def _side_stream_for(self, cur, device):
+        """The side stream paired with `cur` (one per stream a backward runs on).  Streams are only CREATED outside a capture
+        (a spare is kept for the capture stream a later GraphedTrainStep will run the backward on)."""
+        key = (cur.cuda_stream, device.index)
+        side = self._wg_side.get(key)
+        if side is None:
+            spare = self._wg_side.setdefault(("spare", device.index), [])
+            if not torch.cuda.is_current_stream_capturing():
+                while len(spare) < 4:
+                    spare.append(torch.cuda.Stream(device=device))
+            if not spare:
+                return None
+            side = self._wg_side[key] = spare.pop()
+        return side
 
     def _no_grad_ids(self):
         fc = getattr(self.backbone, "fc", None)
