@@ -257,7 +257,10 @@ int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* 
 int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* h_params_s, void* const* h_grads,
                              void* const* h_exp_avg, void* const* h_params_t, void* wpack_s, void* wpack_t, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha,
-                             float one_minus_alpha, int do_adam);
+                             float one_minus_alpha, int do_adam, long long grad2_delta_bytes);
+/* grad2_delta_bytes != 0: the gradient is h_grads[i] + the tensor grad2_delta_bytes behind it (the second per-pass gradient buffer
+ * of a step whose two backward passes ran on different streams; a multiple of 16): the sum udapose_axpy_f32 would have written
+ * first, taken in the same sweep.  h_grads itself is left holding the first pass's share. */
 
 /* Dynamic loss scaling = torch.cuda.amp.GradScaler (train_human.py:260,285-287,324,436-440) on the device, for the fp16 build.
  * dev_state is the optimizer's 8-float state: [5] = found_inf, [6] = loss scale S, [7] = growth tracker, [4] = 1/S.

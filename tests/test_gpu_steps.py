@@ -450,3 +450,37 @@ def test_weight_gradients_on_a_side_stream_are_bit_identical_eager_and_captured(
         assert torch.isfinite(out["loss_all"])
         res[side] = [p.detach().clone() for p in stu.parameters()]
     assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
+
+
+def test_gradient_buffers_summed_inside_the_fused_tail_are_bit_identical_to_the_separate_sum():
+    """udapose_net_fused_update(grad2_delta_bytes): the two passes' gradient buffers added inside the Adam / EMA / pack sweep give
+    exactly the parameters of axpy-then-sweep, eagerly and captured; p.grad is completed on demand by finish_grads()."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=6)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    res = {}
+    for in_tail in (False, True):
+        stu, tea = _tiny(K, seed=4).cuda(), _tiny(K, seed=4).cuda()
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
+        tr.sum_grads_in_tail = in_tail
+        tr.train_step(*args)
+        assert tr.fused_last
+        assert stu.pending_grad_sum() == 0                     # taken by the tail (or summed before it)
+        gs = GraphedTrainStep(tr, *args, warmup=1)
+        for _ in range(2):
+            gs.step(*args)
+        res[in_tail] = [p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
+    assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
+    # a deferred sum is completed by finish_grads() for anyone who wants p.grad itself
+    stu, tea = _tiny(K, seed=4).cuda(), _tiny(K, seed=4).cuda()
+    tr = MeanTeacherTrainer(stu, tea, image_size=S, heatmap_size=S // 4)
+    theta = lambda ap: __import__("uda_poseestimation_amd.warp", fromlist=["x"]).recon_thetas(ap, N, 4.0, "cuda")
+    tr._forward_backward(args[0], args[1], args[2], args[3], [args[4]], theta(args[5]), [theta(args[6])])
+    torch.cuda.synchronize()
+    assert stu.pending_grad_sum() != 0
+    part = stu.head.weight.grad.clone()
+    stu.finish_grads()
+    assert stu.pending_grad_sum() == 0 and not torch.equal(part, stu.head.weight.grad)

@@ -60,7 +60,7 @@ int net_bind_grads(void*, void* const*);
 long long net_grad_split_param(void*);
 int net_bind_update(void*, void*, void* const*, void* const*, void* const*, void* const*, void* const*, void*, void*);
 int net_fused_update(void*, void*, hipStream_t, void* const*, void* const*, void* const*, void* const*, void*, void*, float, float, float, float, float,
-                     int, float, float*, float, float, int);
+                     int, float, float*, float, float, int, long long);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -254,10 +254,10 @@ int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* 
 int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* params_s, void* const* grads,
                              void* const* exp_avg, void* const* params_t, void* wpack_s, void* wpack_t, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha, float one_minus_alpha,
-                             int do_adam) {
+                             int do_adam, long long grad2_delta_bytes) {
     if (!student || !teacher) return UDAPOSE_ERR_ARG;
     return net_fused_update(student, teacher, S(stream), params_s, grads, exp_avg, params_t, wpack_s, wpack_t, lr, beta1, beta2, eps, weight_decay,
-                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam);
+                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam, grad2_delta_bytes);
 }
 
 int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out) {

@@ -41,7 +41,7 @@ int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, in
 size_t opt_tail_job_bytes();
 int opt_chunk();
 void opt_tail_job_fill(void*, float*, const float*, float*, float*, float*, void*, void*, void*, void*, int, int, int, int, long long);
-int opt_tail(hipStream_t, const void*, const int*, const int*, int, float, float, float, float, float, int, float, float*, float, float, int);
+int opt_tail(hipStream_t, const void*, const int*, const int*, int, float, float, float, float, float, int, float, float*, float, float, int, long long);
 int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
 int pw_pack_strided_f32(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long);
 int pw_bn_apply_f32(hipStream_t, const float*, const float*, float*, size_t, int, const float*, const float*, int);
@@ -948,14 +948,14 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
 
 int net_fused_update(void* hs, void* ht, hipStream_t s, void* const* params_s, void* const* grads, void* const* h_m, void* const* params_t,
                      void* wpack_s_, void* wpack_t_, float lr, float beta1, float beta2, float eps, float wd, int step, float gscale,
-                     float* dev_state, float alpha, float oma, int do_adam) {
+                     float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta) {
     Net& n = *(Net*)hs;
     const Net& nt = *(const Net*)ht;
     DbgSyncScope dbg(n.policy.debug_sync);
     const Net::UpdTab& u = n.upd;
     if (!u.jobs || u.k_ps != params_s[0] || u.k_pt != params_t[0] || u.k_g != grads[0] || u.k_m != h_m[0] || u.k_ws != wpack_s_ || u.k_wt != wpack_t_)
         return UDAPOSE_ERR_NOT_PREPARED;
-    CK(opt_tail(s, u.jobs, u.blk_job, u.blk_sub, u.nblocks, lr, beta1, beta2, eps, wd, step, gscale, dev_state, alpha, oma, do_adam));
+    CK(opt_tail(s, u.jobs, u.blk_job, u.blk_sub, u.nblocks, lr, beta1, beta2, eps, wd, step, gscale, dev_state, alpha, oma, do_adam, grad2_delta));
     // the two packs that are not a cast or a per-tap transpose of a whole tensor: the stem's 3 -> 8 channel gather (both
     // networks) and the head's zero-padded dgrad pack (student)
     CK(pack_conv(s, n, n.stem, (const void* const*)params_s, (char*)wpack_s_, false));

@@ -160,7 +160,7 @@ struct TailJob {
     long long n;
 };
 
-struct TailHyper { float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, gscale, alpha, oma; int do_adam; };
+struct TailHyper { float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, gscale, alpha, oma; int do_adam; long long g2; };   // g2: byte distance to a second gradient buffer (0: none)
 
 __device__ __forceinline__ void tail1(const TailHyper& h, bool adam, float& pv, float gr, float& mi, float& vi, float& tv) {
     if (adam) {
@@ -189,7 +189,9 @@ __global__ __launch_bounds__(TPB) void opt_tail_k(const TailJob* __restrict__ jo
         for (long long i = off + threadIdx.x; i < end; i += TPB) {
             float pv = j.p[i], tv = j.t[i], mi = 0.f, vi = 0.f;
             if (adam) { mi = j.m[i]; vi = j.v[i]; }
-            tail1(h, adam, pv, adam ? j.g[i] : 0.f, mi, vi, tv);
+            float gr = adam ? j.g[i] : 0.f;
+            if (adam && h.g2) gr += *(const float*)((const char*)(j.g + i) + h.g2);      // (the two passes' gradients: g1 + g2 as axpy would)
+            tail1(h, adam, pv, gr, mi, vi, tv);
             if (adam) { j.p[i] = pv; j.m[i] = mi; j.v[i] = vi; }
             j.t[i] = tv;
             if (j.sd) j.sd[i] = (elem_t)pv;
@@ -207,7 +209,10 @@ __global__ __launch_bounds__(TPB) void opt_tail_k(const TailJob* __restrict__ jo
         const size_t idx = ((size_t)(a0 + a) * j.T + t) * j.B + b0 + c4;
         f32x4 pv = *(const f32x4*)(j.p + idx), tv = *(const f32x4*)(j.t + idx);
         f32x4 mi = {0.f, 0.f, 0.f, 0.f}, vi = mi, gr = mi;
-        if (adam) { mi = *(const f32x4*)(j.m + idx); vi = *(const f32x4*)(j.v + idx); gr = *(const f32x4*)(j.g + idx); }
+        if (adam) {
+            mi = *(const f32x4*)(j.m + idx); vi = *(const f32x4*)(j.v + idx); gr = *(const f32x4*)(j.g + idx);
+            if (h.g2) { const f32x4 g2 = *(const f32x4*)((const char*)(j.g + idx) + h.g2); gr[0] += g2[0]; gr[1] += g2[1]; gr[2] += g2[2]; gr[3] += g2[3]; }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float p1 = pv[e], m1 = mi[e], v1 = vi[e], t1 = tv[e];
@@ -244,12 +249,13 @@ void opt_tail_job_fill(void* dst, float* p, const float* g, float* m, float* v, 
     *(TailJob*)dst = j;
 }
 int opt_tail(hipStream_t s, const void* d_jobs, const int* blk_job, const int* blk_sub, int nblocks, float lr, float beta1, float beta2, float eps,
-             float wd, int step, float gscale, float* dev_state, float alpha, float oma, int do_adam) {
+             float wd, int step, float gscale, float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta) {
     if (nblocks <= 0) return UDAPOSE_OK;
+    if (grad2_delta % 16) return UDAPOSE_ERR_ARG;
     double bc1 = 1.0, bc2 = 1.0;
     if (dev_state) { if (do_adam) hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(1), 0, s, dev_state, beta1, beta2); }
     else { bc1 = 1.0 - pow((double)beta1, (double)step); bc2 = 1.0 - pow((double)beta2, (double)step); }
-    TailHyper h{lr, beta1, beta2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, alpha, oma, do_adam};
+    TailHyper h{lr, beta1, beta2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, alpha, oma, do_adam, grad2_delta};
     hipLaunchKernelGGL(opt_tail_k, dim3(nblocks), dim3(TPB), 0, s, (const TailJob*)d_jobs, blk_job, blk_sub, h, dev_state);
     return udapose_check_launch();
 }

@@ -136,6 +136,7 @@ class MeanTeacherTrainer:
         # (None: whenever a process group is active and the network has the layer3 boundary)
         self.overlap_allreduce = None
         self.fuse_tail = True               # Adam + EMA + weight packs in one sweep (optim.FusedAdam.fused_tail_step)
+        self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
 
     # ------------------------------------------------------------------ train_human.py:262-302
@@ -332,18 +333,26 @@ class MeanTeacherTrainer:
         elif student._pending_lower:
             self._backward_lower(grads_part=0)      # weight gradients of the upper part on side streams | the lower part
         else:
-            student.finish_grads()          # adds the second pass's gradient buffer (no-op when both ran on one stream)
+            # adds the second pass's gradient buffer (no-op when both ran on one stream) - unless the fused optimizer tail will
+            # read both buffers itself (one rank: nothing else looks at the gradients in between)
+            student.finish_grads(defer=self._tail_sums_grads())
         return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": st["y_s"].detach()}
 
     def _forward_backward(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
         st = self._forward_part(x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea)
         return self._loss_backward_part(st, gather_activates(st["activates"]))
 
+    def _tail_sums_grads(self):
+        return bool(self.fuse_tail and self.sum_grads_in_tail and not _dist_on() and hasattr(self.stu_optimizer, "fused_tail_step")
+                    and hasattr(self.student, "pending_grad_sum"))
+
     def _update(self):
         # Adam, the EMA and the next forwards' weight packs of both networks in ONE sweep when the layout allows ...
         fuse = self.fuse_tail and hasattr(self.stu_optimizer, "fused_tail_step")
         self.fused_last = bool(fuse and self.stu_optimizer.fused_tail_step(self.student, self.teacher, self.tea_optimizer))
         if not self.fused_last:
+            if hasattr(self.student, "finish_grads"):
+                self.student.finish_grads()     # (a sum left to the fused tail that did not run)
             self.stu_optimizer.step()
             self.tea_optimizer.step()       # EMA after the optimizer step (train_human.py:437-438)
 

@@ -315,17 +315,31 @@ class PoseResNet(nn.Module):
             check(hd.L.udapose_net_apply_running(hd.h, _hip.stream(), ptr(act), ba, float(self.bn_momentum)), "net_apply_running")
         self._deferred_bn = []
 
-    def finish_grads(self, part=0):
+    def finish_grads(self, part=0, defer=False):
         """Sum the second per-pass gradient buffer into p.grad's buffer (only needed when two backward passes ran on
         different streams; the caller has already made the current stream wait for both).  part 1 / 2: only the suffix /
-        prefix of the flat buffer that backward part 1 / part 2 produced (split_backward)."""
+        prefix of the flat buffer that backward part 1 / part 2 produced (split_backward).
+        defer (whole buffer only): leave the sum to a consumer that reads both buffers itself (the fused optimizer tail takes
+        pending_grad_sum()); until then p.grad holds the first pass's share only - a later finish_grads() completes it."""
         st = self._grad_state
+        if defer and part == 0:
+            return
         if st is not None and st[1]:
             n, off = self._flat_grad.numel(), (self.grad_split_offset() if part else 0)
             lo, cnt = (0, n) if part == 0 else ((off, n - off) if part == 1 else (0, off))
             check(lib().udapose_axpy_f32(_hip.stream(), self._flat_grad.data_ptr() + 4 * lo, self._flat_grad2.data_ptr() + 4 * lo, cnt), "axpy")
         if part != 1:
             self._grad_state = None
+
+    def pending_grad_sum(self, take=False):
+        """Byte distance from p.grad's buffer to the second per-pass buffer whose sum is still pending (0: nothing pending)."""
+        st = self._grad_state
+        if st is None or not st[1]:
+            return 0
+        delta = self._flat_grad2.data_ptr() - self._flat_grad.data_ptr()
+        if take:
+            self._grad_state = None
+        return delta
 
     def grad_split_offset(self):
         """Element offset into the flat gradient buffer where backward part 1's gradients start (layer3's first parameter)."""

@@ -215,10 +215,15 @@ class FusedAdam(_FusedBase):
         b1, b2 = group["betas"]
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()
+        if self._scaler is not None and hasattr(student, "finish_grads"):
+            student.finish_grads()              # (the inf / nan check of the loss scaler reads the summed gradients)
         self._pre_sweep(tab, ent)
+        # a pending sum of the two passes' gradient buffers is taken in the sweep itself (no separate axpy over 220 MB)
+        delta = student.pending_grad_sum(take=True) if hasattr(student, "pending_grad_sum") else 0
         check(hd_s.L.udapose_net_fused_update(hd_s.h, hd_t.h, _hip.stream(), pa_s, ga, ma, pa_t, ptr(hd_s.wpack), ptr(hd_t.wpack), float(group["lr"]),
                                               float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(group["step"]),
-                                              float(group.get("grad_scale", 1.0)), ptr(ent[0]), float(ema.alpha), float(1.0 - ema.alpha), 1),
+                                              float(group.get("grad_scale", 1.0)), ptr(ent[0]), float(ema.alpha), float(1.0 - ema.alpha), 1,
+                                              int(delta)),
               "net_fused_update")
         self._post_sweep(ent)
         _bump_versions(ps)
