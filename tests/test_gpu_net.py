@@ -359,3 +359,33 @@ def test_poseresnet101_bf16_forward_backward_256_n2_vs_oracle(gamma3):
         assert err_g <= 1.6 * noise_g + 0.05, (name, err_g, noise_g)
     for key, (ng, eg, cs) in groups.items():
         print(f"  gradients {key:10s} worst rel err: bf16-storage emulation vs fp32 {ng:.3f} | device vs fp32 {eg:.3f} (min cosine {cs:.4f})")
+
+
+def test_stem_fusion_is_bit_identical_to_separate_launches():
+    """Policy stem_fused: BN apply + ReLU + max-pool in one sweep (z of the stem never stored) and the max-pool backward gathered
+    inside the BN backward give exactly the outputs, running statistics and gradients of the separate launches - train mode with
+    backward (odd tie patterns included: ReLU zeros tie inside pool windows), and eval mode."""
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    torch.manual_seed(3)
+    base = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 1, 1], False, False)
+    x = torch.randn(3, 3, 160, 96, generator=torch.Generator().manual_seed(5)).cuda()
+    d = torch.randn(3, 16, 40, 24, generator=torch.Generator().manual_seed(6)).cuda()
+    res = {}
+    for fused in (0, 1):
+        net = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 1, 1], False, False)
+        net.load_state_dict(base.state_dict())
+        net = net.cuda().train()
+        net.policy, net._handles = {"stem_fused": fused}, {}
+        y = net(x)
+        y.backward(d)
+        torch.cuda.synchronize()
+        grads = [p.grad.clone() for p in net.parameters() if p.grad is not None]
+        bufs = [b.clone() for b in net.buffers()]
+        net.eval()
+        with torch.no_grad():
+            ye = net(x)
+        res[fused] = (y.detach().clone(), grads, bufs, ye.clone())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][3], res[1][3])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    assert float(res[1][1][0].abs().sum()) > 0          # (the stem's weight gradient is there)

@@ -30,6 +30,9 @@ int pw_bn_bwd_pre(hipStream_t, const void*, int, const elem_t*, elem_t*, size_t,
                   float*, float*, float, int, int);
 int pw_maxpool3x3s2_fwd(hipStream_t, const elem_t*, elem_t*, unsigned char*, int, int, int, int);
 int pw_maxpool3x3s2_bwd(hipStream_t, const elem_t*, const unsigned char*, elem_t*, int, int, int, int);
+int pw_bn_relu_maxpool3x3s2(hipStream_t, const elem_t*, elem_t*, unsigned char*, int, int, int, int, const float*, const float*);
+int pw_bn_bwd_pooled(hipStream_t, const elem_t*, const unsigned char*, int, int, const elem_t*, elem_t*, size_t, int, const float*, const float*,
+                     const float*, float*, float*, float*, float*, float, const float*);
 int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
 int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
 int pw_bn_running_update_multi(hipStream_t, const BnRunJob*, int, int, const void*, float);
@@ -285,7 +288,7 @@ int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* pa
 }
 
 int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const void* const* params, void* const* buffers, const char* wpack,
-                char* act, char* ws, int training, float momentum, const elem_t* res, int relu, bool upd) {
+                char* act, char* ws, int training, float momentum, const elem_t* res, int relu, bool upd, bool no_apply = false) {
     ConvEpilogue e;
     float* slab = (float*)(ws + n.ws_slab);
     float* scale = (float*)(ws + n.ws_coef);
@@ -297,7 +300,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
-    if (training && !n.f32) {
+    if (training && !n.f32 && !no_apply) {
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
                                            beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
@@ -311,6 +314,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
                           save, save + b.C));
     else
         CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
+    if (no_apply) return UDAPOSE_OK;      // (the caller's next launch applies scale / shift itself: the stem's fused pool)
     if (n.f32)
         return pw_bn_apply_f32(s, (const float*)(act + c.y_off), (const float*)res, (float*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
     return pw_bn_apply(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
@@ -470,8 +474,12 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     char* ws = (char*)ws_;
     if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (elem_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
-    CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1, upd));
-    if (n.f32)
+    const bool stem_fused = n.policy.stem_fused && !n.f32;
+    CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1, upd, stem_fused));
+    if (stem_fused)     // BN apply + ReLU + max-pool in one sweep; z of the stem is never materialised (the backward masks from y)
+        CK(pw_bn_relu_maxpool3x3s2(s, (const elem_t*)(act + n.stem.y_off), (elem_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
+                                   n.Hs, n.Ws, 64, (const float*)(ws + n.ws_coef), (const float*)(ws + n.ws_coef) + 2048));
+    else if (n.f32)
         CK(pw_maxpool3x3s2_fwd_f32(s, (const float*)(act + n.stem_bn.z_off), (float*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
                                    n.Hs, n.Ws, 64));
     else
@@ -846,12 +854,22 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         return UDAPOSE_OK;
     }
     // stem: maxpool -> bn/relu -> conv (no input gradient)
+    if (n.policy.stem_fused && grouped && n.policy.wgrad_group_stem) {
+        // the max-pool backward is gathered inside the BN backward's two sweeps: the full-resolution gradient is never stored
+        const BnL& sb = n.stem_bn;
+        const float* save = (const float*)(act + sb.save_off);
+        CK(pw_bn_bwd_pooled(s, dz, (const unsigned char*)(act + n.poolidx_off), n.Hs, n.Ws, (const elem_t*)(act + n.stem.y_off),
+                            (elem_t*)(ws + n.stem.dy_off), sb.npix, sb.C, (const float*)params[sb.g_idx], save, save + sb.C, (float*)(ws + n.ws_slab),
+                            (float*)(ws + n.ws_coef) + 4096, (float*)grads[sb.g_idx], (float*)grads[sb.b_idx], beta, (const float*)params[sb.b_idx]));
+        pool.put(dz);
+    } else {
     elem_t* dzs = pool.get();
     CK(pw_maxpool3x3s2_bwd(s, dz, (const unsigned char*)(act + n.poolidx_off), dzs, n.N, n.Hs, n.Ws, 64));
     pool.put(dz);
     elem_t* none = nullptr;
     CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 2, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
+    }
     if (grouped && phase == 0) CK(run_wg_group(s, n, act, ws, grads, beta, part));
     // backbone.fc is not part of the forward: zero gradient when overwriting
     if (beta == 0.f && part == 0) {

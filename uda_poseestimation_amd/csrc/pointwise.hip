@@ -294,12 +294,44 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
     for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
 }
 
+// The gradient entering the stem's BatchNorm, gathered on the fly from the gradient of the 3x3 stride-2 max-pool's OUTPUT and the
+// saved winning taps (what maxpool3x3s2_bwd_k would have written: the <= 4 windows that contain the pixel, fp32 sum, rounded to
+// the storage type exactly as that kernel stores it) - the full-resolution gradient tensor (67 MB per pass at 256x256, b=32) is
+// never written or re-read.  pix = flat NHW index of the pool INPUT.
+struct PoolSrc { const elem_t* dy; const unsigned char* idx; int H, W; };
+__device__ __forceinline__ void pool_grad8(const PoolSrc& ps, size_t pix, int C, int c0, float (&d)[8]) {
+    const int w = (int)(pix % ps.W);
+    const size_t r = pix / ps.W;
+    const int h = (int)(r % ps.H);
+    const size_t n = r / ps.H;
+    const int Ho = (ps.H - 1) / 2 + 1, Wo = (ps.W - 1) / 2 + 1;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int ho = h >> 1; ho <= ((h + 1) >> 1); ++ho)
+        for (int wo = w >> 1; wo <= ((w + 1) >> 1); ++wo) {
+            if (ho >= Ho || wo >= Wo) continue;
+            const int kh = h - (ho * 2 - 1), kw = w - (wo * 2 - 1);
+            if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
+            const size_t o = ((n * Ho + ho) * Wo + wo) * C + c0;
+            const unsigned long long pk = *(const unsigned long long*)(ps.idx + o);
+            const elem8 dd = *(const elem8*)(ps.dy + o);
+            const unsigned tap = (unsigned)(kh * 3 + kw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (((pk >> (8 * e)) & 0xFF) == tap) acc[e] += (float)dd[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = (float)(elem_t)acc[e];
+}
+
 // Backward reduce: per-channel sum(g) and sum(g*xhat), g = dz * (z>0) when relu.  Partial slab [blocks][2][C].
 // Requires C/8 to be a power of two <= 256 (thread's channel group is loop-invariant).
-template <typename DZ>
+template <typename DZ, bool POOL = false>
 __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const elem_t* __restrict__ z, const elem_t* __restrict__ y,
                                 size_t npix, int C, const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                float* __restrict__ slab, int pix_per_block, const float* __restrict__ gamma, const float* __restrict__ beta) {
+                                float* __restrict__ slab, int pix_per_block, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                PoolSrc ps = PoolSrc{nullptr, nullptr, 0, 0}) {
     __shared__ float red[TPB][17];
     const int G = C >> 3;
     const int g = threadIdx.x % G, prow = threadIdx.x / G, pstep = TPB / G;
@@ -317,7 +349,8 @@ __global__ void bn_bwd_reduce_k(const DZ* __restrict__ dz, const elem_t* __restr
     for (size_t p = p0 + prow; p < p1; p += pstep) {
         const size_t off = p * C + c0;
         float d[8];
-        load8<DZ>(dz + off, d);
+        if constexpr (POOL) pool_grad8(ps, p, C, c0, d);
+        else load8<DZ>(dz + off, d);
         const elem8 yy = *(const elem8*)(y + off);
         elem8 zz = {};
         if (relu == 1) zz = *(const elem8*)(z + off);
@@ -364,16 +397,17 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_k(const float* __restri
     coef[2 * C + c] = (float)(s2 / count);
 }
 // dy = ca*(g - cb - xhat*cc); optionally also write g (masked dz) for the skip branch
-template <typename DZ>
+template <typename DZ, bool POOL = false>
 __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const elem_t* __restrict__ z, const elem_t* __restrict__ y,
                                elem_t* __restrict__ dy, elem_t* __restrict__ gout, size_t n8, int C, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ coef, int relu, const float* __restrict__ gamma,
-                               const float* __restrict__ beta) {
+                               const float* __restrict__ beta, PoolSrc ps = PoolSrc{nullptr, nullptr, 0, 0}) {
     const int G = C >> 3;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
         const int c0 = (int)(i % G) * 8;
         float d[8];
-        load8<DZ>(dz + i * 8, d);
+        if constexpr (POOL) pool_grad8(ps, i / G, C, c0, d);
+        else load8<DZ>(dz + i * 8, d);
         const elem8 yy = *(const elem8*)(y + i * 8);
         elem8 zz = {};
         if (relu == 1) zz = *(const elem8*)(z + i * 8);
@@ -766,6 +800,52 @@ __global__ void maxpool3x3s2_fwd_k(const T* __restrict__ x, T* __restrict__ y, u
         }
     }
 }
+// The stem's BatchNorm apply + ReLU + 3x3 stride-2 max-pool in ONE sweep: z = relu(y*scale + shift) is formed per tap in registers,
+// rounded to the storage type (so values, ties and winning taps are exactly those of bn_apply_k followed by maxpool3x3s2_fwd_k) and
+// never written: the backward recomputes the ReLU mask from y.  Saves one 67 MB write and one (1.5x amplified) read per pass.
+__global__ void bn_relu_maxpool3x3s2_k(const elem_t* __restrict__ x, elem_t* __restrict__ y, unsigned char* __restrict__ idx, int N, int H, int W,
+                                       int C, int Ho, int Wo, const float* __restrict__ scale, const float* __restrict__ shift) {
+    const int G = C >> 3;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int g = (int)(i % G);
+        size_t r = i / G;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float sc[8], sh[8];
+        load8<float>(scale + g * 8, sc);
+        load8<float>(shift + g * 8, sh);
+        float best[8];
+        unsigned char bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int h = ho * 2 - 1 + kh, w = wo * 2 - 1 + kw;
+                if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                    float v[8];
+                    ld8<elem_t>(x + (((size_t)n * H + h) * W + w) * C + g * 8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float o = v[e] * sc[e] + sh[e];
+                        o = o < 0.f ? 0.f : o;                       // (bn_apply_k's expression and ReLU)
+                        const float f = (float)(elem_t)o;            // ... and its rounding to the storage type
+                        if (first || f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(kh * 3 + kw); }
+                    }
+                    first = false;
+                }
+            }
+        st8<elem_t>(y + i * 8, best);
+        unsigned long long pk = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk |= (unsigned long long)bi[e] << (8 * e);
+        *(unsigned long long*)(idx + i * 8) = pk;
+    }
+}
 // gather-style backward (no atomics): each input pixel checks the <=4 windows that contain it
 __global__ void maxpool3x3s2_bwd_k(const elem_t* __restrict__ dy, const unsigned char* __restrict__ idx, elem_t* __restrict__ dx, int N,
                                    int H, int W, int C, int Ho, int Wo) {
@@ -1103,6 +1183,33 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
 int pw_maxpool3x3s2_fwd(hipStream_t s, const elem_t* x, elem_t* y, unsigned char* idx, int N, int H, int W, int C) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3x3s2_fwd_k<elem_t>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_bn_relu_maxpool3x3s2(hipStream_t s, const elem_t* x, elem_t* y, unsigned char* idx, int N, int H, int W, int C, const float* scale,
+                            const float* shift) {
+    if (C % 8 || !idx) return UDAPOSE_ERR_ARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bn_relu_maxpool3x3s2_k, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo, scale, shift);
+    return udapose_check_launch();
+}
+// BN backward (relu mask recomputed from y) whose incoming gradient is the max-pool backward of (pool_dy, pool_idx), gathered on the
+// fly: reduce -> finalize -> apply; H x W = the pool's input size, npix = N*H*W
+int pw_bn_bwd_pooled(hipStream_t s, const elem_t* pool_dy, const unsigned char* pool_idx, int H, int W, const elem_t* y, elem_t* dy, size_t npix, int C,
+                     const float* gamma, const float* mean, const float* invstd, float* slab, float* coef, float* dgamma, float* dbeta, float beta_acc,
+                     const float* beta) {
+    const int G = C / 8;
+    if (C % 8 || G > 256 || (G & (G - 1)) || !beta || npix % ((size_t)H * W)) return UDAPOSE_ERR_UNSUPPORTED;
+    const PoolSrc ps{pool_dy, pool_idx, H, W};
+    const int pstep = TPB / G;
+    size_t want = (npix + pstep - 1) / pstep;
+    if (want > 1024) want = 1024;
+    const int rows = (int)(want < 1 ? 1 : want);
+    const int ppb = (int)((npix + rows - 1) / rows);
+    hipLaunchKernelGGL((bn_bwd_reduce_k<elem_t, true>), dim3(rows), dim3(TPB), 0, s, (const elem_t*)nullptr, (const elem_t*)nullptr, y, npix, C, mean, invstd,
+                       2, slab, ppb, gamma, beta, ps);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
+    hipLaunchKernelGGL((bn_bwd_apply_k<elem_t, true>), dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const elem_t*)nullptr, (const elem_t*)nullptr, y, dy,
+                       (elem_t*)nullptr, npix * G, C, mean, invstd, coef, 2, gamma, beta, ps);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_fwd_f32(hipStream_t s, const float* x, float* y, unsigned char* idx, int N, int H, int W, int C) {
