@@ -164,6 +164,35 @@ def test_network_forward_backward_fp16_vs_oracle():
     print("fp16 network: worst gradient cosine vs fp32 autograd", worst)
 
 
+def test_poseresnet101_fp16_vs_bf16_heatmap_error_on_the_conditioned_benched_network():
+    """VERDICT r1 #2(d), measured: the benched network (PoseResNet-101, K=16, 256x256, train-mode BN, trained-like conditioning
+    bn3.gamma = 0.1 as in tests/test_gpu_net.py) in fp16 - the reference's own autocast dtype, 1927 img/s on configs[1] - and in
+    bf16 against the fp32 CPU oracle.  fp16 is ~7x closer (10 mantissa bits against 7: 1.7e-2 against 1.2e-1 on heat-maps of
+    maximum 2.8, i.e. 6e-3 against 4e-2 relative) but NO 16-bit storage meets north_star's 1e-3 through 33 train-mode-BN
+    bottlenecks of a randomly initialised network; the fp32 mode does (test_gpu_net.py, 3.5e-5).  Arg-max key points agree
+    wherever the fp32 peak margin exceeds the error."""
+    from test_gpu_net import _pair
+    ref, net = _pair((3, 4, 23, 3), 16, seed=3, gamma3=0.1)
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(11)).clamp(-2.1, 2.6)
+    ref.train(); net.train()
+    with torch.no_grad():
+        y_ref = ref(x)
+        net.precision = "fp16"
+        y16 = net(x.cuda()).cpu()
+        net.precision = "bf16"
+        ybf = net(x.cuda()).cpu()
+    scale = y_ref.abs().max().item()
+    e16, ebf = (y16 - y_ref).abs().max().item(), (ybf - y_ref).abs().max().item()
+    print(f"R101 256x256 bn3.gamma=0.1: max|y|={scale:.4f}  |fp16 - fp32 oracle|={e16:.3e}  |bf16 - fp32 oracle|={ebf:.3e}")
+    assert e16 <= 1e-2 * scale, (e16, scale)
+    assert e16 < 0.25 * ebf
+    fr, f16 = y_ref.reshape(32, -1), y16.reshape(32, -1)
+    top2 = fr.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * e16
+    assert torch.equal(fr.argmax(1)[clear], f16.argmax(1)[clear])
+    print(f"  fp16 arg-max identical on {int((fr.argmax(1) == f16.argmax(1)).sum())}/32 rows ({int(clear.sum())} with a clear fp32 margin)")
+
+
 def test_fp16_training_step_with_device_side_loss_scaling():
     """MeanTeacherTrainer(precision='fp16'): GradScaler semantics on the device.  (1) a step matches the fp32 oracle step;
     (2) an overflowing gradient (inf) skips the Adam step - parameters AND step counter untouched, EMA still runs
