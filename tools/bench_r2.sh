@@ -2,7 +2,8 @@
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 3 > gpurun_out/r2_bench_steps20.json 2> gpurun_out/r2_bench_steps20.err; echo "steps20 rc=$?"
 python3 bench.py > gpurun_out/r2_bench_default.json 2> gpurun_out/r2_bench_default.err; echo "default rc=$?"
-python3 bench.py --config2 --steps 20 --no-cpu-baseline > gpurun_out/r2_bench_config2.json 2>/dev/null; echo "config2 rc=$?"
+python3 bench.py --config2 --steps 20 --no-cpu-baseline > gpurun_out/r2_bench_config2_captured.json 2>/dev/null; echo "config2 captured rc=$?"
+python3 bench.py --config2 --eager --steps 20 --no-cpu-baseline > gpurun_out/r2_bench_config2.json 2>/dev/null; echo "config2 eager rc=$?"
 python3 bench.py --image-size 384 --keypoints 18 --sigma 1.0 --dtype fp16 --steps 40 --no-cpu-baseline > gpurun_out/r2_bench_config4_fp16.json 2>/dev/null; echo "config4 fp16 rc=$?"
 python3 bench.py --image-size 384 --keypoints 18 --sigma 1.0 --dtype bf16 --steps 40 --no-cpu-baseline > gpurun_out/r2_bench_config4_bf16.json 2>/dev/null; echo "config4 bf16 rc=$?"
 python3 bench.py --dtype fp16 --steps 60 --no-cpu-baseline > gpurun_out/r2_bench_config1_fp16.json 2>/dev/null; echo "config1 fp16 rc=$?"
