@@ -149,6 +149,7 @@ def main():
                     "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
     ap.add_argument("--wgrad-side", action="store_true", help="tuning: the upper part's weight gradients on a side stream under the lower "
                     "part's gradient chain instead of after the whole chain (measured slower: profiles/r2_ab_runs.txt)")
+    ap.add_argument("--stream-priority", type=int, default=0, help="tuning: priority of the three branch streams (-1 = high; side streams stay 0)")
     ap.add_argument("--no-sum-in-tail", action="store_true", help="tuning: a separate launch adds the two passes' gradient buffers")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -248,6 +249,7 @@ def main():
                                  heatmap_size=S // 4, precision=args.dtype, **extra)
     if args.no_fuse_tail:
         trainer.fuse_tail = False
+    trainer.stream_priority = args.stream_priority
     if args.no_sum_in_tail:
         trainer.sum_grads_in_tail = False
     # configs[2] captured: the occlusion decisions are taken on the device (four uniform draws per sample, no read-back);

@@ -136,6 +136,7 @@ class MeanTeacherTrainer:
         # (None: whenever a process group is active and the network has the layer3 boundary)
         self.overlap_allreduce = None
         self.fuse_tail = True               # Adam + EMA + weight packs in one sweep (optim.FusedAdam.fused_tail_step)
+        self.stream_priority = 0            # priority of the branch streams (and of a captured step's origin stream): -1 = high
         self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
 
@@ -232,7 +233,8 @@ class MeanTeacherTrainer:
         # target-domain forward are applied after the join, in the reference's call order (x_s first, then x_t_stu).
         main = torch.cuda.current_stream()
         if self._side is None or self._side[0].device != x_s.device:
-            self._side = (torch.cuda.Stream(device=x_s.device), torch.cuda.Stream(device=x_s.device))
+            pr = self.stream_priority
+            self._side = (torch.cuda.Stream(device=x_s.device, priority=pr), torch.cuda.Stream(device=x_s.device, priority=pr))
         s_tea, s_stu = self._side if self.concurrent else (main, main)
         occl = self._occl if self.occlude_rate > -1 else None
         student.prepare(x_s)                # bf16 weight packs refreshed on `main` before the branches fork
@@ -439,6 +441,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         self.g_style = {}
+        self._cap = {"stream": torch.cuda.Stream(device=dev, priority=trainer.stream_priority)} if trainer.stream_priority else {}
         with torch.cuda.stream(side):
             if self.styled:             # (the style net's plans and packs; no model state involved)
                 self._style_pass("s2t")
@@ -476,30 +479,30 @@ class GraphedTrainStep:
         self.overlap = trainer._overlap()
         self.g_lb2 = None
         if not self.split:
-            with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
                 self.out = trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
                                                      st["theta_stu"], [st["theta_tea"]])
                 if trainer.student._pending_lower:      # (overlap forced on one rank: both backward parts in the one graph)
                     trainer._backward_lower()
         else:
             self.g_lb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb, capture_error_mode=mode):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
                 self.fwd_state = trainer._forward_part(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
                                                        st["theta_stu"], [st["theta_tea"]])
             g0 = gather_activates(self.fwd_state["activates"])
             self.gathered = g0.clone() if g0 is not None else self.fwd_state["activates"].reshape(-1).clone()
-            with torch.cuda.graph(self.g_lb, pool=self.g_fb.pool(), capture_error_mode=mode):
+            with torch.cuda.graph(self.g_lb, pool=self.g_fb.pool(), capture_error_mode=mode, **self._cap):
                 self.out = trainer._loss_backward_part(self.fwd_state, self.gathered)
             if self.overlap:
                 trainer.sync.start_upper()
                 self.g_lb2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_lb2, pool=self.g_fb.pool(), capture_error_mode=mode):
+                with torch.cuda.graph(self.g_lb2, pool=self.g_fb.pool(), capture_error_mode=mode, **self._cap):
                     trainer._backward_lower()
         if self.g_lb2 is not None:
             trainer.sync.finish()
         else:
             trainer.sync()
-        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode):
+        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode, **self._cap):
             trainer._update()
         for m in (trainer.student, trainer.teacher):
             m._capture_token = None
