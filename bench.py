@@ -149,6 +149,9 @@ def main():
                     "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
     ap.add_argument("--wgrad-side", action="store_true", help="tuning: the upper part's weight gradients on a side stream under the lower "
                     "part's gradient chain instead of after the whole chain (measured slower: profiles/r2_ab_runs.txt)")
+    ap.add_argument("--two-graphs", action="store_true", help="tuning: the optimizer tail as its own graph on one rank too")
+    ap.add_argument("--force-overlap", action="store_true", help="tuning: the data-parallel backward (two parts, gradient sums per part) without a "
+                    "process group: isolates what the cut costs on one rank")
     ap.add_argument("--stream-priority", type=int, default=0, help="tuning: priority of the three branch streams (-1 = high; side streams stay 0)")
     ap.add_argument("--no-sum-in-tail", action="store_true", help="tuning: a separate launch adds the two passes' gradient buffers")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
@@ -250,6 +253,10 @@ def main():
     if args.no_fuse_tail:
         trainer.fuse_tail = False
     trainer.stream_priority = args.stream_priority
+    if args.two_graphs:
+        trainer.single_graph = False
+    if args.force_overlap:
+        trainer.overlap_allreduce = True
     if args.no_sum_in_tail:
         trainer.sum_grads_in_tail = False
     # configs[2] captured: the occlusion decisions are taken on the device (four uniform draws per sample, no read-back);
@@ -273,6 +280,10 @@ def main():
 
         def step():
             if host is None:
+                if os.environ.get("UDAPOSE_EXP_NO_THETA") == "1":
+                    return graphed.step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], None, None)
+                if os.environ.get("UDAPOSE_EXP_NO_THETA") == "2":
+                    return graphed.step()
                 return graphed.step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
             # host batches: this step consumes the batch staged during the previous one, and the next batch's H2D copies
             # are started on the copy stream so that they run under this step's replay
@@ -353,7 +364,7 @@ def main():
                                                     (f", K={K}, {args.dtype} (BASELINE.json configs[4] shape and dtype on one GPU; NOT the metric)"
                                                      if (S, K, args.arch, args.dtype) == (384, 18, "pose_resnet101", "fp16") else f", K={K}, {args.dtype}"))),
                        "global_batch": world * N, "parallelism": f"dp{world}"},
-            "loss": loss, "launch": "eager" if args.eager else ("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else "2 hipGraphs") + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
+            "loss": loss, "launch": "eager" if args.eager else ("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else ("1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs")) + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,

@@ -569,7 +569,7 @@ def test_one_rank_rccl_step():
         lines = [l for l in out.stdout.splitlines() if l.strip()]
         assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]     # ONE JSON line, RCCL's banner goes to stderr
         res[tag] = json.loads(lines[0])
-    assert "4 hipGraphs" in res["rccl"]["launch"] and "2 hipGraphs" in res["plain"]["launch"]
+    assert "4 hipGraphs" in res["rccl"]["launch"] and "1 hipGraph" in res["plain"]["launch"]
     assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
     assert res["rccl"]["rccl_ranks"] == 1 and res["plain"]["rccl_ranks"] == 0
     a, b = res["rccl"]["loss"], res["plain"]["loss"]

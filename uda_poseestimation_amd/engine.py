@@ -137,6 +137,7 @@ class MeanTeacherTrainer:
         self.overlap_allreduce = None
         self.fuse_tail = True               # Adam + EMA + weight packs in one sweep (optim.FusedAdam.fused_tail_step)
         self.stream_priority = 0            # priority of the branch streams (and of a captured step's origin stream): -1 = high
+        self.single_graph = True            # one rank: the optimizer tail is captured into the step's graph (one launch per step)
         self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
 
@@ -398,8 +399,8 @@ def validate(batches, model, criterion=None):
 
 
 class GraphedTrainStep:
-    """The mean-teacher step captured into two hipGraphs (forward/backward, then Adam+EMA) around the eager gradient
-    all-reduce: ~2500 kernel launches per step are replayed by two graph launches, which removes the host launch gaps.
+    """The mean-teacher step captured into hipGraphs: ~1300 kernel launches per step are replayed by ONE graph launch on one
+    rank (forwards, losses, backward, Adam + EMA + packs), which removes the host launch gaps.
     Data parallel: four graphs - forwards | losses + backward part 1 | backward part 2 | Adam + EMA - with the confidence
     all-gather after the first, the all-reduce of the finished gradient suffix launched after the second (it runs on the
     communicator's stream under the third) and the small prefix all-reduce after the third.
@@ -478,12 +479,17 @@ class GraphedTrainStep:
         # the communicator's stream while the second segment replays
         self.overlap = trainer._overlap()
         self.g_lb2 = None
+        # one rank, nothing eager between backward and the optimizer: the update is captured into the same graph (one launch per step)
+        self.one_graph = (not self.split) and (not _dist_on()) and trainer.single_graph
         if not self.split:
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
                 self.out = trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
                                                      st["theta_stu"], [st["theta_tea"]])
                 if trainer.student._pending_lower:      # (overlap forced on one rank: both backward parts in the one graph)
                     trainer._backward_lower()
+                if self.one_graph:
+                    trainer._sync_grads()
+                    trainer._update()
         else:
             self.g_lb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
@@ -498,12 +504,15 @@ class GraphedTrainStep:
                 self.g_lb2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_lb2, pool=self.g_fb.pool(), capture_error_mode=mode, **self._cap):
                     trainer._backward_lower()
-        if self.g_lb2 is not None:
-            trainer.sync.finish()
+        if self.one_graph:
+            self.g_up = None
         else:
-            trainer.sync()
-        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode, **self._cap):
-            trainer._update()
+            if self.g_lb2 is not None:
+                trainer.sync.finish()
+            else:
+                trainer.sync()
+            with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode, **self._cap):
+                trainer._update()
         for m in (trainer.student, trainer.teacher):
             m._capture_token = None
             m.weights_changed()
@@ -600,6 +609,8 @@ class GraphedTrainStep:
                     with torch.enable_grad() if bwd else torch.no_grad():
                         m.prepare(self.static["x_s"])
         self._draw_and_style()
+        if self.one_graph:
+            self.t.stu_optimizer.sync_hyper()    # lr scheduler / loss scale -> device state read by the captured sweep
         self.g_fb.replay()
         if self.split:
             g = gather_activates(self.fwd_state["activates"])
@@ -611,8 +622,9 @@ class GraphedTrainStep:
             self.t.sync.finish()
         else:
             self.t.sync()
-        self.t.stu_optimizer.sync_hyper()        # lr scheduler / loss scale -> device state read by the captured sweep
-        self.g_up.replay()
+        if not self.one_graph:
+            self.t.stu_optimizer.sync_hyper()    # lr scheduler / loss scale -> device state read by the captured sweep
+            self.g_up.replay()
         # the replayed Adam / EMA kernels changed both networks' parameters behind torch's back: every executor plan (other
         # batch sizes, validate(), fp32 mode) must re-pack its bf16 weights before its next forward
         self.t.student.weights_changed()
