@@ -280,10 +280,6 @@ def main():
 
         def step():
             if host is None:
-                if os.environ.get("UDAPOSE_EXP_NO_THETA") == "1":
-                    return graphed.step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], None, None)
-                if os.environ.get("UDAPOSE_EXP_NO_THETA") == "2":
-                    return graphed.step()
                 return graphed.step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
             # host batches: this step consumes the batch staged during the previous one, and the next batch's H2D copies
             # are started on the copy stream so that they run under this step's replay
