@@ -25,6 +25,7 @@ struct Policy {
     int bn_fwd_chunked = 1;     // BN forward: finalize + apply in one channel-chunked launch where it pays
     int bn_bwd_chunked = 1;     // BN backward: channel-chunked forms without a finalize launch
     int bn_bwd_pre_legacy = 0;  // BN backward from pre-reduced sums through the generic apply kernel (A/B)
+    int igemm_wg_min = 512;     // 128x64 tiles as soon as they give this many work-groups (else 64x64): 2 per CU measured best in-step
     int stem_fused = 1;         // stem: BN apply + ReLU + max-pool in one sweep, max-pool backward gathered inside the BN backward (0: separate launches)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null

@@ -908,7 +908,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
     // variant (tile 12, W <= 16) is faster alone (layer3 18.5 us, layer4 22.7) but its 77 KB of LDS leave room for two work-groups
     // per CU, and inside the three-stream step that costs more than it gains (+0.13 ms per step against tile 10's -0.15 ms): the
     // other streams' kernels need the residency.  It stays selectable (mode 4) for single-stream use.
-    if (h3_ok && h3 == 1) { if (b12864 < 512) return 10; if (h3_ok >= 2) return 11; }
+    if (h3_ok && h3 == 1) { if (b12864 < pol.igemm_wg_min) return 10; if (h3_ok >= 2) return 11; }
     if (h3_ok && h3 == 2) return 10;
     if (h3_ok && h3 == 4) return 12;                  // (row-grouped 64-row form; falls back inside igemm_launch when W > 16)
     if (h3_ok >= 2 && h3 == 3) return 11;              // (h3_ok >= 2: W <= 32, the 128-row form fits; 3: W <= 16)
@@ -917,7 +917,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
     // they give two work-groups per CU, else 64x64 with a 3-stage ring for long K and a 2-stage ring otherwise.  Every
     // choice lands on THREE resident work-groups per CU (48 KB of LDS each): deeper rings (4 stages = 2 per CU) and one deep
     // 128x64 work-group per CU both measured slower - overlapping the fixed phases of several work-groups beats prefetch depth.
-    if (b12864 >= 512) return 6;
+    if (b12864 >= pol.igemm_wg_min) return 6;
     return K >= 1024 ? 9 : 5;
 }
 
