@@ -59,6 +59,7 @@ typedef struct {
     int wgrad_group, wgrad_stages, wgrad_group_stem;
     int bn_bwd_fused, bn_fwd_chunked, bn_bwd_chunked, bn_bwd_pre_legacy;
     int igemm_wg_min;
+    int bn3_mask;
     int stem_fused;
     int debug_sync;
     void* timeline;

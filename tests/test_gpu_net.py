@@ -389,3 +389,29 @@ def test_stem_fusion_is_bit_identical_to_separate_launches():
     assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
     assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
     assert float(res[1][1][0].abs().sum()) > 0          # (the stem's weight gradient is there)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_relu_bit_mask_of_block_outputs_is_bit_identical_to_reading_z(precision):
+    """Policy bn3_mask: every block's BN3 + residual + ReLU apply also saves one bit per element (stored z > 0), and the data gradients
+    that mask for that BatchNorm read the byte mask instead of z (1/16 of the bytes).  Same outputs, same gradients, bit for bit -
+    including fp16, where small positive values underflow to a stored 0 (the bit follows the STORED value)."""
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    torch.manual_seed(4)
+    base = pr._pose_resnet("t", 16, pr.Bottleneck_default, [2, 1, 2, 1], False, False)
+    x = torch.randn(3, 3, 128, 160, generator=torch.Generator().manual_seed(5)).cuda()
+    d = torch.randn(3, 16, 32, 40, generator=torch.Generator().manual_seed(6)).cuda() * (1e-4 if precision == "fp16" else 1.0)
+    res = {}
+    for on in (0, 1):
+        net = pr._pose_resnet("t", 16, pr.Bottleneck_default, [2, 1, 2, 1], False, False)
+        net.load_state_dict(base.state_dict())
+        net = net.cuda().train()
+        net.precision = precision
+        net.policy, net._handles = {"bn3_mask": on}, {}
+        y = net(x)
+        y.backward(d)
+        torch.cuda.synchronize()
+        res[on] = (y.detach().clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None])
+    assert torch.equal(res[0][0], res[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+    assert all(torch.isfinite(g_).all() for g_ in res[1][1]) and float(res[1][1][0].abs().sum()) > 0

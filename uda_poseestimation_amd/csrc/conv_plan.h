@@ -26,6 +26,7 @@ struct Policy {
     int bn_bwd_chunked = 1;     // BN backward: channel-chunked forms without a finalize launch
     int bn_bwd_pre_legacy = 0;  // BN backward from pre-reduced sums through the generic apply kernel (A/B)
     int igemm_wg_min = 512;     // 128x64 tiles as soon as they give this many work-groups (else 64x64): 2 per CU measured best in-step
+    int bn3_mask = 1;           // block outputs: the forward saves the ReLU bit mask, the data gradients read it instead of z (0: read z)
     int stem_fused = 1;         // stem: BN apply + ReLU + max-pool in one sweep, max-pool backward gathered inside the BN backward (0: separate launches)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null
@@ -103,6 +104,7 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* 
 struct DgradBnStat {
     const elem_t* y = nullptr;      // the BN's input (pre-BN conv output)
     const elem_t* z = nullptr;      // mask source (BN + residual + ReLU output) or null: mask recomputed from y
+    const unsigned char* mask = nullptr;   // ... or the ReLU bit mask the forward saved (bit e of byte i: channel 8i+e of the flat NHWC tensor is > 0): 1/16 of z's bytes
     const float* mean = nullptr; const float* invstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
     float* slab = nullptr;
     int rows = 0;

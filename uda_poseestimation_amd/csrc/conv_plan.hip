@@ -175,10 +175,11 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const elem_t* dy, const elem_t*
     p.flags = (out_f32 ? IG_FLAG_OUT_F32 : 0) | ((!g.transposed && g.stride == 1) ? IG_FLAG_MIRROR : 0);   // (stride-1 data gradient: mirrored taps)
     const int tile = igemm_pick_tile(p.M, p.Co, p.nclass, p.cls[0].ntaps * p.Ci, conv_h3_ok(g), g.policy());
     if (bs) {
-        p.bs_y = bs->y; p.bs_z = bs->z; p.bs_mean = bs->mean; p.bs_invstd = bs->invstd; p.bs_gamma = bs->gamma; p.bs_beta = bs->beta;
+        p.bs_y = bs->y; p.bs_z = bs->mask ? (const elem_t*)bs->mask : bs->z; p.bs_mean = bs->mean; p.bs_invstd = bs->invstd; p.bs_gamma = bs->gamma; p.bs_beta = bs->beta;
+        if (bs->mask) p.flags |= IG_FLAG_BSMASK;
         p.stats = bs->slab;
         bs->rows = igemm_stat_rows(p.M, p.Co, p.nclass, tile);
-        if (!bs->y || !bs->slab || !bs->mean || !bs->invstd || (!bs->z && (!bs->gamma || !bs->beta))) return UDAPOSE_ERR_ARG;
+        if (!bs->y || !bs->slab || !bs->mean || !bs->invstd || (!bs->z && !bs->mask && (!bs->gamma || !bs->beta))) return UDAPOSE_ERR_ARG;
     }
     const int tok = prof_before(s, 1, alg_flops(g));
     const int rc = igemm_launch(p, tile, s, g.policy());

@@ -14,6 +14,7 @@ struct IgClass { int tap_off, ntaps, oa, ob; };
 #define IG_FLAG_F32 128      // x, w, res and y are fp32 (exact fp32 MFMA path, forward only)
 #define IG_FLAG_MIRROR 2048   // 3x3 run-staged form: taps are the mirrored ones of a data gradient (dy, dx) = (1 - kh, 1 - kw)
 #define IG_FLAG_TAP0 1024     // every class has at most the one tap (dy, dx, widx) = (0, 0, 0): no tap-table read
+#define IG_FLAG_BSMASK 32     // bs_z points at the consumer BN's saved ReLU bit mask (one byte per 8 channels) instead of its output z
 #define IG_FLAG_SMALLC 16     // Ci == 8: one 32-wide K step covers 4 taps (stem / first VGG conv)
 
 struct IgParams {

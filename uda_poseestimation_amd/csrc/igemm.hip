@@ -653,12 +653,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
         // (the generic loop loads the residual, waits, loads y and z, waits: 8 exposed HBM latencies per 128-row tile, and these
         // launches are HBM-bound: layer1's 64->256 data gradient moves 285 MB)
         constexpr int NP = ER / RPP;
-        const bool use_z = p.bs_z != nullptr, use_res = p.res != nullptr;
+        const bool use_mask = (p.flags & IG_FLAG_BSMASK) != 0;      // the saved ReLU bit mask (1 byte per 8 channels) instead of z
+        const bool use_z = p.bs_z != nullptr && !use_mask, use_res = p.res != nullptr;
+        const unsigned char* const bs_mask = (const unsigned char*)p.bs_z;
 #pragma unroll
         for (int ch = 0; ch < TM / ER; ++ch) {
             size_t offs[NP];
             bool oks[NP];
             elem8 yv[NP], zv[NP], rv[NP];
+            unsigned mv[NP];
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
                 const int m = m0 + wm * TM + ch * ER + ps * RPP + rsub;
@@ -676,8 +679,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
                 oks[ps] = ok;
                 offs[ps] = ok ? opix * p.Co + cbase : 0;
                 yv[ps] = elem8{}; zv[ps] = elem8{}; rv[ps] = elem8{};
+                mv[ps] = 0u;
                 if (ok) {
                     yv[ps] = *(const elem8*)(p.bs_y + offs[ps]);
+                    if (use_mask) mv[ps] = bs_mask[offs[ps] >> 3];
                     if (use_z) zv[ps] = *(const elem8*)(p.bs_z + offs[ps]);
                     if (use_res) rv[ps] = *(const elem8*)(p.res + offs[ps]);
                 }
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
                         const float yf = (float)yv[ps][e];
                         const float val = v[e] + (float)rv[ps][e];             // (rv is zero without a skip gradient)
                         const float ty = yf * bsc[e] + bsh[e];
-                        const float t = use_z ? (float)zv[ps][e] : ty;
+                        const float t = use_mask ? (float)((mv[ps] >> e) & 1u) : (use_z ? (float)zv[ps][e] : ty);
                         float gv = t > 0.f ? val : 0.f;
                         if (!outf32) gv = (float)(elem_t)gv;                    // the sums see exactly the value the BN apply kernel will read
                         bs1[e] += gv;

@@ -22,7 +22,7 @@ int pw_unpack_strided(hipStream_t, const float*, float*, int, int, int, int, int
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
                    float*, float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
-int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int);
+int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int, unsigned char*);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
               float*, float*, float*, float*, float, const float*, int);
@@ -37,7 +37,7 @@ int pw_plane_sum(hipStream_t, const float*, float*, int, int, int, float);
 int pw_bn_running_update(hipStream_t, const float*, int, float*, float*, long long*, float);
 int pw_bn_running_update_multi(hipStream_t, const BnRunJob*, int, int, const void*, float);
 int pw_bn_train_fused(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, int, const float*, const float*, float*, float*,
-                      long long*, float, float, float*, int, int);
+                      long long*, float, float, float*, int, int, unsigned char*);
 int pw_zero_multi(hipStream_t, const ZeroJob*, int, void*);
 int pw_pack_multi(hipStream_t, const void*, const int*, const int*, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
@@ -77,6 +77,7 @@ struct BnL {
     int rm_idx = -1, rv_idx = -1, nbt_idx = -1;   // buffer indices
     size_t save_off = 0;    // fp32 [3][C] saved mean / invstd / unbiased var in the arena
     size_t z_off = 0;       // post-BN(-ReLU) output
+    size_t mask_off = 0;    // bn3 of a block: ReLU bit mask of z (one byte per 8 channels), what the data gradients read instead of z
     size_t npix = 0;
 };
 struct Block {
@@ -193,6 +194,7 @@ Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
             add_bn(n, b.b2, P, (size_t)N * Ho * Wo);
             add_conv(n, b.c3, Ho, Wo, P, P * 4, 1, 1, 0, 0, b.b2.z_off, true);
             add_bn(n, b.b3, P * 4, (size_t)N * Ho * Wo);
+            if (!n.f32) b.b3.mask_off = act_alloc(n, (size_t)N * Ho * Wo * (P * 4) / 8);
             if (b.has_ds) {
                 add_conv(n, b.cd, Hc, Wc, Cc, P * 4, 1, stride, 0, 0, cur, true);
                 add_bn(n, b.bd, P * 4, (size_t)N * Ho * Wo);
@@ -296,6 +298,8 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     float* save = (float*)(act + b.save_off);
     e.stats = training ? slab : nullptr;
     e.f32 = n.f32;
+    // block outputs: the apply also saves the ReLU bit mask of z (1/16 of z's bytes) for the data gradients that mask with it
+    unsigned char* mask = (b.mask_off && n.policy.bn3_mask && relu) ? (unsigned char*)(act + b.mask_off) : nullptr;
     const void* wptr = (n.f32 && !c.g.smallc() && !c.g.transposed) ? params[c.w_idx] : (const void*)(wpack + c.wf_off);
     CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
@@ -304,7 +308,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
                                            beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
-                                           upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked);
+                                           upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked, mask);
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }
@@ -317,7 +321,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     if (no_apply) return UDAPOSE_OK;      // (the caller's next launch applies scale / shift itself: the stem's fused pool)
     if (n.f32)
         return pw_bn_apply_f32(s, (const float*)(act + c.y_off), (const float*)res, (float*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
-    return pw_bn_apply(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
+    return pw_bn_apply(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu, mask);
 }
 
 }  // namespace
@@ -550,6 +554,7 @@ DgradBnStat bn_stat_of(const Net& n, const ConvL& c, const BnL& b, const void* c
     const float* save = (const float*)(act + b.save_off);
     st.y = (const elem_t*)(act + c.y_off);
     st.z = relu == 1 ? (const elem_t*)(act + b.z_off) : nullptr;
+    st.mask = (relu == 1 && b.mask_off && n.policy.bn3_mask) ? (const unsigned char*)(act + b.mask_off) : nullptr;
     st.mean = save; st.invstd = save + b.C;
     st.gamma = (const float*)params[b.g_idx]; st.beta = (const float*)params[b.b_idx];
     st.slab = (float*)(ws + n.ws_slabf);

@@ -255,7 +255,7 @@ __global__ void bn_eval_coeff_k(int C, const float* __restrict__ gamma, const fl
 // z = [relu]( y*scale[c] + shift[c] [+ res] ), NHWC (bf16 or fp32 storage), 8 channels per thread
 template <typename T>
 __global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, size_t n8, int C,
-                           const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+                           const float* __restrict__ scale, const float* __restrict__ shift, int relu, unsigned char* __restrict__ mask = nullptr) {
     const int G = C >> 3;
     // the launcher keeps gridDim.x * TPB a multiple of G (G is a power of two <= TPB, or the grid is one block per G-aligned
     // stride), so a thread's channel group never changes: its coefficients are loaded once
@@ -277,6 +277,12 @@ __global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (relu && o[e] < 0.f) ? 0.f : o[e];
         st8<T>(z + i * 8, o);
+        if (mask) {     // bit e: the STORED value of channel e is > 0 (what a reader of z would see)
+            unsigned mb = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mb |= ((float)(T)o[e] > 0.f ? 1u : 0u) << e;
+            mask[i] = (unsigned char)mb;
+        }
     }
 }
 
@@ -452,7 +458,8 @@ __global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const elem_t* __restrict
                                                         size_t npix, int C, const float* __restrict__ slab, int rows, double count,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                        long long* __restrict__ nbt, float* __restrict__ save, int relu, int P) {
+                                                        long long* __restrict__ nbt, float* __restrict__ save, int relu, int P,
+                                                        unsigned char* __restrict__ mask) {
     __shared__ double part[8][128];
     __shared__ float scs[64], shs[64];
     const int chunk = blockIdx.x, sp = blockIdx.y;
@@ -524,6 +531,12 @@ __global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const elem_t* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (relu && o[e] < 0.f) ? 0.f : o[e];
         st8<elem_t>(z + off, o);
+        if (mask) {
+            unsigned mb = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mb |= ((float)(elem_t)o[e] > 0.f ? 1u : 0u) << e;
+            mask[off >> 3] = (unsigned char)mb;
+        }
     }
 }
 
@@ -1011,7 +1024,7 @@ int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double cou
 // pw_bn_finalize + pw_bn_apply, < 0 on error
 int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, size_t npix, int C, const float* slab, int rows,
                       const float* gamma, const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* save,
-                      int relu, int enabled) {
+                      int relu, int enabled, unsigned char* mask) {
     // layer3 / layer4 / the first deconv (<= 8 K pixels, <= 128 slab rows): measured -0.1 ms per step; with the 32 K-pixel
     // layers included the 128-byte row segments of the chunked layout cost what the saved launches gain
     // (enabled: Policy::bn_fwd_chunked)
@@ -1024,7 +1037,7 @@ int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t*
     P = (P + 31) & ~31;
     S = (int)((npix + P - 1) / P);
     hipLaunchKernelGGL(bn_apply_chunk_k, dim3(chunks, S), dim3(TPB), 0, s, y, res, z, npix, C, slab, rows, (double)npix, gamma, beta, eps, momentum, rm,
-                       rv, nbt, save, relu, P);
+                       rv, nbt, save, relu, P, mask);
     return udapose_check_launch() == UDAPOSE_OK ? 1 : UDAPOSE_ERR_LAUNCH;
 }
 // the same for every BN layer of a net in one launch: jobs[blockIdx.x], channels blockIdx.y*TPB..; save = act + save_off
@@ -1078,14 +1091,15 @@ static int bn_apply_grid(size_t n8, int C) {
     }
     return g;
 }
-int pw_bn_apply(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, size_t n, int C, const float* scale, const float* shift, int relu) {
+int pw_bn_apply(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, size_t n, int C, const float* scale, const float* shift, int relu,
+                unsigned char* mask) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(bn_apply_k<elem_t>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    hipLaunchKernelGGL(bn_apply_k<elem_t>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu, mask);
     return udapose_check_launch();
 }
 int pw_bn_apply_f32(hipStream_t s, const float* y, const float* res, float* z, size_t n, int C, const float* scale, const float* shift, int relu) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(bn_apply_k<float>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu);
+    hipLaunchKernelGGL(bn_apply_k<float>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu, (unsigned char*)nullptr);
     return udapose_check_launch();
 }
 int pw_bn_bwd_rows(size_t npix) {
