@@ -907,7 +907,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
     if (pol.igemm_tile >= 0) return pol.igemm_tile;
     const int h3 = pol.igemm_h3;
     const long b12864 = (long)((M + 127) / 128) * ((Co + 63) / 64) * nclass;
-    // run-staged 3x3 form (measured per shape at N = 32, tools/time_shapes.py): 64-row tiles where the tap-staged form would take
+    // run-staged 3x3 form (measured per shape at N = 32, a round-1 per-shape timing script): 64-row tiles where the tap-staged form would take
     // 64x64 (layer3: 21.0 vs 21.9 us, layer4: 27.3 vs 27.9), 128-row tiles where it would take 128x64 and the run fits (layer2:
     // 20.7 vs 22.1); layer1 (W = 64: a 194-row run per 64 output rows) stays tap-staged (27.6 vs 35.0).  The three-taps-per-barrier
     // variant (tile 12, W <= 16) is faster alone (layer3 18.5 us, layer4 22.7) but its 77 KB of LDS leave room for two work-groups

@@ -378,7 +378,7 @@ class PoseResNet(nn.Module):
                 act.record_stream(stream)
                 ws.record_stream(stream)
         # The side streams join the CALLER's stream, not the stream they forked from: inside a stream capture on this ROCm a
-        # stream that waits back on its own fork (a -> b -> a) brings hipStreamEndCapture down (tools/_t_cap.py patterns Q1 / Q5),
+        # stream that waits back on its own fork (a -> b -> a) brings hipStreamEndCapture down (tools/capture_fork_patterns.py patterns Q1 / Q5),
         # while joining the fork into the capture's origin stream is fine (Q2 / Q6).  The caller sums the gradients on this stream.
         here = torch.cuda.current_stream()
         for stream, sd in joins:
