@@ -381,8 +381,10 @@ def main():
                                            "peak_TBps": 8.0, "note": "whole-step HBM traffic of the conv / BN / weight-gradient kernels (PMC passes under "
                                            "profiles/) over this run's step time: the step is bound by bytes and by latency-bound launch chains, "
                                            "not by the MFMA pipes"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # (the CPU leg runs on rank 0 of the ONE-rank run only; N > 1 lines carry null)
             res["cpu_baseline"] = cpu_baseline(args.cpu_images, layers)
+        elif world > 1:
+            res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
