@@ -291,9 +291,20 @@ def main():
 
     # Device spin-up (untimed, before the W warm-up steps): an idle MI355X needs ~2-3 s of sustained load to reach its
     # steady clocks (measured: 770 img/s in a cold first run vs 970 img/s after 2.5 s of load, same binary, same box).
+    # Every rank must run the SAME number of spin-up steps (each step issues collectives): the stop decision is rank 0's clock,
+    # shared with a one-element all-reduce after every step (a rank-local clock test lets ranks disagree by one step at the
+    # boundary, after which the collectives of the timed region no longer pair up).
     t_spin = time.perf_counter()
     spin_ms = []
-    while time.perf_counter() - t_spin < args.spinup:
+    go = torch.zeros(1, device=dev) if dist.is_initialized() else None
+    while True:
+        more = time.perf_counter() - t_spin < args.spinup
+        if go is not None:
+            go.fill_(1.0 if (more and rank == 0) else 0.0)
+            dist.all_reduce(go)
+            more = bool(go.item() > 0)
+        if not more:
+            break
         t_a = time.perf_counter()
         out = step()
         torch.cuda.synchronize()

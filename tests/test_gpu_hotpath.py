@@ -491,12 +491,13 @@ def test_two_rank_step_on_one_gpu_gloo():
     """The data-parallel launch (one process per rank, three hipGraphs cut around the confidence all-gather and the gradient
     all-reduce, max-over-ranks timing) run for real with two ranks; both share cuda:0 and talk over gloo, because the
     test box has one GPU (bench.py's UDAPOSE_BENCH_SHARE_GPU hook).  Checks the launch contract and that the two ranks
-    end with the same averaged gradient step (identical losses are not expected: every rank has its own shard)."""
+    end with the same averaged gradient step (identical losses are not expected: every rank has its own shard).  With a spin-up
+    phase: its length is rank 0's decision, shared after every step (rank-local clocks would let the ranks disagree by a step)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, UDAPOSE_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "0",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "0.7",
            "--arch", "pose_resnet50", "--batch", "4", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
