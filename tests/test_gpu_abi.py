@@ -112,3 +112,41 @@ def test_policy_is_explicit_and_per_plan():
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         if pa.grad is not None:
             assert torch.isfinite(pb.grad).all(), n
+
+
+def test_error_codes_of_the_round2_entry_points():
+    """Argument validation at the C ABI: bad arguments return UDAPOSE_ERR_ARG (-1) before anything is enqueued - null pointers,
+    row sizes that are not 16-byte multiples, an unknown backward phase, a phase split without grouped weight gradients."""
+    import ctypes as C
+    from uda_poseestimation_amd import _hip
+    L = _hip.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    conf = torch.zeros(4, 16, device="cuda")
+    idx = torch.zeros(4, 16, dtype=torch.int32, device="cuda")
+    u = torch.zeros(4, 4, device="cuda")
+    boxes = torch.zeros(4, 6, dtype=torch.int32, device="cuda")
+    ap = torch.zeros(4, dtype=torch.uint8, device="cuda")
+    p = lambda t: t.data_ptr()
+    assert L.udapose_occlusion_pick(s, None, p(idx), p(u), 4, 16, 64, 4.0, 256, 0.5, 0.9, 10, p(boxes), p(ap)) == -1
+    assert L.udapose_occlusion_pick(s, p(conf), p(idx), p(u), 0, 16, 64, 4.0, 256, 0.5, 0.9, 10, p(boxes), p(ap)) == -1
+    assert L.udapose_occlusion_pick(s, p(conf), p(idx), p(u), 4, 16, 64, 4.0, 256, 0.5, 0.9, 10, p(boxes), p(ap)) == 0
+    torch.cuda.synchronize()
+    assert int(ap.sum()) == 0 and int(boxes.abs().sum()) == 0            # (no confidence reaches 0.9: nothing selected, zero-area boxes)
+    a, b, d = (torch.zeros(4, 30, device="cuda") for _ in range(3))
+    assert L.udapose_select_rows(s, p(d), p(a), p(b), p(ap), 4, 30) == -1            # 30 floats: not a multiple of 16 bytes
+    assert L.udapose_select_rows(s, p(d), p(a), None, p(ap), 4, 32) == -1
+    x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
+    assert L.udapose_adain_alpha_dev(s, p(x), p(x), p(x), 1, 16, 16, 64, 1e-5, None, None, 0) == -1
+    net = _tiny().cuda().train()
+    xin = torch.randn(2, 3, 64, 64, device="cuda")
+    y = net(xin)
+    y.sum().backward()                                                   # (plans, tables and gradient placement now exist)
+    hd = net._last_hd
+    pa, ba, params = net._pointers()
+    act = torch.empty(hd.act_bytes, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(hd.ws.numel(), dtype=torch.uint8, device="cuda")
+    gp = net._grad_ptrs[1]
+    args = (hd.h, s, None, pa, p(hd.wpack), p(act), p(ws), gp, C.c_float(0.0))
+    assert hd.L.udapose_net_backward_phase(*args, 1, 3) == -1            # unknown phase
+    assert hd.L.udapose_net_backward_phase(*args, 3, 0) == -1            # unknown part
+    assert hd.L.udapose_net_backward_phase(None, s, None, pa, p(hd.wpack), p(act), p(ws), gp, C.c_float(0.0), 1, 1) == -1
