@@ -159,10 +159,15 @@ __global__ void unpack_strided_k(const float* __restrict__ src, float* __restric
 // Column sums of a partial-sum slab [rows][2][C]: block = 32 channels x 32 row lanes (1024 threads), 128-byte coalesced
 // row segments, fp64 accumulation, LDS tree over the row lanes.  Result for channel c0+cl in (s1, s2) of lanes rl == 0.
 #ifndef UDAPOSE_FIN_C
-#define UDAPOSE_FIN_C 32
+#define UDAPOSE_FIN_C 8
 #endif
-constexpr int FIN_C = UDAPOSE_FIN_C;    // channels per block (32: 128-byte row segments; 8: 32-byte segments, 4x the blocks)
-constexpr int FIN_RL = 32;              // row lanes per block
+constexpr int FIN_C = UDAPOSE_FIN_C;    // channels per block.  8 (32-byte row segments, C/8 blocks of 256 threads): the finalize kernels sit in
+                                        // every layer's dependency chain and are pure latency - 4x the blocks of the 128-byte-segment form (32)
+                                        // measured -0.1 ms per step (profiles/r2_ab_runs.txt); 4 / 16 channels and more row lanes measured slower
+#ifndef UDAPOSE_FIN_RL
+#define UDAPOSE_FIN_RL 32
+#endif
+constexpr int FIN_RL = UDAPOSE_FIN_RL;  // row lanes per block
 constexpr int FIN_T = FIN_C * FIN_RL;
 __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int rows, int C, int c, bool cvalid, double& s1, double& s2,
                                             double (*red)[FIN_C][2]) {
