@@ -774,7 +774,6 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     // head
     elem_t* dyh = (elem_t*)(ws + n.ws_dyhead);
     CK(pw_nchw_f32_to_nhwc_bf16(s, dout_nchw, dyh, n.N, n.K, HWo, 64));
-    CK(pw_plane_sum(s, dout_nchw, (float*)grads[n.head.bias_idx], n.N, n.K, HWo, beta));
     ConvGeom hg = n.head.g;
     hg.Co = 64;   // dy is channel-padded to 64 (one 64-wide K step)
     float* tmp = (float*)(ws + n.ws_dwtmp);
@@ -793,6 +792,8 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     // slab + apply) for the wide layers and finalize + apply for the others.  `cur` describes the pending statistics of dz.
     if (fused) { cur = bn_stat_of(n, n.up[2], n.up_bn[2], params, act, ws, 2); have = true; }
     CK(conv_dgrad(s, hg, dyh, (const elem_t*)(wpack + n.head.wb_off), dz, nullptr, 1, have ? &cur : nullptr));
+    // (the head's bias gradient is off the gradient chain: launched behind the first data gradient, not in front of it)
+    CK(pw_plane_sum(s, dout_nchw, (float*)grads[n.head.bias_idx], n.N, n.K, HWo, beta));
     // deconv stack
     for (int i = 2; i >= 0; --i) {
         elem_t* dx = nullptr;

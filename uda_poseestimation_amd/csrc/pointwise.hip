@@ -174,8 +174,21 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
     const int cl = threadIdx.x % FIN_C, rl = threadIdx.x / FIN_C;
     double a = 0.0, b = 0.0;
     if (cvalid) {
-        // 4 independent row loads in flight per thread (the loop is latency-bound otherwise)
+        // 8, then 4 independent row loads in flight per thread (the loop is pure latency: 1024 slab rows = 32 per lane); the
+        // additions keep the order of the 4-row form, so the sums are bit-identical to it
         int r = rl;
+        for (; r + 7 * FIN_RL < rows; r += 8 * FIN_RL) {
+            const float* q = slab + (size_t)r * 2 * C + c;
+            const size_t st = (size_t)FIN_RL * 2 * C;
+            const float a0 = q[0], b0 = q[C], a1 = q[st], b1 = q[st + C];
+            const float a2 = q[2 * st], b2 = q[2 * st + C], a3 = q[3 * st], b3 = q[3 * st + C];
+            const float a4 = q[4 * st], b4 = q[4 * st + C], a5 = q[5 * st], b5 = q[5 * st + C];
+            const float a6 = q[6 * st], b6 = q[6 * st + C], a7 = q[7 * st], b7 = q[7 * st + C];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+            a += ((double)a4 + (double)a5) + ((double)a6 + (double)a7);
+            b += ((double)b4 + (double)b5) + ((double)b6 + (double)b7);
+        }
         for (; r + 3 * FIN_RL < rows; r += 4 * FIN_RL) {
             const float* q = slab + (size_t)r * 2 * C + c;
             const size_t st = (size_t)FIN_RL * 2 * C;
@@ -473,6 +486,20 @@ __global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const elem_t* __restrict
         const float* base = slab + (size_t)(q >> 4) * C + chunk * 64 + (q & 15) * 4;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int r = rg;
+        for (; r + 56 < rows; r += 64) {      // eight independent 16-byte loads in flight (same order of additions as the four-load form)
+            const f32x4 u = *(const f32x4*)(base + (size_t)r * 2 * C), v = *(const f32x4*)(base + (size_t)(r + 8) * 2 * C);
+            const f32x4 w = *(const f32x4*)(base + (size_t)(r + 16) * 2 * C), x = *(const f32x4*)(base + (size_t)(r + 24) * 2 * C);
+            const f32x4 u2 = *(const f32x4*)(base + (size_t)(r + 32) * 2 * C), v2 = *(const f32x4*)(base + (size_t)(r + 40) * 2 * C);
+            const f32x4 w2 = *(const f32x4*)(base + (size_t)(r + 48) * 2 * C), x2 = *(const f32x4*)(base + (size_t)(r + 56) * 2 * C);
+            a0 += ((double)u[0] + (double)v[0]) + ((double)w[0] + (double)x[0]);
+            a1 += ((double)u[1] + (double)v[1]) + ((double)w[1] + (double)x[1]);
+            a2 += ((double)u[2] + (double)v[2]) + ((double)w[2] + (double)x[2]);
+            a3 += ((double)u[3] + (double)v[3]) + ((double)w[3] + (double)x[3]);
+            a0 += ((double)u2[0] + (double)v2[0]) + ((double)w2[0] + (double)x2[0]);
+            a1 += ((double)u2[1] + (double)v2[1]) + ((double)w2[1] + (double)x2[1]);
+            a2 += ((double)u2[2] + (double)v2[2]) + ((double)w2[2] + (double)x2[2]);
+            a3 += ((double)u2[3] + (double)v2[3]) + ((double)w2[3] + (double)x2[3]);
+        }
         for (; r + 24 < rows; r += 32) {      // four independent 16-byte loads in flight
             const f32x4 u = *(const f32x4*)(base + (size_t)r * 2 * C), v = *(const f32x4*)(base + (size_t)(r + 8) * 2 * C);
             const f32x4 w = *(const f32x4*)(base + (size_t)(r + 16) * 2 * C), x = *(const f32x4*)(base + (size_t)(r + 24) * 2 * C);
@@ -717,6 +744,20 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_chunk_k(const DZ* __rest
         const float* base = slab + (size_t)(q >> 4) * C + chunk * 64 + (q & 15) * 4;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int r = rg;
+        for (; r + 56 < rows; r += 64) {      // eight independent 16-byte loads in flight (same order of additions as the four-load form)
+            const f32x4 u = *(const f32x4*)(base + (size_t)r * 2 * C), v = *(const f32x4*)(base + (size_t)(r + 8) * 2 * C);
+            const f32x4 w = *(const f32x4*)(base + (size_t)(r + 16) * 2 * C), x = *(const f32x4*)(base + (size_t)(r + 24) * 2 * C);
+            const f32x4 u2 = *(const f32x4*)(base + (size_t)(r + 32) * 2 * C), v2 = *(const f32x4*)(base + (size_t)(r + 40) * 2 * C);
+            const f32x4 w2 = *(const f32x4*)(base + (size_t)(r + 48) * 2 * C), x2 = *(const f32x4*)(base + (size_t)(r + 56) * 2 * C);
+            a0 += ((double)u[0] + (double)v[0]) + ((double)w[0] + (double)x[0]);
+            a1 += ((double)u[1] + (double)v[1]) + ((double)w[1] + (double)x[1]);
+            a2 += ((double)u[2] + (double)v[2]) + ((double)w[2] + (double)x[2]);
+            a3 += ((double)u[3] + (double)v[3]) + ((double)w[3] + (double)x[3]);
+            a0 += ((double)u2[0] + (double)v2[0]) + ((double)w2[0] + (double)x2[0]);
+            a1 += ((double)u2[1] + (double)v2[1]) + ((double)w2[1] + (double)x2[1]);
+            a2 += ((double)u2[2] + (double)v2[2]) + ((double)w2[2] + (double)x2[2]);
+            a3 += ((double)u2[3] + (double)v2[3]) + ((double)w2[3] + (double)x2[3]);
+        }
         for (; r + 24 < rows; r += 32) {      // four independent 16-byte loads in flight
             const f32x4 u = *(const f32x4*)(base + (size_t)r * 2 * C), v = *(const f32x4*)(base + (size_t)(r + 8) * 2 * C);
             const f32x4 w = *(const f32x4*)(base + (size_t)(r + 16) * 2 * C), x = *(const f32x4*)(base + (size_t)(r + 24) * 2 * C);
