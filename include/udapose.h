@@ -51,7 +51,11 @@ int udapose_elem_kind(void);
  * igemm_h3: run-staged 3x3 form 0 off, 1 measured per-shape policy, 2 / 3 force the 64- / 128-row form, 4 three taps per
  * barrier; wgrad_group: one grouped weight-gradient launch per tile class in udapose_net_backward (0: layer by layer),
  * wgrad_stages: 64-pixel stages a work-group reduces before a layer's pixel range is split; bn_bwd_fused: dgrad epilogues
- * mask for the consumer BatchNorm and reduce its backward sums; timeline: device buffer ([work-groups][8] uint64) for
+ * mask for the consumer BatchNorm and reduce its backward sums; bn_fwd_chunked / bn_bwd_chunked: finalize + apply of the wide,
+ * small-spatial BatchNorm layers in one launch (0 off, 1 on, > 1: on with that target work-group count instead of 1024);
+ * igemm_wg_min: 128x64 tiles as soon as they give that many work-groups, else 64x64; bn3_mask: block outputs save a ReLU bit mask
+ * that the masking data gradients read instead of z; stem_fused: the stem's BN + ReLU + max-pool in one sweep and the max-pool
+ * backward gathered inside the BN backward; timeline: device buffer ([work-groups][8] uint64) for
  * per-work-group s_memrealtime stamps, or NULL. */
 typedef struct {
     int igemm_tile, igemm_h3, igemm_lean, igemm_short_lds, igemm_tap0;

@@ -1076,7 +1076,7 @@ int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t*
     // (enabled: Policy::bn_fwd_chunked)
     if (!enabled || C < 256 || C % 64 || npix > 8192 || npix < 1024 || rows > 128) return 0;
     const int chunks = C / 64;
-    int S = 1024 / chunks;
+    int S = (enabled > 1 ? enabled : 1024) / chunks;      // (policy value > 1: the target work-group count; tuning)
     if (S > 64) S = 64;
     if (S < 1) S = 1;
     int P = (int)((npix + S - 1) / S);
@@ -1208,7 +1208,7 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
     if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
     if (chunked && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
         const int chunks = C / 64;
-        int S = 1024 / chunks;
+        int S = (chunked > 1 ? chunked : 1024) / chunks;
         if (S > 64) S = 64;
         if (S < 1) S = 1;
         int P = (int)((npix + S - 1) / S);
