@@ -442,3 +442,38 @@ def test_run_staged_3x3_form(dev, case, mode):
         close(nchw(out[mode][2].cuda()), xr.grad, 1.2e-2)
         np.testing.assert_allclose(out[mode][1][0].cpu().numpy(), ref.detach().double().sum((0, 2, 3)).numpy(), rtol=2e-3,
                                    atol=2e-3 * ref.abs().sum().item() / Co)
+
+
+@pytest.mark.parametrize("case", [(4, 16, 16, 256, 256), (2, 64, 64, 64, 64), (8, 8, 8, 512, 128), (3, 32, 32, 128, 64), (2, 16, 8, 64, 192)])
+def test_weight_gradient_filter_row_form_3x3(case):
+    """Policy wgrad_row3: the weight gradient of a 3x3 stride-1 pad-1 convolution with one work-group per (64x64 tile, filter row) -
+    the row's three taps share one staged dy tile and one x window, the zero padding is a zero dy row (rows) and lane masks on the
+    dy fragments (column wrap).  Against torch's fp32 weight gradient on the same bf16-rounded operands, and against the one-tap
+    form; split reductions and the accumulate mode included."""
+    from uda_poseestimation_amd import ops, _hip
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(N, Co, H, W, generator=g).bfloat16().float()
+    xr = x.clone().requires_grad_(False)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    torch.nn.functional.conv2d(xr, w, padding=1).backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)                       # [Co][tap][Ci]
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    d = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1)
+    scale = ref.abs().max().item()
+    outs = {}
+    for row3 in (1, 0):
+        for ks in (0, 4):
+            dd = ops.with_policy(d, _hip.policy(wgrad_row3=row3, wgrad_ksplit=ks if ks else -1))
+            dw = ops.conv2d_bwd_weight(nhwc(dy), nhwc(x), dd)
+            err = (dw.cpu() - ref).abs().max().item()
+            assert err <= 2e-3 * scale, (row3, ks, err, scale)
+            outs[(row3, ks)] = dw
+    assert (outs[(1, 0)] - outs[(0, 0)]).abs().max().item() <= 1e-3 * scale
+    # every tap, border columns included: the wrap masks (dx = -1 at j = 0, dx = +1 at j = W - 1) change the result where they act
+    for t in range(9):
+        assert (outs[(1, 0)][:, t].cpu() - ref[:, t]).abs().max().item() <= 2e-3 * scale, t
+    dd = ops.with_policy(d, _hip.policy(wgrad_row3=1))
+    acc = ops.conv2d_bwd_weight(nhwc(dy), nhwc(x), dd, dw=outs[(1, 0)].clone())
+    assert (acc.cpu() - 2 * ref).abs().max().item() <= 4e-3 * scale

@@ -203,6 +203,7 @@ int conv_wgrad_params(const ConvGeom& g, const elem_t* dy, const elem_t* x, floa
     p.M = g.N * p.Hg * p.Wg;
     p.wtaps = rowtap ? g.KH : g.wtaps();
     p.flags = (g.smallc() ? IG_FLAG_SMALLC : 0) | (g.transposed ? WG_FLAG_SWAP : 0);
+    if (g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && !g.smallc() && !g.reflect && !g.upsample) p.flags |= WG_FLAG_ROW3_OK;
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     p.total_taps = (int)tp->taps.size();

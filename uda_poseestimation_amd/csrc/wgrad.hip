@@ -206,6 +206,8 @@ __device__ u32x4 g_wzero16[2];
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -429,6 +431,181 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
             }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Filter-ROW form for 3x3, stride-1, pad-1 convolutions on power-of-two maps (W <= 64): one work-group computes the 64 x 64 tile
+// of dW for the THREE taps (dy, -1), (dy, 0), (dy, +1) of one filter row.  The three taps read the same dy pixels and x pixels that
+// differ by one column, so a stage holds ONE dy tile [64 pixels][64 channels] and ONE x window [64 + 2 pixels (padded to 72)][64
+// channels] starting one pixel early; tap dx reads the window at row offset dx + 1.  LDS fill per FLOP is a third of the
+// one-tap form at the same tile size.  Measured (tools/exp_wgrad_row3.py): as fast as the 128x128 one-tap form, not faster - what
+// bounds these kernels is LDS bandwidth as a whole (per work-group and 64-pixel stage 17 KB of DMA writes + 64 KB of transposing
+// reads = 630 LDS cycles against 384 MFMA cycles here; 48 KB = 375 against 256 for the 128x128 one-tap form), and the read
+// bytes per FLOP go with the WAVE tile: 32x32 here, 64x64 there.  Selected by Policy::wgrad_row3 (off by default).
+// Zero padding: a pixel whose row i + dy falls outside the image gets a zero dy row (it contributes to none of the three taps);
+// the column wrap (j = 0 with dx = -1, j = W-1 with dx = +1: the neighbour in memory belongs to another image row) is cut out of
+// the dy FRAGMENTS per tap with loop-invariant lane masks (stages are 64 pixels, W divides 64: a lane's pixels keep their j).
+struct Row3Cfg {
+    static constexpr int PX = 64, P_BYTES = PX * 128, QR = PX + 8, Q_BYTES = QR * 128, STAGE1 = P_BYTES + Q_BYTES, DUMP = 1024;
+    static constexpr int lds_bytes(int ns) { return ns * STAGE1 + DUMP; }
+};
+template <int NS>
+__device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
+                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
+    using R = Row3Cfg;
+    constexpr int PX = R::PX, LPS = 5;                                 // 2 dy pieces + 3 x-window pieces per wave and stage
+    struct {
+        const elem_t* dy; const elem_t* x; float* dw;
+        int Hi, Wi, Ci, Co, M, wtaps, flags, ksplit, c_tiles, rows_valid;
+    } p = {(const elem_t*)((uintptr_t)gp.dy + dy_base), (const elem_t*)((uintptr_t)gp.x + x_base),
+           (float*)((uintptr_t)gp.dw + ((gp.flags & WG_FLAG_DW_WS) ? dy_base : dw_base)), gp.Hi, gp.Wi, gp.Ci, gp.Co, gp.M, gp.wtaps, gp.flags,
+           gp.ksplit, gp.c_tiles, gp.rows_valid};
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int c_tile = bx % p.c_tiles, r_tile = bx / p.c_tiles;
+    const int r0 = r_tile * 64, c0 = c_tile * 64;
+    const int dyk = (int)by - 1;                                       // this work-group's filter row: dy = -1, 0, +1
+    const int ms_total = (p.M + PX - 1) / PX;
+    const int per = (ms_total + p.ksplit - 1) / p.ksplit;
+    const int ms0 = bz * per;
+    int ms1 = ms0 + per;
+    if (ms1 > ms_total) ms1 = ms_total;
+    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const char* zsrc = (const char*)g_wzero16;
+    char* const dump = smem + NS * R::STAGE1;
+    const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
+    const int lgw = 31 - __builtin_clz((unsigned)p.Wi);
+    const int lrow = lane >> 3, pch = lane & 7;
+    const int xoff0 = dyk * p.Wi - 1;                                  // x pixel of window row 0 relative to the stage's first pixel
+
+    auto issue_stage = [&](int st, int buf) {
+        const int mb = (ms0 + st) * PX;
+        char* P = smem + buf * R::STAGE1;
+        char* Q = P + R::P_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 4 + wid) * 8 + lrow;
+            const int lc = pch ^ wswz<64>(row);
+            const int m = mb + row;
+            const bool ok = m < p.M && (unsigned)((int)(((unsigned)m & hw_mask) >> lgw) + dyk) < (unsigned)p.Hi;
+            const unsigned od = __umul24((unsigned)m, (unsigned)p.Co) + (unsigned)(r0 + lc * 8);
+            const char* sp = ok ? (const char*)p.dy + (size_t)od * 2 : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = i * 4 + wid;                                  // wave-uniform piece index; pieces 9..11 do not exist
+            const int row = k * 8 + lrow;
+            const int lc = pch ^ wswz<64>(row);
+            const int xp = mb + xoff0 + row;
+            const bool ok = k < 9 && (unsigned)xp < (unsigned)p.M;
+            const unsigned ox = __umul24((unsigned)(ok ? xp : 0), (unsigned)p.Ci) + (unsigned)(c0 + lc * 8);
+            const char* sq = ok ? (const char*)p.x + (size_t)ox * 2 : zsrc;
+            char* dst = k < 9 ? Q + k * 1024 : dump;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int issued = 0;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nsteps) { issue_stage(st, st); ++issued; }
+
+    const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+    // fragment element e of a lane is pixel row 32*kk + 16*(e >> 2) + 4*g + (e & 3) of the stage; stages start at multiples of 64
+    // and W divides 64, so that pixel's column j is the same in every stage: the wrap masks are computed once
+    unsigned mL[2][4], mR[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            unsigned l = 0u, r = 0u;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int e = 2 * v + hh;
+                const unsigned j = (unsigned)(32 * kk + 16 * (e >> 2) + 4 * g + (e & 3)) & w_mask;
+                if (j != 0u) l |= 0xFFFFu << (16 * hh);
+                if (j != w_mask) r |= 0xFFFFu << (16 * hh);
+            }
+            mL[kk][v] = l; mR[kk][v] = r;
+        }
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st % NS;
+        if (issued - st - 1 >= NS - 2) wg_wait_vmcnt<LPS*(NS - 2)>();
+        else wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (issued < nsteps) { issue_stage(issued, issued % NS); ++issued; }
+        const char* P = smem + buf * R::STAGE1;
+        const char* Q = P + R::P_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            union F8 { struct { s16x4 a, b; } s; elem8 v; u32x4 w; };
+            F8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int col = wr * 32 + i * 16 + 4 * pp;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 32 * kk + 16 * h + 4 * g + qq;
+                    const int off = row * 128 + ((((col >> 3) ^ wswz<64>(row)) << 4) | ((col & 4) << 1));
+                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, P + off));
+                    if (h == 0) af[i].s.a = v; else af[i].s.b = v;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                F8 bfr[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = wc * 32 + j * 16 + 4 * pp;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = 32 * kk + 16 * h + 4 * g + qq + t;       // window row = pixel row + 1 + dx
+                        const int off = row * 128 + ((((col >> 3) ^ wswz<64>(row)) << 4) | ((col & 4) << 1));
+                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, Q + off));
+                        if (h == 0) bfr[j].s.a = v; else bfr[j].s.b = v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    F8 a = af[i];
+                    if (t == 0) { a.w[0] &= mL[kk][0]; a.w[1] &= mL[kk][1]; a.w[2] &= mL[kk][2]; a.w[3] &= mL[kk][3]; }
+                    if (t == 2) { a.w[0] &= mR[kk][0]; a.w[1] &= mR[kk][1]; a.w[2] &= mR[kk][2]; a.w[3] &= mR[kk][3]; }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[t][i][j] = UDAPOSE_MFMA_16x16x32(a.v, bfr[j].v, acc[t][i][j]);
+                }
+            }
+        }
+    }
+
+    const bool atomic = (p.flags & WG_FLAG_ATOMIC) != 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = r0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
+                    const int cc = c0 + wc * 32 + j * 16 + (lane & 15);
+                    if (rr >= p.Co || rr >= p.rows_valid || cc >= p.Ci) continue;
+                    const size_t off = ((size_t)rr * p.wtaps + (3 * by + t)) * p.Ci + cc;      // tap (dy, dx) -> weight slab 3*(dy+1) + (dx+1)
+                    const float v = acc[t][i][j][r];
+                    if (atomic) atomicAdd(p.dw + off, v);
+                    else p.dw[off] = v;
+                }
+}
+
 template <int RT, int CT, int WR, int WC, int NS>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -437,6 +614,9 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
     const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
     const uint32_t bz = lin / gxy, bxy = lin - bz * gxy;
     const uint32_t by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
+    if constexpr (RT == 64 && CT == 64) {
+        if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem); return; }
+    }
     if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, 64, true>(p, bx, by, bz, smem);
     else wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem);
 }
@@ -456,6 +636,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void w
     const uint32_t gx = (uint32_t)(p.r_tiles * p.c_tiles), gxy = gx * (uint32_t)p.total_taps;
     const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
     const uint32_t by = bxy / gx, bx = bxy - by * gx;
+    if constexpr (RT == 64 && CT == 64 && PX == 64) {
+        if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base); return; }
+    }
     if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
     else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
 }
@@ -464,12 +647,13 @@ template <int RT, int CT, int WR, int WC, int NS, int PX>
 int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
                     hipStream_t stream) {
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
+    constexpr int LDS = (RT == 64 && CT == 64 && PX == 64 && Row3Cfg::lds_bytes(NS) > C::LDS_BYTES) ? Row3Cfg::lds_bytes(NS) : C::LDS_BYTES;
     static std::atomic<unsigned long long> attr_done{0};
     static std::mutex attr_mu;
     once_per_device(attr_done, attr_mu, [] {
-        (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd), dim3(256), C::LDS_BYTES, stream, d_tab, d_blk,
+    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd), dim3(256), LDS, stream, d_tab, d_blk,
                        (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base);
     return udapose_check_launch();
 }
@@ -477,6 +661,7 @@ int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd,
 template <int RT, int CT, int WR, int WC, int NS>
 int launch_wd(WgParams& p, hipStream_t stream) {
     using C = WdCfg<RT, CT, WR, WC, NS>;
+    constexpr int LDS = (RT == 64 && CT == 64 && Row3Cfg::lds_bytes(NS) > C::LDS_BYTES) ? Row3Cfg::lds_bytes(NS) : C::LDS_BYTES;
     const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
     p.r_tiles = (Rdim + RT - 1) / RT;
@@ -484,10 +669,10 @@ int launch_wd(WgParams& p, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};
     static std::mutex attr_mu;
     once_per_device(attr_done, attr_mu, [] {
-        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<RT, CT, WR, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<RT, CT, WR, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
     dim3 grid(p.r_tiles * p.c_tiles, p.total_taps, p.ksplit);
-    hipLaunchKernelGGL((wgrad_dma_kernel<RT, CT, WR, WC, NS>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((wgrad_dma_kernel<RT, CT, WR, WC, NS>), grid, dim3(256), LDS, stream, p);
     return udapose_check_launch();
 }
 
@@ -515,6 +700,13 @@ static bool wg_fastgeo_ok(const WgParams& p, const Policy& pol) {
            (long long)p.M * (p.Ci > p.Co ? p.Ci : p.Co) < (1ll << 31);
 }
 
+// the filter-row form (wgrad_row3_body): 3x3 stride-1 pad-1 plain conv in the loader's fast geometry, W <= 64 (a 64-pixel stage
+// holds whole image rows, so the column-wrap masks are loop invariants), 64-channel tiles on both sides
+static bool wg_row3_ok(const WgParams& p, const Policy& pol) {
+    return pol.wgrad_row3 && (p.flags & WG_FLAG_ROW3_OK) && p.total_taps == 9 && p.wtaps == 9 && wg_fastgeo_ok(p, pol) && p.Wi >= 8 && p.Wi <= 64 &&
+           p.Ci % 64 == 0 && p.Co % 64 == 0;
+}
+
 // tile ids: 0 = 128x128, 1 = 64x64, 2 = 64x32 (Ci==8 stem), 3 = 32x128 (narrow-row: head)
 int wgrad_pick_tile(int Rdim, int Cdim, int smallc, const Policy& pol) {
     if (smallc) return 2;
@@ -535,6 +727,11 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     // measured (tools/tune_conv.py, LDS-DMA kernels): 128x128 tiles for multi-tap convs with >= 128 channels on both sides
     // (3x3 trunk convs, 4x4 deconvs), 64x64 otherwise
     if (tile == 1 && pol.wgrad_tile < 0 && Rdim >= 128 && Cdim >= 128 && p.total_taps >= 9) tile = 0;
+    if ((tile == 0 || tile == 1) && pol.wgrad_tile < 0 && wg_row3_ok(p, pol)) {      // three taps per work-group: a third of the LDS fill per FLOP
+        tile = 1;
+        p.flags |= WG_FLAG_ROW3;
+        p.total_taps = 3;
+    }
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
     const bool dma = !smallc && (tile == 0 || tile == 1) && (p.Ci % 64 == 0) && (p.Co % 64 == 0);
@@ -573,7 +770,12 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     // inside a group the other layers fill the chip, so a layer takes the 128x128 tile (half the L2->LDS bytes per FLOP of
     // 64x64) whenever both of its dimensions allow
-    const int tile = (Rdim >= 128 && Cdim >= 128) ? 0 : 1;
+    int tile = (Rdim >= 128 && Cdim >= 128) ? 0 : 1;
+    if (wg_row3_ok(p, pol)) {       // filter-row form: 64x64 tiles, one work-group per (tile, filter row)
+        tile = 1;
+        p.flags |= WG_FLAG_ROW3;
+        p.total_taps = 3;
+    }
     const int T = tile == 0 ? 128 : 64;
     p.r_tiles = (Rdim + T - 1) / T;
     p.c_tiles = (Cdim + T - 1) / T;
