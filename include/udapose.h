@@ -53,7 +53,8 @@ int udapose_elem_kind(void);
  * wgrad_stages: 64-pixel stages a work-group reduces before a layer's pixel range is split; bn_bwd_fused: dgrad epilogues
  * mask for the consumer BatchNorm and reduce its backward sums; bn_fwd_chunked / bn_bwd_chunked: finalize + apply of the wide,
  * small-spatial BatchNorm layers in one launch (0 off, 1 on, > 1: on with that target work-group count instead of 1024);
- * wgrad_row3: weight gradients of 3x3 stride-1 convolutions with one work-group per (64x64 tile, filter row) - the row's three taps
+ * wgrad_fastgeo: loader of the weight-gradient kernels on power-of-two maps (0 general, 1 bit-field coordinates, 2 buffer loads
+ * with out-of-range zero fill and an unrolled ring: the production form); wgrad_row3: weight gradients of 3x3 stride-1 convolutions with one work-group per (64x64 tile, filter row) - the row's three taps
  * share one staged dy tile and one x window (3x the FLOPs per byte filled into LDS, which is what bounds these kernels);
  * igemm_wg_min: 128x64 tiles as soon as they give that many work-groups, else 64x64; bn3_mask: block outputs save a ReLU bit mask
  * that the masking data gradients read instead of z; stem_fused: the stem's BN + ReLU + max-pool in one sweep and the max-pool

@@ -477,3 +477,40 @@ def test_weight_gradient_filter_row_form_3x3(case):
     dd = ops.with_policy(d, _hip.policy(wgrad_row3=1))
     acc = ops.conv2d_bwd_weight(nhwc(dy), nhwc(x), dd, dw=outs[(1, 0)].clone())
     assert (acc.cpu() - 2 * ref).abs().max().item() <= 4e-3 * scale
+
+
+@pytest.mark.parametrize("case", [(4, 16, 16, 256, 256, 3), (2, 64, 64, 64, 64, 3), (8, 8, 8, 512, 128, 3), (3, 32, 32, 128, 64, 3),
+                                  (4, 16, 16, 1024, 256, 1), (2, 32, 32, 128, 512, 1), (2, 16, 8, 64, 192, 3)])
+def test_weight_gradient_buffer_load_loader_is_bit_identical(case):
+    """Policy wgrad_fastgeo = 2: the fast-geometry weight-gradient loop with buffer_load ... lds (constant lane offsets, scalar
+    stage offsets, out-of-range offsets for taps outside the image: the hardware writes the zeros) and the ring unrolled over its
+    buffers.  Same tiles, same MFMA order: bit-identical to the pointer-select loader (one pixel split), and within fp32 atomic
+    reordering of it when the pixel reduction is split; both forms against torch."""
+    from uda_poseestimation_amd import ops, _hip
+    N, H, W, Ci, Co, K = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(N, Co, H, W, generator=g).bfloat16().float()
+    w = torch.zeros(Co, Ci, K, K, requires_grad=True)
+    torch.nn.functional.conv2d(x, w, padding=K // 2).backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Co, K * K, Ci)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    d = ops.conv_desc(N, H, W, Ci, Co, K, 1, K // 2)
+    scale = ref.abs().max().item()
+    out = {}
+    for fg in (1, 2):
+        for tile in (0, 1):
+            if tile == 0 and (Ci < 128 or Co < 128):
+                continue
+            for ks in (1, 4):
+                dd = ops.with_policy(d, _hip.policy(wgrad_fastgeo=fg, wgrad_tile=tile, wgrad_ksplit=ks, wgrad_row3=0))
+                dw = ops.conv2d_bwd_weight(nhwc(dy), nhwc(x), dd)
+                assert (dw.cpu() - ref).abs().max().item() <= 2e-3 * scale, (fg, tile, ks)
+                out[(fg, tile, ks)] = dw
+    for (fg, tile, ks), dw in out.items():
+        if fg == 2:
+            other = out[(1, tile, ks)]
+            if ks == 1:
+                assert torch.equal(dw, other), (tile, ks)
+            else:
+                assert (dw - other).abs().max().item() <= 1e-4 * scale

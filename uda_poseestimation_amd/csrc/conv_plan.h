@@ -17,7 +17,8 @@ struct Policy {
     int igemm_tap0 = 1;         // 1x1 kernels skip the tap-table read
     int wgrad_tile = -1;        // force a weight-gradient tile id (-1: heuristics)
     int wgrad_ksplit = -1;      // force the pixel-split count of a per-layer weight-gradient launch
-    int wgrad_fastgeo = 1;      // bit-field pixel coordinates in the weight-gradient loader where eligible
+    int wgrad_fastgeo = 2;      // weight-gradient loader on power-of-two maps: 0 general, 1 bit-field pixel coordinates (pointer selects),
+                                // 2 the same through buffer_load ... lds with out-of-range zero fill and an unrolled ring (wgrad_fast2_body)
     int wgrad_group = 1;        // net backward: one grouped weight-gradient launch per tile class (0: layer by layer)
     int wgrad_stages = 128;     // grouped launch: 64-pixel stages a work-group reduces before a layer's pixel range is split
     int wgrad_group_stem = 1;   // the Ci == 8 stem joins the 64x64 group in its row-tap form

@@ -76,6 +76,7 @@ struct WgGroupBlk { int prob, local; };   // grouped wgrad: problem index (< 0: 
 #define WG_FLAG_SWAP 32       // rows of dW come from x (deconv weight layout [Ci][tap][Co])
 #define WG_FLAG_DW_WS 256     // grouped launch: dw is an offset into the workspace (dy base), not into the gradient buffer
 #define WG_FLAG_FASTGEO 512   // loader: stride-1 same-size conv on power-of-two maps (bit-field pixel coordinates, 32-bit offsets)
+#define WG_FLAG_FAST2 16384    // fast geometry, second loader form: buffer loads with out-of-range zero fill, unrolled ring (wgrad_fast2_body)
 #define WG_FLAG_ROW3_OK 8192  // geometry: 3x3, stride 1, pad 1, plain conv (set by conv_wgrad_params)
 #define WG_FLAG_ROW3 4096     // one work-group per (tile, filter ROW): the three taps of the row share one dy stage and one x window (wgrad_row3_body)
 #define WG_FLAG_ATOMIC 64     // accumulate into dw with fp32 atomics (ksplit>1 or beta=1)

@@ -432,6 +432,180 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast-geometry body, second form (WG_FLAG_FAST2): the same tiles, ring and MFMA loop as wgrad_dma_body<.., FAST = true>, with the
+// per-stage instruction stream cut down.  That loop issues 63 vector + 58 scalar instructions per 16 MFMAs and is bound by
+// instruction issue (rocprofv3: 3.9 non-MFMA vector instructions per MFMA, 31 % MFMA-busy with the chip to itself):
+//   * operands are fetched with buffer_load_dwordx4 ... lds: a lane's byte offset inside a stage is a CONSTANT, the stage's
+//     position is the scalar offset, and a lane whose tap falls outside the image gets an out-of-range offset, for which the
+//     hardware writes zeros into LDS (tools/probe/buf_lds.hip) - no 64-bit address arithmetic, no pointer selects, no zero page;
+//   * the ring is unrolled over its NS buffers, so LDS destinations (M0) and fragment read offsets are compile-time constants;
+//   * pixel counts are multiples of the stage (power-of-two maps), so there is no row-validity test at all for centre taps.
+template <int U> struct WIC { static constexpr int value = U; };
+template <int N, typename F> __device__ __forceinline__ void w_static_for(F&& f) {
+    if constexpr (N > 0) { w_static_for<N - 1>(f); f(WIC<N - 1>{}); }
+}
+template <int RT, int CT, int WR, int WC, int NS, int PX>
+__device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
+                                                 const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
+    static_assert(RT == CT, "P and Q share their row mapping");
+    struct {
+        const elem_t* dy; const elem_t* x; float* dw; const IgTap* taps;
+        int Hi, Wi, Ci, Co, M, wtaps, flags, ksplit, c_tiles, rows_valid;
+    } p = {(const elem_t*)((uintptr_t)gp.dy + dy_base), (const elem_t*)((uintptr_t)gp.x + x_base),
+           (float*)((uintptr_t)gp.dw + ((gp.flags & WG_FLAG_DW_WS) ? dy_base : dw_base)), gp.taps, gp.Hi, gp.Wi, gp.Ci, gp.Co, gp.M, gp.wtaps,
+           gp.flags, gp.ksplit, gp.c_tiles, gp.rows_valid};
+    using C = WdCfg<RT, CT, WR, WC, NS, PX>;
+    constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
+    static_assert(P_PW == Q_PW, "RT == CT");
+    constexpr int LPS = P_PW + Q_PW;
+    constexpr int P_RPI = 1024 / C::PROW, P_CPR = C::PROW / 16;
+    constexpr int OOB = 0x7fffffff;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid / WC, wc = wid % WC;
+    const int c_tile = bx % p.c_tiles, r_tile = bx / p.c_tiles;
+    const int r0 = r_tile * RT, c0 = c_tile * CT;
+    // (the tap is wave-uniform; said explicitly, so that the x buffer descriptor built from it lives in scalar registers - a
+    // descriptor the compiler cannot prove uniform costs a readfirstlane waterfall loop per load)
+    const IgTap tp0 = p.taps[by];
+    struct { int dy, dx, widx; } tp = {__builtin_amdgcn_readfirstlane(tp0.dy), __builtin_amdgcn_readfirstlane(tp0.dx),
+                                       __builtin_amdgcn_readfirstlane(tp0.widx)};
+    const int toff = tp.dy * p.Wi + tp.dx;
+    const bool center = tp.dy == 0 && tp.dx == 0;
+    const int ms_total = p.M / PX;                                    // (M % PX == 0: checked on the host)
+    const int per = (ms_total + p.ksplit - 1) / p.ksplit;
+    const int ms0 = bz * per;
+    int ms1 = ms0 + per;
+    if (ms1 > ms_total) ms1 = ms_total;
+    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
+    const int lgw = 31 - __builtin_clz((unsigned)p.Wi);
+    // raw buffers over the two tensors; the x buffer starts at the tap's pixel offset (possibly in front of the tensor: every pixel
+    // that would be read from outside the tensor is a tap outside the image and gets the out-of-range offset instead)
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Co * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (long long)toff * p.Ci * 2), 0, p.M * p.Ci * 2, 0x00020000);
+    const int lrow = lane / P_CPR, pch = lane % P_CPR;
+    int vd[P_PW], vx[P_PW], rowl[P_PW];
+#pragma unroll
+    for (int i = 0; i < P_PW; ++i) {
+        const int row = (i * 4 + wid) * P_RPI + lrow;
+        const int lc = pch ^ wswz<RT>(row);
+        rowl[i] = row;
+        vd[i] = (r0 + lc * 8 < p.Co) ? (row * p.Co + r0 + lc * 8) * 2 : OOB;
+        vx[i] = (c0 + lc * 8 < p.Ci) ? (row * p.Ci + c0 + lc * 8) * 2 : OOB;
+    }
+    const int sd_step = PX * p.Co * 2, sx_step = PX * p.Ci * 2;
+
+    auto issue_stage = [&](int st, auto ub) __attribute__((always_inline)) {
+        constexpr int UB = decltype(ub)::value;
+        const int mb = (ms0 + st) * PX;
+        const int sd = (ms0 + st) * sd_step, sx = (ms0 + st) * sx_step;      // scalar byte offsets of the stage
+        char* P = smem + UB * C::STAGE1;
+        char* Q = P + C::P_BYTES;
+#pragma unroll
+        for (int i = 0; i < P_PW; ++i) {
+            int ox = vx[i];
+            if (!center) {
+                const unsigned rem = (unsigned)(mb + rowl[i]) & hw_mask;
+                const int ii = (int)(rem >> lgw), jj = (int)(rem & w_mask);
+                const bool ok = (unsigned)(ii + tp.dy) < (unsigned)p.Hi && (unsigned)(jj + tp.dx) < (unsigned)p.Wi;
+                ox = ok ? ox : OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, vd[i], sd, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Q + (i * 4 + wid) * 1024), 16, ox, sx, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int issued = 0;
+    w_static_for<NS - 1>([&](auto u) {
+        constexpr int U = decltype(u)::value;
+        if (U < nsteps) { issue_stage(U, u); ++issued; }
+    });
+
+    const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+    // lane part of the fragment read offsets (the stage buffer, kk, h and the fragment index are compile-time constants)
+    int a_lo[MT][2], b_lo[NT][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 16 * h + 4 * g + qq;                        // (+ 32 * kk: the swizzle only looks at row bits 0..2, PROW * 32 is added below)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int col = wr * TR + i * 16 + 4 * pp;
+            a_lo[i][h] = row * C::PROW + ((((col >> 3) ^ wswz<RT>(row)) << 4) | ((col & 4) << 1));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = wc * TC + j * 16 + 4 * pp;
+            b_lo[j][h] = C::P_BYTES + row * C::QROW + ((((col >> 3) ^ wswz<CT>(row)) << 4) | ((col & 4) << 1));
+        }
+    }
+
+    auto compute = [&](auto ub) __attribute__((always_inline)) {
+        constexpr int UB = decltype(ub)::value;
+        const char* S = smem + UB * C::STAGE1;
+#pragma unroll
+        for (int kk = 0; kk < PX / 32; ++kk) {
+            elem8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                union { struct { s16x4 a, b; } s; elem8 v; } u;
+                u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, S + a_lo[i][0] + kk * 32 * C::PROW));
+                u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, S + a_lo[i][1] + kk * 32 * C::PROW));
+                af[i] = u.v;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                union { struct { s16x4 a, b; } s; elem8 v; } u;
+                u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, S + b_lo[j][0] + kk * 32 * C::QROW));
+                u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, S + b_lo[j][1] + kk * 32 * C::QROW));
+                bfr[j] = u.v;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = UDAPOSE_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
+        }
+    };
+
+    for (int st0 = 0; st0 < nsteps; st0 += NS) {
+        w_static_for<NS>([&](auto u) {
+            constexpr int U = decltype(u)::value;
+            const int st = st0 + U;
+            if (st < nsteps) {
+                if (issued - st - 1 >= NS - 2) wg_wait_vmcnt<LPS*(NS - 2)>();
+                else wg_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (issued < nsteps) { issue_stage(issued, WIC<(U + NS - 1) % NS>{}); ++issued; }
+                compute(u);
+            }
+        });
+    }
+
+    const bool atomic = (p.flags & WG_FLAG_ATOMIC) != 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = r0 + wr * TR + i * 16 + (lane >> 4) * 4 + r;
+                const int cc = c0 + wc * TC + j * 16 + (lane & 15);
+                if (rr >= p.Co || rr >= p.rows_valid || cc >= p.Ci) continue;
+                const size_t off = ((size_t)rr * p.wtaps + tp.widx) * p.Ci + cc;
+                const float v = acc[i][j][r];
+                if (atomic) atomicAdd(p.dw + off, v);
+                else p.dw[off] = v;
+            }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Filter-ROW form for 3x3, stride-1, pad-1 convolutions on power-of-two maps (W <= 64): one work-group computes the 64 x 64 tile
 // of dW for the THREE taps (dy, -1), (dy, 0), (dy, +1) of one filter row.  The three taps read the same dy pixels and x pixels that
@@ -617,7 +791,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
     if constexpr (RT == 64 && CT == 64) {
         if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem); return; }
     }
-    if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, 64, true>(p, bx, by, bz, smem);
+    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, 64>(p, bx, by, bz, smem);
+    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, 64, true>(p, bx, by, bz, smem);
     else wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem);
 }
 
@@ -639,7 +814,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void w
     if constexpr (RT == 64 && CT == 64 && PX == 64) {
         if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base); return; }
     }
-    if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
     else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
 }
 
@@ -750,6 +926,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
         if (hipMemsetAsync(p.dw, 0, n * sizeof(float), stream) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }
     if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
+    if ((p.flags & WG_FLAG_FASTGEO) && !(p.flags & WG_FLAG_ROW3) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0) p.flags |= WG_FLAG_FAST2; else p.flags &= ~WG_FLAG_FAST2;
     if (dma) return tile == 0 ? launch_wd<128, 128, 2, 2, 2>(p, stream) : launch_wd<64, 64, 2, 2, 4>(p, stream);
     switch (tile) {
         case 0: return launch_wg<128, 128, 2, 2>(p, stream);
@@ -786,6 +963,7 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
     p.msteps_per_split = (ms_total + ks - 1) / ks;
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
     if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
+    if ((p.flags & WG_FLAG_FASTGEO) && !(p.flags & WG_FLAG_ROW3) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0) p.flags |= WG_FLAG_FAST2; else p.flags &= ~WG_FLAG_FAST2;
     return tile;
 }
 
