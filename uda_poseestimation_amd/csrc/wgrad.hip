@@ -971,8 +971,9 @@ int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, cons
                        const void* dy_base, void* dw_base) {
     if (per_xcd <= 0) return UDAPOSE_OK;
     // 32-pixel stages for the 128x128 tile (32 KB of LDS, 128 VGPRs: four resident work-groups per CU instead of two with
-    // 64-pixel stages) and a 3-stage ring of 64-pixel stages for the 64x64 tile (48 KB: three per CU): measured -0.7 ms per
-    // step against {64-pixel stages, 2 / 4-stage rings}; occupancy beats prefetch depth here as in the igemm
+    // 64-pixel stages) and a 2-stage ring of 64-pixel stages for the 64x64 tile (35 KB with the filter-row form's reserve: four per
+    // CU; round 1 ran three stages = three per CU, with the buffer-load loader two measure -4.5 % alone and -0.05 ms in the step):
+    // occupancy beats prefetch depth here as in the igemm (a 3-stage ring for the 128x128 tile: +40 % alone)
     if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
-    return launch_wd_group<64, 64, 2, 2, 3, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
+    return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
 }
