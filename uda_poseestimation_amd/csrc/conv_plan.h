@@ -27,10 +27,9 @@ struct Policy {
     int bn_bwd_chunked = 1;     // BN backward: channel-chunked forms without a finalize launch
     int bn_bwd_pre_legacy = 0;  // BN backward from pre-reduced sums through the generic apply kernel (A/B)
     int igemm_wg_min = 512;     // 128x64 tiles as soon as they give this many work-groups (else 64x64): 2 per CU measured best in-step
-    int wgrad_row3 = 0;         // 3x3 stride-1 convs: one weight-gradient work-group per (64x64 tile, filter row), three taps sharing the staged
-                                // operands.  OFF: a third of the LDS fill per FLOP, but its 32x32 wave tiles read MORE LDS bytes per FLOP than the
-                                // 64x64 wave tiles of the 128x128 one-tap form, and LDS bandwidth (DMA writes + transposing reads) is what bounds
-                                // these kernels: equal speed alone (545 vs 529 TFLOP/s), neutral in the step (profiles/r2_ab_runs.txt)
+    int wgrad_row3 = 1;         // 3x3 stride-1 convs: one weight-gradient work-group per (64x64 tile, filter row), three taps sharing the staged
+                                // operands (a third of the LDS fill per FLOP).  As fast as the 128x128 one-tap form alone; in the grouped launch
+                                // with the 64x64 kernel at four work-groups per CU: 1366 vs 1387 us per pass alone, -0.10 ms per step
     int bn3_mask = 1;           // block outputs: the forward saves the ReLU bit mask, the data gradients read it instead of z (0: read z)
     int stem_fused = 1;         // stem: BN apply + ReLU + max-pool in one sweep, max-pool backward gathered inside the BN backward (0: separate launches)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line

@@ -613,8 +613,8 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
 // channels] starting one pixel early; tap dx reads the window at row offset dx + 1.  LDS fill per FLOP is a third of the
 // one-tap form at the same tile size.  Measured (tools/exp_wgrad_row3.py): as fast as the 128x128 one-tap form, not faster - what
 // bounds these kernels is LDS bandwidth as a whole (per work-group and 64-pixel stage 17 KB of DMA writes + 64 KB of transposing
-// reads = 630 LDS cycles against 384 MFMA cycles here; 48 KB = 375 against 256 for the 128x128 one-tap form), and the read
-// bytes per FLOP go with the WAVE tile: 32x32 here, 64x64 there.  Selected by Policy::wgrad_row3 (off by default).
+// reads; 48 KB for the 128x128 one-tap form).  In the grouped launch (64x64 kernel, 2-stage ring, four work-groups per CU) it is worth
+// 1.5 % of the weight-gradient time and -0.10 ms per step.  Selected by Policy::wgrad_row3 (on by default).
 // Zero padding: a pixel whose row i + dy falls outside the image gets a zero dy row (it contributes to none of the three taps);
 // the column wrap (j = 0 with dx = -1, j = W-1 with dx = +1: the neighbour in memory belongs to another image row) is cut out of
 // the dy FRAGMENTS per tap with loop-invariant lane masks (stages are 64 pixels, W divides 64: a lane's pixels keep their j).
