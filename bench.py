@@ -149,6 +149,7 @@ def main():
                     "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
     ap.add_argument("--wgrad-side", action="store_true", help="tuning: the upper part's weight gradients on a side stream under the lower "
                     "part's gradient chain instead of after the whole chain (measured slower: profiles/r2_ab_runs.txt)")
+    ap.add_argument("--no-merge-wgrad", action="store_true", help="tuning: each pass launches its own grouped weight gradients")
     ap.add_argument("--two-graphs", action="store_true", help="tuning: the optimizer tail as its own graph on one rank too")
     ap.add_argument("--force-overlap", action="store_true", help="tuning: the data-parallel backward (two parts, gradient sums per part) without a "
                     "process group: isolates what the cut costs on one rank")
@@ -253,6 +254,8 @@ def main():
     if args.no_fuse_tail:
         trainer.fuse_tail = False
     trainer.stream_priority = args.stream_priority
+    if args.no_merge_wgrad:
+        trainer.merge_wgrad = False
     if args.two_graphs:
         trainer.single_graph = False
     if args.force_overlap:

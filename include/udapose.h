@@ -205,6 +205,11 @@ int udapose_net_backward_part(udapose_net_t net, void* stream, const float* dout
  * one device: the weight gradients of part 1 run under the gradient chain of part 2. */
 int udapose_net_backward_phase(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
                                void* act, void* ws, void* const* h_grads, float beta, int part, int phase);
+/* The grouped weight-gradient launches (phase 2) of TWO passes of one plan whose gradient chains (phase 1) have run - each with its
+ * own act / ws arenas, gradient tensors and beta - as ONE launch per tile class: the two student passes of a mean-teacher step end
+ * together and their weight gradients are exposed there; one grid of twice the size has half the tail. */
+int udapose_net_wgrad_pair(udapose_net_t net, void* stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a,
+                           const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int part);
 long long udapose_net_grad_split_param(udapose_net_t net);
 
 /* ---------------------------------------------------------------- heat-map losses and decode (fp32 NCHW rows [R=B*K][HW]) */

@@ -484,3 +484,28 @@ def test_gradient_buffers_summed_inside_the_fused_tail_are_bit_identical_to_the_
     part = stu.head.weight.grad.clone()
     stu.finish_grads()
     assert stu.pending_grad_sum() == 0 and not torch.equal(part, stu.head.weight.grad)
+
+
+def test_merged_weight_gradient_launch_is_bit_identical():
+    """udapose_net_wgrad_pair: both passes' grouped weight gradients as one launch per tile class (engine.merge_wgrad) against each
+    pass launching its own - same tables, same kernels, bit-identical parameters; eager and captured, and with gradient accumulation
+    in front (an accumulate-mode pass paired with an overwrite-mode one)."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=8)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    res = {}
+    for merge in (False, True):
+        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda()
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
+        tr.merge_wgrad = merge
+        tr.train_step(*args)
+        assert not stu._pending_wg
+        gs = GraphedTrainStep(tr, *args, warmup=1)
+        for _ in range(2):
+            out = gs.step(*args)
+        assert torch.isfinite(out["loss_all"])
+        res[merge] = [p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
+    assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))

@@ -89,6 +89,7 @@ _SIGS = {
     "udapose_net_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf]),
     "udapose_net_backward_part": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci]),
     "udapose_net_backward_phase": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]),
+    "udapose_net_wgrad_pair": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, cf, ci]),
     "udapose_net_grad_split_param": (ll, [vp]),
     "udapose_net_bind_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "udapose_net_fused_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, cf, cf, ci, ll]),

@@ -71,6 +71,7 @@ void net_out_shape(void*, int*);
 int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
 int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
 int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int, int);
+int net_wgrad_pair(void*, hipStream_t, const void*, void*, void* const*, float, const void*, void*, void* const*, float, int);
 
 static Policy from_c(const udapose_policy& c) {
     Policy p;
@@ -239,6 +240,11 @@ int udapose_net_backward_part(udapose_net_t n, void* stream, const float* dout, 
                               void* ws, void* const* grads, float beta, int part) {
     if (part != 1 && part != 2) return UDAPOSE_ERR_ARG;
     return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part, 0);
+}
+int udapose_net_wgrad_pair(udapose_net_t n, void* stream, const void* act_a, void* ws_a, void* const* grads_a, float beta_a, const void* act_b,
+                           void* ws_b, void* const* grads_b, float beta_b, int part) {
+    if (!n || !act_a || !ws_a || !grads_a || !act_b || !ws_b || !grads_b) return UDAPOSE_ERR_ARG;
+    return net_wgrad_pair(n, S(stream), act_a, ws_a, grads_a, beta_a, act_b, ws_b, grads_b, beta_b, part);
 }
 int udapose_net_backward_phase(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act,
                                void* ws, void* const* grads, float beta, int part, int phase) {

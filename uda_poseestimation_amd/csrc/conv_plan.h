@@ -91,7 +91,8 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
 int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Policy& pol);
 // the x / dy / dw fields of the table entries are byte offsets from the three bases
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
-                       const void* dy_base, void* dw_base);
+                       const void* dy_base, void* dw_base, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr,
+                       const void* x_base2 = nullptr, const void* dy_base2 = nullptr, void* dw_base2 = nullptr);
 
 struct ConvEpilogue {
     const elem_t* res = nullptr;

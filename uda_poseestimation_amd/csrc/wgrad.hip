@@ -803,9 +803,18 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
 // OFFSETS in its x / dy / dw fields, relative to the three bases passed per launch, so one table serves every pass.
 template <int RT, int CT, int WR, int WC, int NS, int PX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
-                                                              const uint32_t per_xcd, const char* x_base, const char* dy_base, char* dw_base) {
+                                                              const uint32_t per_xcd, const char* x_base, const char* dy_base, char* dw_base,
+                                                              const WgParams* __restrict__ tab2, const WgGroupBlk* __restrict__ blk2,
+                                                              const char* x_base2, const char* dy_base2, char* dw_base2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const WgGroupBlk b = blk[(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)];
+    // PAIR launch (tab2 != null): the groups of TWO passes of one plan (same table shape, their own arenas and gradient buffers) in one
+    // grid, interleaved slot by slot - the second pass's heavy work-groups start beside the first's instead of behind its tail
+    uint32_t slot = blockIdx.x >> 3;
+    if (tab2) {
+        if (slot & 1u) { tab = tab2; blk = blk2; x_base = x_base2; dy_base = dy_base2; dw_base = dw_base2; }
+        slot >>= 1;
+    }
+    const WgGroupBlk b = blk[(blockIdx.x & 7u) * per_xcd + slot];
     if (b.prob < 0) return;
     const WgParams& p = tab[b.prob];
     const uint32_t gx = (uint32_t)(p.r_tiles * p.c_tiles), gxy = gx * (uint32_t)p.total_taps;
@@ -821,7 +830,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void w
 
 template <int RT, int CT, int WR, int WC, int NS, int PX>
 int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
-                    hipStream_t stream) {
+                    hipStream_t stream, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr, const void* x_base2 = nullptr,
+                    const void* dy_base2 = nullptr, void* dw_base2 = nullptr) {
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     constexpr int LDS = (RT == 64 && CT == 64 && PX == 64 && Row3Cfg::lds_bytes(NS) > C::LDS_BYTES) ? Row3Cfg::lds_bytes(NS) : C::LDS_BYTES;
     static std::atomic<unsigned long long> attr_done{0};
@@ -829,8 +839,9 @@ int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd,
     once_per_device(attr_done, attr_mu, [] {
         (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd), dim3(256), LDS, stream, d_tab, d_blk,
-                       (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base);
+    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd * (d_tab2 ? 2 : 1)), dim3(256), LDS, stream, d_tab, d_blk,
+                       (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base, d_tab2, d_blk2, (const char*)x_base2,
+                       (const char*)dy_base2, (char*)dw_base2);
     return udapose_check_launch();
 }
 
@@ -968,12 +979,13 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
 }
 
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
-                       const void* dy_base, void* dw_base) {
+                       const void* dy_base, void* dw_base, const WgParams* d_tab2, const WgGroupBlk* d_blk2, const void* x_base2,
+                       const void* dy_base2, void* dw_base2) {
     if (per_xcd <= 0) return UDAPOSE_OK;
     // 32-pixel stages for the 128x128 tile (32 KB of LDS, 128 VGPRs: four resident work-groups per CU instead of two with
     // 64-pixel stages) and a 2-stage ring of 64-pixel stages for the 64x64 tile (35 KB with the filter-row form's reserve: four per
     // CU; round 1 ran three stages = three per CU, with the buffer-load loader two measure -4.5 % alone and -0.05 ms in the step):
     // occupancy beats prefetch depth here as in the igemm (a 3-stage ring for the 128x128 tile: +40 % alone)
-    if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
-    return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream);
+    if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
+    return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
 }

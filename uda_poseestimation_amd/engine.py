@@ -137,6 +137,7 @@ class MeanTeacherTrainer:
         self.overlap_allreduce = None
         self.fuse_tail = True               # Adam + EMA + weight packs in one sweep (optim.FusedAdam.fused_tail_step)
         self.stream_priority = 0            # priority of the branch streams (and of a captured step's origin stream): -1 = high
+        self.merge_wgrad = True             # one rank: both passes' grouped weight gradients in one launch (pose_resnet.finish_wgrad)
         self.single_graph = True            # one rank: the optimizer tail is captured into the step's graph (one launch per step)
         self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
@@ -318,6 +319,9 @@ class MeanTeacherTrainer:
         # one device: the same cut, used to run the upper part's weight gradients on side streams under the lower part's chains
         side = (not overlap) and getattr(student, "wgrad_side_stream", False) and hasattr(student, "finish_backward")
         student.split_backward = True if overlap else ("side" if side else False)
+        # one rank: the two passes' grouped weight gradients go out as ONE launch after both gradient chains (finish_wgrad)
+        merge = (not overlap) and (not side) and self.merge_wgrad and hasattr(student, "finish_wgrad")
+        student.merge_wgrad = bool(merge)
         loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
@@ -329,6 +333,9 @@ class MeanTeacherTrainer:
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
         student.split_backward = False
+        if merge:
+            student.merge_wgrad = False
+            student.finish_wgrad()
         if overlap:
             student.finish_grads(part=1)    # the suffix of both passes is final: sum it ...
             if not torch.cuda.is_current_stream_capturing():

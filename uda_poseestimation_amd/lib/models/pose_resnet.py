@@ -77,7 +77,8 @@ class _NetHandle:
         self.wpack = torch.empty(L.udapose_net_wpack_bytes(h), dtype=torch.uint8, device=device)
         self.wpack_version = None
         # (the backward can be cut at layer3's first block, and its weight gradients are grouped launches)
-        self.can_split = L.udapose_net_grad_split_param(h) >= 0 and int((policy or {}).get("wgrad_group", 1)) != 0
+        self.grouped = int((policy or {}).get("wgrad_group", 1)) != 0
+        self.can_split = L.udapose_net_grad_split_param(h) >= 0 and self.grouped
         self.act_nograd = None
         self._fin = weakref.finalize(self, L.udapose_net_destroy, h)
 
@@ -150,6 +151,11 @@ class PoseResNet(nn.Module):
         # concurrency costs the memory-bound lower chains more than it hides.
         self.wgrad_side_stream = False
         self._wg_side = {}
+        # merge_wgrad (set by the engine around a step's backward): backward() runs the gradient chain only and finish_wgrad() then
+        # launches the grouped weight gradients - of BOTH passes in one grid when two passes of the same plan are pending
+        # (udapose_net_wgrad_pair): the passes end together and their weight-gradient launches are exposed at the step's end
+        self.merge_wgrad = False
+        self._pending_wg = []
         self._to_channels_last()
 
     # ------------------------------------------------------------------ layout / pointer bookkeeping
@@ -170,6 +176,7 @@ class PoseResNet(nn.Module):
         self._deferred_bn = []
         self._handles = {}
         self._pending_lower = []
+        self._pending_wg = []
         self._split_off = None
         return r
 
@@ -432,6 +439,10 @@ class PoseResNet(nn.Module):
             check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 1, int(side)),
                   "net_backward part 1")
             self._pending_lower.append((hd, act, ws, gptrs, beta, cur, side))       # (keeps the arenas alive until part 2 has run)
+        elif self.merge_wgrad and hd.grouped:
+            check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 1),
+                  "net_backward gradient chain")
+            self._pending_wg.append((hd, act, ws, gptrs, beta, cur))          # (keeps the arenas alive until the weight gradients have run)
         else:
             check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not
@@ -440,6 +451,25 @@ class PoseResNet(nn.Module):
         for p, v in zip(params, views):
             if p.requires_grad and id(p) not in nograd:
                 p.grad = v
+
+    def finish_wgrad(self):
+        """Launch the grouped weight gradients of the backward passes that ran with merge_wgrad, on the current stream (the caller
+        has made it wait for the streams those passes ran on): two pending passes of one plan go out as ONE launch per tile class."""
+        pend, self._pending_wg = self._pending_wg, []
+        if not pend:
+            return
+        s = _hip.stream()
+        cur = torch.cuda.current_stream()
+        pa, ba, params = self._pointers()
+        if len(pend) == 2 and pend[0][0] is pend[1][0]:
+            (hd, actA, wsA, gA, bA, _), (_, actB, wsB, gB, bB, _) = pend
+            check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0), "net_wgrad_pair")
+        else:
+            for hd, act, ws, gptrs, beta, _ in pend:
+                check(hd.L.udapose_net_backward_phase(hd.h, s, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 2), "net_backward weight gradients")
+        for _, act, ws, _, _, _ in pend:
+            act.record_stream(cur)
+            ws.record_stream(cur)
 
     def _side_stream_for(self, cur, device):
         """The side stream paired with `cur` (one per stream a backward runs on).  Streams are only CREATED outside a capture
