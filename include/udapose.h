@@ -57,7 +57,7 @@ int udapose_elem_kind(void);
  * with out-of-range zero fill and an unrolled ring: the production form); wgrad_row3: weight gradients of 3x3 stride-1 convolutions with one work-group per (64x64 tile, filter row) - the row's three taps
  * share one staged dy tile and one x window (3x the FLOPs per byte filled into LDS, which is what bounds these kernels);
  * igemm_wg_min: 128x64 tiles as soon as they give that many work-groups, else 64x64; bn3_mask: block outputs save a ReLU bit mask
- * that the masking data gradients read instead of z; stem_fused: the stem's BN + ReLU + max-pool in one sweep and the max-pool
+ * that the masking data gradients read instead of z; stem_fused: 1 = the stem's BN + ReLU + max-pool in one sweep, 2 = also the max-pool
  * backward gathered inside the BN backward; timeline: device buffer ([work-groups][8] uint64) for
  * per-work-group s_memrealtime stamps, or NULL. */
 typedef struct {

@@ -371,7 +371,7 @@ def test_stem_fusion_is_bit_identical_to_separate_launches():
     x = torch.randn(3, 3, 160, 96, generator=torch.Generator().manual_seed(5)).cuda()
     d = torch.randn(3, 16, 40, 24, generator=torch.Generator().manual_seed(6)).cuda()
     res = {}
-    for fused in (0, 1):
+    for fused in (0, 1, 2):       # separate launches | fused forward | fused forward and the pooled backward
         net = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 1, 1], False, False)
         net.load_state_dict(base.state_dict())
         net = net.cuda().train()
@@ -385,9 +385,10 @@ def test_stem_fusion_is_bit_identical_to_separate_launches():
         with torch.no_grad():
             ye = net(x)
         res[fused] = (y.detach().clone(), grads, bufs, ye.clone())
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][3], res[1][3])
-    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
-    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    for k in (1, 2):
+        assert torch.equal(res[0][0], res[k][0]) and torch.equal(res[0][3], res[k][3])
+        assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[k][1]))
+        assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[k][2]))
     assert float(res[1][1][0].abs().sum()) > 0          # (the stem's weight gradient is there)
 
 

@@ -910,7 +910,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         return UDAPOSE_OK;
     }
     // stem: maxpool -> bn/relu -> conv (no input gradient)
-    if (n.policy.stem_fused && grouped && n.policy.wgrad_group_stem) {
+    if (n.policy.stem_fused >= 2 && grouped && n.policy.wgrad_group_stem) {
         // the max-pool backward is gathered inside the BN backward's two sweeps: the full-resolution gradient is never stored
         const BnL& sb = n.stem_bn;
         const float* save = (const float*)(act + sb.save_off);
