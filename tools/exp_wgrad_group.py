@@ -24,8 +24,23 @@ check(hd.L.udapose_net_bind_grads(hd.h, gp), "bind_grads")
 dout = torch.randn(hd.out_shape, device="cuda") * 1e-3
 check(hd.L.udapose_net_backward(hd.h, s, ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gp, C.c_float(0.0)), "bwd")
 torch.cuda.synchronize()
+# a second pass (own arenas, own gradient buffer) for the pair launch
+act2, ws2 = torch.empty_like(act), torch.empty_like(ws)
+check(hd.L.udapose_net_forward(hd.h, s, ptr(x), pa, ba, ptr(hd.wpack), ptr(act2), ptr(ws2), ptr(out), 3, 0.1), "fwd2")
+flat2 = torch.zeros_like(net._flat_grad)
+off, arr = 0, []
+for p_ in params:
+    arr.append(flat2.data_ptr() + 4 * off); off += p_.numel()
+gp2 = (C.c_void_p * len(arr))(*arr)
+check(hd.L.udapose_net_bind_grads(hd.h, gp2), "bind_grads2")
+check(hd.L.udapose_net_backward(hd.h, s, ptr(dout), pa, ptr(hd.wpack), ptr(act2), ptr(ws2), gp2, C.c_float(0.0)), "bwd2")
+torch.cuda.synchronize()
+PAIR = True
 def run():
-    check(hd.L.udapose_net_backward_phase(hd.h, s, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gp, C.c_float(0.0), 0, 2), "wgrad group")
+    if PAIR:
+        check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(act), ptr(ws), gp, C.c_float(0.0), ptr(act2), ptr(ws2), gp2, C.c_float(0.0), 0), "wgrad pair")
+    else:
+        check(hd.L.udapose_net_backward_phase(hd.h, s, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gp, C.c_float(0.0), 0, 2), "wgrad group")
 for _ in range(5): run()
 torch.cuda.synchronize()
 for rep in range(3):
@@ -33,4 +48,4 @@ for rep in range(3):
     a.record()
     for _ in range(20): run()
     b.record(); torch.cuda.synchronize()
-    print(f"grouped weight gradients (both launches), N={N}: {a.elapsed_time(b) / 20 * 1e3:.1f} us", flush=True)
+    print(f"grouped weight gradients of TWO passes in one pair launch, N={N} each: {a.elapsed_time(b) / 20 * 1e3:.1f} us", flush=True)
