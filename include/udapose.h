@@ -89,6 +89,13 @@ int udapose_conv_prepare(const udapose_conv_desc* d);
 #define UDAPOSE_EPI_RELU 1
 #define UDAPOSE_EPI_OUT_F32 2
 #define UDAPOSE_EPI_F32 4   /* x, w_fwd ([Co][taps][Ci] fp32), res and y are fp32: exact fp32 MFMA path (Ci multiple of 32 or 8) */
+/* x, w_fwd, res - and y unless UDAPOSE_EPI_OUT_F32 - are "f16x2" split tensors: the FAST fp32-grade mode (forward only).  A split
+ * tensor has the byte footprint and addressing of the fp32 tensor of the same shape; every group of 8 consecutive channels
+ * (32 bytes) holds [8 x h fp16][8 x l fp16] with value = h + l * 2^-11, |value| <= 65504 (udapose_f32_to_split /
+ * udapose_split_to_f32 convert).  The kernel multiplies with three v_mfma_f32_16x16x32_f16 per 32-deep K step (h.h, h.l, l.h; fp32
+ * accumulation): products carry ~2^-22 relative error against the fp32 the reference computes the teacher, validate() and the
+ * style network in (train_human.py:346-358,461-500), at 3/16 of the exact-fp32 MFMA's cost. */
+#define UDAPOSE_EPI_SPLIT 8
 void udapose_conv_out_hw(const udapose_conv_desc* d, int* Ho, int* Wo);
 int udapose_conv_stat_rows(const udapose_conv_desc* d);
 /* y[N,Ho,Wo,Co] = conv(x, w_fwd) (+bias[Co]) (+res) (ReLU); stats (optional): [stat_rows][2][Co] fp32 partial
@@ -121,7 +128,13 @@ int udapose_pack_strided(void* stream, const float* src, void* dst, int A, int K
 int udapose_nchw_f32_to_nhwc_bf16(void* stream, const float* src, void* dst, int N, int C, int HW, int Cpad);
 /* the same into fp32 NHWC (style path at the reference's precision: it runs outside autocast, train_human.py:347-356) */
 int udapose_nchw_f32_to_nhwc_f32(void* stream, const float* src, float* dst, int N, int C, int HW, int Cpad);
+/* the same into an f16x2 split NHWC tensor (UDAPOSE_EPI_SPLIT), and the element-wise conversions fp32 <-> split (n % 8 == 0;
+ * udapose_f32_to_split may run in place) */
+int udapose_nchw_f32_to_nhwc_split(void* stream, const float* src, void* dst, int N, int C, int HW, int Cpad);
+int udapose_f32_to_split(void* stream, const float* src, void* dst, size_t n);
+int udapose_split_to_f32(void* stream, const void* src, float* dst, size_t n);
 /* optional per-channel clamp lo/hi[C] = the "recover" clamp of train_human.py:32-33,276,351,356 */
+/* src_is_f32: 0 = the library's 16-bit element type, 1 = fp32, 2 = f16x2 split */
 int udapose_nhwc_to_nchw_f32(void* stream, const void* src, int src_is_f32, float* dst, int N, int C, int HW, int Cstride,
                              const float* lo, const float* hi);
 
@@ -155,13 +168,16 @@ int udapose_maxpool3x3s2_fwd(void* stream, const void* x, void* y, unsigned char
 int udapose_maxpool3x3s2_bwd(void* stream, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C);
 int udapose_maxpool2x2_ceil(void* stream, const void* x, void* y, int N, int H, int W, int C);
 int udapose_maxpool2x2_ceil_f32(void* stream, const float* x, float* y, int N, int H, int W, int C);   /* fp32 NHWC (Style_net.py:72) */
+int udapose_maxpool2x2_ceil_split(void* stream, const void* x, void* y, int N, int H, int W, int C);   /* f16x2 split NHWC */
 
 /* ---------------------------------------------------------------- whole pose network (lib/models/pose_resnet.py:59-126:
  * PoseResNet.forward = head(upsampling(backbone(x)))), parameters by index in .parameters() order (host arrays of
  * device pointers), buffers in .buffers() order.  4-D weights are fp32 in channels_last physical layout. */
 typedef void* udapose_net_t;
-/* fp32 != 0: fp32 activations and exact fp32 MFMA, FORWARD ONLY (the reference runs the teacher and validate() in fp32,
- * train_human.py:347-358,461-500); fp32 == 0: bf16 compute with fp32 accumulation, forward and backward. */
+/* fp32 == 1: fp32 activations and exact fp32 MFMA, FORWARD ONLY (the reference runs the teacher and validate() in fp32,
+ * train_human.py:347-358,461-500); fp32 == 2: the fast fp32-grade form of the same (f16x2 split activations and weight packs,
+ * UDAPOSE_EPI_SPLIT; pre-BatchNorm conv outputs and statistics in fp32), FORWARD ONLY; fp32 == 0: the library's 16-bit
+ * element type with fp32 accumulation, forward and backward. */
 int udapose_net_create(const int layers[4], int num_keypoints, int N, int H, int W, int fp32, udapose_net_t* out);
 void udapose_net_destroy(udapose_net_t net);
 int udapose_net_num_params(udapose_net_t net);
@@ -293,6 +309,10 @@ int udapose_adain(void* stream, const void* content, const void* style, void* ou
 /* the same on fp32 NHWC features (the reference's precision); out may be NULL: statistics only (calc_mean_std) */
 int udapose_adain_f32(void* stream, const float* content, const float* style, float* out, int N, int HWc, int HWs, int C, float eps,
                       float alpha, float* stats_out);
+/* the same on f16x2 split NHWC features (UDAPOSE_EPI_SPLIT): statistics and blend in fp32, out (may be NULL) split;
+ * alpha_dev != NULL: the blend factor is read from device memory at run time */
+int udapose_adain_split(void* stream, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps,
+                        float alpha, const float* alpha_dev, float* stats_out);
 /* the same with the blend factor read from device memory at run time (one float): a launch captured in a hipGraph then follows
  * the step's draw of alpha.  is_f32 selects the fp32 form (content / style / out are float*), else the library's element type. */
 int udapose_adain_alpha_dev(void* stream, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps,

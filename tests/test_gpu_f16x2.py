@@ -1,0 +1,181 @@
+"""The fast fp32-grade mode ("f16x2": split fp16 storage, three fp16 MFMAs per K step, fp32 accumulation; include/udapose.h
+UDAPOSE_EPI_SPLIT) against fp64 / fp32 CPU references: the precision the reference runs the teacher, validate() and the style
+network in (train_human.py:346-358,461-500 are outside autocast) at a usable speed.  Tolerances are those of north_star:
+heat-maps within 1e-3 of the fp32 CPU oracle and identical arg-max key points."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(golden_dir, name):
+    import os
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_split_storage_round_trip_and_range():
+    """value -> (h, l) -> value: ~2^-22 relative over fp16's normal range, graceful below it, saturating above 65504."""
+    from uda_poseestimation_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1 << 16, generator=g) * torch.exp(torch.randn(1 << 16, generator=g) * 3.0)).clamp(-6e4, 6e4)
+    x[:8] = torch.tensor([0.0, -0.0, 65504.0, -65504.0, 1e-7, 6.1e-5, 1.0, -1.0])
+    y = ops.split_to_f32(ops.f32_to_split(x.cuda())).cpu()
+    rel = ((y - x).abs() / x.abs().clamp(min=1e-3)).max().item()
+    print(f"split round trip: max relative error {rel:.2e} (2^-22 = {2.0 ** -22:.2e})")
+    assert rel < 2.0 ** -21
+    assert (y[:4] == x[:4]).all() and abs(y[4] - 1e-7) < 3e-11      # tiny values keep an ABSOLUTE precision of 2^-24 / 2^11
+    big = torch.tensor([1e5, -3e38, float("inf"), 7e4] + [0.0] * 4)
+    yb = ops.split_to_f32(ops.f32_to_split(big.cuda())).cpu()
+    assert torch.equal(yb[:4], torch.tensor([65504.0, -65504.0, 65504.0, 65504.0]))        # saturates, never NaN
+
+
+def _pack(w, d):
+    """torch weight [Co,Ci,KH,KW] (transposed: [Ci,Co,KH,KW]) -> fp32 GEMM layout [Co][taps][Ci] -> split"""
+    from uda_poseestimation_amd import ops
+    if d.transposed:
+        wp = w.permute(1, 2, 3, 0).contiguous()
+    elif d.Ci == 8:
+        wp = torch.zeros(d.Co, d.KH, ops.kwp(d), 8, device=w.device)
+        wp[:, :, :d.KW, :w.shape[1]] = w.permute(0, 2, 3, 1)
+    else:
+        wp = w.permute(0, 2, 3, 1).contiguous()
+    return ops.f32_to_split(wp.contiguous())
+
+
+CASES = [
+    # name, N, H, W, Ci(real), Co, K, stride, pad, transposed, reflect, upsample
+    ("1x1 lean", 2, 16, 16, 256, 128, 1, 1, 0, False, False, False),
+    ("1x1 s2", 2, 16, 16, 128, 64, 1, 2, 0, False, False, False),
+    ("3x3 s1", 2, 16, 16, 64, 64, 3, 1, 1, False, False, False),
+    ("3x3 s2 ragged", 3, 14, 10, 64, 72, 3, 2, 1, False, False, False),
+    ("7x7 stem", 2, 64, 64, 3, 64, 7, 2, 3, False, False, False),
+    ("deconv 4x4", 2, 8, 8, 128, 64, 4, 2, 1, True, False, False),
+    ("reflect 3x3", 2, 12, 12, 64, 32, 3, 1, 1, False, True, False),
+    ("upsample+reflect", 2, 8, 8, 64, 64, 3, 1, 1, False, True, True),
+    ("head K=16", 2, 16, 16, 256, 16, 1, 1, 0, False, False, False),
+    ("vgg first 3x3", 1, 32, 32, 3, 64, 3, 1, 1, False, True, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_split_conv_matches_fp64_convolution(case):
+    """Every loader form of the igemm in the f16x2 mode (1x1 lean, strided, 3x3, the 8-channel stem, sub-pixel deconv,
+    reflection, folded upsample, the 16-channel head with bias) against torch's fp64 convolution: <= 2e-6 * max|y| (an fp32
+    convolution itself sits at ~1e-6 of fp64), split and fp32 outputs, bias + ReLU epilogue, BN partial statistics."""
+    from uda_poseestimation_amd import ops
+    name, N, H, W, Ci, Co, K, stride, pad, tr, refl, up = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = (torch.randn(Ci, Co, K, K, generator=g) if tr else torch.randn(Co, Ci, K, K, generator=g)) / np.sqrt(Ci * K * K)
+    b = torch.randn(Co, generator=g)
+    xd, wd = x.double(), w.double()
+    if up:
+        xd = F.interpolate(xd, scale_factor=2, mode="nearest")
+    if tr:
+        ref = F.conv_transpose2d(xd, wd, stride=stride, padding=pad)
+    elif refl:
+        ref = F.conv2d(F.pad(xd, (pad,) * 4, mode="reflect"), wd, stride=stride)
+    else:
+        ref = F.conv2d(xd, wd, stride=stride, padding=pad)
+    cpad = 8 if Ci == 3 else Ci
+    d = ops.conv_desc(N, H, W, cpad, Co, K, stride, pad, transposed=tr, reflect=refl, upsample=up)
+    xs = ops.to_nhwc_split(x.cuda(), cpad)
+    ws = _pack(w.cuda(), d)
+    # plain output in fp32 (+ the BN partial statistics of the raw accumulators)
+    y, stats = ops.conv2d_fwd(xs, ws, d, out_f32=True, want_stats=True)
+    torch.cuda.synchronize()
+    yr = ref.permute(0, 2, 3, 1)
+    e = (y.cpu().double() - yr).abs().max().item() / yr.abs().max().item()
+    s1 = stats[:, 0].sum(0).cpu().double()
+    es = (s1 - yr.sum((0, 1, 2))).abs().max().item() / max(yr.sum((0, 1, 2)).abs().max().item(), 1.0)
+    # bias + ReLU with a split output
+    y2 = ops.split_to_f32(ops.conv2d_fwd(xs, ws, d, bias=b.cuda(), relu=True)) if Co % 8 == 0 else None
+    e2 = 0.0
+    if y2 is not None:
+        r2 = torch.relu(yr + b.double())
+        e2 = (y2.cpu().double() - r2).abs().max().item() / r2.abs().max().item()
+    print(f"{name}: fp32-out err {e:.2e} * max, split-out (bias, relu) err {e2:.2e} * max, stats err {es:.2e}")
+    assert e < 2e-6 and e2 < 2e-6 and es < 1e-5
+
+
+@pytest.mark.parametrize("arch", ["pose_resnet50", "pose_resnet101"])
+def test_f16x2_mode_meets_the_1e3_heatmap_bar_and_identical_argmax(arch):
+    """north_star's bar in the FAST fp32-grade mode: PoseResNet forward (reference initialisation, training-mode BN, 256x256)
+    vs the fp32 CPU oracle: heat-maps within 1e-3 (measured ~1e-5: the level at which two fp32 evaluations differ), arg-max
+    key points identical, running statistics updated like torch; and the mode against the exact-fp32 MFMA mode."""
+    import uda_poseestimation_amd.lib.models as models
+    from oracle import pose_resnet_ref
+    from oracle.keypoints_ref import get_max_preds_ref
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    torch.manual_seed(0)
+    ref = getattr(pose_resnet_ref, arch + "_ref")(16)
+    net = models.__dict__[arch](num_keypoints=16, pretrained_backbone=False)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda()
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(1)).clamp(-2.1, 2.6)
+    ref.train(); net.train()
+    bufs0 = {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+    with torch.no_grad():
+        y_ref = ref(x)
+        net.precision = "fp32"
+        y32 = net(x.cuda())
+        net.load_state_dict(bufs0, strict=False)
+        net.precision = "f16x2"
+        y = net(x.cuda())
+    err = (y.cpu() - y_ref).abs().max().item()
+    err32 = (y32.cpu() - y_ref).abs().max().item()
+    print(f"{arch} f16x2: max|y|={y_ref.abs().max().item():.4f} max|device - oracle|={err:.3e} (exact-fp32 mode: {err32:.3e}; "
+          f"f16x2 vs exact-fp32 mode {(y - y32).abs().max().item():.3e})")
+    assert err < 1e-3
+    p_dev, _ = kd.get_max_preds(y)
+    p_ref, _ = get_max_preds_ref(y_ref.numpy())
+    top2 = y_ref.reshape(32, -1).topk(2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 4 * err).reshape(2, 16).numpy()
+    assert np.array_equal(p_dev.cpu().numpy()[clear], p_ref[clear]) and clear.mean() > 0.9
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-3, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        net(x.cuda())            # grad-enabled forward is refused in the forward-only precision
+    # eval mode (validate(): running statistics) through the same plan family
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        e_eval = (net(x.cuda()).cpu() - ref(x)).abs().max().item()
+    print(f"{arch} f16x2 eval mode: {e_eval:.3e}")
+    assert e_eval < 1e-3
+
+
+def test_style_net_f16x2_matches_reference_golden(golden_dir):
+    """A10-A13 in the fast fp32-grade mode against the reference's own outputs (tests/golden/style.npz): relu4_1, g_t within
+    1e-3 * max, content / Gram style losses to 1e-3, the recover clamp; a device-resident alpha gives the same result."""
+    from seeded import fill_style_weights
+    from uda_poseestimation_amd.lib.models import Style_net
+    z = _g(golden_dir, "style.npz")
+    fill_style_weights(Style_net.vgg, 11)
+    fill_style_weights(Style_net.decoder, 12)
+    Style_net.vgg.cuda(); Style_net.decoder.cuda()
+    vgg31 = torch.nn.Sequential(*list(Style_net.vgg.children())[:31])
+    net = Style_net.Net(vgg31, Style_net.decoder).cuda().eval()
+    content, style = torch.from_numpy(z["content"]).cuda(), torch.from_numpy(z["style"]).cuda()
+
+    def err(a, b):
+        return (a.cpu() - torch.from_numpy(b)).abs().max().item() / np.abs(b).max()
+    net.precision, net.compute_losses = "f16x2", True
+    with torch.no_grad():
+        lc, ls, g = net(content, style, float(z["alpha"]))
+        feat = net.encode(content)
+    e_feat, e_g = err(feat, z["feat"]), err(g, z["g_t"])
+    print(f"style f16x2: relu4_1 err {e_feat:.2e} * max, g_t err {e_g:.2e} * max; loss_c {float(lc):.6f} (ref {float(z['loss_c']):.6f}) "
+          f"loss_s {float(ls):.6e} (ref {float(z['loss_s']):.6e}); max|relu4_1| {np.abs(z['feat']).max():.2f}")
+    assert e_feat <= 1e-3 and e_g <= 1e-3
+    assert abs(float(lc) - float(z["loss_c"])) <= 1e-3 * float(z["loss_c"])
+    assert abs(float(ls) - float(z["loss_s"])) <= 1e-3 * float(z["loss_s"])
+    net.compute_losses = False
+    lo, hi = torch.tensor([-0.5, -0.4, -0.3]).cuda(), torch.tensor([0.5, 0.6, 0.7]).cuda()
+    with torch.no_grad():
+        g_c = net(content, style, float(z["alpha"]), clamp=(lo, hi))[2]
+        g_a = net(content, style, torch.tensor([float(z["alpha"])], device="cuda"))[2]
+    assert torch.allclose(g_c, torch.maximum(torch.minimum(g.permute(0, 2, 3, 1), hi), lo).permute(0, 3, 1, 2), atol=1e-6)
+    assert torch.equal(g_a, g)

@@ -63,6 +63,11 @@ _SIGS = {
     "udapose_nchw_f32_to_nhwc_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci]),
     "udapose_nchw_f32_to_nhwc_f32": (ci, [vp, vp, vp, ci, ci, ci, ci]),
     "udapose_nhwc_to_nchw_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
+    "udapose_nchw_f32_to_nhwc_split": (ci, [vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_f32_to_split": (ci, [vp, vp, vp, sz]),
+    "udapose_split_to_f32": (ci, [vp, vp, vp, sz]),
+    "udapose_maxpool2x2_ceil_split": (ci, [vp, vp, vp, ci, ci, ci, ci]),
+    "udapose_adain_split": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp, vp]),
     "udapose_bn_finalize": (ci, [vp, vp, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp]),
     "udapose_bn_eval_coeff": (ci, [vp, ci, vp, vp, vp, vp, cf, vp, vp]),
     "udapose_bn_apply": (ci, [vp, vp, vp, vp, sz, ci, vp, vp, ci]),

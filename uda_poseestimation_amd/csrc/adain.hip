@@ -19,7 +19,18 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o
 #pragma unroll
     for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
 }
+template <> __device__ __forceinline__ void ld8<sp32>(const sp32* p, float (&o)[8]) {      // f16x2 split storage (common.h)
+    const char* c = (const char*)p;
+    sp_join8(*(const half8*)c, *(const half8*)(c + 16), o);
+}
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<sp32>(sp32* p, const float (&v)[8]) {
+    half8 h, l;
+    sp_split8(v, h, l);
+    char* c = (char*)p;
+    *(half8*)c = h;
+    *(half8*)(c + 16) = l;
+}
 template <> __device__ __forceinline__ void st8<elem_t>(elem_t* p, const float (&v)[8]) {
     elem8 o;
 #pragma unroll
@@ -44,6 +55,9 @@ constexpr int ATPB = 1024, APL = ATPB / 8, CACHE = 8;
 template <typename T> struct Raw8;
 template <> struct Raw8<elem_t> { elem8 v; };
 template <> struct Raw8<float> { f32x4 a, b; };
+template <> struct Raw8<sp32> { half8 h, l; };
+__device__ __forceinline__ void ldraw(const sp32* p, Raw8<sp32>& r) { const char* c = (const char*)p; r.h = *(const half8*)c; r.l = *(const half8*)(c + 16); }
+__device__ __forceinline__ void unraw(const Raw8<sp32>& r, float (&o)[8]) { sp_join8(r.h, r.l, o); }
 __device__ __forceinline__ void ldraw(const elem_t* p, Raw8<elem_t>& r) { r.v = *(const elem8*)p; }
 __device__ __forceinline__ void ldraw(const float* p, Raw8<float>& r) { r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); }
 __device__ __forceinline__ void unraw(const Raw8<elem_t>& r, float (&o)[8]) {
@@ -174,5 +188,12 @@ int adain_launch_f32(hipStream_t s, const float* content, const float* style, fl
                      const float* alpha_dev, float* stats_out) {
     if (C % 64 || HWc < 2 || HWs < 2) return UDAPOSE_ERR_ARG;
     hipLaunchKernelGGL(adain_k<float>, dim3(N * (C / 64)), dim3(ATPB), 0, s, content, style, out, HWc, HWs, C, eps, alpha, alpha_dev, stats_out);
+    return udapose_check_launch();
+}
+int adain_launch_split(hipStream_t s, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps, float alpha,
+                       const float* alpha_dev, float* stats_out) {
+    if (C % 64 || HWc < 2 || HWs < 2) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(adain_k<sp32>, dim3(N * (C / 64)), dim3(ATPB), 0, s, (const sp32*)content, (const sp32*)style, (sp32*)out, HWc, HWs, C, eps, alpha,
+                       alpha_dev, stats_out);
     return udapose_check_launch();
 }

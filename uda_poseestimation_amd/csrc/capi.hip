@@ -27,6 +27,11 @@ int hm_mask_count(hipStream_t, const unsigned char*, size_t, float*);
 int pw_maxpool2x2_ceil_f32(hipStream_t, const float*, float*, int, int, int, int);
 int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, int);
 int adain_launch_f32(hipStream_t, const float*, const float*, float*, int, int, int, int, float, float, const float*, float*);
+int adain_launch_split(hipStream_t, const void*, const void*, void*, int, int, int, int, float, float, const float*, float*);
+int pw_nchw_f32_to_nhwc_split(hipStream_t, const float*, void*, int, int, int, int);
+int pw_f32_to_split(hipStream_t, const float*, void*, size_t);
+int pw_split_to_f32(hipStream_t, const void*, float*, size_t);
+int pw_maxpool2x2_ceil_split(hipStream_t, const void*, void*, int, int, int, int);
 int hm_argmax_rectify(hipStream_t, const float*, int, int, int, float*, int*, float*, float*, const float*, int);
 int hm_kth_mask(hipStream_t, const float*, const float*, int, int, float*, unsigned char*, const float*, int);
 int hm_pck(hipStream_t, const float*, const float*, int, int, float, float, float, float*, float*);
@@ -116,6 +121,8 @@ int udapose_conv2d_fwd(void* stream, const udapose_conv_desc* d, const void* x, 
     if (!d || !x || !w_fwd || !y) return UDAPOSE_ERR_ARG;
     ConvEpilogue e;
     e.res = CB16(res); e.bias = bias; e.stats = stats; e.relu = (flags & UDAPOSE_EPI_RELU) != 0; e.out_f32 = (flags & UDAPOSE_EPI_OUT_F32) != 0; e.f32 = (flags & UDAPOSE_EPI_F32) != 0;
+    e.split = (flags & UDAPOSE_EPI_SPLIT) != 0;
+    if (e.split && e.f32) return UDAPOSE_ERR_ARG;
     Geom G(d);
     return conv_fprop(S(stream), G.g, CB16(x), CB16(w_fwd), y, e);
 }
@@ -188,6 +195,22 @@ int udapose_maxpool2x2_ceil_f32(void* stream, const float* x, float* y, int N, i
 }
 int udapose_nchw_f32_to_nhwc_f32(void* stream, const float* src, float* dst, int N, int C, int HW, int Cpad) {
     return pw_nchw_f32_to_nhwc_f32(S(stream), src, dst, N, C, HW, Cpad);
+}
+int udapose_nchw_f32_to_nhwc_split(void* stream, const float* src, void* dst, int N, int C, int HW, int Cpad) {
+    if (!src || !dst) return UDAPOSE_ERR_ARG;
+    return pw_nchw_f32_to_nhwc_split(S(stream), src, dst, N, C, HW, Cpad);
+}
+int udapose_f32_to_split(void* stream, const float* src, void* dst, size_t n) {
+    if (!src || !dst) return UDAPOSE_ERR_ARG;
+    return pw_f32_to_split(S(stream), src, dst, n);
+}
+int udapose_split_to_f32(void* stream, const void* src, float* dst, size_t n) {
+    if (!src || !dst) return UDAPOSE_ERR_ARG;
+    return pw_split_to_f32(S(stream), src, dst, n);
+}
+int udapose_maxpool2x2_ceil_split(void* stream, const void* x, void* y, int N, int H, int W, int C) {
+    if (!x || !y) return UDAPOSE_ERR_ARG;
+    return pw_maxpool2x2_ceil_split(S(stream), x, y, N, H, W, C);
 }
 
 int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32, udapose_net_t* out) {
@@ -336,6 +359,11 @@ int udapose_adain_alpha_dev(void* stream, const void* c, const void* s, void* ou
 int udapose_adain_f32(void* stream, const float* c, const float* s, float* out, int N, int HWc, int HWs, int C, float eps, float alpha,
                       float* stats_out) {
     return adain_launch_f32(S(stream), c, s, out, N, HWc, HWs, C, eps, alpha, nullptr, stats_out);
+}
+int udapose_adain_split(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha,
+                        const float* alpha_dev, float* stats_out) {
+    if (!c || !s) return UDAPOSE_ERR_ARG;
+    return adain_launch_split(S(stream), c, s, out, N, HWc, HWs, C, eps, alpha, alpha_dev, stats_out);
 }
 
 int udapose_patch_paste(void* stream, float* img, const int* boxes, int n, int C, int H, int W, int max_patch_elems) {

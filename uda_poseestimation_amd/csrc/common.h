@@ -31,6 +31,45 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// ---- "f16x2" storage: the fp32-grade precision mode (both builds of the library carry it; it does not depend on elem_t).
+// A value v is kept as two fp16 numbers (h, l) with v = h + l * 2^-11 to ~2^-22 relative: h = fp16(v), l = fp16((v - h) * 2^11)
+// (the remainder is scaled so that it stays in fp16's normal range whenever h does).  A product of two such values is
+// h_a h_b + (h_a l_b + l_a h_b) 2^-11 + O(2^-22): THREE v_mfma_f32_16x16x32_f16 per 32-deep K step with two fp32 accumulators,
+// against eight v_mfma_f32_16x16x4_f32 at a quarter of the rate each for the exact fp32 form (gfx950 has no xf32).
+// Memory layout of a split tensor: every group of 8 consecutive channels is 32 bytes, [8 x h][8 x l] - byte for byte the
+// footprint and the addressing of an fp32 NHWC tensor (element stride 4 bytes, 16-byte chunks), so the fp32 loaders of the
+// igemm kernel and the 8-channel pointwise kernels serve it unchanged, and one 128-byte LDS row of 32 channels holds the
+// MFMA fragments of lane group q as chunk 2q (h) and chunk 2q+1 (l).  Range: |v| <= 65504 (saturating).
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+struct sp32 { unsigned int bits; };      // 4-byte stride type of a split tensor (never read as a scalar: groups of 8 only)
+#define UDAPOSE_SP_SCALE 2048.f
+#define UDAPOSE_SP_INV (1.f / 2048.f)
+__device__ __forceinline__ void sp_split8(const float (&v)[8], half8& h, half8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float c = fminf(fmaxf(v[e], -65504.f), 65504.f);
+        const _Float16 hh = (_Float16)c;
+        h[e] = hh;
+        l[e] = (_Float16)((c - (float)hh) * UDAPOSE_SP_SCALE);
+    }
+}
+__device__ __forceinline__ void sp_join8(const half8& h, const half8& l, float (&o)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)h[e] + (float)l[e] * UDAPOSE_SP_INV;
+}
+// element e (any index) of a split tensor
+__device__ __forceinline__ float sp_load1(const void* base, size_t e) {
+    const _Float16* g = (const _Float16*)((const char*)base + (e >> 3) * 32);
+    return (float)g[e & 7] + (float)g[8 + (e & 7)] * UDAPOSE_SP_INV;
+}
+__device__ __forceinline__ void sp_store1(void* base, size_t e, float v) {
+    _Float16* g = (_Float16*)((char*)base + (e >> 3) * 32);
+    const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+    const _Float16 hh = (_Float16)c;
+    g[e & 7] = hh;
+    g[8 + (e & 7)] = (_Float16)((c - (float)hh) * UDAPOSE_SP_SCALE);
+}
+
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 static inline int udapose_check_launch() {

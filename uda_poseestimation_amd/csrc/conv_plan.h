@@ -102,6 +102,7 @@ struct ConvEpilogue {
     int relu = 0;
     int out_f32 = 0;
     int f32 = 0;            // x, w, res, y are fp32 (exact fp32 MFMA path; forward only)
+    int split = 0;          // x, w, res (and y unless out_f32) are f16x2 split tensors: the fp32-grade mode (forward only)
 };
 // y = conv(x, w_fwd[Co][wtaps][Ci])
 int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* w_fwd, void* y, const ConvEpilogue& e);

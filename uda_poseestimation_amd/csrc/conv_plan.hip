@@ -132,7 +132,8 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* 
     p.M = g.N * p.Hg * p.Wg;
     p.wtaps = g.wtaps();
     p.flags = (g.reflect ? IG_FLAG_REFLECT : 0) | (g.upsample ? IG_FLAG_UPSAMPLE : 0) | (e.relu ? IG_FLAG_RELU : 0) |
-              (e.out_f32 ? IG_FLAG_OUT_F32 : 0) | (g.smallc() ? IG_FLAG_SMALLC : 0) | (e.f32 ? IG_FLAG_F32 : 0);
+              (e.out_f32 ? IG_FLAG_OUT_F32 : 0) | (g.smallc() ? IG_FLAG_SMALLC : 0) | ((e.f32 || e.split) ? IG_FLAG_F32 : 0) |
+              (e.split ? IG_FLAG_SPLIT : 0);
     p.nclass = tp->nclass;
     for (int c = 0; c < tp->nclass; ++c) p.cls[c] = tp->cls[c];
     p.tap0 = plan_is_tap0(*tp);

@@ -12,6 +12,8 @@ struct IgClass { int tap_off, ntaps, oa, ob; };
 #define IG_FLAG_RELU 4
 #define IG_FLAG_OUT_F32 8     // y is fp32 NHWC instead of bf16 NHWC
 #define IG_FLAG_F32 128      // x, w, res and y are fp32 (exact fp32 MFMA path, forward only)
+#define IG_FLAG_SPLIT 64     // with IG_FLAG_F32: x, w, res (and y, unless IG_FLAG_OUT_F32) are f16x2 split tensors (common.h): the
+                             // fp32-grade mode, three fp16 MFMAs per 32-deep K step; forward only
 #define IG_FLAG_MIRROR 2048   // 3x3 run-staged form: taps are the mirrored ones of a data gradient (dy, dx) = (1 - kh, 1 - kw)
 #define IG_FLAG_TAP0 1024     // every class has at most the one tap (dy, dx, widx) = (0, 0, 0): no tap-table read
 #define IG_FLAG_BSMASK 32     // bs_z points at the consumer BN's saved ReLU bit mask (one byte per 8 channels) instead of its output z

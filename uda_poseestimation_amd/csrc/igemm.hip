@@ -71,17 +71,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Main loop: NS-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers), counted vmcnt waits and
 // ONE raw s_barrier per K step, so NS-1 stages of loads stay in flight across barriers while the MFMAs of the current
 // stage run (the loads are latency-bound otherwise: a 64x64 tile only has 64 MFMA cycles of work per 32-deep step).
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0, bool SP = false>
 // amdgpu_waves_per_eu(4): a register budget of 128 per lane.  Left alone the compiler spends 168 + 24 AGPRs on the 128x64 tile
 // (two resident work-groups per CU); with the hint it needs 110 and none of the configurations the heuristic picks spills
 // (the 128x128 ones, reachable only through the tuning override, do).  Measured: -0.65 ms per step.
 // The BS variants (dgrads with the consumer BatchNorm's backward reduction in the epilogue) take waves_per_eu(3) = 168 registers:
 // their tiles are resident three per CU by LDS either way, and the epilogue keeps a whole chunk's y / z / skip loads in flight.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 == 1 || H3 == 2) ? 3 : 4))) void igemm_kernel(const IgParams p) {
+// SP (with T = float as the 4-byte stride type): the operands are f16x2 split tensors (common.h) - the loaders are the fp32 ones
+// byte for byte, the fragments of a 32-channel stage are the row's chunk pairs (2q, 2q+1) = (h, l) of lane group q, and a stage is
+// three fp16 MFMAs per fragment pair into two accumulator sets (h.h | h.l + l.h, the second scaled by 2^-11 at the end).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 == 1 || H3 == 2 || SP) ? 3 : 4))) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
     // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.
     constexpr bool F32 = sizeof(T) == 4;
+    static_assert(!SP || (F32 && !BS && !RS && (H3 == 0 || H3 == 3)), "SP: fp32-shaped loaders, plain or lean form, forward epilogue");
     constexpr int EPC = 16 / (int)sizeof(T);      // elements per 16-byte chunk
     constexpr int BKE = 128 / (int)sizeof(T);     // K elements per stage
     constexpr int TPS = BKE / 8;                  // taps per stage on the Ci == 8 path
@@ -279,10 +283,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
     };
 
     f32x4 acc[MT][NT];
+    f32x4 acc2[SP ? MT : 1][SP ? NT : 1];       // SP: the cross terms h.l + l.h (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SP) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
     // per-lane fragment offsets inside a stage (row * 128 + swizzled chunk), computed once
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -303,7 +311,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
     auto compute = [&](auto u) __attribute__((always_inline)) {
         constexpr int U = decltype(u)::value;
         const char* S = stage + U * C::STAGE1;
-        if constexpr (!F32) {
+        if constexpr (SP) {
+            // lane group q = lane>>4 owns k = 8q..8q+7 of the 32-deep stage: chunk 2q holds their h halves, chunk 2q+1 their l halves
+            // (a_fo / b_fo [.][0] and [.][1] of the fp32 form are exactly these two chunks)
+            half8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { ah[i] = *(const half8*)(S + a_fo[i][0]); al[i] = *(const half8*)(S + a_fo[i][1]); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { bh[j] = *(const half8*)(S + b_fo[j][0]); bl[j] = *(const half8*)(S + b_fo[j][1]); }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
+                }
+        } else if constexpr (!F32) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 elem8 af[MT], bfr[NT];
@@ -588,6 +612,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // all LDS reads of the ring are done before the epilogue reuses it
+    if constexpr (SP) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += acc2[i][j][r] * UDAPOSE_SP_INV;
+    }
     if (dbg && tid == 0) dbg[3] = __builtin_amdgcn_s_memrealtime();
 
     // ---- epilogue: accumulators -> LDS (per-wave region) -> 8-channel vectors -> global
@@ -596,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
     const int cg = lane % LPR, rsub = lane / LPR;
     const int cbase = n0 + wn * TN + cg * 8;
     const bool relu = (p.flags & IG_FLAG_RELU) != 0;
-    const bool outf32 = F32 || (p.flags & IG_FLAG_OUT_F32) != 0;
+    const bool outf32 = (F32 && !SP) || (p.flags & IG_FLAG_OUT_F32) != 0;
     const bool lin_out = p.os == 1 && cls.oa == 0 && cls.ob == 0 && p.Hg == p.Ho && p.Wg == p.Wo;
     if (!BS && p.stats) {
         // BN partial statistics straight from the accumulators: a lane holds rows (lane>>4)*4+r of every 16-row tile for
@@ -765,7 +797,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias[e];
                 if (p.res) {
-                    if constexpr (F32) {
+                    if constexpr (SP) {
+                        const char* rp = (const char*)p.res + off * 4;
+                        float rr[8];
+                        sp_join8(*(const half8*)rp, *(const half8*)(rp + 16), rr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                    } else if constexpr (F32) {
                         const f32x4 r0 = *(const f32x4*)((const float*)p.res + off), r1 = *(const f32x4*)((const float*)p.res + off + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
@@ -788,6 +826,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
 #pragma unroll
                         for (int e = 0; e < 8; ++e) if (cbase + e < p.Co) yo[e] = v[e];
                     }
+                } else if constexpr (SP) {
+                    half8 oh, ol;
+                    sp_split8(v, oh, ol);
+                    char* yo = (char*)p.y + off * 4;
+                    *(half8*)yo = oh;
+                    *(half8*)(yo + 16) = ol;
                 } else {
                     elem8 o;
 #pragma unroll
@@ -839,7 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 =
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS = false, int H3 = 0, bool SP = false>
 int launch_cfg_t(IgParams& p, hipStream_t stream, const Policy& pol) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     p.m_tiles = (p.M + BM - 1) / BM;
@@ -847,7 +891,7 @@ int launch_cfg_t(IgParams& p, hipStream_t stream, const Policy& pol) {
     static std::atomic<unsigned long long> attr_done{0};
     static std::mutex attr_mu;
     once_per_device(attr_done, attr_mu, [] {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, (H3 == 1 || H3 == 2) ? 112 * 1024 : C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (H3 == 1 || H3 == 2) ? 112 * 1024 : C::LDS_BYTES);
     });
     dim3 grid(p.m_tiles * p.n_tiles, 1, p.nclass);
     // A launch whose K loop is ONE stage (K <= 128 bytes per row: layer1's 64-channel 1x1 convs and their data gradients, the
@@ -867,7 +911,7 @@ int launch_cfg_t(IgParams& p, hipStream_t stream, const Policy& pol) {
         const int ra = (BM + 2 * (p.Wi + 1) + 7) & ~7;
         lds = C::TAP_BYTES + std::max(2 * (ra + 1) * 128 + (H3 == 2 ? 6 : 3) * C::BNL * 128 + 1024, C::EPI_BYTES + WM * 2 * BN * 4);
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, RS, BS, H3, SP>), grid, dim3(256), lds, stream, p);
     return udapose_check_launch();
 }
 
@@ -879,10 +923,24 @@ int launch_cfg(IgParams& p, hipStream_t stream, const Policy& pol) {
         return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false>(p, stream, pol);
     } else {
         // lean 1x1 form: stride-1 single-tap convolution whose tiles are all full (M % BM, Co % BN), offsets in 32 bits
-        const bool lean = pol.igemm_lean && BN >= 64 && !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.tap0 &&
+        const bool split = (p.flags & IG_FLAG_SPLIT) != 0;
+        const long long esz = split ? 4 : 2;
+        const bool lean = pol.igemm_lean && BN >= 64 && (split || !(p.flags & IG_FLAG_F32)) && !(p.flags & (IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.tap0 &&
                           p.nclass == 1 && p.cls[0].ntaps == 1 && p.s == 1 && p.os == 1 && p.Hg == p.Hi && p.Wg == p.Wi && p.Hg == p.Ho &&
                           p.Wg == p.Wo && p.M % BM == 0 && p.Co % BN == 0 && p.Ci % 64 == 0 && p.wtaps == 1 &&
-                          (long long)p.M * p.Ci * 2 < (1ll << 32) && (long long)p.Co * p.Ci * 2 < (1ll << 32);
+                          (long long)p.M * p.Ci * esz < (1ll << 32) && (long long)p.Co * p.Ci * esz < (1ll << 32);
+        if (split) {
+            // f16x2 operands (fp32-shaped loaders, three fp16 MFMAs per stage): forward epilogue only
+            if (!(p.flags & IG_FLAG_F32) || p.bs_y || (!(p.flags & IG_FLAG_OUT_F32) && (p.Co % 8))) return UDAPOSE_ERR_ARG;
+            // (instantiated for the tiles igemm_launch maps split launches to)
+            constexpr bool sp_cfg = (BM == 128 && BN == 64 && NS == 2) || (BM == 64 && BN == 64 && (NS == 2 || NS == 3)) || (BM == 128 && BN == 32);
+            if constexpr (sp_cfg) {
+                if constexpr (BN >= 64) { if (lean) return launch_cfg_t<float, BM, BN, WM, WN, NS, false, false, 3, true>(p, stream, pol); }
+                return launch_cfg_t<float, BM, BN, WM, WN, NS, false, false, 0, true>(p, stream, pol);
+            } else {
+                return UDAPOSE_ERR_ARG;
+            }
+        }
         if (p.bs_y) {
             // dgrad with the consumer BatchNorm's backward reduction in the epilogue (bf16 operands; bf16 or fp32 output)
             if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_RELU)) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
@@ -947,6 +1005,15 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream, const Policy& pol) {
     }
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
+    if (p.flags & IG_FLAG_SPLIT) {
+        // f16x2 launches take the plain (or lean 1x1) form of three tiles: 128x64 / 64x64 with the ring depth of the bf16 choice
+        switch (tile) {
+            case 3: case 5: case 6: case 9: break;
+            case 0: case 1: case 4: case 8: case 11: tile = 6; break;
+            case 2: case 7: case 10: case 12: tile = 9; break;
+            default: return UDAPOSE_ERR_ARG;
+        }
+    }
     switch (tile) {
         case 0: return launch_cfg<128, 128, 2, 2, 3>(p, stream, pol);
         case 1: return launch_cfg<128, 64, 2, 2, 3>(p, stream, pol);

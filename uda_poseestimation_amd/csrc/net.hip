@@ -49,6 +49,12 @@ int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
 int pw_pack_strided_f32(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long);
 int pw_bn_apply_f32(hipStream_t, const float*, const float*, float*, size_t, int, const float*, const float*, int);
 int pw_maxpool3x3s2_fwd_f32(hipStream_t, const float*, float*, unsigned char*, int, int, int, int);
+int pw_nchw_f32_to_nhwc_split(hipStream_t, const float*, void*, int, int, int, int);
+int pw_f32_to_split(hipStream_t, const float*, void*, size_t);
+int pw_transpose_split(hipStream_t, const float*, void*, int, int, int);
+int pw_pack_strided_split(hipStream_t, const float*, void*, int, int, int, int, int, int, long, long, long, long);
+int pw_bn_apply_split(hipStream_t, const float*, const void*, void*, size_t, int, const float*, const float*, int);
+int pw_maxpool3x3s2_fwd_split(hipStream_t, const void*, void*, unsigned char*, int, int, int, int);
 
 namespace {
 
@@ -93,6 +99,8 @@ struct Net {
     int split_dz_idx = -1;  // pool buffer holding the gradient that net_backward part 1 hands to part 2 (a function of the plan)
     Policy policy;          // dispatch policy of this plan (udapose_net_set_policy); every ConvGeom below points at it
     int f32 = 0;            // 1: fp32 storage + exact fp32 MFMA (forward only: the reference's teacher / validate() precision)
+                            // 2: f16x2 split storage (common.h), three fp16 MFMAs per K step: the FAST fp32-grade mode (forward only);
+                            //    conv inputs (z, pooled map, image) and weight packs are split tensors, pre-BN conv outputs y are fp32
     size_t es = 2;          // bytes per activation element
     int n_params = 0, n_buffers = 0;
     std::vector<long long> param_numel;
@@ -146,7 +154,7 @@ void add_conv(Net& n, ConvL& c, int Hi, int Wi, int Ci, int Co, int K, int strid
     c.in_off = in_off;
     const size_t welems = (size_t)Co * c.g.wtaps() * Ci;
     // fp32 mode reads plain-conv weights straight from the fp32 master ([Co][taps][Ci] is its physical layout)
-    if (!n.f32 || c.g.smallc() || transposed) c.wf_off = wp_alloc(n, welems * n.es);
+    if (n.f32 != 1 || c.g.smallc() || transposed) c.wf_off = wp_alloc(n, welems * n.es);
     if (need_bwd_pack && !n.f32) c.wb_off = wp_alloc(n, welems * 2);
     c.y_off = act_alloc(n, (size_t)n.N * c.g.Ho() * c.g.Wo() * Co * n.es);
 }
@@ -163,7 +171,7 @@ void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true) {
 Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
     Net* np = new Net();
     Net& n = *np;
-    n.f32 = f32 ? 1 : 0;
+    n.f32 = f32 == 2 ? 2 : (f32 ? 1 : 0);
     n.es = f32 ? 4 : 2;
     for (int i = 0; i < 4; ++i) n.layers[i] = layers[i];
     n.K = K; n.N = N; n.H = H; n.W = W;
@@ -215,7 +223,7 @@ Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
     n.head.w_idx = n.n_params++; n.param_numel.push_back((long long)K * 256);
     n.head.bias_idx = n.n_params++; n.param_numel.push_back(K);
     n.head.in_off = cur;
-    n.head.wf_off = wp_alloc(n, (size_t)K * 256 * 2);
+    n.head.wf_off = wp_alloc(n, (size_t)K * 256 * n.es);
     n.head.wb_off = wp_alloc(n, (size_t)256 * 64 * 2);      // [256][1][64] zero-padded for dgrad
     n.head_out_off = act_alloc(n, (size_t)N * Hc * Wc * K * 4);
     n.Hout = Hc; n.Wout = Wc;
@@ -267,6 +275,13 @@ int pack_conv(hipStream_t s, const Net& n, const ConvL& c, const void* const* pa
     elem_t* wf = (elem_t*)(wpack + c.wf_off);
     elem_t* wb = (elem_t*)(wpack + c.wb_off);
     const int T = g.KH * g.KW;
+    if (n.f32 == 2) {
+        // f16x2 packs: the fp32 GEMM layouts, every group of 8 values split into [8 h][8 l]
+        if (g.smallc())
+            return pw_pack_strided_split(s, w, wpack + c.wf_off, g.Co, g.KH, g.KWp(), g.KW, 8, 3, (long)g.KH * g.KW * 3, (long)g.KW * 3, 3, 1);
+        if (g.transposed) return pw_transpose_split(s, w, wpack + c.wf_off, g.Ci, T, g.Co);
+        return pw_f32_to_split(s, w, wpack + c.wf_off, (size_t)g.Co * T * g.Ci);
+    }
     if (n.f32) {
         if (g.smallc())
             return pw_pack_strided_f32(s, w, (float*)(wpack + c.wf_off), g.Co, g.KH, g.KWp(), g.KW, 8, 3, (long)g.KH * g.KW * 3, (long)g.KW * 3, 3, 1);
@@ -297,10 +312,12 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     float* shift = scale + 2048;
     float* save = (float*)(act + b.save_off);
     e.stats = training ? slab : nullptr;
-    e.f32 = n.f32;
+    e.f32 = n.f32 != 0;
+    e.split = n.f32 == 2;
+    e.out_f32 = n.f32 == 2;       // (f16x2: the pre-BN output stays fp32; the BN apply writes the split z)
     // block outputs: the apply also saves the ReLU bit mask of z (1/16 of z's bytes) for the data gradients that mask with it
     unsigned char* mask = (b.mask_off && n.policy.bn3_mask && relu) ? (unsigned char*)(act + b.mask_off) : nullptr;
-    const void* wptr = (n.f32 && !c.g.smallc() && !c.g.transposed) ? params[c.w_idx] : (const void*)(wpack + c.wf_off);
+    const void* wptr = (n.f32 == 1 && !c.g.smallc() && !c.g.transposed) ? params[c.w_idx] : (const void*)(wpack + c.wf_off);
     CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
@@ -319,6 +336,8 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     else
         CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
     if (no_apply) return UDAPOSE_OK;      // (the caller's next launch applies scale / shift itself: the stem's fused pool)
+    if (n.f32 == 2)
+        return pw_bn_apply_split(s, (const float*)(act + c.y_off), res, act + b.z_off, b.npix * b.C, b.C, scale, shift, relu);
     if (n.f32)
         return pw_bn_apply_f32(s, (const float*)(act + c.y_off), (const float*)res, (float*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
     return pw_bn_apply(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu, mask);
@@ -359,11 +378,13 @@ void add_pack_jobs(const Net& n, const ConvL& c, const void* const* params, char
     const int T = g.KH * g.KW;
     elem_t* wf = (elem_t*)(wpack + c.wf_off);
     elem_t* wb = (elem_t*)(wpack + c.wb_off);
+    const int sp = n.f32 == 2 ? 2 : 0;          // (kind bit 1: f16x2 split output, forward packs only)
+    if (sp) with_bwd = false;
     if (!g.transposed) {
-        jobs.push_back(PackJobH{w, wf, 0, 0, 0, 0, (long long)g.Co * T * g.Ci});
+        jobs.push_back(PackJobH{w, wf, 0, 0, 0, sp, (long long)g.Co * T * g.Ci});
         if (with_bwd) jobs.push_back(PackJobH{w, wb, g.Co, T, g.Ci, 1, 0});
     } else {
-        jobs.push_back(PackJobH{w, wf, g.Ci, T, g.Co, 1, 0});
+        jobs.push_back(PackJobH{w, wf, g.Ci, T, g.Co, 1 | sp, 0});
         if (with_bwd) jobs.push_back(PackJobH{w, wb, 0, 0, 0, 0, (long long)g.Ci * T * g.Co});
     }
 }
@@ -376,11 +397,11 @@ int build_pack_table(Net& n, Net::PackTab& tab, const void* const* params, char*
         if (b.has_ds) add_pack_jobs(n, b.cd, params, wpack, with_bwd, jobs);
     }
     for (int i = 0; i < 3; ++i) add_pack_jobs(n, n.up[i], params, wpack, with_bwd, jobs);
-    jobs.push_back(PackJobH{(const float*)params[n.head.w_idx], (elem_t*)(wpack + n.head.wf_off), 0, 0, 0, 0, (long long)n.K * 256});
+    jobs.push_back(PackJobH{(const float*)params[n.head.w_idx], (elem_t*)(wpack + n.head.wf_off), 0, 0, 0, n.f32 == 2 ? 2 : 0, (long long)n.K * 256});
     std::vector<int> bj, bs;
     for (size_t j = 0; j < jobs.size(); ++j) {
         const PackJobH& q = jobs[j];
-        const long nb = q.kind == 0 ? (long)((q.n + 8191) / 8192) : (long)((q.A + 31) / 32) * ((q.B + 31) / 32) * q.T;
+        const long nb = (q.kind & 1) == 0 ? (long)((q.n + 8191) / 8192) : (long)((q.A + 31) / 32) * ((q.B + 31) / 32) * q.T;
         for (long k = 0; k < nb; ++k) { bj.push_back((int)j); bs.push_back((int)k); }
     }
     if (tab.jobs) { (void)hipFree(tab.jobs); (void)hipFree(tab.blk_job); (void)hipFree(tab.blk_sub); }
@@ -428,9 +449,9 @@ int net_bind(void* h, const void* const* params, void* const* buffers, void* wpa
     }
     for (int i = 0; i < 3; ++i) CK(conv_prepare(n.up[i].g));
     { ConvGeom hg = n.head.g; CK(conv_prepare(hg)); hg.Co = 64; CK(conv_prepare(hg)); }
-    if (!n.f32) {
+    if (n.f32 != 1) {
         CK(build_pack_table(n, n.pack_fwd, params, wpack, false));
-        CK(build_pack_table(n, n.pack_all, params, wpack, true));
+        CK(build_pack_table(n, n.pack_all, params, wpack, n.f32 == 0));
     }
     if (buffers) CK(build_run_jobs(n, buffers));
     return UDAPOSE_OK;
@@ -440,8 +461,9 @@ int net_pack_weights(void* h, hipStream_t s, const void* const* params, void* wp
     Net& n = *(Net*)h;
     DbgSyncScope dbg(n.policy.debug_sync);
     char* wpack = (char*)wpack_;
-    if (!n.f32) {
+    if (n.f32 != 1) {
         // ONE launch casts / transposes every weight through the job table net_bind built for these pointers
+        if (n.f32 == 2) with_bwd = 0;
         Net::PackTab& tab = with_bwd ? n.pack_all : n.pack_fwd;
         if (!tab.jobs || tab.key0 != params[0] || tab.key1 != params[n.n_params - 1] || tab.keyw != (const void*)wpack)
             return UDAPOSE_ERR_NOT_PREPARED;
@@ -476,13 +498,16 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
-    if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
+    if (n.f32 == 2) CK(pw_nchw_f32_to_nhwc_split(s, x_nchw, act + n.x8_off, n.N, 3, n.H * n.W, 8));
+    else if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (elem_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     const bool stem_fused = n.policy.stem_fused && !n.f32;
     CK(conv_bn_fwd(s, n, n.stem, n.stem_bn, params, buffers, wpack, act, ws, training, momentum, nullptr, 1, upd, stem_fused));
     if (stem_fused)     // BN apply + ReLU + max-pool in one sweep; z of the stem is never materialised (the backward masks from y)
         CK(pw_bn_relu_maxpool3x3s2(s, (const elem_t*)(act + n.stem.y_off), (elem_t*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
                                    n.Hs, n.Ws, 64, (const float*)(ws + n.ws_coef), (const float*)(ws + n.ws_coef) + 2048));
+    else if (n.f32 == 2)
+        CK(pw_maxpool3x3s2_fwd_split(s, act + n.stem_bn.z_off, act + n.pool_off, (unsigned char*)(act + n.poolidx_off), n.N, n.Hs, n.Ws, 64));
     else if (n.f32)
         CK(pw_maxpool3x3s2_fwd_f32(s, (const float*)(act + n.stem_bn.z_off), (float*)(act + n.pool_off), (unsigned char*)(act + n.poolidx_off), n.N,
                                    n.Hs, n.Ws, 64));
@@ -503,8 +528,9 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     ConvEpilogue e;
     e.bias = (const float*)params[n.head.bias_idx];
     e.out_f32 = 1;
-    e.f32 = n.f32;
-    const void* hwp = n.f32 ? params[n.head.w_idx] : (const void*)(wpack + n.head.wf_off);
+    e.f32 = n.f32 != 0;
+    e.split = n.f32 == 2;
+    const void* hwp = n.f32 == 1 ? params[n.head.w_idx] : (const void*)(wpack + n.head.wf_off);
     CK(conv_fprop(s, n.head.g, (const elem_t*)(act + n.head.in_off), (const elem_t*)hwp, act + n.head_out_off, e));
     return pw_nhwc_to_nchw_f32(s, act + n.head_out_off, 1, out_nchw, n.N, n.K, n.Hout * n.Wout, n.K, nullptr, nullptr);
 }

@@ -22,7 +22,22 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o
 #pragma unroll
     for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
 }
+template <> __device__ __forceinline__ void ld8<sp32>(const sp32* p, float (&o)[8]) {      // f16x2 split storage (common.h): 32 bytes = [8 h][8 l]
+    const char* c = (const char*)p;
+    sp_join8(*(const half8*)c, *(const half8*)(c + 16), o);
+}
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<sp32>(sp32* p, const float (&v)[8]) {
+    half8 h, l;
+    sp_split8(v, h, l);
+    char* c = (char*)p;
+    *(half8*)c = h;
+    *(half8*)(c + 16) = l;
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p, size_t i) { return (float)p[i]; }
+template <> __device__ __forceinline__ float ld1<sp32>(const sp32* p, size_t i) { return sp_load1(p, i); }
+template <typename T> __device__ __forceinline__ void st1(T* p, size_t i, float v) { p[i] = (T)v; }
+template <> __device__ __forceinline__ void st1<sp32>(sp32* p, size_t i, float v) { sp_store1(p, i, v); }
 template <> __device__ __forceinline__ void st8<elem_t>(elem_t* p, const float (&v)[8]) {
     elem8 o;
 #pragma unroll
@@ -61,7 +76,7 @@ __global__ void nhwc_to_nchw_f32_k(const T* __restrict__ src, float* __restrict_
     for (size_t pix = (size_t)blockIdx.x * TPB + threadIdx.x; pix < total; pix += (size_t)gridDim.x * TPB) {
         const size_t n = pix / HW, hw = pix % HW;
         for (int c = 0; c < C; ++c) {
-            float v = (float)src[pix * Cs + c];
+            float v = ld1<T>(src, pix * Cs + c);
             if (lo) v = fmaxf(fminf(v, hi[c]), lo[c]);
             dst[(n * C + c) * HW + hw] = v;
         }
@@ -89,22 +104,28 @@ __global__ void transpose_cast_k(const float* __restrict__ src, D* __restrict__ 
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int b = b0 + r, a = a0 + tx;
-        if (a < A && b < B) dst[((size_t)b * T + t) * A + a] = (D)tile[tx][r];
+        if (a < A && b < B) st1<D>(dst, ((size_t)b * T + t) * A + a, tile[tx][r]);
     }
 }
 // One launch packs every weight of a network: a job is either a contiguous cast (T == 0: n elements) or a per-tap
 // transpose [A][T][B] fp32 -> [B][T][A] bf16; block b works on job blk_job[b], sub-block blk_sub[b].
+// kind: bit 0 = transpose, bit 1 = f16x2 split output (the fp32-grade plans) instead of the element type.
 struct PackJob { const float* src; elem_t* dst; int A, T, B, kind; long long n; };
 __global__ void pack_multi_k(const PackJob* __restrict__ jobs, const int* __restrict__ blk_job, const int* __restrict__ blk_sub) {
     __shared__ float tile[32][33];
     const PackJob j = jobs[blk_job[blockIdx.x]];
     const int sub = blk_sub[blockIdx.x];
-    if (j.kind == 0) {
+    if ((j.kind & 1) == 0) {
         const long long base = (long long)sub * 8192;           // 8192 elements per block
         for (long long i = base + threadIdx.x * 8; i < base + 8192 && i < j.n; i += TPB * 8) {
             const f32x4 a = *(const f32x4*)(j.src + i), b = *(const f32x4*)(j.src + i + 4);
-            elem8 o = {(elem_t)a[0], (elem_t)a[1], (elem_t)a[2], (elem_t)a[3], (elem_t)b[0], (elem_t)b[1], (elem_t)b[2], (elem_t)b[3]};
-            *(elem8*)(j.dst + i) = o;
+            if (j.kind & 2) {
+                const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                st8<sp32>((sp32*)j.dst + i, v);
+            } else {
+                elem8 o = {(elem_t)a[0], (elem_t)a[1], (elem_t)a[2], (elem_t)a[3], (elem_t)b[0], (elem_t)b[1], (elem_t)b[2], (elem_t)b[3]};
+                *(elem8*)(j.dst + i) = o;
+            }
         }
         return;
     }
@@ -119,7 +140,10 @@ __global__ void pack_multi_k(const PackJob* __restrict__ jobs, const int* __rest
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int b = b0 + r, a = a0 + tx;
-        if (a < j.A && b < j.B) j.dst[((size_t)b * j.T + t) * j.A + a] = (elem_t)tile[tx][r];
+        if (a < j.A && b < j.B) {
+            if (j.kind & 2) sp_store1(j.dst, ((size_t)b * j.T + t) * j.A + a, tile[tx][r]);
+            else j.dst[((size_t)b * j.T + t) * j.A + a] = (elem_t)tile[tx][r];
+        }
     }
 }
 
@@ -136,7 +160,7 @@ __global__ void pack_strided_k(const float* __restrict__ src, D* __restrict__ ds
         const int a = (int)(r / KH);
         float v = 0.f;
         if (kw < KW && b < B) v = src[a * sa + kh * skh + kw * skw + b * sb];
-        dst[i] = (D)v;
+        st1<D>(dst, i, v);
     }
 }
 // inverse of pack_strided for gradients: dst[a*sa + kh*skh + kw*skw + b*sb] (beta*dst +) = src[a][kh][kwp][bp] (fp32)
@@ -271,8 +295,9 @@ __global__ void bn_eval_coeff_k(int C, const float* __restrict__ gamma, const fl
 }
 
 // z = [relu]( y*scale[c] + shift[c] [+ res] ), NHWC (bf16 or fp32 storage), 8 channels per thread
-template <typename T>
-__global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, size_t n8, int C,
+// (TY: storage of the conv output y; T: storage of the residual and of z - the f16x2 mode keeps y in fp32 and z split)
+template <typename T, typename TY = T>
+__global__ void bn_apply_k(const TY* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, size_t n8, int C,
                            const float* __restrict__ scale, const float* __restrict__ shift, int relu, unsigned char* __restrict__ mask = nullptr) {
     const int G = C >> 3;
     // the launcher keeps gridDim.x * TPB a multiple of G (G is a power of two <= TPB, or the grid is one block per G-aligned
@@ -282,7 +307,7 @@ __global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T
     const f32x4 ha = *(const f32x4*)(shift + c0), hb = *(const f32x4*)(shift + c0 + 4);
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
         float v[8];
-        ld8<T>(y + i * 8, v);
+        ld8<TY>(y + i * 8, v);
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = v[e] * (e < 4 ? sa[e] : sb[e - 4]) + (e < 4 ? ha[e] : hb[e - 4]);
@@ -295,11 +320,13 @@ __global__ void bn_apply_k(const T* __restrict__ y, const T* __restrict__ res, T
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (relu && o[e] < 0.f) ? 0.f : o[e];
         st8<T>(z + i * 8, o);
+        if constexpr (sizeof(T) == 2) {
         if (mask) {     // bit e: the STORED value of channel e is > 0 (what a reader of z would see)
             unsigned mb = 0u;
 #pragma unroll
             for (int e = 0; e < 8; ++e) mb |= ((float)(T)o[e] > 0.f ? 1u : 0u) << e;
             mask[i] = (unsigned char)mb;
+        }
         }
     }
 }
@@ -1023,8 +1050,16 @@ int pw_nchw_f32_to_nhwc_f32(hipStream_t s, const float* src, float* dst, int N, 
     hipLaunchKernelGGL(nchw_f32_to_nhwc_k<float>, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, dst, N, C, HW, Cp);
     return udapose_check_launch();
 }
+int pw_nchw_f32_to_nhwc_split(hipStream_t s, const float* src, void* dst, int N, int C, int HW, int Cp) {
+    if (Cp % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_k<sp32>, dim3(grid_for((size_t)N * HW * (Cp / 8))), dim3(TPB), 0, s, src, (sp32*)dst, N, C, HW, Cp);
+    return udapose_check_launch();
+}
+// src_is_f32: 0 = element type, 1 = fp32, 2 = f16x2 split
 int pw_nhwc_to_nchw_f32(hipStream_t s, const void* src, int src_is_f32, float* dst, int N, int C, int HW, int Cs, const float* lo, const float* hi) {
-    if (src_is_f32)
+    if (src_is_f32 == 2)
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_k<sp32>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const sp32*)src, dst, N, C, HW, Cs, lo, hi);
+    else if (src_is_f32)
         hipLaunchKernelGGL(nhwc_to_nchw_f32_k<float>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const float*)src, dst, N, C, HW, Cs, lo, hi);
     else
         hipLaunchKernelGGL(nhwc_to_nchw_f32_k<elem_t>, dim3(grid_for((size_t)N * HW)), dim3(TPB), 0, s, (const elem_t*)src, dst, N, C, HW, Cs, lo, hi);
@@ -1041,6 +1076,39 @@ int pw_transpose_cast(hipStream_t s, const float* src, elem_t* dst, int A, int T
 }
 int pw_transpose_f32(hipStream_t s, const float* src, float* dst, int A, int T, int B) {
     hipLaunchKernelGGL(transpose_cast_k<float>, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, dst, A, T, B);
+    return udapose_check_launch();
+}
+// fp32 -> f16x2 split, n % 8 == 0 (src == dst allowed: every thread reads its 32 bytes before it writes them)
+__global__ void f32_to_split_k(const float* src, sp32* dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+        float v[8];
+        ld8<float>(src + i * 8, v);
+        st8<sp32>(dst + i * 8, v);
+    }
+}
+__global__ void split_to_f32_k(const sp32* src, float* dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+        float v[8];
+        ld8<sp32>(src + i * 8, v);
+        st8<float>(dst + i * 8, v);
+    }
+}
+int pw_f32_to_split(hipStream_t s, const float* src, void* dst, size_t n) {
+    if (n % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(f32_to_split_k, dim3(grid_for(n / 8)), dim3(TPB), 0, s, src, (sp32*)dst, n / 8);
+    return udapose_check_launch();
+}
+int pw_split_to_f32(hipStream_t s, const void* src, float* dst, size_t n) {
+    if (n % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(split_to_f32_k, dim3(grid_for(n / 8)), dim3(TPB), 0, s, (const sp32*)src, dst, n / 8);
+    return udapose_check_launch();
+}
+int pw_transpose_split(hipStream_t s, const float* src, void* dst, int A, int T, int B) {
+    hipLaunchKernelGGL(transpose_cast_k<sp32>, dim3((B + 31) / 32, (A + 31) / 32, T), dim3(TPB), 0, s, src, (sp32*)dst, A, T, B);
+    return udapose_check_launch();
+}
+int pw_pack_strided_split(hipStream_t s, const float* src, void* dst, int A, int KH, int KWp, int KW, int Bp, int B, long sa, long skh, long skw, long sb) {
+    hipLaunchKernelGGL(pack_strided_k<sp32>, dim3(grid_for((size_t)A * KH * KWp * Bp)), dim3(TPB), 0, s, src, (sp32*)dst, A, KH, KWp, KW, Bp, B, sa, skh, skw, sb);
     return udapose_check_launch();
 }
 int pw_pack_multi(hipStream_t s, const void* jobs, const int* blk_job, const int* blk_sub, int nblocks) {
@@ -1141,6 +1209,13 @@ int pw_bn_apply(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, si
                 unsigned char* mask) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
     hipLaunchKernelGGL(bn_apply_k<elem_t>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu, mask);
+    return udapose_check_launch();
+}
+// f16x2 mode: y fp32 (the conv epilogue's fp32 output), residual and z split
+int pw_bn_apply_split(hipStream_t s, const float* y, const void* res, void* z, size_t n, int C, const float* scale, const float* shift, int relu) {
+    if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL((bn_apply_k<sp32, float>), dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, (const sp32*)res, (sp32*)z, n / 8, C, scale, shift, relu,
+                       (unsigned char*)nullptr);
     return udapose_check_launch();
 }
 int pw_bn_apply_f32(hipStream_t s, const float* y, const float* res, float* z, size_t n, int C, const float* scale, const float* shift, int relu) {
@@ -1275,6 +1350,17 @@ int pw_bn_bwd_pooled(hipStream_t s, const elem_t* pool_dy, const unsigned char* 
 int pw_maxpool3x3s2_fwd_f32(hipStream_t s, const float* x, float* y, unsigned char* idx, int N, int H, int W, int C) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3x3s2_fwd_k<float>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, x, y, idx, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_maxpool3x3s2_fwd_split(hipStream_t s, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_k<sp32>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, (const sp32*)x, (sp32*)y, idx, N, H, W, C, Ho, Wo);
+    return udapose_check_launch();
+}
+int pw_maxpool2x2_ceil_split(hipStream_t s, const void* x, void* y, int N, int H, int W, int C) {
+    if (C % 8) return UDAPOSE_ERR_ARG;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(maxpool2x2_ceil_k<sp32>, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(TPB), 0, s, (const sp32*)x, (sp32*)y, N, H, W, C, Ho, Wo);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_bwd(hipStream_t s, const elem_t* dy, const unsigned char* idx, elem_t* dx, int N, int H, int W, int C) {

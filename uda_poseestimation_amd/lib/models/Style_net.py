@@ -156,6 +156,7 @@ class _SeqRunner:
         self._packs = {}
 
     def _packed(self, st, d, f32):
+        """f32: False (16-bit element type), True (fp32) or 'split' (f16x2)"""
         conv = st.conv
         ver = (conv.weight._version, conv.bias._version, conv.weight.data_ptr(),
                None if st.pre1x1 is None else (st.pre1x1.weight._version, st.pre1x1.bias._version))
@@ -175,6 +176,8 @@ class _SeqRunner:
                 wp[:, :, :d.KW, :w.shape[1]] = w.permute(0, 2, 3, 1)
             else:
                 wp = w.permute(0, 2, 3, 1).contiguous()             # [Co][KH][KW][Ci] = the GEMM layout [Co][taps][Ci]
+            if f32 == 'split':
+                wp = ops.f32_to_split(wp)                           # the same layout, every 8 values as [8 h][8 l]
             hit = (ver, wp, b.contiguous())
             self._packs[(id(conv), f32)] = hit
         return hit[1], hit[2]
@@ -182,7 +185,7 @@ class _SeqRunner:
     def run(self, x, taps=None, final_f32=False):
         """x NHWC bf16 or fp32.  `taps`: step indices after which to record the activation (encode_with_intermediate)."""
         outs = []
-        f32 = x.dtype == torch.float32
+        f32 = 'split' if x.dtype == ops.SPLIT else x.dtype == torch.float32
         for si, st in enumerate(self.steps):
             if st.kind == "pool":
                 x = ops.maxpool2x2_ceil(x)
@@ -244,9 +247,11 @@ class Net(nn.Module):
 
     def _image_in(self, img):
         _hip.require_cuda(img)
-        if self.precision not in ('bf16', 'fp32'):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if self.precision not in ('bf16', 'fp32', 'f16x2'):
+            raise ValueError("precision must be 'f16x2', 'fp32' or 'bf16'")
         x = img.detach().float().contiguous()
+        if self.precision == 'f16x2':
+            return ops.to_nhwc_split(x, 8)
         return ops.to_nhwc_f32(x, 8) if self.precision == 'fp32' else ops.to_nhwc_bf16(x, 8)
 
     def _intermediate(self, x_nhwc):

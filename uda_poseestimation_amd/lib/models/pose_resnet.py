@@ -59,7 +59,7 @@ class _NetHandle:
         L = self.L = lib('fp16' if precision == 'fp16' else 'bf16')
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
-        check(L.udapose_net_create(arr, K, N, H, W, int(precision == 'fp32'), C.byref(h)), "net_create")
+        check(L.udapose_net_create(arr, K, N, H, W, {'fp32': 1, 'f16x2': 2}.get(precision, 0), C.byref(h)), "net_create")
         self.h = h
         if policy:
             pol = _hip.policy(**policy)
@@ -218,8 +218,8 @@ class PoseResNet(nn.Module):
         N, Cc, H, W = x.shape
         if Cc != 3:
             raise ValueError("PoseResNet expects [N,3,H,W] input")
-        if self.precision not in ('bf16', 'fp16', 'fp32'):
-            raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
+        if self.precision not in ('bf16', 'fp16', 'fp32', 'f16x2'):
+            raise ValueError("precision must be 'bf16', 'fp16', 'f16x2' or 'fp32'")
         key = (N, H, W, x.device.index, self.precision)
         hd = self._handles.get(key)
         if hd is None:
@@ -292,8 +292,8 @@ class PoseResNet(nn.Module):
         x = x.contiguous()
         hd = self._handle(x)
         self._last_hd = hd            # the plan of the most recent forward (the fused optimizer tail keeps ITS packs fresh)
-        if save and self.precision == 'fp32':
-            raise RuntimeError("precision='fp32' is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
+        if save and self.precision in ('fp32', 'f16x2'):
+            raise RuntimeError(f"precision={self.precision!r} is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
         pa, ba, params = self._pointers()
         s = _hip.stream()
         self._pack(hd, pa, params, need_bwd=save)

@@ -10,7 +10,10 @@ import torch
 from . import _hip
 from ._hip import ConvDesc, check, lib, lib_for, ptr, require_cuda, stream
 
-EPI_RELU, EPI_OUT_F32, EPI_F32 = 1, 2, 4
+EPI_RELU, EPI_OUT_F32, EPI_F32, EPI_SPLIT = 1, 2, 4, 8
+# "f16x2" split tensors (include/udapose.h, UDAPOSE_EPI_SPLIT: the fast fp32-grade mode) have the byte footprint of the fp32 tensor
+# of the same shape; torch sees them as int32 tensors (never interpreted by torch: only handed to the library)
+SPLIT = torch.int32
 
 
 def conv_desc(N, Hi, Wi, Ci, Co, K, stride=1, pad=0, transposed=False, reflect=False, upsample=False, policy=None):
@@ -62,7 +65,8 @@ def pack_weight(w, d, direction="fwd", dtype=torch.bfloat16):
 def conv2d_fwd(x, w_fwd, d, res=None, bias=None, relu=False, out_f32=False, want_stats=False):
     require_cuda(x, w_fwd)
     f32 = x.dtype == torch.float32          # exact fp32 path: w_fwd must be fp32 [Co][taps][Ci] too
-    assert x.dtype in (torch.bfloat16, torch.float16, torch.float32) and w_fwd.dtype == x.dtype and x.is_contiguous()
+    split = x.dtype == SPLIT                # f16x2 path: x, w_fwd (and y unless out_f32) are split tensors
+    assert x.dtype in (torch.bfloat16, torch.float16, torch.float32, SPLIT) and w_fwd.dtype == x.dtype and x.is_contiguous()
     assert tuple(x.shape) == (d.N, d.Hi, d.Wi, d.Ci)
     ho, wo = conv_out_hw(d)
     y = torch.empty(d.N, ho, wo, d.Co, dtype=torch.float32 if (out_f32 or f32) else x.dtype, device=x.device)
@@ -70,7 +74,7 @@ def conv2d_fwd(x, w_fwd, d, res=None, bias=None, relu=False, out_f32=False, want
     if want_stats:
         rows = lib().udapose_conv_stat_rows(C.byref(d))
         stats = torch.empty(rows, 2, d.Co, dtype=torch.float32, device=x.device)
-    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_F32 if f32 else 0)
+    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_F32 if f32 else 0) | (EPI_SPLIT if split else 0)
     check(lib_for(x).udapose_conv2d_fwd(stream(), C.byref(d), ptr(x), ptr(w_fwd), ptr(y), ptr(res), ptr(bias), ptr(stats), flags), "conv2d_fwd")
     return (y, stats) if want_stats else y
 
@@ -129,12 +133,41 @@ def to_nhwc_f32(x_nchw, cpad=None):
     return out
 
 
+def to_nhwc_split(x_nchw, cpad=None):
+    """NCHW fp32 -> NHWC f16x2 split (channels zero-padded to cpad): the style path in the fast fp32-grade mode."""
+    require_cuda(x_nchw)
+    N, Cc, H, W = x_nchw.shape
+    cpad = cpad or (Cc + 7) // 8 * 8
+    out = torch.empty(N, H, W, cpad, dtype=SPLIT, device=x_nchw.device)
+    check(lib().udapose_nchw_f32_to_nhwc_split(stream(), ptr(x_nchw.float().contiguous()), ptr(out), N, Cc, H * W, cpad), "to_nhwc_split")
+    return out
+
+
+def f32_to_split(x):
+    """fp32 tensor (contiguous, last dimension a multiple of 8) -> f16x2 split tensor of the same shape."""
+    require_cuda(x)
+    x = x.float().contiguous()
+    assert x.shape[-1] % 8 == 0
+    out = torch.empty(x.shape, dtype=SPLIT, device=x.device)
+    check(lib().udapose_f32_to_split(stream(), ptr(x), ptr(out), x.numel()), "f32_to_split")
+    return out
+
+
+def split_to_f32(x):
+    require_cuda(x)
+    assert x.dtype == SPLIT and x.is_contiguous() and x.shape[-1] % 8 == 0
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().udapose_split_to_f32(stream(), ptr(x), ptr(out), x.numel()), "split_to_f32")
+    return out
+
+
 def to_nchw_f32(x_nhwc, channels=None, lo=None, hi=None):
     require_cuda(x_nhwc)
     N, H, W, Cs = x_nhwc.shape
     Cc = channels or Cs
     out = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x_nhwc.device)
-    check(lib_for(x_nhwc).udapose_nhwc_to_nchw_f32(stream(), ptr(x_nhwc), int(x_nhwc.dtype == torch.float32), ptr(out), N, Cc, H * W, Cs, ptr(lo), ptr(hi)),
+    kind = 2 if x_nhwc.dtype == SPLIT else int(x_nhwc.dtype == torch.float32)
+    check(lib_for(x_nhwc).udapose_nhwc_to_nchw_f32(stream(), ptr(x_nhwc), kind, ptr(out), N, Cc, H * W, Cs, ptr(lo), ptr(hi)),
           "to_nchw")
     return out
 
@@ -202,7 +235,8 @@ def maxpool3x3s2_bwd(dy, idx, H, W):
 def maxpool2x2_ceil(x):
     N, H, W, C_ = x.shape
     y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C_, dtype=x.dtype, device=x.device)
-    fn = lib().udapose_maxpool2x2_ceil_f32 if x.dtype == torch.float32 else lib_for(x).udapose_maxpool2x2_ceil
+    fn = lib().udapose_maxpool2x2_ceil_split if x.dtype == SPLIT else (
+        lib().udapose_maxpool2x2_ceil_f32 if x.dtype == torch.float32 else lib_for(x).udapose_maxpool2x2_ceil)
     check(fn(stream(), ptr(x), ptr(y), N, H, W, C_), "maxpool2x2")
     return y
 
@@ -210,12 +244,18 @@ def maxpool2x2_ceil(x):
 def adain(content, style, alpha=1.0, eps=1e-5, want_stats=False, stats_only=False):
     """NHWC bf16 or fp32 (both operands alike).  stats_only: no output tensor, [N,C,4] = (mean_c, std_c, mean_s, std_s)."""
     N, H, W, C_ = content.shape
-    assert content.dtype == style.dtype and content.dtype in (torch.bfloat16, torch.float16, torch.float32)
+    assert content.dtype == style.dtype and content.dtype in (torch.bfloat16, torch.float16, torch.float32, SPLIT)
     assert style.shape[0] == N and style.shape[3] == C_
     out = None if stats_only else torch.empty_like(content)
     st = torch.empty(N, C_, 4, dtype=torch.float32, device=content.device) if (want_stats or stats_only) else None
     f32 = content.dtype == torch.float32
-    if torch.is_tensor(alpha):      # the blend factor as ONE fp32 device scalar: read at run time (captured launches follow it)
+    if content.dtype == SPLIT:
+        dev_alpha = torch.is_tensor(alpha)
+        if dev_alpha:
+            assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.numel() == 1
+        check(lib().udapose_adain_split(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps,
+                                        1.0 if dev_alpha else float(alpha), ptr(alpha) if dev_alpha else None, ptr(st)), "adain")
+    elif torch.is_tensor(alpha):      # the blend factor as ONE fp32 device scalar: read at run time (captured launches follow it)
         assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.numel() == 1
         L = lib() if f32 else lib_for(content)
         check(L.udapose_adain_alpha_dev(stream(), ptr(content), ptr(style), ptr(out), N, H * W, style.shape[1] * style.shape[2], C_, eps,
