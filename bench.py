@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--sigma", type=float, default=2, help="label / rectify sigma (configs[4]: 1.0)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="storage / MFMA element type: bf16 = the metric; fp16 = the "
                     "reference's autocast dtype (BASELINE.json configs[4]), with GradScaler-style loss scaling kept on the device")
+    ap.add_argument("--precision", default=None, choices=["reference"], help="not the metric: 'reference' = the reference's own precision mix "
+                    "(train_human.py:346-358,414): student fp16 + device-side GradScaler, teacher and style network in the fp32-grade f16x2 mode")
     ap.add_argument("--strong", action="store_true", help="not the metric: strong scaling, global batch fixed at --batch (what the reference's "
                     "nn.DataParallel does): every rank takes batch / world images per domain")
     ap.add_argument("--config2", action="store_true", help="not the metric: BASELINE.json configs[2] = the same step + AdaIN s2t / t2s style "
@@ -210,6 +212,8 @@ def main():
     from uda_poseestimation_amd import _hip, synthetic
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
     import uda_poseestimation_amd.lib.models as models
+    if args.precision == "reference":
+        args.dtype = "fp16"                # (the student's element type: the library the roofline sample's profiler hooks live in)
     lib = _hip.lib(args.dtype)
     # tuning flags -> explicit dispatch policy of both networks' executor plans (udapose_policy; empty = production policy)
     tune = {}
@@ -245,12 +249,13 @@ def main():
         torch.manual_seed(1)
         Style_net.vgg.to(dev); Style_net.decoder.to(dev)
         style = Style_net.Net(torch.nn.Sequential(*list(Style_net.vgg.children())[:31]), Style_net.decoder).to(dev)
+        style.precision = "bf16"           # the fast mode unless --precision reference (MeanTeacherTrainer sets 'f16x2' then)
         lo = torch.tensor([-2.1179, -2.0357, -1.8044], device=dev)      # (0 - mean) / std and (1 - mean) / std (train_human.py:32-33)
         hi = torch.tensor([2.2489, 2.4285, 2.64], device=dev)
         extra = dict(style_net=style, recover=(lo, hi), s2t_freq=1.0, t2s_freq=1.0, s2t_alpha=(0.5, 0.5), t2s_alpha=(0.5, 0.5),
                      rng=np.random.RandomState(0), occlude_rate=0.5, occlude_thresh=0.9, occlude_size=10)
     trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
-                                 heatmap_size=S // 4, precision=args.dtype, **extra)
+                                 heatmap_size=S // 4, precision=(args.precision or args.dtype), **extra)
     if args.no_fuse_tail:
         trainer.fuse_tail = False
     trainer.stream_priority = args.stream_priority
@@ -368,12 +373,16 @@ def main():
         res = {
             "metric": f"images/sec (student+teacher step) {S}x{S} b={N}", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": "fp16 (student) + f16x2 fp32-grade (teacher, style)" if args.precision == "reference" else args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
                                    f"Adam, EMA), {S}x{S}, b={N}/GPU, " + ("AdaIN s2t + t2s style passes and adaptive occlusion (BASELINE.json configs[2]; NOT the metric)" if args.config2 else "no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch, args.dtype) == (256, 16, 32, "pose_resnet101", "bf16") else
                                                     (f", K={K}, {args.dtype} (BASELINE.json configs[4] shape and dtype on one GPU; NOT the metric)"
                                                      if (S, K, args.arch, args.dtype) == (384, 18, "pose_resnet101", "fp16") else f", K={K}, {args.dtype}"))),
-                       "global_batch": world * N, "parallelism": f"dp{world}"},
+                       "global_batch": world * N, "parallelism": f"dp{world}",
+                       **({"precision": "reference mix (train_human.py:346-358,414): student fp16 + device-side GradScaler, teacher"
+                                        + (", style network" if args.config2 else "") + " in the fp32-grade f16x2 mode; NOT the metric"}
+                          if args.precision == "reference" else {})},
             "loss": loss, "launch": "eager" if args.eager else ("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else ("1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs")) + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",

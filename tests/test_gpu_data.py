@@ -11,6 +11,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+
+@pytest.fixture(autouse=True)
+def _bf16_unless_stated(monkeypatch):
+    """The tests of this module exercise the 16-bit executor: networks start in 'bf16' (BASELINE.json's benched precision) unless a
+    test sets another precision.  (A new module's default is 'auto': autocast dtype / fp32-grade teacher, tests/test_gpu_dropin_loop.py.)"""
+    from uda_poseestimation_amd.lib.models.pose_resnet import PoseResNet
+    monkeypatch.setattr(PoseResNet, "default_precision", "bf16")
+
 def test_views_bit_exact_with_pil_oracle():
     from oracle import transforms_ref as R
     from oracle.mean_teacher_ref import generate_target_ref

@@ -108,6 +108,9 @@ def test_reference_call_forms_pretrain_and_train_iteration():
         y_s = student(x_s)
         loss_s = criterion(y_s, label_s, weight_s)
     loss_all = loss_s
+    # the reference's precisions, selected the way the reference selects them: autocast() -> fp16 student (train_human.py:280),
+    # the style network outside autocast -> fp32-grade
+    assert student.module._last_hd.precision == "fp16" and style_net.module.precision == "f16x2"
     scaler.scale(loss_all).backward()
     w0 = [p.detach().clone() for p in student.module.parameters()]
     scaler.step(stu_optimizer)
@@ -169,6 +172,17 @@ def test_reference_call_forms_pretrain_and_train_iteration():
             y_t_tea_recon[ind] = torch.mean(recons, dim=0)
             tea_mask[ind] = 1.
         angle, [trans_x, trans_y], [shear_x, shear_y], scale = meta_t_stu['aug_param_stu']
+    # the teacher ran under no_grad OUTSIDE autocast: fp32 in the reference (train_human.py:358), the fp32-grade mode here - its
+    # heat-maps meet north_star's 1e-3 bar against the fp32 oracle teacher on the same weights
+    assert teacher.module._last_hd.precision == "f16x2"
+    ref_t.train()
+    bufs_t = {k: v.clone() for k, v in ref_t.state_dict().items() if "running" in k or "num_batches" in k}
+    with torch.no_grad():
+        y_t_ref = ref_t(b["x_t_tea"])
+    ref_t.load_state_dict(bufs_t, strict=False)          # (train_step_ref below runs the oracle teacher's forward itself)
+    e_tea = (y_t_teas[0].cpu() - y_t_ref).abs().max().item()
+    print(f"drop-in teacher (auto -> f16x2) vs fp32 oracle: max|dheatmap| {e_tea:.2e} (max|y| {y_t_ref.abs().max().item():.3f})")
+    assert e_tea < 1e-3
     with torch.cuda.amp.autocast():
         y_s = student(x_s)
         y_t_stu = student(x_t_stu)
@@ -186,6 +200,7 @@ def test_reference_call_forms_pretrain_and_train_iteration():
         tea_mask = tea_mask * activates > mask_thresh
         loss_c = con_criterion(y_t_stu_recon, y_t_tea_recon, tea_mask=tea_mask)
     loss_all = loss_s + args.lambda_c * loss_c
+    assert student.module._last_hd.precision == "fp16"
     t0 = [p.detach().clone() for p in teacher.module.parameters()]
     scaler.scale(loss_all).backward()
     scaler.step(stu_optimizer)

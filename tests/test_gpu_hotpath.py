@@ -10,6 +10,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+
+@pytest.fixture(autouse=True)
+def _bf16_unless_stated(monkeypatch):
+    """The tests of this module exercise the 16-bit executor: networks start in 'bf16' (BASELINE.json's benched precision) unless a
+    test sets another precision.  (A new module's default is 'auto': autocast dtype / fp32-grade teacher, tests/test_gpu_dropin_loop.py.)"""
+    from uda_poseestimation_amd.lib.models.pose_resnet import PoseResNet
+    monkeypatch.setattr(PoseResNet, "default_precision", "bf16")
+
 def _g(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
@@ -172,8 +180,10 @@ def test_style_net_matches_reference_golden(golden_dir):
 
     def err(a, b):
         return (a.cpu() - torch.from_numpy(b)).abs().max().item() / np.abs(b).max()
-    # ---- bf16 (default, fast): the loop's [2]; losses are not computed (NaN, never a silent zero)
-    assert net.precision == "bf16" and net.compute_losses is False
+    # ---- bf16 (the fast mode; the default is the fp32-grade 'f16x2', tests/test_gpu_f16x2.py): the loop's [2]; losses are not
+    # computed (NaN, never a silent zero)
+    assert net.precision == "f16x2" and net.compute_losses is False
+    net.precision = "bf16"
     with torch.no_grad():
         lc, ls, g_t = net(content, style, float(z["alpha"]))
         feat = net.encode(content)

@@ -9,6 +9,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+
+@pytest.fixture(autouse=True)
+def _bf16_unless_stated(monkeypatch):
+    """The tests of this module exercise the 16-bit executor: networks start in 'bf16' (BASELINE.json's benched precision) unless a
+    test sets another precision.  (A new module's default is 'auto': autocast dtype / fp32-grade teacher, tests/test_gpu_dropin_loop.py.)"""
+    from uda_poseestimation_amd.lib.models.pose_resnet import PoseResNet
+    monkeypatch.setattr(PoseResNet, "default_precision", "bf16")
+
 def _pair(layers, K, seed=0, gamma3=None):
     import uda_poseestimation_amd.lib.models.pose_resnet as pr
     from oracle.pose_resnet_ref import PoseResNetRef

@@ -992,7 +992,10 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
                     void* wpack_s_, void* wpack_t_) {
     Net& n = *(Net*)hs;
     const Net& nt = *(const Net*)ht;
-    if (n.f32 || nt.f32 || n.n_params != nt.n_params || n.wpack_bytes != nt.wpack_bytes) return UDAPOSE_ERR_UNSUPPORTED;
+    // teacher in the f16x2 mode (the reference's precision mix: fp16 student, fp32-grade teacher): its split packs are not written
+    // by this sweep (the caller re-packs the teacher's plan with udapose_net_pack_weights after it), the EMA still is
+    const bool t_split = nt.f32 == 2;
+    if (n.f32 || nt.f32 == 1 || n.n_params != nt.n_params || (!t_split && n.wpack_bytes != nt.wpack_bytes)) return UDAPOSE_ERR_UNSUPPORTED;
     char* ws_ = (char*)wpack_s_;
     char* wt_ = (char*)wpack_t_;
     const size_t jb = opt_tail_job_bytes();
@@ -1020,9 +1023,9 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
         const int T = g.KH * g.KW;
         if (g.smallc()) return push(c.w_idx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);     // stem: packed by its own strided launch
         if (!g.transposed)   // master [Co][T][Ci]: fprop pack = cast, dgrad pack = per-tap transpose; the teacher needs the fprop pack
-            return push(c.w_idx, ws_ + c.wf_off, wt_ + c.wf_off, ws_ + c.wb_off, nullptr, g.Co, T, g.Ci);
+            return push(c.w_idx, ws_ + c.wf_off, t_split ? nullptr : wt_ + c.wf_off, ws_ + c.wb_off, nullptr, g.Co, T, g.Ci);
         // ConvTranspose2d master [Ci][T][Co]: dgrad pack = cast, fprop pack = per-tap transpose
-        return push(c.w_idx, ws_ + c.wb_off, nullptr, ws_ + c.wf_off, wt_ + c.wf_off, g.Ci, T, g.Co);
+        return push(c.w_idx, ws_ + c.wb_off, nullptr, ws_ + c.wf_off, t_split ? nullptr : wt_ + c.wf_off, g.Ci, T, g.Co);
     };
     CK(conv(n.stem));
     for (auto& b : n.blocks) {
@@ -1030,7 +1033,7 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
         if (b.has_ds) CK(conv(b.cd));
     }
     for (int i = 0; i < 3; ++i) CK(conv(n.up[i]));
-    CK(push(n.head.w_idx, ws_ + n.head.wf_off, wt_ + n.head.wf_off, nullptr, nullptr, 0, 0, 0));      // [K][256]: the fprop pack is a cast
+    CK(push(n.head.w_idx, ws_ + n.head.wf_off, t_split ? nullptr : wt_ + n.head.wf_off, nullptr, nullptr, 0, 0, 0));      // [K][256]: the fprop pack is a cast
     for (int i = 0; i < n.n_params; ++i)
         if (!covered[i]) CK(push(i, nullptr, nullptr, nullptr, nullptr, 0, 0, 0));                   // BN vectors, head bias, backbone.fc
     Net::UpdTab& u = n.upd;
@@ -1059,7 +1062,7 @@ int net_fused_update(void* hs, void* ht, hipStream_t s, void* const* params_s, v
     // the two packs that are not a cast or a per-tap transpose of a whole tensor: the stem's 3 -> 8 channel gather (both
     // networks) and the head's zero-padded dgrad pack (student)
     CK(pack_conv(s, n, n.stem, (const void* const*)params_s, (char*)wpack_s_, false));
-    CK(pack_conv(s, nt, nt.stem, (const void* const*)params_t, (char*)wpack_t_, false));
+    if (nt.f32 != 2) CK(pack_conv(s, nt, nt.stem, (const void* const*)params_t, (char*)wpack_t_, false));
     CK(pw_pack_strided(s, (const float*)params_s[n.head.w_idx], (elem_t*)((char*)wpack_s_ + n.head.wb_off), 256, 1, 1, 1, 64, n.K, 1, 0, 0, 256));
     return UDAPOSE_OK;
 }

@@ -102,10 +102,18 @@ class MeanTeacherTrainer:
                  loss_scale_init=65536.0, loss_scale_interval=2000):
         self.student, self.teacher = student, teacher
         self.criterion, self.con_criterion = JointsMSELoss(), ConsLoss()
-        # precision: None keeps what the two networks are set to; 'fp16' = the reference's autocast dtype for the student
-        # (train_human.py:280,414) with GradScaler-style dynamic loss scaling kept on the device (optim.py); here the teacher
-        # runs in the same precision (the reference runs it in fp32 outside autocast: teacher.precision = 'fp32' selects that)
-        if precision is not None:
+        # precision: None keeps what the networks are set to (a new PoseResNet is 'auto': a differentiable forward outside
+        # autocast runs bf16, the teacher's no-grad forward the fp32-grade 'f16x2' mode).
+        # 'reference' = the reference's own precision mix (train_human.py:346-358,414): the student in fp16 (its autocast dtype)
+        #   with GradScaler's dynamic loss scaling kept on the device (optim.py), the teacher and the style network OUTSIDE autocast
+        #   in fp32 - here the fp32-grade 'f16x2' mode (three fp16 MFMAs per K step; heat-maps within ~4e-5 of the fp32 oracle).
+        # 'bf16' / 'fp16': student AND teacher in that 16-bit type (BASELINE.json's benched configuration is 'bf16'; the style
+        #   network keeps its own setting).
+        if precision == "reference":
+            student.precision, teacher.precision = "fp16", "f16x2"
+            if style_net is not None and hasattr(style_net, "precision"):
+                style_net.precision = "f16x2"
+        elif precision is not None:
             student.precision = precision
             teacher.precision = precision
         scaled = getattr(student, "precision", "bf16") == "fp16"

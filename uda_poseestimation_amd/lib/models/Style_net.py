@@ -7,11 +7,14 @@ The children are parameter containers: `Net.forward` walks them and issues one f
 [ReflectionPad2d -> Conv2d -> ReLU] group (reflection, nearest x2 upsample, bias and ReLU live inside the conv
 kernel), the ceil-mode max-pools, and the AdaIN kernel, on NHWC activations.
 
-Two precisions (`Net.precision`):
-  'bf16' (default): bf16 storage, bf16 MFMA, fp32 accumulation - the fast mode; g_t within ~8e-2 * max of the fp32 result
+Three precisions (`Net.precision`):
+  'f16x2' (default): the fast fp32-grade mode - the loop runs the style net OUTSIDE autocast, in fp32 (train_human.py:347-356).
+                    Activations and weights as fp16 pairs (h, l), three fp16 MFMAs per K step, fp32 accumulation, fp32 AdaIN
+                    statistics: g_t within ~5e-6 * max of the reference's output (tests/test_gpu_f16x2.py), 2.5x the speed of
+                    the exact mode.  Range of activations: |x| <= 65504 (saturating).
+  'fp32':           fp32 storage and the exact fp32 MFMA (v_mfma_f32_16x16x4_f32); ~5x slower than bf16.
+  'bf16':           bf16 storage, bf16 MFMA, fp32 accumulation - the fastest mode; g_t within ~8e-2 * max of the fp32 result
                     after 19 un-normalised conv layers (tests/test_gpu_hotpath.py).
-  'fp32':           fp32 storage and the exact fp32 MFMA (v_mfma_f32_16x16x4_f32) - the reference's own precision (the loop
-                    runs the style net outside autocast, train_human.py:347-356); ~1e-5 of the reference, ~10x slower.
 
 `forward` returns (loss_c, loss_s, g_t) like the reference.  The training loop consumes only [2] (train_human.py:275,350,355)
 and the two losses cost a third encoder pass plus eight Gram matrices, so they are computed only when
@@ -213,7 +216,7 @@ class Net(nn.Module):
         for name in ['enc_1', 'enc_2', 'enc_3', 'enc_4']:
             for param in getattr(self, name).parameters():
                 param.requires_grad = False
-        self.precision = 'bf16'           # 'fp32': the reference's precision (module docstring)
+        self.precision = 'f16x2'          # fp32-grade: the reference runs this network in fp32 (module docstring); 'bf16' is the fast mode
         self.compute_losses = False       # True: loss_c / loss_s as in Style_net.py:151-177 (a third encoder pass + Gram matrices)
         self._enc = _SeqRunner(enc_layers[:31])
         self._dec = _SeqRunner(list(decoder.children()))

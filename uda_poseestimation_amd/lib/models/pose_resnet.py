@@ -61,6 +61,7 @@ class _NetHandle:
         arr = (C.c_int * 4)(*layers)
         check(L.udapose_net_create(arr, K, N, H, W, {'fp32': 1, 'f16x2': 2}.get(precision, 0), C.byref(h)), "net_create")
         self.h = h
+        self.precision = precision
         if policy:
             pol = _hip.policy(**policy)
             check(L.udapose_net_set_policy(h, C.byref(pol)), "net_set_policy")
@@ -105,6 +106,7 @@ class _PoseNetFn(torch.autograd.Function):
 
 class PoseResNet(nn.Module):
     """Simple Baseline for key-point detection (pose_resnet.py:59-91) on the MI355X executor."""
+    default_precision = 'auto'      # what a new module's `precision` starts as (see __init__)
 
     def __init__(self, backbone, upsampling, feature_dim, num_keypoints, finetune=False):
         super().__init__()
@@ -119,12 +121,18 @@ class PoseResNet(nn.Module):
             raise NotImplementedError("the MI355X executor implements the reference configuration: 3 x deconv(256, k=4), no bias")
         self.num_keypoints = num_keypoints
         self.bn_momentum = 0.1
+        # 'auto' (default): what the reference's scripts get from torch - inside `torch.cuda.amp.autocast()` the autocast dtype
+        #         (fp16 by default: the student of train_human.py:280,414; bf16 if the context names it); outside autocast, a
+        #         forward that keeps no backward state (the teacher under no_grad, validate(): train_human.py:346-358,461-500 run in
+        #         fp32) takes the fp32-grade 'f16x2' mode; a differentiable forward outside autocast takes 'bf16' (there is no fp32
+        #         backward: the reference's scripts always train under autocast).
         # 'bf16': bf16 storage + MFMA, fp32 accumulation (training and inference; BASELINE.json's benched precision).
         # 'fp16': fp16 storage + MFMA (v_mfma_f32_16x16x32_f16), fp32 accumulation - the reference's autocast dtype
         #         (train_human.py:280,414); gradients need loss scaling (GradScaler, or optim.FusedAdam(dynamic_loss_scale=True)).
-        # 'fp32': exact fp32 MFMA, forward only - the precision the reference uses for the teacher and validate()
-        #         (no autocast there); ~16x slower.
-        self.precision = 'bf16'
+        # 'f16x2': the FAST fp32-grade mode, forward only: activations and weights as fp16 pairs (h, l), three fp16 MFMAs per K step,
+        #         fp32 accumulation / BatchNorm statistics - heat-maps within ~4e-5 of the fp32 CPU oracle, 1.7x the exact mode's speed.
+        # 'fp32': exact fp32 MFMA (v_mfma_f32_16x16x4_f32), forward only; 3x slower than bf16.
+        self.precision = type(self).default_precision
         self._handles = {}
         self._ptr_cache = None
         self._flat_grad = None
@@ -214,16 +222,28 @@ class PoseResNet(nn.Module):
             self._grad_view_list = views
         return self._grad_view_list
 
-    def _handle(self, x):
+    def resolved_precision(self, differentiable):
+        """The precision a forward started now would run in ('auto' resolved, see __init__)."""
+        prec = self.precision
+        if prec not in ('auto', 'bf16', 'fp16', 'fp32', 'f16x2'):
+            raise ValueError("precision must be 'auto', 'bf16', 'fp16', 'f16x2' or 'fp32'")
+        if prec != 'auto':
+            return prec
+        if torch.is_autocast_enabled():
+            return 'bf16' if torch.get_autocast_dtype('cuda') == torch.bfloat16 else 'fp16'
+        return 'bf16' if differentiable else 'f16x2'
+
+    def _handle(self, x, differentiable=None):
         N, Cc, H, W = x.shape
         if Cc != 3:
             raise ValueError("PoseResNet expects [N,3,H,W] input")
-        if self.precision not in ('bf16', 'fp16', 'fp32', 'f16x2'):
-            raise ValueError("precision must be 'bf16', 'fp16', 'f16x2' or 'fp32'")
-        key = (N, H, W, x.device.index, self.precision)
+        if differentiable is None:
+            differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        prec = self.resolved_precision(differentiable)
+        key = (N, H, W, x.device.index, prec)
         hd = self._handles.get(key)
         if hd is None:
-            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, self.precision, dict(self.policy))
+            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, prec, dict(self.policy))
             params = list(self.parameters())
             assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
             for i, p in enumerate(params):
@@ -290,10 +310,10 @@ class PoseResNet(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        hd = self._handle(x)
+        hd = self._handle(x, differentiable=save)
         self._last_hd = hd            # the plan of the most recent forward (the fused optimizer tail keeps ITS packs fresh)
-        if save and self.precision in ('fp32', 'f16x2'):
-            raise RuntimeError(f"precision={self.precision!r} is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
+        if save and hd.precision in ('fp32', 'f16x2'):
+            raise RuntimeError(f"precision={hd.precision!r} is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
         pa, ba, params = self._pointers()
         s = _hip.stream()
         self._pack(hd, pa, params, need_bwd=save)

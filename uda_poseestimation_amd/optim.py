@@ -182,7 +182,12 @@ class FusedAdam(_FusedBase):
         group = self.param_groups[0]
         ps = list(student.parameters())
         hd_s, hd_t = getattr(student, "_last_hd", None), getattr(teacher, "_last_hd", None)
-        if hd_s is None or hd_t is None or hd_s.L is not hd_t.L or student.precision == "fp32" or teacher.precision != student.precision:
+        # the teacher either shares the student's 16-bit element type (its packs are written by the sweep) or runs the fp32-grade
+        # f16x2 mode (the reference's precision mix: its split packs are refreshed by one pack launch right after the sweep)
+        if hd_s is None or hd_t is None or hd_s.precision not in ("bf16", "fp16"):
+            return False
+        t_split = hd_t.precision == "f16x2"
+        if not t_split and (hd_s.L is not hd_t.L or hd_t.precision != hd_s.precision):
             return False
         if len(group["params"]) != len(ps) or any(a is not b for a, b in zip(group["params"], ps)):
             return False
@@ -229,6 +234,9 @@ class FusedAdam(_FusedBase):
         _bump_versions(ps)
         _bump_versions(tps)
         student.packs_refreshed(hd_s, True)
+        if t_split:
+            pa_t_ = teacher._pointers()[0]
+            check(hd_t.L.udapose_net_pack_weights(hd_t.h, _hip.stream(), pa_t_, ptr(hd_t.wpack), 0), "net_pack_weights (teacher, f16x2)")
         teacher.packs_refreshed(hd_t, False)
         return True
 
