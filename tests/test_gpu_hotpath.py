@@ -307,20 +307,8 @@ def test_mean_teacher_step_matches_cpu_oracle():
     o2 = gs.step(*args)
     o3 = tr3.train_step(*args)
     assert abs(float(o2["loss_all"]) - float(o3["loss_all"])) <= 2e-3 * abs(float(o3["loss_all"]))
-    # the data-parallel form (three graphs cut around the two collectives) gives the same step on one rank
-    torch.manual_seed(0)
-    s4 = pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
-    t4 = pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
-    s4.load_state_dict(s2.state_dict() if False else s3.state_dict())
-    # (s3 has been trained for 3 steps; compare one further step of the split-graph trainer against the eager trainer)
-    t4.load_state_dict(t3.state_dict())
-    tr4 = MeanTeacherTrainer(s4.cuda(), t4.cuda(), image_size=S, heatmap_size=S // 4)
-    t4.load_state_dict(t3.state_dict())          # (the EMA ctor copied the student into the teacher: restore)
-    gs4 = GraphedTrainStep(tr4, *args, warmup=1, split=True)   # (one eager warm-up step: plans/tables are built outside capture)
-    o5 = tr3.train_step(*args)
-    o4 = gs4.step(*args)
-    o5 = tr3.train_step(*args)
-    assert torch.isfinite(o4["loss_all"]) and abs(float(o4["loss_all"]) - float(o5["loss_all"])) <= 0.2 * abs(float(o5["loss_all"]))
+    # (the data-parallel split-graph form is compared with its eager twin from identical state in
+    # tests/test_gpu_steps.py::test_captured_steps_equal_their_eager_twin_*: a looser check of it here could not fail)
 
 
 def test_occlusion_matches_oracle():

@@ -76,3 +76,38 @@ def mean_teacher_batch(n, num_keypoints=16, image_size=256, heatmap_size=64, sig
         "aug_param_stu": aug_params(n, rs),
         "aug_param_tea": aug_params(n, rs),
     }
+
+
+# 16+ well separated colours in the normalised-image range (one per key point): what makes `keypoint_images` learnable
+_BLOB_LEVELS = (-1.6, 0.2, 2.0)
+
+
+def keypoint_images(keypoints, image_size, seed, noise=0.35, radius=7.0):
+    """Images whose CONTENT determines the labels (unlike `images`, whose noise carries no information about the key points): weak
+    noise plus one Gaussian blob per key point at its location, coloured by the key-point index.  A network can learn the
+    task in a few hundred steps and generalises to unseen images - used to produce trained-like weights for the parity tests.
+    keypoints [N,K,2] px -> [N,3,S,S] f32."""
+    n, K, _ = keypoints.shape
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, image_size, image_size, generator=g) * noise
+    cols = [(a, b, c) for a in _BLOB_LEVELS for b in _BLOB_LEVELS for c in _BLOB_LEVELS if not (a == b == c)]
+    ys = torch.arange(image_size, dtype=torch.float32).view(1, -1, 1)
+    xs = torch.arange(image_size, dtype=torch.float32).view(1, 1, -1)
+    kp = torch.as_tensor(keypoints, dtype=torch.float32)
+    for k in range(K):
+        col = torch.tensor(cols[k % len(cols)], dtype=torch.float32).view(1, 3, 1, 1)
+        w = torch.exp(-((xs - kp[:, k, 0].view(-1, 1, 1)) ** 2 + (ys - kp[:, k, 1].view(-1, 1, 1)) ** 2) / (2 * radius ** 2)).unsqueeze(1)
+        x = x * (1 - w) + col * w
+    lo = torch.tensor((0 - IMAGENET_MEAN) / IMAGENET_STD).view(1, 3, 1, 1)
+    hi = torch.tensor((1 - IMAGENET_MEAN) / IMAGENET_STD).view(1, 3, 1, 1)
+    return torch.maximum(torch.minimum(x, hi), lo)
+
+
+def keypoint_batch(n, num_keypoints=16, image_size=256, heatmap_size=64, sigma=2, seed=0):
+    """(x [n,3,S,S], label [n,K,h,w], weight [n,K,1]) with learnable content (keypoint_images); key points kept off the border."""
+    rs = np.random.RandomState(seed)
+    kp = rs.uniform(0.08 * image_size, 0.92 * image_size, size=(n, num_keypoints, 2)).astype(np.float32)
+    vis = np.ones((num_keypoints, 1), np.float32)
+    lab = [gaussian_labels(kp[i], vis, (heatmap_size, heatmap_size), sigma, (image_size, image_size)) for i in range(n)]
+    return (keypoint_images(kp, image_size, seed), torch.from_numpy(np.stack([l[0] for l in lab])),
+            torch.from_numpy(np.stack([l[1] for l in lab])))
