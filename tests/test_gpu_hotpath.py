@@ -308,7 +308,7 @@ def test_mean_teacher_step_matches_cpu_oracle():
     o3 = tr3.train_step(*args)
     assert abs(float(o2["loss_all"]) - float(o3["loss_all"])) <= 2e-3 * abs(float(o3["loss_all"]))
     # (the data-parallel split-graph form is compared with its eager twin from identical state in
-    # tests/test_gpu_steps.py::test_captured_steps_equal_their_eager_twin_*: a looser check of it here could not fail)
+    # tests/test_gpu_steps.py::test_captured_steps_equal_eager_steps_from_identical_state_with_varying_batches: a looser check of it here could not fail)
 
 
 def test_occlusion_matches_oracle():

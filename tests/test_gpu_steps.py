@@ -517,3 +517,167 @@ def test_merged_weight_gradient_launch_is_bit_identical():
         assert torch.isfinite(out["loss_all"])
         res[merge] = [p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
     assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
+
+
+@pytest.mark.parametrize("seed", [123, 4, 14])       # both directions drawn | t2s only | s2t only
+def test_config2_eager_step_matches_whole_step_oracle(seed):
+    """BASELINE.json configs[2]'s whole step - AdaIN style transfer in both directions (drawn with probability 0.7
+    each, random alpha), recover clamp, adaptive occlusion with the reference's host draws - on the device against
+    oracle.step_ref.train_step_full_ref (train_human.py:345-438 in the reference's order of np.random draws) from identical
+    weights, inputs and generator state, in the reference's precision mix (fp16 student, fp32-grade teacher and style network):
+    drawn alphas, stylised inputs, occluded sample set and occluded images, mask, both losses, and the generator state the step
+    leaves behind (= the same number and kind of draws were consumed)."""
+    from seeded import fill_style_weights
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_full_ref
+    from oracle.style_ref import make_decoder_ref, make_vgg_ref
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    from uda_poseestimation_amd.lib.models import Style_net
+    N, K, S, layers = 4, 16, 128, [1, 1, 1, 1]
+    fill_style_weights(Style_net.vgg, 11)
+    fill_style_weights(Style_net.decoder, 12)
+    vgg_ref, dec_ref = make_vgg_ref(), make_decoder_ref()
+    vgg_ref.load_state_dict(Style_net.vgg.state_dict())
+    dec_ref.load_state_dict(Style_net.decoder.state_dict())
+    vgg31_ref = torch.nn.Sequential(*list(vgg_ref.children())[:31]).eval()
+    Style_net.vgg.cuda(); Style_net.decoder.cuda()
+    net = Style_net.Net(torch.nn.Sequential(*list(Style_net.vgg.children())[:31]), Style_net.decoder).cuda()
+    lo_c, hi_c = torch.tensor([-2.1179, -2.0357, -1.8044]), torch.tensor([2.2489, 2.4285, 2.64])
+    torch.manual_seed(5)
+    ref_s, ref_t = PoseResNetRef(layers, K), PoseResNetRef(layers, K)
+    ref_t.load_state_dict(ref_s.state_dict())
+    stu, tea = _tiny(K, layers), _tiny(K, layers)
+    stu.load_state_dict(ref_s.state_dict())
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=60 + seed)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    # occlusion threshold inside the range of the (random-init) teacher's confidences, so that the candidate sets are data dependent
+    ref_t.train()
+    with torch.no_grad():
+        bufs = {k: v.clone() for k, v in ref_t.state_dict().items() if "running" in k or "num_batches" in k}
+        conf0 = ref_t(b["x_t_tea"]).amax(dim=(2, 3))
+        ref_t.load_state_dict(bufs, strict=False)
+    thresh = float(conf0.flatten().kthvalue(int(0.8 * conf0.numel()))[0])
+    kw = dict(s2t_freq=0.7, t2s_freq=0.7, s2t_alpha=(0.2, 1.0), t2s_alpha=(0.2, 1.0), occlude_rate=0.6, occlude_thresh=thresh, occlude_size=10)
+    rng_dev, rng_ref = np.random.RandomState(seed), np.random.RandomState(seed)
+    tr = MeanTeacherTrainer(stu.cuda(), tea.cuda(), lr=1e-4, image_size=S, heatmap_size=S // 4, style_net=net, recover=(lo_c.cuda(), hi_c.cuda()),
+                            rng=rng_dev, precision="reference", **kw)
+    tr.device_occlusion = False
+    # the effective inputs of the device step, captured on the way
+    seen = {}
+    orig = tr._forward_backward
+
+    def spy(x_s_in, label_s, weight_s, x_t_stu, x_t_teas_in, theta_stu, thetas_tea):
+        seen["x_s_in"], seen["x_t_tea_in"] = x_s_in.detach().clone(), x_t_teas_in[0].detach().clone()
+        return orig(x_s_in, label_s, weight_s, x_t_stu, x_t_teas_in, theta_stu, thetas_tea)
+    tr._forward_backward = spy
+    out = tr.train_step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    torch.cuda.synchronize()
+    opt = torch.optim.Adam(ref_s.parameters(), lr=1e-4)
+    ref = train_step_full_ref(ref_s, ref_t, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"],
+                              b["aug_param_tea"], ratio=4.0, style=(vgg31_ref, dec_ref), rng=rng_ref, recover=(lo_c, hi_c), image_size=S, **kw)
+    # ---- the host generators consumed the same draws (number AND kind: the states are identical)
+    st_d, st_r = rng_dev.get_state(), rng_ref.get_state()
+    assert st_d[2] == st_r[2] and np.array_equal(st_d[1], st_r[1])
+    # ---- style decisions and stylised inputs (fp32-grade style network: 1e-3 of the image range)
+    for key, which in (("x_s_in", "alpha_s2t"), ("x_t_tea_in", "alpha_t2s")):
+        e = (seen[key].cpu() - ref[key]).abs().max().item()
+        print(f"seed {seed}: {which} = {ref[which]}, max|device - oracle| of the effective input {e:.2e}")
+        assert e < 5e-4
+    # ---- occlusion: same samples, same images up to isolated nearest-neighbour ties of the warps
+    assert list(tr.occluded) == list(ref["occluded"]), (tr.occluded, ref["occluded"])
+    # ---- mask and losses
+    assert torch.equal(out["tea_mask"].cpu().bool(), ref["tea_mask"].bool())                   # the k-th value mask, element for element
+    assert abs(float(out["loss_s"]) - float(ref["loss_s"])) <= 1e-3 * float(ref["loss_s"]), (float(out["loss_s"]), float(ref["loss_s"]))
+    assert abs(float(out["loss_c"]) - float(ref["loss_c"])) <= 5e-3 * float(ref["loss_c"]) + 1e-7, (float(out["loss_c"]), float(ref["loss_c"]))
+    print(f"seed {seed}: occluded {ref['occluded']} (threshold {thresh:.4f}); loss_s {float(out['loss_s']):.6f} / {float(ref['loss_s']):.6f}, "
+          f"loss_c {float(out['loss_c']):.4e} / {float(ref['loss_c']):.4e}")
+    # EMA and Adam ran: the teacher equals the oracle's teacher to the first update's size
+    d = max((a.detach().cpu() - r.detach()).abs().max().item() for a, r in zip(tea.parameters(), ref_t.parameters()))
+    assert d < 1e-6 + 1e-3 * 1e-4 * 10, d
+
+
+def test_fused_sgd_resumes_from_a_torch_sgd_checkpoint_with_its_momentum():
+    """torch.optim.SGD checkpoints (train_human.py:136,157,231 save and restore `stu_optimizer`) carry no step
+    counter; the restored momentum buffers must NOT be re-initialised by a 'first step'.  torch.optim.SGD (nesterov, weight decay)
+    -> state_dict -> FusedSGD -> one step == one further torch step on the same gradients."""
+    from uda_poseestimation_amd import optim as fo
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 3, 7, 7), (128,), (33, 17), (256, 64, 1, 1)]
+    ps_t = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    ps_f = [torch.nn.Parameter(p.detach().clone()) for p in ps_t]
+    kw = dict(lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    ref = torch.optim.SGD(ps_t, **kw)
+    for _ in range(3):                                  # three torch steps build up momentum
+        for p in ps_t:
+            p.grad = torch.randn(p.shape, generator=g).cuda()
+        ref.step()
+    for a, b in zip(ps_f, ps_t):
+        a.data.copy_(b.data)
+    import copy
+    sd = copy.deepcopy(ref.state_dict())               # (as after torch.save / torch.load: load_state_dict would alias same-device tensors)
+    assert "step" not in sd["param_groups"][0]
+    opt = fo.FusedSGD(ps_f, **kw)
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["step"] >= 1
+    grads = [torch.randn(p.shape, generator=g).cuda() for p in ps_t]
+    for a, b, gr in zip(ps_f, ps_t, grads):
+        a.grad, b.grad = gr.clone(), gr.clone()
+    opt.step()
+    ref.step()
+    for a, b in zip(ps_f, ps_t):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (a - b).abs().max()
+    for a, b in zip(ps_f, ps_t):                        # the momentum buffers continued, they were not re-seeded with the gradient
+        assert torch.allclose(opt.state[a]["momentum_buffer"], ref.state[b]["momentum_buffer"], rtol=1e-6, atol=1e-7)
+
+
+def test_optimizer_load_state_dict_after_capture_reaches_the_replays():
+    """`stu_optimizer.load_state_dict()` between two replays of a captured step.  The restore is IN PLACE (moment
+    tensors and device state keep their storage), so the captured Adam continues from the restored moments, step counter and lr -
+    checked against an eager twin that loads the same checkpoint; replacing the state tensors wholesale is refused loudly."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    base = _tiny(K, seed=9)
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=12)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    trs = []
+    for _ in range(2):
+        s_, t_ = _tiny(K, seed=9), _tiny(K, seed=9)
+        s_.load_state_dict(base.state_dict())
+        trs.append(MeanTeacherTrainer(s_.cuda(), t_.cuda(), lr=1e-3, image_size=S, heatmap_size=S // 4))
+    tr_g, tr_e = trs
+    gs = GraphedTrainStep(tr_g, *args, warmup=1)
+    tr_e.train_step(*args)
+    gs.step(*args)
+    tr_e.train_step(*args)
+    ckpt = {k: (v if not isinstance(v, dict) else v) for k, v in tr_e.stu_optimizer.state_dict().items()}
+    import copy
+    ckpt = copy.deepcopy(ckpt)
+    ckpt["param_groups"][0]["lr"] = 3e-4                              # the checkpoint's lr differs from the running one
+    snap_s = copy.deepcopy(tr_e.student.state_dict())
+    snap_t = copy.deepcopy(tr_e.teacher.state_dict())
+    for tr in (tr_g, tr_e):                                           # "resume": weights and optimizer from the checkpoint
+        tr.student.load_state_dict(snap_s)
+        tr.teacher.load_state_dict(snap_t)
+        ptr0 = tr.stu_optimizer.state[next(iter(tr.student.parameters()))]["exp_avg"].data_ptr()
+        tr.stu_optimizer.load_state_dict(copy.deepcopy(ckpt))
+        assert tr.stu_optimizer.state[next(iter(tr.student.parameters()))]["exp_avg"].data_ptr() == ptr0      # restored in place
+    for _ in range(2):
+        og = gs.step(*args)
+        oe = tr_e.train_step(*args)
+    assert tr_g.stu_optimizer.state_dict()["param_groups"][0]["step"] == tr_e.stu_optimizer.state_dict()["param_groups"][0]["step"] == 4
+    num = den = 0.0
+    for pg, pe, q in zip(tr_g.student.parameters(), tr_e.student.parameters(), snap_s.values()):
+        num += float(((pg.detach() - pe.detach()) ** 2).sum())
+    for pe, (k_, q) in zip(tr_e.student.parameters(), [(k_, v) for k_, v in snap_s.items() if "running" not in k_ and "num_batches" not in k_]):
+        den += float(((pe.detach() - q.cuda()) ** 2).sum())
+    rel = (num / max(den, 1e-30)) ** 0.5
+    print(f"replays after an in-place optimizer restore vs the eager twin: relative parameter distance {rel:.3e}")
+    assert rel < 1e-3
+    # state tensors REPLACED behind the captured launches: refused
+    st = tr_g.stu_optimizer.state[next(iter(tr_g.student.parameters()))]
+    st["exp_avg"] = st["exp_avg"].clone()
+    with pytest.raises(RuntimeError, match="replaced after capture"):
+        gs.step(*args)

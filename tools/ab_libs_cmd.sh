@@ -4,6 +4,8 @@
 TAGS="$1"; R="$2"; shift 2
 L=uda_poseestimation_amd/libudapose_hip.so
 cp $L /tmp/lib_keep.so
+# (the production library is restored however the script ends - interrupt, timeout kill, failed cp)
+trap 'cp /tmp/lib_keep.so $L' EXIT
 for i in $(seq 1 $R); do
   for tag in $TAGS; do
     cp tools/_ab/lib_$tag.so $L

@@ -7,6 +7,7 @@
 // bf16 packed [Co][taps][Ci] (fprop) and [Ci][taps][Co] (dgrad) from the fp32 channels_last master copies, BN statistics
 // fp32.  Parameters are addressed by index in torch `.parameters()` order, buffers in `.buffers()` order.
 #include <algorithm>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -132,7 +133,7 @@ struct Net {
         ZeroJob* d_zero = nullptr; int n_zero = 0;       // the same ranges as a device job table, when all are 16-byte granular
         unsigned long long last_use = 0;
     };
-    std::vector<WgGroup> wg_groups;
+    std::deque<WgGroup> wg_groups;       // (stable addresses, never evicted: a captured hipGraph may reference any table built so far)
     // fused optimizer tail (Adam + EMA + weight packs of student and teacher in one sweep): device job table
     struct UpdTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0;
                     const void* k_ps = nullptr; const void* k_pt = nullptr; const void* k_g = nullptr; const void* k_m = nullptr;
@@ -721,14 +722,16 @@ Net::WgGroup* find_wg_group(Net& n, void* const* grads, float beta, int part) {
 // net_bind_grads: allocate + upload the grouped weight-gradient tables (both accumulate modes) for this gradient placement.
 // Synchronous - never inside a stream capture; net_backward itself never builds them.
 int bind_wg_groups(Net& n, void* const* grads) {
-    n.wg_groups.reserve(12);          // (pointers into the vector stay valid: 3 parts x 2 accumulate modes x 2 placements)
+    // 3 parts x 2 accumulate modes per gradient placement (a few KB of device tables each).  Tables are never evicted or rebuilt
+    // in place: launches captured in a hipGraph hold their device pointers, and a process only ever uses a handful of
+    // gradient placements (two per-pass buffers per network).
     for (const int part : {0, 1, 2})
         for (const float beta : {0.f, 1.f}) {
             if (find_wg_group(n, grads, beta, part)) continue;
-            Net::WgGroup* G;
-            if (n.wg_groups.size() < 12) { n.wg_groups.emplace_back(); G = &n.wg_groups.back(); }
-            else { G = &n.wg_groups[0]; for (auto& g : n.wg_groups) if (g.last_use < G->last_use) G = &g; }
-            CK(build_wg_group(n, *G, grads, beta, part));
+            n.wg_groups.emplace_back();
+            Net::WgGroup* G = &n.wg_groups.back();
+            const int rc = build_wg_group(n, *G, grads, beta, part);
+            if (rc != UDAPOSE_OK) { n.wg_groups.pop_back(); return rc; }
             G->last_use = ++n.wg_tick;
         }
     return UDAPOSE_OK;

@@ -354,7 +354,8 @@ class MeanTeacherTrainer:
             # adds the second pass's gradient buffer (no-op when both ran on one stream) - unless the fused optimizer tail will
             # read both buffers itself (one rank: nothing else looks at the gradients in between)
             student.finish_grads(defer=self._tail_sums_grads())
-        return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": st["y_s"].detach()}
+        return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": st["y_s"].detach(),
+                "tea_mask": tea_mask}
 
     def _forward_backward(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
         st = self._forward_part(x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea)
@@ -531,6 +532,7 @@ class GraphedTrainStep:
         for m in (trainer.student, trainer.teacher):
             m._capture_token = None
             m.weights_changed()
+        self._opt_key = self._optimizer_key()
         self._fused_tail = bool(trainer.fused_last)
         self._maintained = [(trainer.student, trainer.student._last_hd, True), (trainer.teacher, trainer.teacher._last_hd, False)]
         if self._fused_tail:
@@ -564,6 +566,18 @@ class GraphedTrainStep:
                     st[src[0]].copy_(st[src[1]], non_blocking=True)
         if self.occl:
             st["u"].copy_(self.t.draw_occlusion_uniforms(self.n), non_blocking=True)
+
+    def _optimizer_key(self):
+        """Storage the captured optimizer launches point at: the device state of every group and the first moment tensor."""
+        opt = self.t.stu_optimizer
+        key = [ent[0].data_ptr() for _, ent in sorted(getattr(opt, "_dev", {}).items())]
+        for g in opt.param_groups:
+            for p in g["params"]:
+                st = opt.state.get(p)
+                if st:
+                    key += [v.data_ptr() for v in st.values() if torch.is_tensor(v)]
+                    break
+        return key
 
     def _frozen_hyper(self):
         t = self.t
@@ -615,6 +629,10 @@ class GraphedTrainStep:
             changed = [a[0] for a, b in zip(self._frozen_hyper(), self._frozen) if a != b]
             raise RuntimeError(f"GraphedTrainStep: {changed} changed after capture; these are baked into the captured launches - "
                                "build a new GraphedTrainStep (lr and grad_scale may change freely)")
+        if self._optimizer_key() != self._opt_key:
+            raise RuntimeError("GraphedTrainStep: the optimizer's state tensors were replaced after capture (a new optimizer, or state moved to "
+                               "another device): the captured launches still point at the old storage - build a new GraphedTrainStep "
+                               "(FusedAdam / FusedSGD.load_state_dict restores IN PLACE and is fine)")
         if self._fused_tail:
             # the captured step relies on the packs its own previous update left: if anything else touched the weights since
             # (an eager optimizer, load_state_dict), re-pack eagerly first

@@ -64,16 +64,20 @@ class _FusedBase(torch.optim.Optimizer):
         """[step, bc1, bc2sqrt, lr, grad_scale, 0, 0, 0] on the device; created from the host's group values."""
         ent = self._dev.get(gi)
         if ent is None or ent[0].device != device:
-            hyper = (float(group["lr"]), float(group.get("grad_scale", 1.0)))
-            scale, tracker = 0.0, 0.0
-            if self._scaler is not None:
-                scale = float(group.get("loss_scale", self._scaler["init_scale"]))
-                tracker = float(group.get("growth_tracker", 0))
-                hyper = (hyper[0], 1.0 / scale)
-            ds = torch.tensor([float(group.get("step", 0)), 0.0, 0.0, hyper[0], hyper[1], 0.0, scale, tracker], dtype=torch.float32, device=device)
-            ent = [ds, hyper]
+            host, hyper = self._host_state(group)
+            ent = [torch.tensor(host, dtype=torch.float32, device=device), hyper]
             self._dev[gi] = ent
         return ent
+
+    def _host_state(self, group):
+        """The 8 floats of a group's device state from the host's group values, and the (lr, grad_scale) pair they carry."""
+        hyper = (float(group["lr"]), float(group.get("grad_scale", 1.0)))
+        scale, tracker = 0.0, 0.0
+        if self._scaler is not None:
+            scale = float(group.get("loss_scale", self._scaler["init_scale"]))
+            tracker = float(group.get("growth_tracker", 0))
+            hyper = (hyper[0], 1.0 / scale)
+        return [float(group.get("step", 0)), 0.0, 0.0, hyper[0], hyper[1], 0.0, scale, tracker], hyper
 
     # ------------------------------------------------------------------ loss scaling (fp16)
     def loss_scale(self):
@@ -128,14 +132,40 @@ class _FusedBase(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        """torch's load, then (1) the group step counter from wherever the checkpoint keeps it, (2) IN PLACE: moment / momentum tensors
+        and device state that already exist keep their storage and receive the loaded values, so kernels captured in a hipGraph
+        (GraphedTrainStep), which hold raw pointers to them, go on working on the restored state."""
+        old_state = {p: dict(st) for p, st in self.state.items()}
+        old_dev = dict(self._dev)
         super().load_state_dict(state_dict)
         for group in self.param_groups:
             if "step" not in group or group["step"] is None:
                 # torch.optim.Adam / SGD checkpoints keep `step` per parameter (or not at all)
                 steps = [float(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
                 group["step"] = int(max(steps)) if steps else 0
+                if not steps and any(torch.is_tensor(self.state.get(p, {}).get("momentum_buffer")) for p in group["params"]):
+                    # torch.optim.SGD keeps no step at all: restored momentum buffers mean "not the first step" (the first step
+                    # INITIALISES the buffer with the gradient, train_human.py:136,157,231 resume SGD runs from such checkpoints)
+                    group["step"] = 1
             group.setdefault("grad_scale", 1.0)
-        self._tables, self._dev = {}, {}          # rebuilt (from group['step'], on the parameters' device) at the next step()
+        for p, st in self.state.items():
+            o = old_state.get(p)
+            if not o:
+                continue
+            for n in self._state_names:
+                a, b = o.get(n), st.get(n)
+                if torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.device == p.device and a.stride() == p.stride():
+                    a.copy_(b)
+                    st[n] = a
+        self._dev = {}
+        for gi, group in enumerate(self.param_groups):
+            ent = old_dev.get(gi)
+            if ent is not None:
+                host, hyper = self._host_state(group)
+                ent[0].copy_(torch.tensor(host, dtype=torch.float32))
+                ent[1] = hyper
+                self._dev[gi] = ent
+        # (job tables are keyed by the tensors' pointers: they stay valid where the storage was kept, and are rebuilt otherwise)
 
 
 class FusedAdam(_FusedBase):
