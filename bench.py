@@ -334,6 +334,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # The synchronous-loop rate (untimed extra, after the timed region): one torch.cuda.synchronize() per step, as a loop that reads
+    # the loss / PCK of every iteration on the host forces (train_human.py:443 moves y_s to the CPU each iteration)
+    sync_ms = []
+    for i in range(min(args.steps, 40)):
+        t_a = time.perf_counter()
+        out = step()
+        torch.cuda.synchronize()
+        sync_ms.append((time.perf_counter() - t_a) * 1e3)
+    sync_ms.sort()
+    ms_synced = sync_ms[len(sync_ms) // 2] if sync_ms else None
     # Roofline sample, UNTIMED, after the timed region: one eager step on ONE stream with HIP events recorded on the launch
     # stream around every convolution launch (events cannot be placed inside a replayed graph; single-stream so that the
     # per-launch durations are comparable with rocprofv3's, which serialises).  A dry run first creates the profiler's event
@@ -373,6 +383,7 @@ def main():
         res = {
             "metric": f"images/sec (student+teacher step) {S}x{S} b={N}", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "ms_per_step_synced": round(ms_synced, 3) if ms_synced is not None else None,
             "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "fp16 (student) + f16x2 fp32-grade (teacher, style)" if args.precision == "reference" else args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "

@@ -323,6 +323,12 @@ int udapose_adain_alpha_dev(void* stream, const void* content, const void* style
  * theta [N][nstage][6] = the inverse affine matrices in application order; backward != 0: src = d(out), dst = d(in). */
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage,
                            int backward);
+/* the loop's matrices on the device, in double precision, from the collated aug_param of lib/transforms/keypoint_detection.py:139:
+ * params[n] = (angle, tx, ty, shear_x, shear_y, scale), angles in degrees (6 doubles per sample).  theta_fwd [N][3][6] (may be NULL):
+ * translate by (tx, ty) / ratio | rotate by angle and scale | shear - the three warps of train_human.py:366-368,421-423;
+ * theta_back [N][1][6] (may be NULL): the occlusion path's warp back (train_human.py:412).  A captured step computes its matrices
+ * with this launch from a static parameter buffer: the host only copies 48 bytes per sample. */
+int udapose_recon_thetas(void* stream, const double* params, int N, double ratio, float* theta_fwd, float* theta_back);
 
 /* occlusion paste (train_human.py:399-409): for image i of img[n][C][H][W] (fp32) and boxes[i] = (r0,r1,c0,c1,rs,cs):
  * img[i][:, r0:r1, c0:c1] = img[i][:, rs:rs+(r1-r0), cs:cs+(c1-c0)] (source read completely before the write). */

@@ -125,6 +125,7 @@ _SIGS = {
     "udapose_prof_begin": (None, []),
     "udapose_prof_end": (ci, [vp]),
     "udapose_affine_nearest": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci]),
+    "udapose_recon_thetas": (ci, [vp, vp, ci, cd, vp, vp]),
 }
 EXPORTS = tuple(_SIGS.keys())
 

@@ -131,6 +131,41 @@ int patch_paste(hipStream_t s, float* img, const int* boxes, int n, int C, int H
     return udapose_check_launch();
 }
 
+// The loop's inverse affine matrices on the device, in double precision (torchvision's _get_inverse_affine_matrix with centre (0,0),
+// as warp.inverse_affine_matrix states it): params[n] = (angle, tx, ty, shear_x, shear_y, scale) of the collated aug_param
+// (lib/transforms/keypoint_detection.py:139), angles in degrees.
+//   fwd[n][3][6]: translate by (tx, ty) / ratio | rotate by angle and scale | shear      (train_human.py:366-368, 421-423)
+//   back[n][1][6]: the occlusion path's single warp back (-angle, (-tx, -ty) / ratio, 1 / scale, -shear)   (train_human.py:412)
+__device__ __forceinline__ void inv_affine(double angle, double tx, double ty, double scale, double shx, double shy, float* m) {
+    const double d2r = 0.017453292519943295;
+    const double rot = angle * d2r, sx = shx * d2r, sy = shy * d2r;
+    const double a = cos(rot - sy) / cos(sy);
+    const double b = -cos(rot - sy) * tan(sx) / cos(sy) - sin(rot);
+    const double c = sin(rot - sy) / cos(sy);
+    const double d = -sin(rot - sy) * tan(sx) / cos(sy) + cos(rot);
+    const double m0 = d / scale, m1 = -b / scale, m3 = -c / scale, m4 = a / scale;
+    m[0] = (float)m0; m[1] = (float)m1; m[2] = (float)(m0 * (-tx) + m1 * (-ty));
+    m[3] = (float)m3; m[4] = (float)m4; m[5] = (float)(m3 * (-tx) + m4 * (-ty));
+}
+__global__ void recon_thetas_k(const double* __restrict__ params, int N, double ratio, float* __restrict__ fwd, float* __restrict__ back) {
+    const int n = blockIdx.x * TPB + threadIdx.x;
+    if (n >= N) return;
+    const double* q = params + (size_t)n * 6;
+    const double angle = q[0], tx = q[1], ty = q[2], shx = q[3], shy = q[4], scale = q[5];
+    if (fwd) {
+        float* f = fwd + (size_t)n * 18;
+        inv_affine(0.0, tx / ratio, ty / ratio, 1.0, 0.0, 0.0, f);
+        inv_affine(angle, 0.0, 0.0, scale, 0.0, 0.0, f + 6);
+        inv_affine(0.0, 0.0, 0.0, 1.0, shx, shy, f + 12);
+    }
+    if (back) inv_affine(-angle, -tx / ratio, -ty / ratio, 1.0 / scale, -shx, -shy, back + (size_t)n * 6);
+}
+int affine_recon_thetas(hipStream_t s, const double* params, int N, double ratio, float* fwd, float* back) {
+    if (N <= 0 || ratio == 0.0) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(recon_thetas_k, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, params, N, ratio, fwd, back);
+    return udapose_check_launch();
+}
+
 int affine_warp_chain(hipStream_t s, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage, int backward) {
     if (nstage < 1 || nstage > 8) return UDAPOSE_ERR_ARG;
     const size_t total = (size_t)N * H * W;

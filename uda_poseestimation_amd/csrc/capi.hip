@@ -49,6 +49,7 @@ int aug_color_op(hipStream_t, unsigned char*, const int*, const float*, int*, in
 int aug_to_tensor(hipStream_t, const unsigned char*, float*, int, int, const float*, const float*);
 int aug_gaussian_labels(hipStream_t, const double*, const float*, float*, float*, int, int, int, double, double, const float*, int);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
+int affine_recon_thetas(hipStream_t, const double*, int, double, float*, float*);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
 int occlusion_pick(hipStream_t, const float*, const int*, const float*, int, int, int, double, int, float, float, int, int*, unsigned char*);
 int select_rows(hipStream_t, float*, const float*, const float*, const unsigned char*, int, size_t);
@@ -377,6 +378,10 @@ int udapose_occlusion_pick(void* stream, const float* conf, const int* flat_idx,
 int udapose_select_rows(void* stream, float* dst, const float* a, const float* b, const unsigned char* flag, int N, size_t row_elems) {
     if (!dst || !a || !b || !flag) return UDAPOSE_ERR_ARG;
     return select_rows(S(stream), dst, a, b, flag, N, row_elems);
+}
+int udapose_recon_thetas(void* stream, const double* params, int N, double ratio, float* theta_fwd, float* theta_back) {
+    if (!params || (!theta_fwd && !theta_back)) return UDAPOSE_ERR_ARG;
+    return affine_recon_thetas(S(stream), params, N, ratio, theta_fwd, theta_back);
 }
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage, int backward) {
     return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);

@@ -207,6 +207,7 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -449,7 +450,6 @@ template <int N, typename F> __device__ __forceinline__ void w_static_for(F&& f)
 template <int RT, int CT, int WR, int WC, int NS, int PX>
 __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
                                                  const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
-    static_assert(RT == CT, "P and Q share their row mapping");
     struct {
         const elem_t* dy; const elem_t* x; float* dw; const IgTap* taps;
         int Hi, Wi, Ci, Co, M, wtaps, flags, ksplit, c_tiles, rows_valid;
@@ -458,9 +458,9 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
            gp.flags, gp.ksplit, gp.c_tiles, gp.rows_valid};
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
-    static_assert(P_PW == Q_PW, "RT == CT");
     constexpr int LPS = P_PW + Q_PW;
-    constexpr int P_RPI = 1024 / C::PROW, P_CPR = C::PROW / 16;
+    // (rows per 1 KiB DMA piece and 16-byte chunks per row, for the dy side P and the x side Q: RT != CT in the 128x256 / 256x128 tiles)
+    constexpr int P_RPI = 1024 / C::PROW, P_CPR = C::PROW / 16, Q_RPI = 1024 / C::QROW, Q_CPR = C::QROW / 16;
     constexpr int OOB = 0x7fffffff;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WC, wc = wid % WC;
@@ -485,14 +485,18 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
     // that would be read from outside the tensor is a tap outside the image and gets the out-of-range offset instead)
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Co * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (long long)toff * p.Ci * 2), 0, p.M * p.Ci * 2, 0x00020000);
-    const int lrow = lane / P_CPR, pch = lane % P_CPR;
-    int vd[P_PW], vx[P_PW], rowl[P_PW];
+    int vd[P_PW], vx[Q_PW], rowl[Q_PW];
 #pragma unroll
     for (int i = 0; i < P_PW; ++i) {
-        const int row = (i * 4 + wid) * P_RPI + lrow;
-        const int lc = pch ^ wswz<RT>(row);
-        rowl[i] = row;
+        const int row = (i * 4 + wid) * P_RPI + lane / P_CPR;
+        const int lc = (lane % P_CPR) ^ wswz<RT>(row);
         vd[i] = (r0 + lc * 8 < p.Co) ? (row * p.Co + r0 + lc * 8) * 2 : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < Q_PW; ++i) {
+        const int row = (i * 4 + wid) * Q_RPI + lane / Q_CPR;
+        const int lc = (lane % Q_CPR) ^ wswz<CT>(row);
+        rowl[i] = row;
         vx[i] = (c0 + lc * 8 < p.Ci) ? (row * p.Ci + c0 + lc * 8) * 2 : OOB;
     }
     const int sd_step = PX * p.Co * 2, sx_step = PX * p.Ci * 2;
@@ -504,16 +508,19 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
         char* P = smem + UB * C::STAGE1;
         char* Q = P + C::P_BYTES;
 #pragma unroll
-        for (int i = 0; i < P_PW; ++i) {
-            int ox = vx[i];
-            if (!center) {
-                const unsigned rem = (unsigned)(mb + rowl[i]) & hw_mask;
-                const int ii = (int)(rem >> lgw), jj = (int)(rem & w_mask);
-                const bool ok = (unsigned)(ii + tp.dy) < (unsigned)p.Hi && (unsigned)(jj + tp.dx) < (unsigned)p.Wi;
-                ox = ok ? ox : OOB;
+        for (int i = 0; i < (P_PW > Q_PW ? P_PW : Q_PW); ++i) {
+            if (i < P_PW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, vd[i < P_PW ? i : 0], sd, 0, 0);
+            if (i < Q_PW) {
+                int ox = vx[i < Q_PW ? i : 0];
+                if (!center) {
+                    const unsigned rem = (unsigned)(mb + rowl[i < Q_PW ? i : 0]) & hw_mask;
+                    const int ii = (int)(rem >> lgw), jj = (int)(rem & w_mask);
+                    const bool ok = (unsigned)(ii + tp.dy) < (unsigned)p.Hi && (unsigned)(jj + tp.dx) < (unsigned)p.Wi;
+                    ox = ok ? ox : OOB;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Q + (i * 4 + wid) * 1024), 16, ox, sx, 0, 0);
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, vd[i], sd, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Q + (i * 4 + wid) * 1024), 16, ox, sx, 0, 0);
         }
     };
 
@@ -796,6 +803,33 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
     else wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem);
 }
 
+// 128x256 / 256x128 tiles (64x128 / 128x64 per wave: 25 % fewer LDS bytes, filled and read, per FLOP than 64x64 per wave), fast
+// geometry only, 32-pixel stages (24 KB per stage); 2 work-groups per CU (192 accumulator + operand registers).
+template <int RT, int CT, int WR, int WC, int NS, int PX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_big_kernel(const WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t gxy = gridDim.x * gridDim.y;
+    const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
+    const uint32_t bz = lin / gxy, bxy = lin - bz * gxy;
+    const uint32_t by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
+    wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem);
+}
+template <int RT, int CT, int WR, int WC, int NS, int PX>
+int launch_wbig(WgParams& p, hipStream_t stream) {
+    using C = WdCfg<RT, CT, WR, WC, NS, PX>;
+    if (!(p.flags & WG_FLAG_FAST2) || p.M % PX) return UDAPOSE_ERR_UNSUPPORTED;
+    p.r_tiles = (p.Co + RT - 1) / RT;
+    p.c_tiles = (p.Ci + CT - 1) / CT;
+    static std::atomic<unsigned long long> attr_done{0};
+    static std::mutex attr_mu;
+    once_per_device(attr_done, attr_mu, [] {
+        (void)hipFuncSetAttribute((const void*)wgrad_big_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    dim3 grid(p.r_tiles * p.c_tiles, p.total_taps, p.ksplit);
+    hipLaunchKernelGGL((wgrad_big_kernel<RT, CT, WR, WC, NS, PX>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    return udapose_check_launch();
+}
+
 // Grouped form: ONE launch computes the weight gradients of many layers.  blk is an [8][per_xcd] table (work-group b runs
 // on XCD b & 7, the hardware's round-robin, and takes entry [b & 7][b >> 3]); an entry names a problem of `tab` and the
 // work-group's linear index inside that problem's (tile, tap, split) grid, or prob < 0 = padding.  The host deals whole
@@ -910,7 +944,8 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
-    static const int RT[4] = {128, 64, 64, 32}, CT[4] = {128, 64, 32, 128};
+    static const int RT[6] = {128, 64, 64, 32, 128, 256}, CT[6] = {128, 64, 32, 128, 256, 128};
+    if (tile < 0 || tile > 5) return UDAPOSE_ERR_ARG;
     // measured (tools/tune_conv.py, LDS-DMA kernels): 128x128 tiles for multi-tap convs with >= 128 channels on both sides
     // (3x3 trunk convs, 4x4 deconvs), 64x64 otherwise
     if (tile == 1 && pol.wgrad_tile < 0 && Rdim >= 128 && Cdim >= 128 && p.total_taps >= 9) tile = 0;
@@ -921,6 +956,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     }
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
+    const bool big = tile == 4 || tile == 5;                  // (tuning ids: 128x256 / 256x128 tiles, fast geometry, 32-pixel stages)
     const bool dma = !smallc && (tile == 0 || tile == 1) && (p.Ci % 64 == 0) && (p.Co % 64 == 0);
     const int ms_total = dma ? (p.M + 63) / 64 : (p.M + 31) / 32;
     // split the pixel reduction until ~512 work-groups exist (2 per CU), keeping >= 16 (128x128) / 4 (64x64) stages per
@@ -938,6 +974,10 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     }
     if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
     if ((p.flags & WG_FLAG_FASTGEO) && !(p.flags & WG_FLAG_ROW3) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0) p.flags |= WG_FLAG_FAST2; else p.flags &= ~WG_FLAG_FAST2;
+    if (big) {
+        if (smallc || swap || p.Ci % 64 || p.Co % 64) return UDAPOSE_ERR_UNSUPPORTED;
+        return tile == 4 ? launch_wbig<128, 256, 2, 2, 3, 32>(p, stream) : launch_wbig<256, 128, 2, 2, 3, 32>(p, stream);
+    }
     if (dma) return tile == 0 ? launch_wd<128, 128, 2, 2, 2>(p, stream) : launch_wd<64, 64, 2, 2, 4>(p, stream);
     switch (tile) {
         case 0: return launch_wg<128, 128, 2, 2>(p, stream);

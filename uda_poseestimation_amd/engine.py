@@ -438,11 +438,19 @@ class GraphedTrainStep:
         dev = x_s.device
         n = x_s.shape[0]
         self.n = n
+        # The re-warp matrices are computed INSIDE the captured step (udapose_recon_thetas, double precision) from the batch's raw
+        # aug_param values: per step the host packs 2 x N x 6 doubles into a pinned buffer and issues one asynchronous copy.
         self.static = {"x_s": x_s.clone(), "label_s": label_s.clone(), "weight_s": weight_s.clone(), "x_t_stu": x_t_stu.clone(),
                        "x_t_tea": x_t_tea.clone(),
-                       "theta_stu": warp.recon_thetas(aug_param_stu, n, trainer.ratio, dev),
-                       "theta_tea": warp.recon_thetas(aug_param_tea, n, trainer.ratio, dev)}
+                       "aug": torch.empty(2, n, 6, dtype=torch.float64, device=dev),
+                       "theta_stu": torch.empty(n, 3, 6, dtype=torch.float32, device=dev),
+                       "theta_tea": torch.empty(n, 3, 6, dtype=torch.float32, device=dev)}
         st = self.static
+        self._aug_pin = [torch.empty(2, n, 6, dtype=torch.float64).pin_memory() for _ in range(4)]
+        self._aug_ev = [None] * 4
+        self._aug_i = 0
+        self._aug_last = None
+        self._stage_aug(aug_param_stu, aug_param_tea)
         # the main graph reads the step's EFFECTIVE inputs: the originals, or what the style graphs wrote
         st["x_s_in"] = st["x_s"].clone() if self.styled else st["x_s"]
         st["x_t_tea_in"] = st["x_t_tea"].clone() if self.styled else st["x_t_tea"]
@@ -450,7 +458,7 @@ class GraphedTrainStep:
             st["alpha_s2t"] = torch.ones(1, dtype=torch.float32, device=dev)
             st["alpha_t2s"] = torch.ones(1, dtype=torch.float32, device=dev)
         if self.occl:
-            st["theta_back"] = warp.occlusion_back_thetas(aug_param_stu, n, trainer.ratio, dev)
+            st["theta_back"] = torch.empty(n, 1, 6, dtype=torch.float32, device=dev)
             st["u"] = torch.zeros(n, 4, dtype=torch.float32, device=dev)
             trainer._occl = ("device", st["theta_back"], st["u"])
         else:
@@ -464,6 +472,7 @@ class GraphedTrainStep:
                 self._style_pass("s2t")
                 self._style_pass("t2s")
             for _ in range(warmup):     # REAL steps (same host draws as step()): fill the plan / table caches, allocator steady state
+                self._thetas()
                 self._draw_and_style()
                 trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]], st["theta_stu"],
                                           [st["theta_tea"]])
@@ -499,6 +508,7 @@ class GraphedTrainStep:
         self.one_graph = (not self.split) and (not _dist_on()) and trainer.single_graph
         if not self.split:
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
+                self._thetas()
                 self.out = trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
                                                      st["theta_stu"], [st["theta_tea"]])
                 if trainer.student._pending_lower:      # (overlap forced on one rank: both backward parts in the one graph)
@@ -509,6 +519,7 @@ class GraphedTrainStep:
         else:
             self.g_lb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
+                self._thetas()
                 self.fwd_state = trainer._forward_part(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
                                                        st["theta_stu"], [st["theta_tea"]])
             g0 = gather_activates(self.fwd_state["activates"])
@@ -539,6 +550,32 @@ class GraphedTrainStep:
             for m, hd, bwd in self._maintained:
                 m.packs_refreshed(hd, bwd)
         torch.cuda.synchronize()
+
+    def _stage_aug(self, aug_param_stu=None, aug_param_tea=None):
+        """The batch's raw aug_param values -> the static [2,N,6] float64 device buffer the captured udapose_recon_thetas launches
+        read (a ring of pinned host buffers and one asynchronous copy: nothing here waits for the device)."""
+        if aug_param_stu is None and aug_param_tea is None:
+            return
+        i = self._aug_i = (self._aug_i + 1) % len(self._aug_pin)
+        if self._aug_ev[i] is not None:
+            self._aug_ev[i].synchronize()             # (the copy issued from this slot four steps ago: long done)
+        pin = self._aug_pin[i]
+        if self._aug_last is not None:
+            pin.copy_(self._aug_last)                 # a side that is not given keeps its previous values
+        if aug_param_stu is not None:
+            warp.pack_aug_param(aug_param_stu, self.n, out=pin[0])
+        if aug_param_tea is not None:
+            warp.pack_aug_param(aug_param_tea, self.n, out=pin[1])
+        self.static["aug"].copy_(pin, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._aug_ev[i], self._aug_last = ev, pin
+
+    def _thetas(self):
+        """Launch the matrix kernels (captured: at the head of the step's first graph) from the static aug buffer."""
+        st, r = self.static, self.t.ratio
+        warp.thetas_from_packed(st["aug"][0], r, want_fwd=True, want_back=self.occl, fwd=st["theta_stu"], back=st.get("theta_back"))
+        warp.thetas_from_packed(st["aug"][1], r, fwd=st["theta_tea"])
 
     def _style_pass(self, which):
         """One direction of the style transfer, from the ORIGINAL images into the main graph's input buffer."""
@@ -619,14 +656,10 @@ class GraphedTrainStep:
         for k, v in (("x_s", x_s), ("label_s", label_s), ("weight_s", weight_s), ("x_t_stu", x_t_stu), ("x_t_tea", x_t_tea)):
             if v is not None and v.data_ptr() != st[k].data_ptr():
                 st[k].copy_(v, non_blocking=True)
-        if aug_param_stu is not None:
-            st["theta_stu"].copy_(warp.recon_thetas(aug_param_stu, self.n, self.t.ratio), non_blocking=True)
-            if self.occl:
-                st["theta_back"].copy_(warp.occlusion_back_thetas(aug_param_stu, self.n, self.t.ratio), non_blocking=True)
-        if aug_param_tea is not None:
-            st["theta_tea"].copy_(warp.recon_thetas(aug_param_tea, self.n, self.t.ratio), non_blocking=True)
-        if self._frozen_hyper() != self._frozen:
-            changed = [a[0] for a, b in zip(self._frozen_hyper(), self._frozen) if a != b]
+        self._stage_aug(aug_param_stu, aug_param_tea)
+        frozen_now = self._frozen_hyper()
+        if frozen_now != self._frozen:
+            changed = [a[0] for a, b in zip(frozen_now, self._frozen) if a != b]
             raise RuntimeError(f"GraphedTrainStep: {changed} changed after capture; these are baked into the captured launches - "
                                "build a new GraphedTrainStep (lr and grad_scale may change freely)")
         if self._optimizer_key() != self._opt_key:

@@ -52,9 +52,38 @@ def _inv_mats(angle, tx, ty, scale, sx, sy):
     return np.stack([m0, m1, m2, m3, m4, m5], -1)
 
 
-def recon_thetas(aug_param, n, ratio=1.0, device=None):
-    """[N,3,6] fp32 matrices of the loop's translate -> rotate+scale -> shear chain for a collated aug_param."""
+def pack_aug_param(aug_param, n, out=None):
+    """The collated aug_param structure -> one [N,6] float64 host tensor (angle, tx, ty, shear_x, shear_y, scale): what
+    udapose_recon_thetas reads.  `out`: a (pinned) host tensor to fill instead of a new one."""
     import numpy as np
+    angle, (tx, ty), (sx, sy), scale = aug_param
+    cols = [np.asarray(_as_list(v, n), np.float64) for v in (angle, tx, ty, sx, sy, scale)]
+    t = out if out is not None else torch.empty(n, 6, dtype=torch.float64)
+    t.numpy()[...] = np.stack(cols, 1)
+    return t
+
+
+def thetas_from_packed(params_dev, ratio, want_fwd=True, want_back=False, fwd=None, back=None):
+    """Device-side matrices (udapose_recon_thetas) from a packed [N,6] float64 DEVICE tensor: (theta_fwd [N,3,6] | None,
+    theta_back [N,1,6] | None); `fwd` / `back` name existing output tensors (a captured step writes its static ones)."""
+    _hip.require_cuda(params_dev)
+    assert params_dev.dtype == torch.float64 and params_dev.is_contiguous() and params_dev.shape[1] == 6
+    n = params_dev.shape[0]
+    if want_fwd and fwd is None:
+        fwd = torch.empty(n, 3, 6, dtype=torch.float32, device=params_dev.device)
+    if want_back and back is None:
+        back = torch.empty(n, 1, 6, dtype=torch.float32, device=params_dev.device)
+    check(lib().udapose_recon_thetas(_hip.stream(), ptr(params_dev), n, float(ratio), ptr(fwd) if want_fwd else None,
+                                     ptr(back) if want_back else None), "recon_thetas")
+    return (fwd if want_fwd else None), (back if want_back else None)
+
+
+def recon_thetas(aug_param, n, ratio=1.0, device=None):
+    """[N,3,6] fp32 matrices of the loop's translate -> rotate+scale -> shear chain for a collated aug_param.  With a CUDA
+    `device` the matrices are computed there (double precision, udapose_recon_thetas); without, on the host."""
+    import numpy as np
+    if device is not None and torch.device(device).type == "cuda":
+        return thetas_from_packed(pack_aug_param(aug_param, n).to(device), ratio)[0]
     angle, (tx, ty), (sx, sy), scale = aug_param
     angle, tx, ty, sx, sy, scale = (np.asarray(_as_list(v, n), np.float64) for v in (angle, tx, ty, sx, sy, scale))
     z, o = np.zeros(n), np.ones(n)
@@ -178,6 +207,8 @@ def occlude_keypoints(x_t_stu, y_t_tea_recon, aug_param_stu, ratio, image_size, 
 
 def occlusion_back_thetas(aug_param_stu, n, ratio, device=None):
     """[N,1,6]: the warp back of the occlusion path (train_human.py:412): -angle, (-tx/ratio, -ty/ratio), 1/scale, (-shear)."""
+    if device is not None and torch.device(device).type == "cuda":
+        return thetas_from_packed(pack_aug_param(aug_param_stu, n).to(device), ratio, want_fwd=False, want_back=True)[1]
     angle, (tx, ty), (sx, sy), scale = aug_param_stu
     a_, tx_, ty_, sx_, sy_, sc_ = (_as_list(v, n) for v in (angle, tx, ty, sx, sy, scale))
     return single_thetas([-v for v in a_], ([-v / ratio for v in tx_], [-v / ratio for v in ty_]), [1.0 / v for v in sc_],
