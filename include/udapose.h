@@ -178,6 +178,8 @@ typedef void* udapose_net_t;
  * train_human.py:347-358,461-500); fp32 == 2: the fast fp32-grade form of the same (f16x2 split activations and weight packs,
  * UDAPOSE_EPI_SPLIT; pre-BatchNorm conv outputs and statistics in fp32), FORWARD ONLY; fp32 == 0: the library's 16-bit
  * element type with fp32 accumulation, forward and backward. */
+/* bit 8 of `fp32` (value | 0x100): the three deconvolutions carry a bias parameter (`deconv_with_bias=True`, lib/models/pose_resnet.py:
+ * 15,41,96) - parameter order weight, bias, then the BatchNorm's, as in the reference's Upsampling. */
 int udapose_net_create(const int layers[4], int num_keypoints, int N, int H, int W, int fp32, udapose_net_t* out);
 void udapose_net_destroy(udapose_net_t net);
 int udapose_net_num_params(udapose_net_t net);

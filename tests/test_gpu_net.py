@@ -424,3 +424,58 @@ def test_relu_bit_mask_of_block_outputs_is_bit_identical_to_reading_z(precision)
     assert torch.equal(res[0][0], res[1][0])
     assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
     assert all(torch.isfinite(g_).all() for g_ in res[1][1]) and float(res[1][1][0].abs().sum()) > 0
+
+
+def test_deconv_with_bias_matches_oracle():
+    """`deconv_with_bias=True` (lib/models/pose_resnet.py:15,41,96 of the reference; never set by its scripts): the three
+    ConvTranspose2d carry a bias in front of their BatchNorm.  Forward in training and eval mode (running statistics carry the
+    bias) against the fp32 oracle in the fp32-grade mode (1e-4) and in bf16; backward: the bias gradient under a training-mode
+    BatchNorm is identically zero (autograd: rounding noise), every other gradient as without the bias."""
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    from oracle.pose_resnet_ref import PoseResNetRef
+    torch.manual_seed(2)
+    ref = PoseResNetRef([1, 1, 1, 1], 16, deconv_with_bias=True)
+    with torch.no_grad():
+        for m in ref.upsampling:
+            if isinstance(m, torch.nn.ConvTranspose2d):
+                m.bias.normal_(0.0, 0.5)
+                m.weight.mul_(30.0)                  # (the reference's std = 0.001 init would make the biases dominate)
+    net = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 1, 1], False, True)
+    assert [k for k in net.state_dict() if k.endswith(".bias") and k.startswith("upsampling.")][:2] == ["upsampling.0.bias", "upsampling.1.bias"]
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda()
+    x = torch.randn(4, 3, 128, 128, generator=torch.Generator().manual_seed(3))
+    ref.train(); net.train()
+    net.precision = "f16x2"
+    with torch.no_grad():
+        y_ref = ref(x)
+        y = net(x.cuda())
+    e = (y.cpu() - y_ref).abs().max().item()
+    print(f"deconv_with_bias f16x2 train: max|y| {y_ref.abs().max().item():.3f} err {e:.2e}")
+    assert e < 1e-4 * max(1.0, y_ref.abs().max().item())
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-3, atol=1e-4)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        e_eval = (net(x.cuda()).cpu() - ref(x)).abs().max().item()
+    assert e_eval < 1e-4 * max(1.0, y_ref.abs().max().item()), e_eval
+    # bf16, forward + backward
+    ref.train(); net.train()
+    net.precision = "bf16"
+    tgt = torch.rand(y_ref.shape, generator=torch.Generator().manual_seed(4))
+    ref.zero_grad()
+    yr = ref(x)
+    (0.5 * (yr - tgt) ** 2).mean().backward()
+    yd = net(x.cuda())
+    (0.5 * (yd - tgt.cuda()) ** 2).mean().backward()
+    assert (yd.detach().cpu() - yr.detach()).abs().max().item() < 5e-2 * yr.abs().max().item()
+    for (name, p_r), (_, p_n) in zip(ref.named_parameters(), net.named_parameters()):
+        if name.startswith("backbone.fc"):
+            continue
+        if name in ("upsampling.0.bias", "upsampling.3.bias", "upsampling.6.bias"):
+            assert p_n.grad is not None and float(p_n.grad.abs().max()) == 0.0
+            assert float(p_r.grad.abs().max()) < 1e-6 * max(float(g.grad.abs().max()) for g in ref.upsampling.parameters())
+        elif name.startswith("upsampling") or name.startswith("head"):
+            cos = torch.nn.functional.cosine_similarity(p_n.grad.cpu().flatten(), p_r.grad.flatten(), dim=0).item()
+            assert cos > 0.9, (name, cos)          # (bf16 gradients of a random-init train-mode-BN network: 0.92-1.0, as without the bias)

@@ -8,7 +8,7 @@ int pw_cast_f32_bf16(hipStream_t, const float*, elem_t*, size_t);
 int pw_transpose_cast(hipStream_t, const float*, elem_t*, int, int, int);
 int pw_pack_strided(hipStream_t, const float*, elem_t*, int, int, int, int, int, int, long, long, long, long);
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
-                   float*, float*);
+                   float*, float*, const float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
 int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int, unsigned char*);
 int pw_bn_bwd_rows(size_t);
@@ -57,7 +57,7 @@ int net_apply_running(void*, hipStream_t, const void*, void* const*, float);
 int pw_axpy(hipStream_t, float*, const float*, size_t);
 void prof_begin();
 int prof_end(double*);
-void* net_create(const int layers[4], int K, int N, int H, int W, int f32);
+void* net_create(const int layers[4], int K, int N, int H, int W, int mode);
 void net_destroy(void*);
 void net_set_policy(void*, const Policy&);
 const Policy& net_get_policy(void*);
@@ -160,7 +160,7 @@ int udapose_nhwc_to_nchw_f32(void* stream, const void* src, int src_is_f32, floa
 }
 int udapose_bn_finalize(void* stream, const float* stats, int rows, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
                         long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
-    return pw_bn_finalize(S(stream), stats, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift, save_mean, save_invstd);
+    return pw_bn_finalize(S(stream), stats, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift, save_mean, save_invstd, nullptr);
 }
 int udapose_bn_eval_coeff(void* stream, int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
                           float* shift) {

@@ -21,7 +21,7 @@ int pw_transpose_cast(hipStream_t, const float*, elem_t*, int, int, int);
 int pw_pack_strided(hipStream_t, const float*, elem_t*, int, int, int, int, int, int, long, long, long, long);
 int pw_unpack_strided(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long, float);
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
-                   float*, float*);
+                   float*, float*, const float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
 int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int, unsigned char*);
 int pw_bn_bwd_rows(size_t);
@@ -102,6 +102,7 @@ struct Net {
     int f32 = 0;            // 1: fp32 storage + exact fp32 MFMA (forward only: the reference's teacher / validate() precision)
                             // 2: f16x2 split storage (common.h), three fp16 MFMAs per K step: the FAST fp32-grade mode (forward only);
                             //    conv inputs (z, pooled map, image) and weight packs are split tensors, pre-BN conv outputs y are fp32
+    int deconv_bias = 0;    // Upsampling(bias=True) (pose_resnet.py:15,41,96 `deconv_with_bias`): every ConvTranspose2d has a bias parameter
     size_t es = 2;          // bytes per activation element
     int n_params = 0, n_buffers = 0;
     std::vector<long long> param_numel;
@@ -169,9 +170,11 @@ void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true) {
     if (alloc_z) b.z_off = act_alloc(n, npix * C * n.es);
 }
 
-Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
+Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
     Net* np = new Net();
     Net& n = *np;
+    const int f32 = mode & 0xff;          // (mode: low byte = precision 0 / 1 / 2, bit 8 = the deconvolutions carry a bias)
+    n.deconv_bias = (mode >> 8) & 1;
     n.f32 = f32 == 2 ? 2 : (f32 ? 1 : 0);
     n.es = f32 ? 4 : 2;
     for (int i = 0; i < 4; ++i) n.layers[i] = layers[i];
@@ -215,6 +218,7 @@ Net* build(const int layers[4], int K, int N, int H, int W, int f32) {
     n.fc_b_idx = n.n_params++; n.param_numel.push_back(1000);
     for (int i = 0; i < 3; ++i) {
         add_conv(n, n.up[i], Hc, Wc, Cc, 256, 4, 2, 1, 1, cur, true);
+        if (n.deconv_bias) { n.up[i].bias_idx = n.n_params++; n.param_numel.push_back(256); }      // (.parameters() order: weight, bias, then the BN)
         Hc = n.up[i].g.Ho(); Wc = n.up[i].g.Wo(); Cc = 256;
         add_bn(n, n.up_bn[i], 256, (size_t)N * Hc * Wc);
         cur = n.up_bn[i].z_off;
@@ -316,13 +320,17 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     e.f32 = n.f32 != 0;
     e.split = n.f32 == 2;
     e.out_f32 = n.f32 == 2;       // (f16x2: the pre-BN output stays fp32; the BN apply writes the split z)
+    // a bias in front of the BatchNorm (deconv_with_bias): added to the stored output; the statistics epilogue sees the raw
+    // accumulators, so the finalize launch shifts the mean by it
+    const float* pre_bias = c.bias_idx >= 0 ? (const float*)params[c.bias_idx] : nullptr;
+    e.bias = pre_bias;
     // block outputs: the apply also saves the ReLU bit mask of z (1/16 of z's bytes) for the data gradients that mask with it
     unsigned char* mask = (b.mask_off && n.policy.bn3_mask && relu) ? (unsigned char*)(act + b.mask_off) : nullptr;
     const void* wptr = (n.f32 == 1 && !c.g.smallc() && !c.g.transposed) ? params[c.w_idx] : (const void*)(wpack + c.wf_off);
     CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
-    if (training && !n.f32 && !no_apply) {
+    if (training && !n.f32 && !no_apply && !pre_bias) {
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
                                            beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
@@ -333,7 +341,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     if (training)
         CK(pw_bn_finalize(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, upd ? (float*)buffers[b.rm_idx] : nullptr,
                           upd ? (float*)buffers[b.rv_idx] : nullptr, upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, scale, shift,
-                          save, save + b.C));
+                          save, save + b.C, pre_bias));
     else
         CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
     if (no_apply) return UDAPOSE_OK;      // (the caller's next launch applies scale / shift itself: the stem's fused pool)
@@ -347,9 +355,9 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
 }  // namespace
 
 // ============================================================================ public (C++) entry points
-void* net_create(const int layers[4], int K, int N, int H, int W, int f32) {
-    if (K < 1 || K > 64 || N < 1 || H % 32 || W % 32) return nullptr;
-    return build(layers, K, N, H, W, f32);
+void* net_create(const int layers[4], int K, int N, int H, int W, int mode) {
+    if (K < 1 || K > 64 || N < 1 || H % 32 || W % 32 || (mode & 0xff) > 2 || (mode >> 9)) return nullptr;
+    return build(layers, K, N, H, W, mode);
 }
 void net_destroy(void* h) {
     Net* n = (Net*)h;
@@ -556,6 +564,11 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
                      save, save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx],
                      n.policy.bn_bwd_chunked));
     const elem_t* xin = (const elem_t*)(act + c.in_off);
+    if (c.bias_idx >= 0 && beta == 0.f) {
+        // bias in front of a training-mode BatchNorm: its gradient is the pixel sum of dy = gamma * invstd * (g - mean(g) - xhat * mean(g xhat)),
+        // which is zero identically (autograd returns rounding noise around 0 there)
+        if (hipMemsetAsync(grads[c.bias_idx], 0, (size_t)c.g.Co * sizeof(float), s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    }
     if (c.g.smallc() && grouped_wgrad && n.policy.wgrad_group_stem) {
         // (the stem's weight gradient joins the grouped launch in its row-tap form, run_wg_group)
     } else if (c.g.smallc()) {

@@ -239,16 +239,20 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
 __global__ __launch_bounds__(FIN_T) void bn_finalize_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                               long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ scale,
-                              float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                              float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                              const float* __restrict__ pre_bias = nullptr) {
     __shared__ double red[FIN_RL][FIN_C][2];
     const int c = blockIdx.x * FIN_C + (threadIdx.x % FIN_C);
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     double s1, s2;
     slab_colsum(slab, rows, C, c, c < C, s1, s2, red);
     if ((threadIdx.x / FIN_C) != 0 || c >= C) return;
-    const double mean = s1 / count;
+    double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
+    // pre_bias: the producing convolution adds a per-channel bias AFTER its statistics epilogue (the sums are those of the raw
+    // accumulators): the mean of what it stored is shifted by it, the variance is not (Upsampling(bias=True), pose_resnet.py:15,41)
+    if (pre_bias) mean += (double)pre_bias[c];
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
     scale[c] = sc;
@@ -1129,9 +1133,9 @@ int pw_unpack_strided(hipStream_t s, const float* src, float* dst, int A, int KH
     return udapose_check_launch();
 }
 int pw_bn_finalize(hipStream_t s, const float* slab, int rows, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
-                   long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd) {
+                   long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd, const float* pre_bias) {
     hipLaunchKernelGGL(bn_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps, scale, shift,
-                       save_mean, save_invstd);
+                       save_mean, save_invstd, pre_bias);
     return udapose_check_launch();
 }
 // finalize + apply in one launch where the chunked form applies; returns 1 when it took the layer, 0 when the caller must use

@@ -54,12 +54,13 @@ class Upsampling(nn.Sequential):
 class _NetHandle:
     """One executor plan (fixed N,H,W) plus its device work areas."""
 
-    def __init__(self, layers, K, N, H, W, device, precision='bf16', policy=None):
+    def __init__(self, layers, K, N, H, W, device, precision='bf16', policy=None, deconv_bias=False):
         # the library build whose element type is this plan's storage / MFMA type ('fp32' plans live in the bf16 build)
         L = self.L = lib('fp16' if precision == 'fp16' else 'bf16')
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
-        check(L.udapose_net_create(arr, K, N, H, W, {'fp32': 1, 'f16x2': 2}.get(precision, 0), C.byref(h)), "net_create")
+        check(L.udapose_net_create(arr, K, N, H, W, {'fp32': 1, 'f16x2': 2}.get(precision, 0) | (0x100 if deconv_bias else 0), C.byref(h)),
+              "net_create")
         self.h = h
         self.precision = precision
         if policy:
@@ -117,8 +118,10 @@ class PoseResNet(nn.Module):
         for m in self.head.modules():
             nn.init.normal_(m.weight, std=0.001)
             nn.init.constant_(m.bias, 0)
-        if getattr(upsampling, "_cfg", None) != ((256, 256, 256), (4, 4, 4), False) or feature_dim != 256:
-            raise NotImplementedError("the MI355X executor implements the reference configuration: 3 x deconv(256, k=4), no bias")
+        cfg = getattr(upsampling, "_cfg", None)
+        if cfg is None or cfg[:2] != ((256, 256, 256), (4, 4, 4)) or feature_dim != 256:
+            raise NotImplementedError("the MI355X executor implements the reference configuration: 3 x deconv(256, k=4)")
+        self._deconv_bias = bool(cfg[2])          # deconv_with_bias (pose_resnet.py:15,41,96)
         self.num_keypoints = num_keypoints
         self.bn_momentum = 0.1
         # 'auto' (default): what the reference's scripts get from torch - inside `torch.cuda.amp.autocast()` the autocast dtype
@@ -243,7 +246,7 @@ class PoseResNet(nn.Module):
         key = (N, H, W, x.device.index, prec)
         hd = self._handles.get(key)
         if hd is None:
-            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, prec, dict(self.policy))
+            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, prec, dict(self.policy), self._deconv_bias)
             params = list(self.parameters())
             assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
             for i, p in enumerate(params):
