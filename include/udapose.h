@@ -359,6 +359,10 @@ int udapose_select_rows(void* stream, float* dst, const float* a, const float* b
  *   weight [R]; patch = the (2*rad+1)^2 Gaussian built by the caller as the reference builds it. */
 int udapose_aug_affine_u8(void* stream, const unsigned char* src, unsigned char* dst, const long long* coef, int N, int H, int W);
 int udapose_aug_color_op(void* stream, unsigned char* img, const int* op, const float* factor, int* mean_scratch, int N, int HW);
+/* PIL.ImageFilter.GaussianBlur (T.GaussianBlur, lib/transforms/keypoint_detection.py:216-225) in place on img [N][H][W][3] uint8 through
+ * the scratch buffer tmp (same size): three box-blur passes per direction in PIL's 8.24 fixed point, bit-exact.  prm[n] = (r, ww, fw)
+ * as uint32 (box radius integer part, centre and far weights: data_gpu.pil_box_blur_params), r = 0xffffffff: sample n is left as is. */
+int udapose_aug_gaussian_blur_u8(void* stream, unsigned char* img, unsigned char* tmp, const unsigned int* prm, int N, int H, int W);
 int udapose_aug_to_tensor(void* stream, const unsigned char* img, float* out, int N, int HW, const float* mean3, const float* std3);
 int udapose_gaussian_labels(void* stream, const double* kp, const float* vis, float* target, float* weight, int R, int Hh, int Wh,
                             double stride_x, double stride_y, const float* patch, int rad);

@@ -4,6 +4,7 @@
                            PIL Image.transform(size, AFFINE, inverse matrix, NEAREST) + the key-point algebra + aug_param
   * color_jitter_ref    <- T.ColorJitter (train_human.py:68,75) on a PIL image = PIL.ImageEnhance Brightness / Contrast / Color
                            applied in the given order
+  * gaussian_blur_ref   <- T.GaussianBlur (lib/transforms/keypoint_detection.py:216-225) = PIL.ImageFilter.GaussianBlur(radius)
   * to_tensor_normalize_ref <- T.ToTensor + T.Normalize (train_human.py:52,70-71)
   * generate_target_ref lives in mean_teacher_ref.py (lib/datasets/util.py:12-70)
 
@@ -16,7 +17,7 @@ import math
 
 import numpy as np
 import torch
-from PIL import Image, ImageEnhance
+from PIL import Image, ImageEnhance, ImageFilter
 
 
 def inverse_matrix_ref(width, height, angle, translate, scale, shear):
@@ -72,6 +73,10 @@ def color_jitter_ref(img_u8, ops, factors):
         if o:
             im = enh[o](im).enhance(f)
     return np.array(im)
+
+
+def gaussian_blur_ref(img_u8, radius):
+    return np.array(Image.fromarray(img_u8).filter(ImageFilter.GaussianBlur(radius)))
 
 
 def to_tensor_normalize_ref(img_u8, mean, std):

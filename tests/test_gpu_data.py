@@ -101,3 +101,35 @@ def test_pipeline_batch_feeds_a_training_step():
     out = trainer.train_step(src["x_s"].cuda(), src["label_s"].cuda(), src["weight_s"].cuda(), x_t_stu, x_t_teas, meta_stu["aug_param_stu"],
                              [m["aug_param_tea"] for m in metas_tea])
     assert torch.isfinite(out["loss_all"]) and float(out["loss_c"]) > 0
+
+
+def test_gaussian_blur_bit_exact_with_pil():
+    """T.GaussianBlur (lib/transforms/keypoint_detection.py:216-225, `--blur_stu / --blur_tea`): PIL's three-pass box blur in 8.24
+    fixed point on the device, byte for byte, for radii from PIL's copy (0) over the reference's typical U(0, 0.8) to boxes wider
+    than the image; non-square images; and inside a whole view (after the colour jitter, before ToTensor)."""
+    from oracle import transforms_ref as R
+    from uda_poseestimation_amd import data_gpu as D
+    rs = np.random.RandomState(5)
+    pipe = D.TargetViewPipeline(image_size=64, heatmap_size=16, sigma=2, rng=random.Random(1))
+    for (N, H, W) in ((7, 64, 64), (3, 17, 40)):
+        base = rs.randint(0, 256, (N, H, W, 3)).astype(np.uint8)
+        base[0, H // 3:H // 2, W // 4:W // 2] = 255
+        radii = [0.0, 0.05, 0.37, 0.8, 1.9, 4.2, 30.0][:N]
+        out = pipe.blur_(torch.from_numpy(base).cuda().clone(), radii).cpu().numpy()
+        for i, r in enumerate(radii):
+            ref = R.gaussian_blur_ref(base[i], r)
+            assert np.array_equal(out[i], ref), f"blur {H}x{W} radius {r}: {(out[i] != ref).sum()} bytes differ from PIL (params {D.pil_box_blur_params(r)})"
+    # a whole student view with blur: warp -> jitter -> blur -> ToTensor + Normalize
+    N, S, K = 4, 64, 16
+    base = rs.randint(0, 256, (N, S, S, 3)).astype(np.uint8)
+    kps = rs.uniform(5, S - 5, (N, K, 2))
+    cfg = D.ViewConfig(rotation=40, color=0.25, blur=0.8)
+    params = [cfg.draw_affine(random.Random(30 + i), (S, S)) for i in range(N)]
+    jit = [cfg.draw_jitter(random.Random(40 + i)) for i in range(N)]
+    blur = [cfg.draw_blur(random.Random(50 + i)) for i in range(N)]
+    assert all(0.0 <= b <= 0.8 for b in blur)
+    x = pipe.view(torch.from_numpy(base).cuda(), kps, cfg, params=params, jitter=jit, blur=blur)[0]
+    for i in range(N):
+        w_ref = R.affine_view_ref(base[i], kps[i], *params[i])[0]
+        t_ref = R.to_tensor_normalize_ref(R.gaussian_blur_ref(R.color_jitter_ref(w_ref, *jit[i]), blur[i]), D.IMAGENET_MEAN, D.IMAGENET_STD)
+        assert torch.equal(x[i].cpu(), t_ref), f"blurred view {i} differs from PIL"

@@ -118,7 +118,61 @@ __global__ void gaussian_labels_k(const double* __restrict__ kp, const float* __
         t[i] = (draw && gx >= 0 && gx < size && gy >= 0 && gy < size) ? patch[gy * size + gx] : 0.f;
     }
 }
+// PIL's ImageFilter.GaussianBlur (lib/transforms/keypoint_detection.py:216-225; libImaging BoxBlur.c): three passes of a box blur
+// per direction, every pass in 8.24 fixed point with replicated edges:
+//   out[x] = (sum_{k=-r..r} in[x+k] * ww + (in[x-r-1] + in[x+r+1]) * fw + 2^23) >> 24     (32-bit unsigned arithmetic)
+// with r = int(box radius), ww = uint32(2^24 / (2 * box radius + 1)) in float32, fw = (2^24 - (2r + 1) * ww) / 2; the box radius
+// follows from the Gaussian radius on the host (data_gpu.pil_box_blur_params restates `_gaussian_blur_radius`).  prm[n] = (r, ww, fw),
+// r < 0: the sample is copied (radius 0: PIL returns a copy).  One launch = one pass over [N][H][W][3] uint8 along x or along y.
+__global__ void box_blur_u8_k(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, const unsigned int* __restrict__ prm,
+                              int H, int W, int vertical) {
+    const int n = blockIdx.y;
+    const int r = (int)prm[n * 3];
+    const unsigned ww = prm[n * 3 + 1], fw = prm[n * 3 + 2];
+    const unsigned char* si = src + (size_t)n * H * W * 3;
+    unsigned char* di = dst + (size_t)n * H * W * 3;
+    const int L = vertical ? H : W;                 // length of a blur line
+    const int step = vertical ? W * 3 : 3;          // bytes between neighbours of a line
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < H * W; i += gridDim.x * TPB) {
+        const int y = i / W, x = i - y * W;
+        const unsigned char* px = si + (size_t)i * 3;
+        if (r < 0) { di[(size_t)i * 3] = px[0]; di[(size_t)i * 3 + 1] = px[1]; di[(size_t)i * 3 + 2] = px[2]; continue; }
+        const int pos = vertical ? y : x;
+        const unsigned char* line = px - (size_t)pos * step;       // element 0 of this pixel's line
+        unsigned a0 = 0, a1 = 0, a2 = 0;
+        for (int k = -r; k <= r; ++k) {
+            int q = pos + k;
+            q = q < 0 ? 0 : (q > L - 1 ? L - 1 : q);
+            const unsigned char* t = line + (size_t)q * step;
+            a0 += t[0]; a1 += t[1]; a2 += t[2];
+        }
+        int ql = pos - r - 1, qr = pos + r + 1;
+        ql = ql < 0 ? 0 : (ql > L - 1 ? L - 1 : ql);
+        qr = qr < 0 ? 0 : (qr > L - 1 ? L - 1 : qr);
+        const unsigned char* tl = line + (size_t)ql * step;
+        const unsigned char* tr = line + (size_t)qr * step;
+        const unsigned b0 = a0 * ww + (unsigned)(tl[0] + tr[0]) * fw, b1 = a1 * ww + (unsigned)(tl[1] + tr[1]) * fw,
+                       b2 = a2 * ww + (unsigned)(tl[2] + tr[2]) * fw;
+        di[(size_t)i * 3] = (unsigned char)((b0 + (1u << 23)) >> 24);
+        di[(size_t)i * 3 + 1] = (unsigned char)((b1 + (1u << 23)) >> 24);
+        di[(size_t)i * 3 + 2] = (unsigned char)((b2 + (1u << 23)) >> 24);
+    }
+}
 }  // namespace
+
+// img [N][H][W][3] uint8 is blurred IN PLACE through the scratch buffer tmp (same size): 3 passes along x, 3 along y
+int aug_gaussian_blur_u8(hipStream_t s, unsigned char* img, unsigned char* tmp, const unsigned int* prm, int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return UDAPOSE_ERR_ARG;
+    int gx = (H * W + TPB - 1) / TPB;
+    if (gx > 256) gx = 256;
+    unsigned char* a = img;
+    unsigned char* b = tmp;
+    for (int pass = 0; pass < 6; ++pass) {
+        hipLaunchKernelGGL(box_blur_u8_k, dim3(gx, N), dim3(TPB), 0, s, a, b, prm, H, W, pass >= 3 ? 1 : 0);
+        unsigned char* t = a; a = b; b = t;
+    }
+    return udapose_check_launch();      // (6 passes: the result is back in img)
+}
 
 int aug_affine_u8(hipStream_t s, const unsigned char* src, unsigned char* dst, const long long* coef, int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return UDAPOSE_ERR_ARG;

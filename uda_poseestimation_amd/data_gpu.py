@@ -14,7 +14,8 @@ the key-point algebra (K x 2 per sample) are drawn / computed on the host exactl
 does, including the `aug_param` tuple that the loop consumes (inverse augmentation, :139).  The result has the collated
 8-tuple layout of Appendix D / `default_collate`, ready for MeanTeacherTrainer.train_step or GraphedTrainStep.prefetch.
 
-GaussianBlur is the identity with the reference's default `--blur_* 0` (radius U(0, 0)); a non-zero radius is not implemented.
+GaussianBlur (`--blur_stu / --blur_tea`, radius U(0, high) per sample; 0 by default = a copy) is PIL's three-pass box blur in
+8.24 fixed point, reproduced bit for bit on the device (udapose_aug_gaussian_blur_u8).
 """
 import math
 import random
@@ -54,6 +55,24 @@ def pil_fixed_coefficients(m):
     return [fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5)]
 
 
+def pil_box_blur_params(radius, passes=3):
+    """PIL's ImageFilter.GaussianBlur(radius) -> (r, ww, fw) of its box-blur passes (libImaging BoxBlur.c `_gaussian_blur_radius`
+    and `ImagingLineBoxBlur*`, float32 / uint32 arithmetic as in the C source); radius 0 -> None (PIL returns a copy)."""
+    if radius == 0:
+        return None
+    f = np.float32
+    sigma2 = f(f(radius) * f(radius) / f(passes))
+    L = f(np.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f(np.floor((float(L) - 1.0) / 2.0))
+    a = f(f(f(2) * l + f(1)) * f(f(l * f(l + f(1))) - f(f(3) * sigma2)))
+    a = f(a / f(f(6) * f(sigma2 - f(f(l + f(1)) * f(l + f(1))))))
+    fr = f(l + a)
+    r = int(fr)
+    ww = int(f(f(1 << 24) / f(fr * f(2) + f(1))))
+    fw = ((1 << 24) - (r * 2 + 1) * ww) // 2
+    return r, ww & 0xFFFFFFFF, fw & 0xFFFFFFFF
+
+
 def transform_keypoints(kp, angle, shear_x, shear_y, trans_x, trans_y, scale, width, height):
     """The key-point side of `affine` (lib/transforms/keypoint_detection.py:141-165): rotate / shear / scale about the image
     centre, then translate."""
@@ -76,12 +95,17 @@ class ViewConfig:
     """Ranges of one view's augmentation = the reference's `--rotation_* --shear_* --translate_* --scale_* --color_*` flags
     (train_human.py:535-557)."""
 
-    def __init__(self, rotation=180, shear=(-30, 30), translate=(0.05, 0.05), scale=(0.6, 1.3), color=0.25):
+    def __init__(self, rotation=180, shear=(-30, 30), translate=(0.05, 0.05), scale=(0.6, 1.3), color=0.25, blur=0.0):
         self.degrees = (-rotation, rotation) if isinstance(rotation, (int, float)) else tuple(rotation)
         self.shear = (-shear, shear) if isinstance(shear, (int, float)) else tuple(shear)
         self.translate = (translate, translate) if isinstance(translate, (int, float)) else tuple(translate)
         self.scale = (scale, scale) if isinstance(scale, (int, float)) else tuple(scale)
         self.color = float(color)
+        self.blur = float(blur)          # T.GaussianBlur(high=blur): radius ~ U(0, blur) per sample (`--blur_stu / --blur_tea`)
+
+    def draw_blur(self, rng):
+        """GaussianBlur.__call__ (keypoint_detection.py:221-223): one uniform radius per sample (the reference draws from np.random)."""
+        return rng.uniform(0.0, self.blur)
 
     def draw_affine(self, rng, img_size):
         """RandomAffineRotation.get_params (lib/transforms/keypoint_detection.py:396-412), same draws in the same order from
@@ -158,6 +182,17 @@ class TargetViewPipeline:
             check(lib().udapose_aug_color_op(_hip.stream(), ptr(img_u8), ptr(op_t[i]), ptr(f_t[i]), ptr(scratch), N, H * W), "aug_color_op")
         return img_u8
 
+    def blur_(self, img_u8, radii):
+        """T.GaussianBlur in place: radii = one Gaussian radius per sample (0: unchanged, like PIL's copy)."""
+        N, H, W, _ = img_u8.shape
+        prm = [pil_box_blur_params(float(r)) or (0xFFFFFFFF, 0, 0) for r in radii]
+        if all(p[0] == 0xFFFFFFFF for p in prm):
+            return img_u8
+        pdev = torch.from_numpy(np.asarray(prm, dtype=np.uint32).view(np.int32)).to(img_u8.device, non_blocking=True)
+        tmp = torch.empty_like(img_u8)
+        check(lib().udapose_aug_gaussian_blur_u8(_hip.stream(), ptr(img_u8), ptr(tmp), ptr(pdev), N, H, W), "aug_gaussian_blur_u8")
+        return img_u8
+
     def to_tensor(self, img_u8):
         N, H, W, _ = img_u8.shape
         c = self._consts(img_u8.device)
@@ -180,7 +215,7 @@ class TargetViewPipeline:
         return target, weight
 
     # ------------------------------------------------------------------ one view of the whole batch
-    def view(self, base_u8, keypoints, cfg, params=None, jitter=None):
+    def view(self, base_u8, keypoints, cfg, params=None, jitter=None, blur=None):
         """-> (image [N,3,H,W] fp32 normalised, key points [N,K,2], aug_param collated, target, weight)"""
         N, H, W, _ = base_u8.shape
         if params is None:
@@ -189,6 +224,10 @@ class TargetViewPipeline:
             jitter = [cfg.draw_jitter(self.rng) for _ in range(N)]
         img = self.warp_images(base_u8, params)
         self.jitter_(img, [j[0] for j in jitter], [j[1] for j in jitter])
+        if blur is None and cfg.blur > 0:
+            blur = [cfg.draw_blur(self.rng) for _ in range(N)]
+        if blur is not None:
+            self.blur_(img, blur)                     # (after the colour jitter, before ToTensor: train_human.py:67-71)
         x = self.to_tensor(img)
         kp = np.stack([transform_keypoints(keypoints[i], *params[i], W, H) for i in range(N)])
         # aug_param = the INVERSE augmentation (keypoint_detection.py:139), collated like default_collate does
