@@ -172,16 +172,3 @@ def test_data_parallel_helpers_gloo_world2():
         assert g0 == 1.5                                           # (1 + 2) / 2
         assert allact == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 100.0, 101.0, 102.0, 103.0, 104.0, 105.0]
         assert thr == 5.0                                          # k = 6 of 12: identical on both ranks (global statistic)
-
-
-def test_schedule_helpers_known_values():
-    """utils.py:28-52 of the reference (ramp helpers the star-import exposes): closed-form known answers."""
-    import math
-    from uda_poseestimation_amd import utils as U
-    assert U.sigmoid_rampup(5, 0) == 1.0
-    assert U.sigmoid_rampup(0, 10) == pytest.approx(math.exp(-5.0)) and U.sigmoid_rampup(10, 10) == 1.0 and U.sigmoid_rampup(99, 10) == 1.0
-    assert U.sigmoid_rampup(5, 10) == pytest.approx(math.exp(-1.25))
-    assert U.cosine_rampdown(0, 8) == 1.0 and U.cosine_rampdown(8, 8) == pytest.approx(0.0, abs=1e-12) and U.cosine_rampdown(4, 8) == pytest.approx(0.5)
-    assert U.rev_sigmoid(0.5) == pytest.approx(0.5) and U.sigmoid(0.5) == pytest.approx(0.5)
-    assert U.rev_sigmoid(-3) == pytest.approx(1 / (1 + math.exp(-5))) and U.sigmoid(7) == pytest.approx(1 / (1 + math.exp(-5)))
-    assert U.rev_sigmoid(0.2) + U.sigmoid(0.2) == pytest.approx(1.0)

@@ -134,15 +134,3 @@ def test_state_dict_contract():
     assert sum(p.numel() for p in m50.parameters()) == 36048440 and len(list(m50.parameters())) == 172
     for K, n in ((18, 55041082), (21, 55041853), (14, 55040054)):
         assert sum(p.numel() for p in pose_resnet101_ref(K).parameters()) == n
-
-
-def test_schedule_helpers_match_reference_golden(golden_dir):
-    """utils.py:28-52: the ramp helpers against values produced by the reference's own functions (ramps.npz)."""
-    from uda_poseestimation_amd import utils as U
-    z = _g(golden_dir, "ramps.npz")
-    up = np.array([[U.sigmoid_rampup(c, L) for L in z["length"]] for c in z["cur"]])
-    down = np.array([[U.cosine_rampdown(c, L) for L in z["length"][1:]] for c in z["cur"]])
-    np.testing.assert_allclose(up, z["up"], rtol=1e-15, atol=0)
-    np.testing.assert_allclose(down, z["down"], rtol=1e-14, atol=1e-16)
-    np.testing.assert_allclose([U.rev_sigmoid(p) for p in z["prog"]], z["rev"], rtol=1e-15)
-    np.testing.assert_allclose([U.sigmoid(p) for p in z["prog"]], z["sig"], rtol=1e-15)

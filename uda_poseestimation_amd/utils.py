@@ -79,35 +79,6 @@ def _bump_versions(params):
             p.detach()[:0].zero_()
 
 
-# ---- schedule helpers of the reference's utils.py:28-52 (host scalars; the reference's scripts import them with `from utils import *`
-# but never call them - kept so that the star-import exposes the same names)
-def _unit(v, hi):
-    return min(max(float(v), 0.0), float(hi))
-
-
-def sigmoid_rampup(current, rampup_length):
-    """exp(-5 (1 - t)^2), t = clip(current, 0, L) / L; 1.0 when L == 0 (utils.py:28-35)."""
-    if rampup_length == 0:
-        return 1.0
-    t = _unit(current, rampup_length) / float(rampup_length)
-    return float(np.exp(-5.0 * (1.0 - t) ** 2))
-
-
-def cosine_rampdown(current, rampdown_length):
-    """(cos(pi * clip(current, 0, L) / L) + 1) / 2 (utils.py:38-42)."""
-    return float(0.5 * (np.cos(np.pi * _unit(current, rampdown_length) / rampdown_length) + 1.0))
-
-
-def rev_sigmoid(progress):
-    """1 / (1 + e^(10 p - 5)), p clipped to [0, 1] (utils.py:44-47)."""
-    return float(1.0 / (1.0 + np.exp(10.0 * _unit(progress, 1.0) - 5.0)))
-
-
-def sigmoid(progress):
-    """1 / (1 + e^(5 - 10 p)), p clipped to [0, 1] (utils.py:49-52)."""
-    return float(1.0 / (1.0 + np.exp(5.0 - 10.0 * _unit(progress, 1.0))))
-
-
 def get_max_preds_torch_raw(batch_heatmaps):
     """(x = idx % W, y = idx // W) [B,K,2] and the maxima [B,K,1] WITHOUT the max>0 masking: what the occlusion code
     computes inline with amax / view().argmax(-1) (train_human.py:378-381)."""
