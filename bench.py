@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--stream-priority", type=int, default=0, help="tuning: priority of the three branch streams (-1 = high; side streams stay 0)")
     ap.add_argument("--no-sum-in-tail", action="store_true", help="tuning: a separate launch adds the two passes' gradient buffers")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="data parallel: wire format of the gradient buckets (bf16: one "
+                    "rounding per contribution, all-to-all + fp32 accumulation on the shard's owner + all-gather: half the bytes per xGMI link)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
@@ -255,7 +257,7 @@ def main():
         extra = dict(style_net=style, recover=(lo, hi), s2t_freq=1.0, t2s_freq=1.0, s2t_alpha=(0.5, 0.5), t2s_alpha=(0.5, 0.5),
                      rng=np.random.RandomState(0), occlude_rate=0.5, occlude_thresh=0.9, occlude_size=10)
     trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
-                                 heatmap_size=S // 4, precision=(args.precision or args.dtype), **extra)
+                                 heatmap_size=S // 4, precision=(args.precision or args.dtype), grad_comm=args.grad_comm, **extra)
     if args.no_fuse_tail:
         trainer.fuse_tail = False
     trainer.stream_priority = args.stream_priority
@@ -326,14 +328,18 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    trainer.sync.profile = dist.is_initialized()      # (HIP events around the communication calls of the compute stream: no host sync)
     t0 = time.perf_counter()
     for i in range(args.steps):         # the timed region: EXACTLY K steps (hipGraph replays unless --eager), nothing else
         out = step()
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0                 # this rank's own time for the K steps (before the closing barrier)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    comm_exposed_ms = trainer.sync.exposed_ms()
+    trainer.sync.profile = False
     # The synchronous-loop rate (untimed extra, after the timed region): one torch.cuda.synchronize() per step, as a loop that reads
     # the loss / PCK of every iteration on the host forces (train_human.py:443 moves y_s to the CPU each iteration)
     sync_ms = []
@@ -357,10 +363,16 @@ def main():
         _hip.check(lib.udapose_prof_end(prof), "prof_end")
     trainer.concurrent = True
     torch.cuda.synchronize()
+    rank_ms = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank diagnostics for a SCALE line: every rank's own ms per step and the time its compute stream waited in communication
+        mine = torch.tensor([t_rank / args.steps * 1e3, comm_exposed_ms if comm_exposed_ms is not None else -1.0], device=dev, dtype=torch.float64)
+        every_t = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_t, mine)
+        rank_ms = [[round(float(e[0]), 3), round(float(e[1]), 3)] for e in every_t]
     loss = float(out["loss_all"])
     assert loss == loss, "loss is NaN"
     in_sync = None
@@ -396,6 +408,10 @@ def main():
                           if args.precision == "reference" else {})},
             "loss": loss, "launch": "eager" if args.eager else ("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else ("1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs")) + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
+            "grad_comm": args.grad_comm if dist.is_initialized() else None,
+            "comm_exposed_ms_per_step": round(comm_exposed_ms, 3) if comm_exposed_ms is not None else None,
+            "rank_ms_per_step_min_max": ([min(r[0] for r in rank_ms), max(r[0] for r in rank_ms)] if rank_ms else None),
+            "rank_comm_exposed_ms": ([r[1] for r in rank_ms] if rank_ms else None),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,
             "roofline": {"bound": "mfma", "kernel": f"igemm_kernel (implicit-GEMM conv fprop+dgrad, {args.dtype} MFMA 16x16x32)",

@@ -304,6 +304,14 @@ int udapose_grad_scaler_check(void* stream, const long long* g, const long long*
                               int nblocks, float* dev_state);
 int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, float backoff, int interval);
 
+/* ---------------------------------------------------------------- gradient all-reduce in bf16 on the wire (data parallel,
+ * the 212 MB fp32 student-gradient buffer): pack = one rounding of the fp32 bucket to bf16 (zero padded to n_padded, a
+ * multiple of the world size); after an all-to-all every rank holds the W ranks' copies of its shard: shard_mean adds them in fp32,
+ * divides by W and writes the averaged shard in bf16; after the all-gather unpack widens the bucket back to fp32. */
+int udapose_comm_pack_bf16(void* stream, const float* src, long long n, void* dst_bf16, long long n_padded);
+int udapose_comm_shard_mean(void* stream, const void* shards_bf16, int world, long long m, void* out_bf16);
+int udapose_comm_unpack_bf16(void* stream, const void* src_bf16, float* dst, long long n);
+
 /* ---------------------------------------------------------------- AdaIN (lib/models/Style_net.py:4-29,167-168), NHWC bf16
  * out = alpha*adain(content, style) + (1-alpha)*content; stats_out (optional) [N][C][4] = (mean_c, std_c, mean_s, std_s) */
 int udapose_adain(void* stream, const void* content, const void* style, void* out, int N, int HWc, int HWs, int C, float eps,

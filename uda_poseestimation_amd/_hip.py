@@ -112,6 +112,9 @@ _SIGS = {
     "udapose_ema_multi": (ci, [vp, vp, vp, vp, vp, vp, ci, cf, cf]),
     "udapose_adam_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, cf, vp]),
     "udapose_sgd_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, ci, ci, cf, vp]),
+    "udapose_comm_pack_bf16": (ci, [vp, vp, ll, vp, ll]),
+    "udapose_comm_shard_mean": (ci, [vp, vp, ci, ll, vp]),
+    "udapose_comm_unpack_bf16": (ci, [vp, vp, vp, ll]),
     "udapose_adain": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_adain_f32": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]),
     "udapose_adain_alpha_dev": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, ci]),

@@ -43,6 +43,9 @@ int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, c
             int, int, float, float*);
 int opt_grad_check(hipStream_t, const long long*, const long long*, const int*, const long long*, int, float*);
 int opt_scaler_update(hipStream_t, float*, float, float, int);
+int comm_pack_bf16(hipStream_t, const float*, long long, void*, long long);
+int comm_shard_mean(hipStream_t, const void*, int, long long, void*);
+int comm_unpack_bf16(hipStream_t, const void*, float*, long long);
 int adain_launch(hipStream_t, const elem_t*, const elem_t*, elem_t*, int, int, int, int, float, float, const float*, float*);
 int aug_affine_u8(hipStream_t, const unsigned char*, unsigned char*, const long long*, int, int, int);
 int aug_color_op(hipStream_t, unsigned char*, const int*, const float*, int*, int, int);
@@ -348,6 +351,18 @@ int udapose_grad_scaler_check(void* stream, const long long* g, const long long*
 }
 int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, float backoff, int interval) {
     return opt_scaler_update(S(stream), dev_state, growth, backoff, interval);
+}
+int udapose_comm_pack_bf16(void* stream, const float* src, long long n, void* dst_bf16, long long n_padded) {
+    if (!src || !dst_bf16) return UDAPOSE_ERR_ARG;
+    return comm_pack_bf16(S(stream), src, n, dst_bf16, n_padded);
+}
+int udapose_comm_shard_mean(void* stream, const void* shards_bf16, int world, long long m, void* out_bf16) {
+    if (!shards_bf16 || !out_bf16) return UDAPOSE_ERR_ARG;
+    return comm_shard_mean(S(stream), shards_bf16, world, m, out_bf16);
+}
+int udapose_comm_unpack_bf16(void* stream, const void* src_bf16, float* dst, long long n) {
+    if (!src_bf16 || !dst) return UDAPOSE_ERR_ARG;
+    return comm_unpack_bf16(S(stream), src_bf16, dst, n);
 }
 int udapose_adain(void* stream, const void* c, const void* s, void* out, int N, int HWc, int HWs, int C, float eps, float alpha, float* stats_out) {
     return adain_launch(S(stream), CB16(c), CB16(s), B16(out), N, HWc, HWs, C, eps, alpha, nullptr, stats_out);

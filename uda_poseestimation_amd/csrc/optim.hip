@@ -302,3 +302,38 @@ int opt_sgd(hipStream_t s, const long long* p, const long long* g, const long lo
     hipLaunchKernelGGL(sgd_k, dim3(nblocks), dim3(TPB), 0, s, t, lr, momentum, wd, nesterov, first_step, gscale, dev_state);
     return udapose_check_launch();
 }
+
+// ---- gradient communication in bf16 (engine.GradSync(comm_dtype='bf16')): the fp32 bucket is rounded ONCE to bf16 for the wire,
+// every rank receives its 1/W shard of all W ranks (all-to-all), adds them in fp32, and the averaged shard travels back in bf16
+// (all-gather): half the bytes of an fp32 all-reduce on every xGMI link, one bf16 rounding per contribution, fp32 accumulation.
+namespace {
+__global__ void comm_pack_bf16_k(const float* __restrict__ src, long long n, __bf16* __restrict__ dst, long long npad) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npad; i += (long long)gridDim.x * 256) dst[i] = (__bf16)(i < n ? src[i] : 0.f);
+}
+__global__ void comm_shard_mean_k(const __bf16* __restrict__ in, int W, long long m, float inv_w, __bf16* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int w = 0; w < W; ++w) a += (float)in[(long long)w * m + i];
+        out[i] = (__bf16)(a * inv_w);
+    }
+}
+__global__ void comm_unpack_bf16_k(const __bf16* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (float)src[i];
+}
+inline int comm_grid(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+}  // namespace
+int comm_pack_bf16(hipStream_t s, const float* src, long long n, void* dst, long long npad) {
+    if (n < 0 || npad < n) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(comm_pack_bf16_k, dim3(comm_grid(npad)), dim3(256), 0, s, src, n, (__bf16*)dst, npad);
+    return udapose_check_launch();
+}
+int comm_shard_mean(hipStream_t s, const void* in, int W, long long m, void* out) {
+    if (W < 1 || m < 0) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(comm_shard_mean_k, dim3(comm_grid(m)), dim3(256), 0, s, (const __bf16*)in, W, m, 1.f / (float)W, (__bf16*)out);
+    return udapose_check_launch();
+}
+int comm_unpack_bf16(hipStream_t s, const void* src, float* dst, long long n) {
+    if (n < 0) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(comm_unpack_bf16_k, dim3(comm_grid(n)), dim3(256), 0, s, (const __bf16*)src, dst, n);
+    return udapose_check_launch();
+}

@@ -40,9 +40,16 @@ class GradSync:
     the first - the suffix holding layer3 / layer4 / upsampling / head, 94 % of the bytes, final when backward part 1 has
     run - travels under backward part 2: `start_upper()` right after part 1, `finish()` after part 2."""
 
-    def __init__(self, model):
+    def __init__(self, model, comm_dtype="fp32"):
         self.model = model
         self._work = None
+        # 'bf16': the buckets travel in bf16 (udapose_comm_*: one rounding per contribution, all-to-all of shards, fp32 accumulation on
+        # the shard's owner, all-gather of the averaged shards): half the bytes per xGMI link.  RCCL backend only.
+        self.comm_dtype = comm_dtype
+        self._cbuf = {}
+        # timing (bench.py): HIP events around finish() on the current stream = what the step WAITS for communication
+        self.profile = False
+        self._events = []
 
     def _flat(self):
         flat = getattr(self.model, "_flat_grad", None)
@@ -50,8 +57,30 @@ class GradSync:
             raise RuntimeError("GradSync: model has no flat gradient buffer yet (run backward first)")
         return flat
 
-    @staticmethod
-    def _reduce(t, async_op=False):
+    def _reduce_bf16(self, t, tag):
+        """Average the fp32 bucket `t` over the ranks with bf16 on the wire (synchronous with respect to the current stream)."""
+        from ._hip import check, lib, ptr, stream
+        if dist.get_backend() != "nccl":
+            raise RuntimeError("GradSync(comm_dtype='bf16') needs the RCCL backend")
+        w, n = dist.get_world_size(), t.numel()
+        m = (n + w - 1) // w
+        m = (m + 7) // 8 * 8
+        buf = self._cbuf.get(tag)
+        if buf is None or buf[0].numel() != w * m or buf[0].device != t.device:
+            buf = (torch.empty(w * m, dtype=torch.bfloat16, device=t.device), torch.empty(w * m, dtype=torch.bfloat16, device=t.device),
+                   torch.empty(m, dtype=torch.bfloat16, device=t.device))
+            self._cbuf[tag] = buf
+        send, recv, mine = buf
+        check(lib().udapose_comm_pack_bf16(stream(), ptr(t), n, ptr(send), w * m), "comm_pack_bf16")
+        dist.all_to_all_single(recv, send)
+        check(lib().udapose_comm_shard_mean(stream(), ptr(recv), w, m, ptr(mine)), "comm_shard_mean")
+        dist.all_gather_into_tensor(send, mine)
+        check(lib().udapose_comm_unpack_bf16(stream(), ptr(send), ptr(t), n), "comm_unpack_bf16")
+
+    def _reduce(self, t, async_op=False, tag="all"):
+        if self.comm_dtype == "bf16":
+            self._reduce_bf16(t, tag)
+            return None
         if dist.get_backend() == "nccl":
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)   # RCCL averages in the collective: no second sweep
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)          # gloo (CPU tests, shared-GPU test) has no AVG
@@ -62,7 +91,30 @@ class GradSync:
     def __call__(self):
         if not _dist_on():
             return
+        ev = self._tick()
         self._reduce(self._flat())
+        self._tock(ev)
+
+    def _tick(self):
+        if not self.profile:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _tock(self, e0):
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._events.append((e0, e1))
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream spent inside the communication calls (after a synchronize)."""
+        if not self._events:
+            return None
+        v = [a.elapsed_time(b) for a, b in self._events]
+        self._events = []
+        return sum(v) / len(v)
 
     def start_upper(self):
         """Launch the all-reduce of the gradient suffix on the communicator's own stream (it waits for what is enqueued on the
@@ -71,19 +123,34 @@ class GradSync:
             return
         flat = self._flat()
         self._upper = flat[self.model.grad_split_offset():]
-        self._work = self._reduce(self._upper, async_op=True)
+        if self.comm_dtype == "bf16":
+            # a side stream runs the bf16 exchange of the suffix beside backward part 2 (the collectives' own streams wait for it)
+            if getattr(self, "_cstream", None) is None:
+                self._cstream = torch.cuda.Stream(device=flat.device)
+            cur = torch.cuda.current_stream()
+            self._cstream.wait_stream(cur)
+            with torch.cuda.stream(self._cstream):
+                self._reduce_bf16(self._upper, "upper")
+            self._work = "stream"
+            return
+        self._work = self._reduce(self._upper, async_op=True, tag="upper")
 
     def finish(self):
         """All-reduce the prefix (layer2 / layer1 / stem: 6 % of the bytes), then join the suffix's collective."""
         if not _dist_on():
             return
         flat = self._flat()
-        self._reduce(flat[:self.model.grad_split_offset()])
-        if self._work is not None:
+        ev = self._tick()
+        self._reduce(flat[:self.model.grad_split_offset()], tag="lower")
+        if self._work == "stream":
+            torch.cuda.current_stream().wait_stream(self._cstream)
+            self._work = None
+        elif self._work is not None:
             self._work.wait()                        # the current stream waits for the suffix's collective
             if dist.get_backend() != "nccl":
                 self._upper.mul_(1.0 / dist.get_world_size())
             self._work = None
+        self._tock(ev)
 
 
 def gather_activates(act):
@@ -99,7 +166,7 @@ class MeanTeacherTrainer:
     def __init__(self, student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=2, image_size=256,
                  heatmap_size=64, use_sgd=False, style_net=None, recover=None, s2t_freq=0.5, t2s_freq=0.5, s2t_alpha=(0.0, 1.0),
                  t2s_alpha=(0.0, 1.0), rng=None, occlude_rate=-1.0, occlude_thresh=0.9, occlude_size=10, image_px=None, precision=None,
-                 loss_scale_init=65536.0, loss_scale_interval=2000):
+                 loss_scale_init=65536.0, loss_scale_interval=2000, grad_comm="fp32"):
         self.student, self.teacher = student, teacher
         self.criterion, self.con_criterion = JointsMSELoss(), ConsLoss()
         # precision: None keeps what the networks are set to (a new PoseResNet is 'auto': a differentiable forward outside
@@ -123,7 +190,7 @@ class MeanTeacherTrainer:
         else:
             self.stu_optimizer = fused_optim.FusedAdam(student.parameters(), lr=lr, **sc)
         self.tea_optimizer = mt.OldWeightEMA(teacher, student, alpha=teacher_alpha)   # ctor copies student -> teacher
-        self.sync = GradSync(student)
+        self.sync = GradSync(student, comm_dtype=grad_comm)
         self.lambda_c, self.mask_ratio, self.sigma = lambda_c, mask_ratio, sigma
         self.ratio = image_size / heatmap_size
         self.style_net, self.recover = style_net, recover
