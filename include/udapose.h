@@ -70,6 +70,9 @@ typedef struct {
     int bn3_mask;
     int stem_fused;
     int debug_sync;
+    int igemm_q_tile;     /* tile id for launches whose 128x64 grid has 769..1024 work-groups (a second, mostly empty round on the 768
+                           * resident slots); -1: the general heuristic */
+    int exp0;             /* tuning scratch value read by whichever experiment is being A/B-ed (0 in production) */
     void* timeline;
 } udapose_policy;
 void udapose_policy_default(udapose_policy* p);

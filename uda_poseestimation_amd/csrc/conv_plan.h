@@ -33,6 +33,8 @@ struct Policy {
     int bn3_mask = 1;           // block outputs: the forward saves the ReLU bit mask, the data gradients read it instead of z (0: read z)
     int stem_fused = 1;         // stem: 1 = BN apply + ReLU + max-pool in one sweep; 2 = also the max-pool backward gathered inside the BN backward's
                                 // two sweeps (0.2 GB less traffic, but 99 + 87 us against 55 + 30 + 48 us for the three separate launches: neutral in the step)
+    int igemm_q_tile = -1;      // tile id for launches whose 128x64 grid has 769..1024 work-groups (second round mostly empty); -1: heuristic
+    int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null
 };

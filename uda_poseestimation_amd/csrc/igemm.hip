@@ -980,6 +980,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
     // they give two work-groups per CU, else 64x64 with a 3-stage ring for long K and a 2-stage ring otherwise.  Every
     // choice lands on THREE resident work-groups per CU (48 KB of LDS each): deeper rings (4 stages = 2 per CU) and one deep
     // 128x64 work-group per CU both measured slower - overlapping the fixed phases of several work-groups beats prefetch depth.
+    if (pol.igemm_q_tile >= 0 && b12864 > 768 && b12864 <= 1024) return pol.igemm_q_tile;
     if (b12864 >= pol.igemm_wg_min) return 6;
     return K >= 1024 ? 9 : 5;
 }
