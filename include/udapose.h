@@ -73,6 +73,9 @@ typedef struct {
     int igemm_q_tile;     /* tile id for launches whose 128x64 grid has 769..1024 work-groups (a second, mostly empty round on the 768
                            * resident slots); -1: the general heuristic */
     int exp0;             /* tuning scratch value read by whichever experiment is being A/B-ed (0 in production) */
+    int wgrad_big;        /* grouped weight gradients: 256x128 tiles (128x64 per wave: 25 % fewer LDS bytes per FLOP than 64x64 per wave) for
+                           * stride-1 layers on power-of-two maps with Co % 256 == 0 and Ci % 128 == 0 (layer3 / layer4, layer2's c3) */
+    int pad0;
     void* timeline;
 } udapose_policy;
 void udapose_policy_default(udapose_policy* p);

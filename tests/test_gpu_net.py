@@ -257,16 +257,19 @@ def test_grouped_weight_gradients_equal_per_layer_launches():
     x = torch.randn(8, 3, 128, 128, generator=torch.Generator().manual_seed(2)).cuda()
     R = torch.randn(8, 6, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
     grads = {}
-    for mode in (0, 1):
-        net.policy, net._handles = {"wgrad_group": mode}, {}      # explicit policy of the plans created from here on
+    # mode 2: the grouped launch with the optional third tile class (policy wgrad_big: 256x128 tiles, 128x64 per wave, for layer3 / layer4's
+    # stride-1 layers - faster per layer, slower inside the grouped launch, profiles/r3_ab_runs.txt: off by default, kept selectable)
+    for mode, pol in ((0, {"wgrad_group": 0}), (1, {"wgrad_group": 1}), (2, {"wgrad_group": 1, "wgrad_big": 1})):
+        net.policy, net._handles = pol, {}      # explicit policy of the plans created from here on
         net.zero_grad(set_to_none=True)
         (net(x) * R).sum().backward()
         (net(x) * R).sum().backward()              # second backward accumulates (atomic adds into the kept buffer)
         grads[mode] = {n_: p_.grad.clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
-    assert len(grads[0]) == len(grads[1]) >= 90
+    assert len(grads[0]) == len(grads[1]) == len(grads[2]) >= 90
     for n_ in grads[0]:
-        a, b = grads[1][n_], grads[0][n_]
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, n_
+        for mode in (1, 2):
+            a, b = grads[mode][n_], grads[0][n_]
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, (n_, mode)
 
 
 @pytest.mark.parametrize("layers,N,HW", [((2, 2, 2, 2), 8, 128), ((1, 2, 1, 1), 3, 160)], ids=["n8_128", "n3_160_odd"])

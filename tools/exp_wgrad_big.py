@@ -19,13 +19,16 @@ for (N, H, Ci, Co, K) in ((512, 16, 256, 256, 3), (512, 16, 1024, 256, 1), (2048
     dy = torch.randn(N, H, H, Co, device='cuda').bfloat16()
     flops = 2.0 * N * H * H * Ci * Co * K * K
     ref = None
-    for t in (0, 4, 5):
-        tr, tc = {0: (128, 128), 4: (128, 256), 5: (256, 128)}[t]
+    for t in (0, 5, 6):
+        tr, tc = {0: (128, 128), 4: (128, 256), 5: (256, 128), 6: (256, 256)}[t]
         if Co % tr or Ci % tc:
             continue
-        for ks in (1, 2, 4, 8, 16, 32, 64):
-            tiles = (Co // tr) * (Ci // tc) * K * K * ks
-            if tiles < 500 or tiles > 2400 or (N * H * H) // (64 * ks) < 4:
+        slots = {0: 512, 4: 512, 5: 512, 6: 256}[t]                  # resident work-groups of the per-layer kernels
+        base = (Co // tr) * (Ci // tc) * K * K
+        cands = sorted({max(1, (slots * r) // base) for r in (1, 2, 3)})
+        for ks in cands:
+            tiles = base * ks
+            if (N * H * H) // (64 * ks) < 8:
                 continue
             dt = ops.with_policy(d, _hip.policy(wgrad_tile=t, wgrad_ksplit=ks))
             dw = ops.conv2d_bwd_weight(dy, x, dt)

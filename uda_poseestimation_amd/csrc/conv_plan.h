@@ -33,6 +33,9 @@ struct Policy {
     int bn3_mask = 1;           // block outputs: the forward saves the ReLU bit mask, the data gradients read it instead of z (0: read z)
     int stem_fused = 1;         // stem: 1 = BN apply + ReLU + max-pool in one sweep; 2 = also the max-pool backward gathered inside the BN backward's
                                 // two sweeps (0.2 GB less traffic, but 99 + 87 us against 55 + 30 + 48 us for the three separate launches: neutral in the step)
+    int wgrad_big = 0;          // grouped weight gradients: 256x128 tiles (128x64 per wave) for fast-geometry layers with Co % 256 == 0, Ci % 128 == 0.
+                                // +16-19 % per layer alone (+40-55 % against the filter-row form on layer3 / layer4's 3x3), but the third class
+                                // launch and its 2 work-groups per CU cost the grouped launch +9 % (2.73 against 2.48 ms for both passes): OFF
     int igemm_q_tile = -1;      // tile id for launches whose 128x64 grid has 769..1024 work-groups (second round mostly empty); -1: heuristic
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
@@ -91,6 +94,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
 // Grouped wgrad (many layers, one launch per tile class).  wgrad_group_plan completes p for the group kernels and returns
 // the tile class (0 = 128x128, 1 = 64x64) or < 0 when the layer needs its own launch; stages_per_block bounds a work-group's
 // pixel range (longer reductions are split and accumulated with fp32 atomics into a zeroed dW).
+#define WG_CLASSES 3      // tile classes of a grouped launch: 0 = 128x128, 1 = 64x64 (+ filter-row form), 2 = 256x128
 int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Policy& pol);
 // the x / dy / dw fields of the table entries are byte offsets from the three bases
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,

@@ -128,8 +128,9 @@ struct Net {
     struct WgGroup {
         float k_beta = -1.f; int k_stages = 0; int k_part = 0;     // part: 0 all layers, 1 upper (head..layer3), 2 lower (layer2..stem)
         std::vector<std::pair<int, ptrdiff_t>> rel;      // (parameter index, byte offset of its gradient from grads[0]) the table assumes
-        WgParams* d_tab[2] = {nullptr, nullptr}; WgGroupBlk* d_blk[2] = {nullptr, nullptr}; int per_xcd[2] = {0, 0};
-        double flops[2] = {0.0, 0.0};
+        // tile classes of the grouped launch: 0 = 128x128, 1 = 64x64 (and the filter-row form), 2 = 256x128 (128x64 per wave)
+        WgParams* d_tab[WG_CLASSES] = {}; WgGroupBlk* d_blk[WG_CLASSES] = {}; int per_xcd[WG_CLASSES] = {};
+        double flops[WG_CLASSES] = {};
         std::vector<std::pair<ptrdiff_t, size_t>> zero;  // dW ranges (offset from grads[0], bytes) cleared first (split reductions, when overwriting)
         ZeroJob* d_zero = nullptr; int n_zero = 0;       // the same ranges as a device job table, when all are 16-byte granular
         unsigned long long last_use = 0;
@@ -365,7 +366,7 @@ void net_destroy(void* h) {
     if (n->d_runjobs) (void)hipFree(n->d_runjobs);
     if (n->upd.jobs) { (void)hipFree(n->upd.jobs); (void)hipFree(n->upd.blk_job); (void)hipFree(n->upd.blk_sub); }
     for (auto& g : n->wg_groups)
-        for (int t = 0; t < 2; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
+        for (int t = 0; t < WG_CLASSES; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
     for (auto& g : n->wg_groups) if (g.d_zero) (void)hipFree(g.d_zero);
     delete n;
 }
@@ -615,12 +616,12 @@ inline int split_block(const Net& n) { return n.layers[0] + n.layers[1]; }
 
 int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int part) {
     const bool upper = part != 2, lower = part != 1;
-    std::vector<WgParams> tab[2];
+    std::vector<WgParams> tab[WG_CLASSES];
     struct Unit { int prob, z, nblk; long load; };
-    std::vector<Unit> units[2];
+    std::vector<Unit> units[WG_CLASSES];
     G.zero.clear();
     G.rel.clear();
-    G.flops[0] = G.flops[1] = 0.0;
+    for (int t = 0; t < WG_CLASSES; ++t) G.flops[t] = 0.0;
     auto add_geom = [&](const ConvGeom& g, int w_idx, size_t dy_off, size_t in_off, int rows_valid) -> int {
         if (g.smallc()) return UDAPOSE_OK;
         WgParams p;
@@ -680,7 +681,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         if (b.has_ds) CK(add(b.cd));
         CK(add(b.c1));
     }
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < WG_CLASSES; ++t) {
         if (G.d_tab[t]) { (void)hipFree(G.d_tab[t]); G.d_tab[t] = nullptr; }
         if (G.d_blk[t]) { (void)hipFree(G.d_blk[t]); G.d_blk[t] = nullptr; }
         G.per_xcd[t] = 0;
@@ -763,7 +764,7 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
     const ConvGeom& sg = n.stem.g;
     const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
     if (with_stem && hipMemsetAsync(ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < WG_CLASSES; ++t) {
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);
         const int rc = wgrad_group_launch(s, t, G->d_tab[t], G->d_blk[t], G->per_xcd[t], act, ws, grads[0]);
@@ -784,7 +785,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     Net::WgGroup* GB = find_wg_group(n, gradsB, betaB, part);
     if (!GA || !GB) return UDAPOSE_ERR_NOT_PREPARED;
     bool same = true;
-    for (int t = 0; t < 2; ++t) same = same && GA->per_xcd[t] == GB->per_xcd[t];
+    for (int t = 0; t < WG_CLASSES; ++t) same = same && GA->per_xcd[t] == GB->per_xcd[t];
     if (!same) {        // (different table shapes: two launches)
         CK(run_wg_group(s, n, actA, wsA, gradsA, betaA, part));
         return run_wg_group(s, n, actB, wsB, gradsB, betaB, part);
@@ -801,7 +802,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
                 if (hipMemsetAsync((char*)sd.grads[0] + z.first, 0, z.second, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         if (with_stem && hipMemsetAsync(sd.ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     }
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < WG_CLASSES; ++t) {
         if (!GA->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, GA->flops[t] + GB->flops[t]);
         const int rc = wgrad_group_launch(s, t, GA->d_tab[t], GA->d_blk[t], GA->per_xcd[t], actA, wsA, gradsA[0], GB->d_tab[t], GB->d_blk[t], actB, wsB,

@@ -224,8 +224,9 @@ struct WdCfg {
     static constexpr int TR = RT / WR, TC = CT / WC;
     static constexpr int MT = TR / 16, NT = TC / 16;
     static constexpr int PROW = RT * 2, QROW = CT * 2;               // bytes per LDS row
+    static constexpr int NW = WR * WC;                                // waves per work-group (4; 8 in the 256x256 tile)
     static constexpr int P_BYTES = PX * PROW, Q_BYTES = PX * QROW;
-    static constexpr int P_PW = P_BYTES / 4096, Q_PW = Q_BYTES / 4096; // DMA instructions per wave per stage
+    static constexpr int P_PW = P_BYTES / (1024 * NW), Q_PW = Q_BYTES / (1024 * NW); // DMA instructions per wave per stage
     static constexpr int STAGE1 = P_BYTES + Q_BYTES;
     static constexpr int LDS_BYTES = NS * STAGE1;
 };
@@ -458,7 +459,7 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
            gp.flags, gp.ksplit, gp.c_tiles, gp.rows_valid};
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     constexpr int TR = C::TR, TC = C::TC, MT = C::MT, NT = C::NT, P_PW = C::P_PW, Q_PW = C::Q_PW;
-    constexpr int LPS = P_PW + Q_PW;
+    constexpr int LPS = P_PW + Q_PW, NW = C::NW;
     // (rows per 1 KiB DMA piece and 16-byte chunks per row, for the dy side P and the x side Q: RT != CT in the 128x256 / 256x128 tiles)
     constexpr int P_RPI = 1024 / C::PROW, P_CPR = C::PROW / 16, Q_RPI = 1024 / C::QROW, Q_CPR = C::QROW / 16;
     constexpr int OOB = 0x7fffffff;
@@ -488,13 +489,13 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
     int vd[P_PW], vx[Q_PW], rowl[Q_PW];
 #pragma unroll
     for (int i = 0; i < P_PW; ++i) {
-        const int row = (i * 4 + wid) * P_RPI + lane / P_CPR;
+        const int row = (i * NW + wid) * P_RPI + lane / P_CPR;
         const int lc = (lane % P_CPR) ^ wswz<RT>(row);
         vd[i] = (r0 + lc * 8 < p.Co) ? (row * p.Co + r0 + lc * 8) * 2 : OOB;
     }
 #pragma unroll
     for (int i = 0; i < Q_PW; ++i) {
-        const int row = (i * 4 + wid) * Q_RPI + lane / Q_CPR;
+        const int row = (i * NW + wid) * Q_RPI + lane / Q_CPR;
         const int lc = (lane % Q_CPR) ^ wswz<CT>(row);
         rowl[i] = row;
         vx[i] = (c0 + lc * 8 < p.Ci) ? (row * p.Ci + c0 + lc * 8) * 2 : OOB;
@@ -510,7 +511,7 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
 #pragma unroll
         for (int i = 0; i < (P_PW > Q_PW ? P_PW : Q_PW); ++i) {
             if (i < P_PW)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(P + (i * 4 + wid) * 1024), 16, vd[i < P_PW ? i : 0], sd, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(P + (i * NW + wid) * 1024), 16, vd[i < P_PW ? i : 0], sd, 0, 0);
             if (i < Q_PW) {
                 int ox = vx[i < Q_PW ? i : 0];
                 if (!center) {
@@ -519,7 +520,7 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
                     const bool ok = (unsigned)(ii + tp.dy) < (unsigned)p.Hi && (unsigned)(jj + tp.dx) < (unsigned)p.Wi;
                     ox = ok ? ox : OOB;
                 }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Q + (i * 4 + wid) * 1024), 16, ox, sx, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Q + (i * NW + wid) * 1024), 16, ox, sx, 0, 0);
             }
         }
     };
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
 // 128x256 / 256x128 tiles (64x128 / 128x64 per wave: 25 % fewer LDS bytes, filled and read, per FLOP than 64x64 per wave), fast
 // geometry only, 32-pixel stages (24 KB per stage); 2 work-groups per CU (192 accumulator + operand registers).
 template <int RT, int CT, int WR, int WC, int NS, int PX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_big_kernel(const WgParams p) {
+__global__ __launch_bounds__(64 * WR * WC) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_big_kernel(const WgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t gxy = gridDim.x * gridDim.y;
     const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
@@ -826,7 +827,7 @@ int launch_wbig(WgParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)wgrad_big_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     });
     dim3 grid(p.r_tiles * p.c_tiles, p.total_taps, p.ksplit);
-    hipLaunchKernelGGL((wgrad_big_kernel<RT, CT, WR, WC, NS, PX>), grid, dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((wgrad_big_kernel<RT, CT, WR, WC, NS, PX>), grid, dim3(64 * WR * WC), C::LDS_BYTES, stream, p);
     return udapose_check_launch();
 }
 
@@ -836,7 +837,7 @@ int launch_wbig(WgParams& p, hipStream_t stream) {
 // (problem, split) units to XCDs by load, so the tiles that re-read one pixel range share an L2.  The table holds byte
 // OFFSETS in its x / dy / dw fields, relative to the three bases passed per launch, so one table serves every pass.
 template <int RT, int CT, int WR, int WC, int NS, int PX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 128 * 128 ? 2 : 4))) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
                                                               const uint32_t per_xcd, const char* x_base, const char* dy_base, char* dw_base,
                                                               const WgParams* __restrict__ tab2, const WgGroupBlk* __restrict__ blk2,
                                                               const char* x_base2, const char* dy_base2, char* dw_base2) {
@@ -857,9 +858,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void w
     if constexpr (RT == 64 && CT == 64 && PX == 64) {
         if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base); return; }
     }
+    if constexpr (RT != CT) {
+        // (the 256x128 class holds fast-geometry layers only: wgrad_group_plan)
+        wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    } else {
     if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
     else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
     else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    }
 }
 
 template <int RT, int CT, int WR, int WC, int NS, int PX>
@@ -944,8 +950,8 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
-    static const int RT[6] = {128, 64, 64, 32, 128, 256}, CT[6] = {128, 64, 32, 128, 256, 128};
-    if (tile < 0 || tile > 5) return UDAPOSE_ERR_ARG;
+    static const int RT[7] = {128, 64, 64, 32, 128, 256, 256}, CT[7] = {128, 64, 32, 128, 256, 128, 256};
+    if (tile < 0 || tile > 6) return UDAPOSE_ERR_ARG;
     // measured (tools/tune_conv.py, LDS-DMA kernels): 128x128 tiles for multi-tap convs with >= 128 channels on both sides
     // (3x3 trunk convs, 4x4 deconvs), 64x64 otherwise
     if (tile == 1 && pol.wgrad_tile < 0 && Rdim >= 128 && Cdim >= 128 && p.total_taps >= 9) tile = 0;
@@ -956,7 +962,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     }
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
-    const bool big = tile == 4 || tile == 5;                  // (tuning ids: 128x256 / 256x128 tiles, fast geometry, 32-pixel stages)
+    const bool big = tile >= 4;                               // (tuning ids: 128x256 / 256x128 / 256x256 tiles, fast geometry)
     const bool dma = !smallc && (tile == 0 || tile == 1) && (p.Ci % 64 == 0) && (p.Co % 64 == 0);
     const int ms_total = dma ? (p.M + 63) / 64 : (p.M + 31) / 32;
     // split the pixel reduction until ~512 work-groups exist (2 per CU), keeping >= 16 (128x128) / 4 (64x64) stages per
@@ -976,6 +982,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     if ((p.flags & WG_FLAG_FASTGEO) && !(p.flags & WG_FLAG_ROW3) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0) p.flags |= WG_FLAG_FAST2; else p.flags &= ~WG_FLAG_FAST2;
     if (big) {
         if (smallc || swap || p.Ci % 64 || p.Co % 64) return UDAPOSE_ERR_UNSUPPORTED;
+        if (tile == 6) return launch_wbig<256, 256, 2, 4, 2, 64>(p, stream);      // 8 waves, 128x64 per wave, 64-pixel stages: 128 KB of LDS
         return tile == 4 ? launch_wbig<128, 256, 2, 2, 3, 32>(p, stream) : launch_wbig<256, 128, 2, 2, 3, 32>(p, stream);
     }
     if (dma) return tile == 0 ? launch_wd<128, 128, 2, 2, 2>(p, stream) : launch_wd<64, 64, 2, 2, 4>(p, stream);
@@ -999,14 +1006,19 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
     // inside a group the other layers fill the chip, so a layer takes the 128x128 tile (half the L2->LDS bytes per FLOP of
     // 64x64) whenever both of its dimensions allow
     int tile = (Rdim >= 128 && Cdim >= 128) ? 0 : 1;
-    if (wg_row3_ok(p, pol)) {       // filter-row form: 64x64 tiles, one work-group per (tile, filter row)
+    // 256x128 tiles (128x64 per wave, 25 % fewer LDS bytes per FLOP: +16-19 % per layer against 128x128, +40-55 % against the filter-row
+    // form on layer3 / layer4's 3x3 convolutions, profiles/r3_ab_runs.txt) for the second fast-geometry loader's layers
+    const bool big = pol.wgrad_big && !smallc && !swap && wg_fastgeo_ok(p, pol) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0 && p.Co % 256 == 0 &&
+                     p.Ci % 128 == 0;
+    if (big) tile = 2;
+    else if (wg_row3_ok(p, pol)) {       // filter-row form: 64x64 tiles, one work-group per (tile, filter row)
         tile = 1;
         p.flags |= WG_FLAG_ROW3;
         p.total_taps = 3;
     }
-    const int T = tile == 0 ? 128 : 64;
-    p.r_tiles = (Rdim + T - 1) / T;
-    p.c_tiles = (Cdim + T - 1) / T;
+    const int TRr = tile == 2 ? 256 : (tile == 0 ? 128 : 64), TCc = tile == 1 ? 64 : 128;
+    p.r_tiles = (Rdim + TRr - 1) / TRr;
+    p.c_tiles = (Cdim + TCc - 1) / TCc;
     const int ms_total = (p.M + 63) / 64;
     int ks = (ms_total + stages_per_block / 2) / stages_per_block;
     if (ks < 1) ks = 1;
@@ -1026,6 +1038,7 @@ int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, cons
     // 64-pixel stages) and a 2-stage ring of 64-pixel stages for the 64x64 tile (35 KB with the filter-row form's reserve: four per
     // CU; round 1 ran three stages = three per CU, with the buffer-load loader two measure -4.5 % alone and -0.05 ms in the step):
     // occupancy beats prefetch depth here as in the igemm (a 3-stage ring for the 128x128 tile: +40 % alone)
+    if (tile == 2) return launch_wd_group<256, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
     if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
     return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
 }
