@@ -37,11 +37,11 @@ FWD_GFLOP_PER_IMAGE = 24.165       # PoseResNet-101, K=16, 256x256 forward (SURV
 
 
 def measured_traffic_per_igemm_launch():
-    """HBM bytes per igemm launch from the committed PMC passes (profiles/r2_pmc_hbm_traffic.txt: separate
+    """HBM bytes per igemm launch from the committed PMC passes (profiles/r3_pmc_hbm_traffic.txt: separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this benchmark; FETCH_SIZE doubled per the gfx950 note)."""
     try:
         import ast
-        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.txt")).read().strip())
+        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.txt")).read().strip())
         n, f = d["fetch"]["igemm"]
         _, w = d["write"]["igemm"]
         return (2.0 * f + w) * 1024.0 / n
@@ -49,12 +49,12 @@ def measured_traffic_per_igemm_launch():
         return None
 
 
-def measured_traffic_per_step(eager_steps=6):
+def measured_traffic_per_step(eager_steps=9):
     """HBM bytes per step of the three kernel families (igemm, BatchNorm, weight gradients) from the same committed PMC passes
-    (6 eager steps in the profiled run): what the whole step moves, next to the per-launch figure of the dominant kernel."""
+    (9 eager steps in the profiled run: `--eager --steps 3 --warmup 1` = 1 + 3 timed + 3 synchronised-loop + 2 roofline steps): what the whole step moves, next to the per-launch figure of the dominant kernel."""
     try:
         import ast
-        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.txt")).read().strip())
+        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.txt")).read().strip())
         return {fam: (2.0 * d["fetch"][fam][1] + d["write"][fam][1]) * 1024.0 / eager_steps for fam in ("igemm", "bn", "wgrad")}
     except Exception:
         return None
@@ -418,7 +418,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic_per_igemm_launch(),
                          "traffic_note": "HBM bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                         "(profiles/r2_pmc_hbm_traffic.txt), not collected live",
+                                         "(profiles/r3_pmc_hbm_traffic.txt), not collected live",
                          "launches_per_step": int(ig_l), "avg_launch_us": round(ig_ms * 1e3 / max(ig_l, 1), 2),
                          "flops_per_launch_avg": ig_fl / max(ig_l, 1), "kernel_ms_per_step": round(ig_ms, 3),
                          "wgrad": {"launches_per_step": int(wl), "kernel_ms_per_step": round(ms_w, 3),

@@ -804,6 +804,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     }
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!GA->per_xcd[t]) continue;
+        if (n.policy.exp0 & (1 << t)) continue;          // (tuning: skip this tile class - timing experiments only)
         const int tok = conv_prof_before(s, 2, GA->flops[t] + GB->flops[t]);
         const int rc = wgrad_group_launch(s, t, GA->d_tab[t], GA->d_blk[t], GA->per_xcd[t], actA, wsA, gradsA[0], GB->d_tab[t], GB->d_blk[t], actB, wsB,
                                           gradsB[0]);
