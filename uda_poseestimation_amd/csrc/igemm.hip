@@ -80,7 +80,7 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, bool RS, bool BS =
 // SP (with T = float as the 4-byte stride type): the operands are f16x2 split tensors (common.h) - the loaders are the fp32 ones
 // byte for byte, the fragments of a 32-channel stage are the row's chunk pairs (2q, 2q+1) = (h, l) of lane group q, and a stage is
 // three fp16 MFMAs per fragment pair into two accumulator sets (h.h | h.l + l.h, the second scaled by 2^-11 at the end).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BS || H3 == 1 || H3 == 2 || SP) ? 3 : 4))) void igemm_kernel(const IgParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN >= 128 * 128 ? 2 : ((BS || H3 == 1 || H3 == 2 || SP) ? 3 : 4)))) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
     // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.
