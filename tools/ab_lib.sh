@@ -3,6 +3,8 @@
 R="${1:-2}"; S="${2:-60}"
 L=uda_poseestimation_amd/libudapose_hip.so
 cp $L /tmp/lib_keep.so
+# the production library is restored however the script ends (interrupt, timeout kill, failed cp)
+trap 'cp /tmp/lib_keep.so $L' EXIT
 for i in $(seq 1 $R); do
   for tag in old new; do
     cp tools/_ab/lib$tag.so $L
