@@ -179,3 +179,7 @@ def test_style_net_f16x2_matches_reference_golden(golden_dir):
         g_a = net(content, style, torch.tensor([float(z["alpha"])], device="cuda"))[2]
     assert torch.allclose(g_c, torch.maximum(torch.minimum(g.permute(0, 2, 3, 1), hi), lo).permute(0, 3, 1, 2), atol=1e-6)
     assert torch.equal(g_a, g)
+    # encode once, transfer twice (what the engine does when both style directions are drawn): bit-identical to forward()
+    f_c, f_s = net.encode_features(content), net.encode_features(style)
+    assert torch.equal(net.transfer_from_features(f_c, f_s, float(z["alpha"])), g)
+    assert torch.equal(net.transfer_from_features(f_s, f_c, 0.3, clamp=(lo, hi)), net(style, content, 0.3, clamp=(lo, hi))[2])

@@ -288,7 +288,19 @@ class MeanTeacherTrainer:
         """Bidirectional style transfer of the step's inputs (train_human.py:345-358), both from the ORIGINAL images."""
         a_s2t, a_t2s = self.draw_style_decisions()
         x_s_ori, x_t_teas_ori = x_s, list(x_t_teas)
+        net = getattr(self.style_net, "module", self.style_net)          # (a single-device DataParallel wrap, as in the reference)
         with torch.no_grad():
+            if hasattr(net, "encode_features") and not getattr(net, "compute_losses", False):
+                # both directions transfer between the same batches: every image is encoded ONCE (the reference's two
+                # style_net(...) calls encode x_s and x_t twice each; same kernels, same inputs - bit-identical results)
+                if a_s2t is not None or a_t2s is not None:
+                    f_s = net.encode_features(x_s_ori)
+                    f_ts = [net.encode_features(x_t) for x_t in (x_t_teas_ori if a_t2s is not None else x_t_teas_ori[:1])]
+                if a_s2t is not None:
+                    x_s = net.transfer_from_features(f_s, f_ts[0], a_s2t, clamp=self.recover)
+                if a_t2s is not None:
+                    x_t_teas = [net.transfer_from_features(f_t, f_s, a_t2s, clamp=self.recover) for f_t in f_ts]
+                return x_s, x_t_teas
             if a_s2t is not None:
                 x_s = self.style_net(x_s_ori, x_t_teas_ori[0], a_s2t, clamp=self.recover)[2]
             if a_t2s is not None:
@@ -536,6 +548,7 @@ class GraphedTrainStep:
         self._cap = {"stream": torch.cuda.Stream(device=dev, priority=trainer.stream_priority)} if trainer.stream_priority else {}
         with torch.cuda.stream(side):
             if self.styled:             # (the style net's plans and packs; no model state involved)
+                self._style_pass("enc")
                 self._style_pass("s2t")
                 self._style_pass("t2s")
             for _ in range(warmup):     # REAL steps (same host draws as step()): fill the plan / table caches, allocator steady state
@@ -549,9 +562,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         style_mode = "thread_local" if _dist_on() else "global"
         if self.styled:
-            for which in ("s2t", "t2s"):
+            for which in ("enc", "s2t", "t2s"):
                 g = torch.cuda.CUDAGraph()
-                pool = {} if not self.g_style else {"pool": self.g_style["s2t"].pool()}
+                pool = {} if not self.g_style else {"pool": self.g_style["enc"].pool()}
                 with torch.cuda.graph(g, capture_error_mode=style_mode, **pool):
                     self._style_pass(which)
                 self.g_style[which] = g
@@ -645,13 +658,21 @@ class GraphedTrainStep:
         warp.thetas_from_packed(st["aug"][1], r, fwd=st["theta_tea"])
 
     def _style_pass(self, which):
-        """One direction of the style transfer, from the ORIGINAL images into the main graph's input buffer."""
+        """"enc": relu4_1 of both ORIGINAL batches into static feature buffers (each image is encoded once per step, whichever
+        directions are drawn); "s2t" / "t2s": AdaIN + decoder of one direction from those features into the main graph's input buffer."""
         st, t = self.static, self.t
+        net = getattr(t.style_net, "module", t.style_net)
         with torch.no_grad():
-            if which == "s2t":
-                st["x_s_in"].copy_(t.style_net(st["x_s"], st["x_t_tea"], st["alpha_s2t"], clamp=t.recover)[2])
+            if which == "enc":
+                f_s, f_t = net.encode_features(st["x_s"]), net.encode_features(st["x_t_tea"])
+                if "f_s" not in st:
+                    st["f_s"], st["f_t"] = torch.empty_like(f_s), torch.empty_like(f_t)
+                st["f_s"].copy_(f_s)
+                st["f_t"].copy_(f_t)
+            elif which == "s2t":
+                st["x_s_in"].copy_(net.transfer_from_features(st["f_s"], st["f_t"], st["alpha_s2t"], clamp=t.recover))
             else:
-                st["x_t_tea_in"].copy_(t.style_net(st["x_t_tea"], st["x_s"], st["alpha_t2s"], clamp=t.recover)[2])
+                st["x_t_tea_in"].copy_(net.transfer_from_features(st["f_t"], st["f_s"], st["alpha_t2s"], clamp=t.recover))
 
     def _draw_and_style(self):
         """The step's host draws, in the eager step's (= the reference's) order, and what follows from them: each style
@@ -659,7 +680,13 @@ class GraphedTrainStep:
         images; the occlusion's uniform numbers go to the device."""
         st = self.static
         if self.styled:
-            for which, a, src in zip(("s2t", "t2s"), self.t.draw_style_decisions(), (("x_s_in", "x_s"), ("x_t_tea_in", "x_t_tea"))):
+            decisions = self.t.draw_style_decisions()
+            if any(a is not None for a in decisions):
+                if "enc" in self.g_style:
+                    self.g_style["enc"].replay()
+                else:
+                    self._style_pass("enc")
+            for which, a, src in zip(("s2t", "t2s"), decisions, (("x_s_in", "x_s"), ("x_t_tea_in", "x_t_tea"))):
                 if a is not None:
                     st["alpha_" + which].fill_(float(a))
                     if which in self.g_style:

@@ -279,6 +279,24 @@ class Net(nn.Module):
         assert (target.requires_grad is False)
         return _mse(gram_matrix(input), gram_matrix(target))
 
+    # ---- the two halves of forward(), for callers that transfer in BOTH directions between the same two batches (the loop's s2t and
+    # t2s passes, train_human.py:347-356, encode x_s and x_t twice each): encode once, transfer twice - same kernels on the same
+    # inputs, so the results are bit-identical to two forward() calls
+    def encode_features(self, img):
+        """relu4_1 of `img` as the internal NHWC tensor of this network's precision (input of transfer_from_features)."""
+        with torch.no_grad():
+            return self._enc.run(self._image_in(img))
+
+    def transfer_from_features(self, content_feat, style_feat, alpha=1.0, clamp=None):
+        """g_t (NCHW fp32) of forward(content, style, alpha, clamp)[2] from the two images' encode_features()."""
+        if not torch.is_tensor(alpha):
+            assert 0 <= alpha <= 1
+        with torch.no_grad():
+            t = ops.adain(content_feat, style_feat, alpha=alpha if torch.is_tensor(alpha) else float(alpha))
+            g = self._dec.run(t, final_f32=True)
+            lo, hi = (None, None) if clamp is None else (clamp[0].float().contiguous(), clamp[1].float().contiguous())
+            return ops.to_nchw_f32(g, 3, lo, hi)
+
     def forward(self, content, style, alpha=1.0, clamp=None):
         """-> (loss_c, loss_s, g_t) (Style_net.py:163-177).  `clamp=(lo[3], hi[3])` fuses the loop's recover clamp
         (train_human.py:351) into the output conversion (the losses, when computed, see the unclamped g_t like the reference).
