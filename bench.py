@@ -134,8 +134,9 @@ def main():
     ap.add_argument("--sigma", type=float, default=2, help="label / rectify sigma (configs[4]: 1.0)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="storage / MFMA element type: bf16 = the metric; fp16 = the "
                     "reference's autocast dtype (BASELINE.json configs[4]), with GradScaler-style loss scaling kept on the device")
-    ap.add_argument("--precision", default=None, choices=["reference"], help="not the metric: 'reference' = the reference's own precision mix "
-                    "(train_human.py:346-358,414): student fp16 + device-side GradScaler, teacher and style network in the fp32-grade f16x2 mode")
+    ap.add_argument("--precision", default=None, choices=["reference", "reference_fp32"], help="not the metric: 'reference' = the reference's own precision mix "
+                    "(train_human.py:346-358,414): student fp16 + device-side GradScaler, teacher and style network in the fp32-grade f16x2 mode; "
+                    "'reference_fp32' = the same with the exact-fp32 MFMA forms for the teacher and the style network (A/B of the f16x2 mode)")
     ap.add_argument("--strong", action="store_true", help="not the metric: strong scaling, global batch fixed at --batch (what the reference's "
                     "nn.DataParallel does): every rank takes batch / world images per domain")
     ap.add_argument("--config2", action="store_true", help="not the metric: BASELINE.json configs[2] = the same step + AdaIN s2t / t2s style "
@@ -214,7 +215,7 @@ def main():
     from uda_poseestimation_amd import _hip, synthetic
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
     import uda_poseestimation_amd.lib.models as models
-    if args.precision == "reference":
+    if args.precision in ("reference", "reference_fp32"):
         args.dtype = "fp16"                # (the student's element type: the library the roofline sample's profiler hooks live in)
     lib = _hip.lib(args.dtype)
     # tuning flags -> explicit dispatch policy of both networks' executor plans (udapose_policy; empty = production policy)
@@ -290,7 +291,9 @@ def main():
 
         def step():
             if host is None:
-                return graphed.step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+                # inputs resident in HBM: the captured step's static input buffers ARE the resident batch (handing over other device
+                # tensors would add five device-to-device copies, 84 MB, per step); the aug_param values are staged every step
+                return graphed.step(None, None, None, None, None, g["aug_param_stu"], g["aug_param_tea"])
             # host batches: this step consumes the batch staged during the previous one, and the next batch's H2D copies
             # are started on the copy stream so that they run under this step's replay
             if not graphed._have_staged:
@@ -397,15 +400,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "ms_per_step_synced": round(ms_synced, 3) if ms_synced is not None else None,
             "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "dtype": "fp16 (student) + f16x2 fp32-grade (teacher, style)" if args.precision == "reference" else args.dtype, "data": "synthetic",
+            "dtype": ("fp16 (student) + f16x2 fp32-grade (teacher, style)" if args.precision == "reference" else
+                      ("fp16 (student) + exact fp32 MFMA (teacher, style)" if args.precision == "reference_fp32" else args.dtype)), "data": "synthetic",
             "config": {"workload": f"{args.arch} K={K} mean-teacher step (student fwd+bwd on 2x{N}, teacher fwd on {N}, JointsMSE+Cons, "
                                    f"Adam, EMA), {S}x{S}, b={N}/GPU, " + ("AdaIN s2t + t2s style passes and adaptive occlusion (BASELINE.json configs[2]; NOT the metric)" if args.config2 else "no AdaIN" + (" (BASELINE.json configs[1])" if (S, K, N, args.arch, args.dtype) == (256, 16, 32, "pose_resnet101", "bf16") else
                                                     (f", K={K}, {args.dtype} (BASELINE.json configs[4] shape and dtype on one GPU; NOT the metric)"
                                                      if (S, K, args.arch, args.dtype) == (384, 18, "pose_resnet101", "fp16") else f", K={K}, {args.dtype}"))),
                        "global_batch": world * N, "parallelism": f"dp{world}",
                        **({"precision": "reference mix (train_human.py:346-358,414): student fp16 + device-side GradScaler, teacher"
-                                        + (", style network" if args.config2 else "") + " in the fp32-grade f16x2 mode; NOT the metric"}
-                          if args.precision == "reference" else {})},
+                                        + (", style network" if args.config2 else "") + (" in the fp32-grade f16x2 mode" if args.precision == "reference" else
+                                                                                          " in the exact-fp32 MFMA mode") + "; NOT the metric"}
+                          if args.precision else {})},
             "loss": loss, "launch": "eager" if args.eager else ("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else ("1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs")) + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "grad_comm": args.grad_comm if dist.is_initialized() else None,

@@ -176,10 +176,14 @@ class MeanTeacherTrainer:
         #   in fp32 - here the fp32-grade 'f16x2' mode (three fp16 MFMAs per K step; heat-maps within ~4e-5 of the fp32 oracle).
         # 'bf16' / 'fp16': student AND teacher in that 16-bit type (BASELINE.json's benched configuration is 'bf16'; the style
         #   network keeps its own setting).
-        if precision == "reference":
-            student.precision, teacher.precision = "fp16", "f16x2"
-            if style_net is not None and hasattr(style_net, "precision"):
-                style_net.precision = "f16x2"
+        if precision in ("reference", "reference_fp32"):
+            # ('reference_fp32': the same mix with the EXACT fp32 MFMA forms for the teacher and the style network - the slow way to the
+            # same numbers, kept for A/B timing of the f16x2 mode)
+            hi = "f16x2" if precision == "reference" else "fp32"
+            student.precision, teacher.precision = "fp16", hi
+            sn = getattr(style_net, "module", style_net)
+            if sn is not None and hasattr(sn, "precision"):
+                sn.precision = hi
         elif precision is not None:
             student.precision = precision
             teacher.precision = precision
