@@ -377,6 +377,13 @@ int udapose_aug_color_op(void* stream, unsigned char* img, const int* op, const 
  * the scratch buffer tmp (same size): three box-blur passes per direction in PIL's 8.24 fixed point, bit-exact.  prm[n] = (r, ww, fw)
  * as uint32 (box radius integer part, centre and far weights: data_gpu.pil_box_blur_params), r = 0xffffffff: sample n is left as is. */
 int udapose_aug_gaussian_blur_u8(void* stream, unsigned char* img, unsigned char* tmp, const unsigned int* prm, int N, int H, int W);
+/* T.RandomResizedCrop's image side (lib/transforms/keypoint_detection.py:456-521 -> resized_crop :66-88 = F.crop + F.resize(BILINEAR) on a
+ * PIL image): src [N][Hs][Ws][3] uint8 -> dst [N][S][S][3] uint8, sample n's crop box[n] = (top, left, h, w) resampled to S x S with PIL's
+ * two-pass 8-bit resampler (libImaging Resample.c: horizontal pass into the uint8 intermediate tmp [N][Hs][S][3], then vertical; 22-bit
+ * fixed-point coefficients), bit-exact.  bounds [N][2][S][2] int32 = (first source index, tap count) per output column (axis 0) / row
+ * (axis 1), coef [N][2][S][ksize] int32: prepared on the host in double as PIL does (data_gpu.pil_resample_coeffs). */
+int udapose_aug_resized_crop_u8(void* stream, const unsigned char* src, unsigned char* dst, unsigned char* tmp, const int* box, const int* bounds,
+                                const int* coef, int N, int Hs, int Ws, int S, int ksize);
 int udapose_aug_to_tensor(void* stream, const unsigned char* img, float* out, int N, int HW, const float* mean3, const float* std3);
 int udapose_gaussian_labels(void* stream, const double* kp, const float* vis, float* target, float* weight, int R, int Hh, int Wh,
                             double stride_x, double stride_y, const float* patch, int rad);

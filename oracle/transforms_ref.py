@@ -4,6 +4,8 @@
                            PIL Image.transform(size, AFFINE, inverse matrix, NEAREST) + the key-point algebra + aug_param
   * color_jitter_ref    <- T.ColorJitter (train_human.py:68,75) on a PIL image = PIL.ImageEnhance Brightness / Contrast / Color
                            applied in the given order
+  * resized_crop_ref    <- T.RandomResizedCrop's transform (lib/transforms/keypoint_detection.py:59-88,507-521): PIL crop + PIL
+                           Image.resize(BILINEAR) + the key-point shift / scale
   * gaussian_blur_ref   <- T.GaussianBlur (lib/transforms/keypoint_detection.py:216-225) = PIL.ImageFilter.GaussianBlur(radius)
   * to_tensor_normalize_ref <- T.ToTensor + T.Normalize (train_human.py:52,70-71)
   * generate_target_ref lives in mean_teacher_ref.py (lib/datasets/util.py:12-70)
@@ -73,6 +75,23 @@ def color_jitter_ref(img_u8, ops, factors):
         if o:
             im = enh[o](im).enhance(f)
     return np.array(im)
+
+
+def resized_crop_ref(img_u8, kp, top, left, h, w, size):
+    """lib/transforms/keypoint_detection.py:66-88: crop (:59-64: F.crop = Image.crop((left, top, left + w, top + h)), key points shifted)
+    then resize (:39-57: asserts a square image, F.resize(image, size, BILINEAR) = Image.resize((size, size), BILINEAR), key points
+    scaled by size / width)."""
+    img = Image.fromarray(np.ascontiguousarray(img_u8)).crop((left, top, left + w, top + h))
+    kp = np.copy(kp).astype(np.float64)
+    kp[:, 0] -= left
+    kp[:, 1] -= top
+    width, height = img.size
+    assert width == height
+    factor = float(size) / float(width)
+    if width != size:
+        img = img.resize((size, size), Image.BILINEAR)
+    kp *= factor
+    return np.asarray(img), kp
 
 
 def gaussian_blur_ref(img_u8, radius):

@@ -133,3 +133,55 @@ def test_gaussian_blur_bit_exact_with_pil():
         w_ref = R.affine_view_ref(base[i], kps[i], *params[i])[0]
         t_ref = R.to_tensor_normalize_ref(R.gaussian_blur_ref(R.color_jitter_ref(w_ref, *jit[i]), blur[i]), D.IMAGENET_MEAN, D.IMAGENET_STD)
         assert torch.equal(x[i].cpu(), t_ref), f"blurred view {i} differs from PIL"
+
+
+def test_resized_crop_bit_exact_with_pil():
+    """T.RandomResizedCrop (train_human.py:55,64; lib/transforms/keypoint_detection.py:456-521): crop + PIL bilinear resize on the device,
+    byte for byte with PIL, at the `_mt` datasets' sizes (512x512 crops -> 256x256; the reference's scale range gives reductions by up
+    to 2x, where PIL widens the filter) and at small odd sizes incl. enlargement and the identity; key points shifted and scaled; and
+    the whole pipeline from raw images (`raw=True`) against the oracle chain."""
+    from oracle import transforms_ref as R
+    from uda_poseestimation_amd import data_gpu as D
+    rs = np.random.RandomState(8)
+    # (1) the real sizes, boxes drawn like the reference draws them
+    pipe = D.TargetViewPipeline(image_size=256, heatmap_size=64, sigma=2, rng=random.Random(2))
+    N, Hs, K = 6, 512, 16
+    raw = rs.randint(0, 256, (N, Hs, Hs, 3)).astype(np.uint8)
+    raw[:, 100:140, 200:300] = 255                       # (edges, so that the filter's support shows)
+    kps = rs.uniform(0, Hs, (N, K, 2))
+    boxes = [D.draw_resized_crop(random.Random(60 + i), Hs, Hs, (0.6, 1.3)) for i in range(N)]
+    boxes[0] = (0, 0, Hs, Hs)                            # the fall-back: whole image
+    boxes[1] = (256, 256, 256, 256)                      # the identity (PIL returns a copy)
+    assert len({b[2] for b in boxes}) >= 4
+    out, kp = pipe.resized_crop(torch.from_numpy(raw).cuda(), kps, boxes=boxes)
+    for i, (top, left, h, w) in enumerate(boxes):
+        ref, kref = R.resized_crop_ref(raw[i], kps[i], top, left, h, w, 256)
+        assert np.array_equal(out[i].cpu().numpy(), ref), f"box {boxes[i]}: {(out[i].cpu().numpy() != ref).sum()} bytes differ from PIL"
+        assert np.array_equal(kp[i], kref)
+    # (2) small sizes: reduction by 3.1x (ksize 9), enlargement, non-multiple sizes
+    pipe2 = D.TargetViewPipeline(image_size=31, heatmap_size=8, sigma=1, rng=random.Random(3))
+    raw2 = rs.randint(0, 256, (5, 97, 97, 3)).astype(np.uint8)
+    kps2 = rs.uniform(0, 97, (5, 3, 2))
+    boxes2 = [(0, 0, 97, 97), (1, 2, 95, 95), (40, 13, 17, 17), (66, 66, 31, 31), (10, 20, 50, 50)]
+    out2, kp2 = pipe2.resized_crop(torch.from_numpy(raw2).cuda(), kps2, boxes=boxes2)
+    for i, (top, left, h, w) in enumerate(boxes2):
+        ref, kref = R.resized_crop_ref(raw2[i], kps2[i], top, left, h, w, 31)
+        assert np.array_equal(out2[i].cpu().numpy(), ref), f"box {boxes2[i]}"
+        assert np.array_equal(kp2[i], kref)
+    with pytest.raises(ValueError):
+        pipe2.resized_crop(torch.from_numpy(raw2).cuda(), kps2, boxes=[(90, 0, 17, 17)] * 5)
+    # (3) the whole `_mt` sample from raw images: same RNG stream on both sides (crop draws first, then the views')
+    pipe3 = D.TargetViewPipeline(image_size=64, heatmap_size=16, sigma=2, k=1, rng=random.Random(77))
+    raw3 = rs.randint(0, 256, (3, 128, 128, 3)).astype(np.uint8)
+    kps3 = rs.uniform(20, 108, (3, K, 2))
+    x_s, t_s, w_s, meta, xs, ts, ws, metas = pipe3(torch.from_numpy(raw3).cuda(), kps3, raw=True)
+    r = random.Random(77)
+    boxes3 = [D.draw_resized_crop(r, 128, 128, (0.6, 1.3)) for _ in range(3)]
+    base = [R.resized_crop_ref(raw3[i], kps3[i], *boxes3[i], 64) for i in range(3)]
+    assert np.array_equal(meta["keypoint2d_ori"], np.stack([b[1] for b in base]))
+    prm = [pipe3.stu.draw_affine(r, (64, 64)) for _ in range(3)]
+    jit = [pipe3.stu.draw_jitter(r) for _ in range(3)]
+    for i in range(3):
+        w_ref = R.affine_view_ref(base[i][0], base[i][1], *prm[i])[0]
+        t_ref = R.to_tensor_normalize_ref(R.color_jitter_ref(w_ref, *jit[i]), D.IMAGENET_MEAN, D.IMAGENET_STD)
+        assert torch.equal(x_s[i].cpu(), t_ref), f"student view {i} from the raw image differs from the PIL chain"

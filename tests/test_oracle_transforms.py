@@ -89,3 +89,40 @@ def test_color_jitter_blend_semantics():
         assert np.array_equal(R.color_jitter_ref(img, [1], [f]), blend(np.zeros_like(img), img, f))
         assert np.array_equal(R.color_jitter_ref(img, [2], [f]), blend(np.full_like(img, mean), img, f))
         assert np.array_equal(R.color_jitter_ref(img, [3], [f]), blend(np.repeat(L[..., None], 3, -1).astype(np.uint8), img, f))
+
+
+def _emulate_resample(img, bounds, coef):
+    """the two passes of aug_resized_crop_u8 in numpy (what resample_u8_k computes), for a square crop `img`"""
+    def one(a):             # along axis 1
+        out = np.zeros((a.shape[0], bounds.shape[0], 3), np.uint8)
+        for o, (first, cnt) in enumerate(bounds):
+            s = (a[:, first:first + cnt].astype(np.int64) * coef[o, :cnt, None]).sum(1) + (1 << 21)
+            out[:, o] = np.clip(s >> 22, 0, 255)
+        return out
+    return one(one(img).transpose(1, 0, 2)).transpose(1, 0, 2)
+
+
+def test_resized_crop_host_tables_match_pil_bilinear_resize():
+    """data_gpu.pil_resample_coeffs (the tables the device kernel walks) against PIL's own Image.resize(BILINEAR): reductions (antialiased,
+    support > 1), enlargements, the identity; and the key-point algebra / parameter draws of RandomResizedCrop."""
+    rs = np.random.RandomState(11)
+    raw = rs.randint(0, 256, (96, 96, 3)).astype(np.uint8)
+    kp = rs.uniform(0, 96, (5, 2))
+    for (top, left, w) in ((0, 0, 96), (3, 7, 64), (10, 2, 75), (20, 30, 37), (0, 0, 64), (5, 5, 90)):
+        ref, kref = R.resized_crop_ref(raw, kp, top, left, w, w, 64)
+        bounds, coef, ksize = D.pil_resample_coeffs(w, 64)
+        assert ksize == int(math.ceil(max(w / 64.0, 1.0))) * 2 + 1
+        assert np.array_equal(_emulate_resample(raw[top:top + w, left:left + w], bounds, coef), ref), (top, left, w)
+        k2 = kp.copy(); k2[:, 0] -= left; k2[:, 1] -= top; k2 *= 64.0 / w
+        assert np.array_equal(k2, kref)
+    # RandomResizedCrop.get_params: uniform area, two randint corners, ten attempts, whole-image fallback
+    box = D.draw_resized_crop(random.Random(3), 512, 512, (0.6, 1.3))
+    r = random.Random(3)
+    exp = None
+    for _ in range(10):
+        side = int(round(math.sqrt(r.uniform(0.6, 1.3) * 512 * 512)))
+        if 0 < side <= 512:
+            exp = (r.randint(0, 512 - side), r.randint(0, 512 - side), side, side)
+            break
+    assert box == (exp or (0, 0, 512, 512))
+    assert D.draw_resized_crop(random.Random(0), 100, 100, (1.5, 2.0)) == (0, 0, 100, 100)

@@ -125,6 +125,7 @@ _SIGS = {
     "udapose_aug_color_op": (ci, [vp, vp, vp, vp, vp, ci, ci]),
     "udapose_aug_to_tensor": (ci, [vp, vp, vp, ci, ci, vp, vp]),
     "udapose_aug_gaussian_blur_u8": (ci, [vp, vp, vp, vp, ci, ci, ci]),
+    "udapose_aug_resized_crop_u8": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     "udapose_gaussian_labels": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cd, cd, vp, ci]),
     "udapose_prof_begin": (None, []),
     "udapose_prof_end": (ci, [vp]),

@@ -158,7 +158,58 @@ __global__ void box_blur_u8_k(const unsigned char* __restrict__ src, unsigned ch
         di[(size_t)i * 3 + 2] = (unsigned char)((b2 + (1u << 23)) >> 24);
     }
 }
+
+// PIL's Image.resize(BILINEAR) of a crop (T.RandomResizedCrop, lib/transforms/keypoint_detection.py:456-521 -> resized_crop :66-88 ->
+// F.crop + F.resize; libImaging Resample.c): a separable convolution whose support grows with the reduction factor, in two passes -
+// horizontal into a uint8 intermediate, then vertical - each  out = clip8((2^21 + sum_k in[min + k] * coef[k]) >> 22)  with the
+// coefficients normalised in double and rounded to 22 fractional bits on the host (data_gpu.pil_resample_coeffs restates
+// `precompute_coeffs` / `normalize_coeffs_8bpc`).  bounds[n][axis][o] = (first source index, tap count), coef[n][axis][o][ksize].
+__device__ __forceinline__ unsigned char clip8_22(int v) {
+    v >>= 22;
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+// pass 0: tmp[n][r][x] (r < box h, x < S) from src[n][top + r][left + ...];  pass 1: dst[n][y][x] (y, x < S) from tmp[n][...][x]
+__global__ void resample_u8_k(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, const int* __restrict__ box,
+                              const int* __restrict__ bounds, const int* __restrict__ coef, int in_h, int in_w, int out_hmax, int S, int ksize,
+                              int vertical) {
+    const int n = blockIdx.y;
+    const int top = box[n * 4], left = box[n * 4 + 1], bh = box[n * 4 + 2];
+    const int rows = vertical ? S : bh;
+    const unsigned char* src = in + (size_t)n * in_h * in_w * 3;
+    unsigned char* dst = out + (size_t)n * out_hmax * S * 3;
+    const int* bnd = bounds + (size_t)(n * 2 + vertical) * S * 2;
+    const int* kk = coef + (size_t)(n * 2 + vertical) * S * ksize;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < rows * S; i += gridDim.x * TPB) {
+        const int y = i / S, x = i - y * S;
+        const int o = vertical ? y : x;
+        const int first = bnd[o * 2], cnt = bnd[o * 2 + 1];
+        const int* k = kk + (size_t)o * ksize;
+        // horizontal: walk along the source row (top + y) from column left + first; vertical: walk down column x of the intermediate
+        const unsigned char* p = vertical ? src + ((size_t)first * in_w + x) * 3 : src + ((size_t)(top + y) * in_w + left + first) * 3;
+        const size_t step = vertical ? (size_t)in_w * 3 : 3;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int t = 0; t < cnt; ++t, p += step) {
+            const int c = k[t];
+            s0 += p[0] * c; s1 += p[1] * c; s2 += p[2] * c;
+        }
+        unsigned char* q = dst + (size_t)i * 3;
+        q[0] = clip8_22(s0); q[1] = clip8_22(s1); q[2] = clip8_22(s2);
+    }
+}
 }  // namespace
+
+// src [N][Hs][Ws][3] uint8 -> dst [N][S][S][3] uint8: crop box[n] = (top, left, h, w) resized to S x S; tmp [N][Hs][S][3] uint8
+int aug_resized_crop_u8(hipStream_t s, const unsigned char* src, unsigned char* dst, unsigned char* tmp, const int* box, const int* bounds,
+                        const int* coef, int N, int Hs, int Ws, int S, int ksize) {
+    if (N <= 0 || Hs <= 0 || Ws <= 0 || S <= 0 || ksize <= 0) return UDAPOSE_ERR_ARG;
+    int gx = (Hs * S + TPB - 1) / TPB;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(resample_u8_k, dim3(gx, N), dim3(TPB), 0, s, src, tmp, box, bounds, coef, Hs, Ws, Hs, S, ksize, 0);
+    gx = (S * S + TPB - 1) / TPB;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(resample_u8_k, dim3(gx, N), dim3(TPB), 0, s, (const unsigned char*)tmp, dst, box, bounds, coef, Hs, S, S, S, ksize, 1);
+    return udapose_check_launch();
+}
 
 // img [N][H][W][3] uint8 is blurred IN PLACE through the scratch buffer tmp (same size): 3 passes along x, 3 along y
 int aug_gaussian_blur_u8(hipStream_t s, unsigned char* img, unsigned char* tmp, const unsigned int* prm, int N, int H, int W) {

@@ -50,6 +50,7 @@ int adain_launch(hipStream_t, const elem_t*, const elem_t*, elem_t*, int, int, i
 int aug_affine_u8(hipStream_t, const unsigned char*, unsigned char*, const long long*, int, int, int);
 int aug_color_op(hipStream_t, unsigned char*, const int*, const float*, int*, int, int);
 int aug_gaussian_blur_u8(hipStream_t, unsigned char*, unsigned char*, const unsigned int*, int, int, int);
+int aug_resized_crop_u8(hipStream_t, const unsigned char*, unsigned char*, unsigned char*, const int*, const int*, const int*, int, int, int, int, int);
 int aug_to_tensor(hipStream_t, const unsigned char*, float*, int, int, const float*, const float*);
 int aug_gaussian_labels(hipStream_t, const double*, const float*, float*, float*, int, int, int, double, double, const float*, int);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
@@ -414,6 +415,11 @@ int udapose_aug_color_op(void* stream, unsigned char* img, const int* op, const 
 int udapose_aug_gaussian_blur_u8(void* stream, unsigned char* img, unsigned char* tmp, const unsigned int* prm, int N, int H, int W) {
     if (!img || !tmp || !prm) return UDAPOSE_ERR_ARG;
     return aug_gaussian_blur_u8(S(stream), img, tmp, prm, N, H, W);
+}
+int udapose_aug_resized_crop_u8(void* stream, const unsigned char* src, unsigned char* dst, unsigned char* tmp, const int* box, const int* bounds,
+                                const int* coef, int N, int Hs, int Ws, int S, int ksize) {
+    if (!src || !dst || !tmp || !box || !bounds || !coef) return UDAPOSE_ERR_ARG;
+    return aug_resized_crop_u8(S(stream), src, dst, tmp, box, bounds, coef, N, Hs, Ws, S, ksize);
 }
 int udapose_aug_to_tensor(void* stream, const unsigned char* img, float* out, int N, int HW, const float* mean3, const float* std3) {
     if (!img || !out || !mean3 || !std3) return UDAPOSE_ERR_ARG;

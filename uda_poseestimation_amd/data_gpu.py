@@ -3,12 +3,12 @@
 The reference feeds its loop from DataLoader workers (`--workers 1` by default, train_human.py:591) that run, per sample and
 per view, PIL / torchvision transforms on the host (train_human.py:63-78, lib/datasets/human36m_mt.py:76-161):
 
-    base crop (RandomResizedCrop, host)                                       -> image [H,W,3] uint8, keypoint2d [K,2]
+    base crop (RandomResizedCrop = F.crop + PIL bilinear F.resize)            -> image [H,W,3] uint8, keypoint2d [K,2]
     student view:  RandomAffineRotation -> ColorJitter -> GaussianBlur(high=0) -> ToTensor -> Normalize, generate_target
     teacher views: the same with the teacher's ranges, k times
 
-At ~1900 img/s that loader cannot keep up.  Here everything after the base crop runs on the device for the whole batch:
-the affine warp, the colour jitter, the tensor conversion and normalisation, and the Gaussian label maps are HIP kernels
+At ~1900 img/s that loader cannot keep up.  Here everything after the image decode runs on the device for the whole batch:
+the base crop + resize (round 3: PIL's two-pass 8-bit resampler), the affine warp, the colour jitter, the tensor conversion and normalisation, and the Gaussian label maps are HIP kernels
 (csrc/augment.hip) that reproduce PIL's integer arithmetic bit for bit; the random parameters (a few floats per sample) and
 the key-point algebra (K x 2 per sample) are drawn / computed on the host exactly as lib/transforms/keypoint_detection.py
 does, including the `aug_param` tuple that the loop consumes (inverse augmentation, :139).  The result has the collated
@@ -73,6 +73,60 @@ def pil_box_blur_params(radius, passes=3):
     return r, ww & 0xFFFFFFFF, fw & 0xFFFFFFFF
 
 
+def pil_resample_coeffs(in_size, out_size):
+    """PIL's BILINEAR resampling coefficients for one axis of Image.resize (libImaging Resample.c `precompute_coeffs` +
+    `normalize_coeffs_8bpc`; box = the whole input): -> (bounds [out,2] int32 = (first source index, tap count), coef [out,ksize] int32
+    with 22 fractional bits, ksize).  Python floats are C doubles, the statements follow the C source one by one."""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 1.0 * filterscale                   # bilinear_filter.support = 1.0
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    coef = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k, ww = [], 0.0
+        for x in range(xmax):
+            t = (x + xmin - center + 0.5) * ss
+            if t < 0.0:
+                t = -t
+            w = 1.0 - t if t < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        for x in range(xmax):
+            if ww != 0.0:
+                k[x] /= ww
+            v = k[x] * (1 << 22)
+            coef[xx, x] = int(-0.5 + v) if k[x] < 0 else int(0.5 + v)
+        bounds[xx] = (xmin, xmax)
+    return bounds, coef, ksize
+
+
+def draw_resized_crop(rng, width, height, scale=(0.6, 1.3)):
+    """RandomResizedCrop.get_params (lib/transforms/keypoint_detection.py:478-505): up to ten draws of a square crop of U(scale) x the
+    image area (aspect ratio 1), then its corner; the whole image if none fits.  Same draws in the same order from `rng` (the reference
+    uses the global `random` module).  -> (top, left, h, w)"""
+    area = height * width
+    for _ in range(10):
+        target_area = rng.uniform(*scale) * area
+        w = int(round(math.sqrt(target_area * 1)))
+        h = int(round(math.sqrt(target_area / 1)))
+        if 0 < w <= width and 0 < h <= height:
+            i = rng.randint(0, height - h)
+            j = rng.randint(0, width - w)
+            return i, j, h, w
+    return 0, 0, height, width
+
+
 def transform_keypoints(kp, angle, shear_x, shear_y, trans_x, trans_y, scale, width, height):
     """The key-point side of `affine` (lib/transforms/keypoint_detection.py:141-165): rotate / shear / scale about the image
     centre, then translate."""
@@ -134,12 +188,14 @@ class TargetViewPipeline:
     """Batched device pipeline for the `_mt` datasets' student / teacher views."""
 
     def __init__(self, image_size=256, heatmap_size=64, sigma=2, k=1, student=None, teacher=None, mean=IMAGENET_MEAN, std=IMAGENET_STD,
-                 rng=None):
+                 rng=None, resize_scale=(0.6, 1.3)):
         self.image_size, self.heatmap_size, self.sigma, self.k = int(image_size), int(heatmap_size), sigma, int(k)
         self.stu, self.tea = student or ViewConfig(), teacher or ViewConfig()
         self.mean, self.std = tuple(mean), tuple(std)
         self.rng = rng if rng is not None else random
+        self.resize_scale = tuple(resize_scale)          # `--resize-scale` (train_human.py:523)
         self._dev = {}
+        self._coef_cache = {}
 
     # ------------------------------------------------------------------ device constants
     def _consts(self, device):
@@ -170,6 +226,48 @@ class TargetViewPipeline:
         out = torch.empty_like(base_u8)
         check(lib().udapose_aug_affine_u8(_hip.stream(), ptr(base_u8), ptr(out), ptr(cdev), N, H, W), "aug_affine_u8")
         return out
+
+    def resized_crop(self, raw_u8, keypoints, boxes=None):
+        """T.RandomResizedCrop(size=image_size, scale=resize_scale) on the whole batch (train_human.py:55,64): raw_u8 [N,Hs,Ws,3] uint8 CUDA
+        (the decoded dataset images; the `_mt` datasets hold square crops, `resize` asserts it), keypoints [N,K,2] pixels;
+        boxes = per-sample (top, left, h, w), drawn like the reference when None -> (base_u8 [N,S,S,3], key points [N,K,2])."""
+        _hip.require_cuda(raw_u8)
+        N, Hs, Ws, C3 = raw_u8.shape
+        assert C3 == 3 and raw_u8.dtype == torch.uint8 and raw_u8.is_contiguous()
+        S = self.image_size
+        if boxes is None:
+            boxes = [draw_resized_crop(self.rng, Ws, Hs, self.resize_scale) for _ in range(N)]
+        tabs, ksize = [], 1
+        for (top, left, h, w) in boxes:
+            if not (0 <= top and 0 <= left and 0 < h and 0 < w and top + h <= Hs and left + w <= Ws):
+                raise ValueError(f"crop box {(top, left, h, w)} outside a {Hs}x{Ws} image")
+            if w != h:
+                raise AssertionError("resize() asserts width == height (lib/transforms/keypoint_detection.py:47)")
+            key = (w, S)
+            if key not in self._coef_cache:
+                self._coef_cache[key] = pil_resample_coeffs(w, S)
+            tabs.append(self._coef_cache[key])
+            ksize = max(ksize, tabs[-1][2])
+        bounds = np.zeros((N, 2, S, 2), np.int32)
+        coef = np.zeros((N, 2, S, ksize), np.int32)
+        for n, (b, c, ks) in enumerate(tabs):
+            bounds[n, 0] = bounds[n, 1] = b        # square crop to a square image: both axes share one table
+            coef[n, :, :, :ks] = c
+        dev = raw_u8.device
+        box_d = torch.tensor(boxes, dtype=torch.int32).to(dev, non_blocking=True)
+        bounds_d = torch.from_numpy(bounds).to(dev, non_blocking=True)
+        coef_d = torch.from_numpy(coef).to(dev, non_blocking=True)
+        tmp = torch.empty(N, Hs, S, 3, dtype=torch.uint8, device=dev)
+        out = torch.empty(N, S, S, 3, dtype=torch.uint8, device=dev)
+        check(lib().udapose_aug_resized_crop_u8(_hip.stream(), ptr(raw_u8), ptr(out), ptr(tmp), ptr(box_d), ptr(bounds_d), ptr(coef_d), N, Hs, Ws,
+                                                S, ksize), "aug_resized_crop_u8")
+        # key points: crop() shifts them, resize() scales them by size / width (keypoint_detection.py:47-49, 59-64)
+        kp = np.array(keypoints, dtype=np.float64, copy=True)
+        for n, (top, left, h, w) in enumerate(boxes):
+            kp[n, :, 0] -= left
+            kp[n, :, 1] -= top
+            kp[n] *= float(S) / float(w)
+        return out, kp
 
     def jitter_(self, img_u8, ops, factors):
         """ColorJitter in place: ops / factors = per-sample lists of three op codes / factors (applied in list order)."""
@@ -239,10 +337,13 @@ class TargetViewPipeline:
         target, weight = self.labels(kp, vis, base_u8.device)
         return x, kp, aug, target, weight
 
-    def __call__(self, base_u8, keypoints):
+    def __call__(self, base_u8, keypoints, raw=False):
         """The collated 8-tuple of the `_mt` datasets (human36m_mt.py:161): (x_t_stu, target_stu, weight_stu, meta_stu, x_t_teas,
-        targets_tea, weights_tea, metas_tea) with the meta fields the loop reads (train_human.py:330-345)."""
+        targets_tea, weights_tea, metas_tea) with the meta fields the loop reads (train_human.py:330-345).  raw=True: `base_u8` are the
+        decoded dataset images and the base transform (RandomResizedCrop, human36m_mt.py:86) runs here first."""
         keypoints = np.asarray(keypoints, dtype=np.float64)
+        if raw:
+            base_u8, keypoints = self.resized_crop(base_u8, keypoints)
         x_s, kp_s, aug_s, t_s, w_s = self.view(base_u8, keypoints, self.stu)
         vis = np.ones((keypoints.shape[0], keypoints.shape[1], 1), np.float32)
         t_ori, w_ori = self.labels(keypoints, vis, base_u8.device)
