@@ -75,7 +75,8 @@ typedef struct {
     int exp0;             /* tuning scratch value read by whichever experiment is being A/B-ed (0 in production) */
     int wgrad_big;        /* grouped weight gradients: 256x128 tiles (128x64 per wave: 25 % fewer LDS bytes per FLOP than 64x64 per wave) for
                            * stride-1 layers on power-of-two maps with Co % 256 == 0 and Ci % 128 == 0 (layer3 / layer4, layer2's c3) */
-    int pad0;
+    int igemm_big_min;    /* > 0: 128x128 tiles (2-stage ring) for single-class launches with Co % 128 == 0 whose 128x64 grid has at least this
+                           * many work-groups - the style network's large maps, run on one stream (+13-18 % there); 0 (default): never */
     void* timeline;
 } udapose_policy;
 void udapose_policy_default(udapose_policy* p);

@@ -7,7 +7,7 @@ from uda_poseestimation_amd.lib.models import Style_net
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 from uda_poseestimation_amd import _hip
 TILE = int(sys.argv[2]) if len(sys.argv) > 2 else -1
-POL = _hip.policy(igemm_tile=TILE) if TILE >= 0 else None
+POL = _hip.policy(igemm_tile=TILE) if TILE >= 0 else None        # None: the style network's own policy
 dev = torch.device("cuda:0")
 Style_net.vgg.to(dev); Style_net.decoder.to(dev)
 net = Style_net.Net(torch.nn.Sequential(*list(Style_net.vgg.children())[:31]), Style_net.decoder).to(dev)
@@ -33,7 +33,7 @@ for prec in (("bf16",) if TILE >= 0 else ("bf16", "f16x2")):
                 fl = 0
             else:
                 Nn, H, W, Cin = x.shape
-                d = ops.conv_desc(Nn, H, W, Cin, st.conv.out_channels, 3, 1, 1, reflect=True, upsample=st.upsample, policy=POL)
+                d = ops.conv_desc(Nn, H, W, Cin, st.conv.out_channels, 3, 1, 1, reflect=True, upsample=st.upsample, policy=POL if POL is not None else runner.policy())
                 w, b = runner._packed(st, d, f32)
                 last = name == "dec" and si == len(runner.steps) - 1
                 us = timeit(lambda: ops.conv2d_fwd(x, w, d, bias=b, relu=st.relu, out_f32=last))

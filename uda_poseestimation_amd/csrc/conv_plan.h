@@ -36,6 +36,7 @@ struct Policy {
     int wgrad_big = 0;          // grouped weight gradients: 256x128 tiles (128x64 per wave) for fast-geometry layers with Co % 256 == 0, Ci % 128 == 0.
                                 // +16-19 % per layer alone (+40-55 % against the filter-row form on layer3 / layer4's 3x3), but the third class
                                 // launch and its 2 work-groups per CU cost the grouped launch +9 % (2.73 against 2.48 ms for both passes): OFF
+    int igemm_big_min = 0;      // > 0: tile 4 (128x128, 2-stage ring) when Co % 128 == 0 and the 128x64 grid has >= this many work-groups
     int igemm_q_tile = -1;      // tile id for launches whose 128x64 grid has 769..1024 work-groups (second round mostly empty); -1: heuristic
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line

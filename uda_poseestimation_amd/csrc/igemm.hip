@@ -933,7 +933,7 @@ int launch_cfg(IgParams& p, hipStream_t stream, const Policy& pol) {
             // f16x2 operands (fp32-shaped loaders, three fp16 MFMAs per stage): forward epilogue only
             if (!(p.flags & IG_FLAG_F32) || p.bs_y || (!(p.flags & IG_FLAG_OUT_F32) && (p.Co % 8))) return UDAPOSE_ERR_ARG;
             // (instantiated for the tiles igemm_launch maps split launches to)
-            constexpr bool sp_cfg = (BM == 128 && BN == 64 && NS == 2) || (BM == 64 && BN == 64 && (NS == 2 || NS == 3)) || (BM == 128 && BN == 32);
+            constexpr bool sp_cfg = (BM == 128 && BN == 128 && NS == 2) || (BM == 128 && BN == 64 && NS == 2) || (BM == 64 && BN == 64 && (NS == 2 || NS == 3)) || (BM == 128 && BN == 32);
             if constexpr (sp_cfg) {
                 if constexpr (BN >= 64) { if (lean) return launch_cfg_t<float, BM, BN, WM, WN, NS, false, false, 3, true>(p, stream, pol); }
                 return launch_cfg_t<float, BM, BN, WM, WN, NS, false, false, 0, true>(p, stream, pol);
@@ -980,6 +980,9 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
     // they give two work-groups per CU, else 64x64 with a 3-stage ring for long K and a 2-stage ring otherwise.  Every
     // choice lands on THREE resident work-groups per CU (48 KB of LDS each): deeper rings (4 stages = 2 per CU) and one deep
     // 128x64 work-group per CU both measured slower - overlapping the fixed phases of several work-groups beats prefetch depth.
+    // single-stream launches with many rounds of work-groups (the style network's 32x32 .. 128x128 maps): 128x128 tiles halve the
+    // L2 -> LDS bytes per FLOP of the B operand (655-700 against 555-616 TFLOP/s on its 256-channel layers); Co % 128 != 0 would idle half a tile
+    if (pol.igemm_big_min > 0 && nclass == 1 && Co % 128 == 0 && b12864 >= pol.igemm_big_min) return 4;
     if (pol.igemm_q_tile >= 0 && b12864 > 768 && b12864 <= 1024) return pol.igemm_q_tile;
     if (b12864 >= pol.igemm_wg_min) return 6;
     return K >= 1024 ? 9 : 5;
@@ -1009,8 +1012,8 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream, const Policy& pol) {
     if (p.flags & IG_FLAG_SPLIT) {
         // f16x2 launches take the plain (or lean 1x1) form of three tiles: 128x64 / 64x64 with the ring depth of the bf16 choice
         switch (tile) {
-            case 3: case 5: case 6: case 9: break;
-            case 0: case 1: case 4: case 8: case 11: tile = 6; break;
+            case 3: case 4: case 5: case 6: case 9: break;
+            case 0: case 1: case 8: case 11: tile = 6; break;
             case 2: case 7: case 10: case 12: tile = 9; break;
             default: return UDAPOSE_ERR_ARG;
         }

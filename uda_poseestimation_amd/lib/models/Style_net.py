@@ -154,9 +154,19 @@ class _SeqRunner:
     """Runs a compiled step list on NHWC tensors (bf16 or fp32: the input's dtype decides); packed weights are cached per
     precision until a parameter changes."""
 
+    # dispatch policy of the style convolutions: they run alone on one stream over 32x32 .. 256x256 maps (hundreds of thousands of
+    # rows), where 128x128 tiles pay (profiles/r3_ab_runs.txt) - unlike in the three-stream pose step, whose policy stays the default
+    policy_overrides = {"igemm_big_min": 1024}
+
     def __init__(self, children):
         self.steps = _compile(children)
         self._packs = {}
+        self._pol = None
+
+    def policy(self):
+        if self._pol is None:
+            self._pol = _hip.policy(**self.policy_overrides)
+        return self._pol
 
     def _packed(self, st, d, f32):
         """f32: False (16-bit element type), True (fp32) or 'split' (f16x2)"""
@@ -194,7 +204,7 @@ class _SeqRunner:
                 x = ops.maxpool2x2_ceil(x)
             else:
                 N, H, W, Cin = x.shape
-                d = ops.conv_desc(N, H, W, Cin, st.conv.out_channels, 3, 1, 1, reflect=True, upsample=st.upsample)
+                d = ops.conv_desc(N, H, W, Cin, st.conv.out_channels, 3, 1, 1, reflect=True, upsample=st.upsample, policy=self.policy())
                 w, b = self._packed(st, d, f32)
                 last = si == len(self.steps) - 1
                 x = ops.conv2d_fwd(x, w, d, bias=b, relu=st.relu, out_f32=(final_f32 and last))
