@@ -37,6 +37,8 @@ struct Policy {
                                 // +16-19 % per layer alone (+40-55 % against the filter-row form on layer3 / layer4's 3x3), but the third class
                                 // launch and its 2 work-groups per CU cost the grouped launch +9 % (2.73 against 2.48 ms for both passes): OFF
     int igemm_big_min = 0;      // > 0: tile 4 (128x128, 2-stage ring) when Co % 128 == 0 and the 128x64 grid has >= this many work-groups
+    int patch_conv = 1;         // the style network's 64 -> 3 and 3 -> 64 reflection-padded 3x3 convolutions through the patch-staged kernels
+                                // (patchconv.hip: the input patch staged once instead of once per tap); 0: the igemm for every layer
     int igemm_q_tile = -1;      // tile id for launches whose 128x64 grid has 769..1024 work-groups (second round mostly empty); -1: heuristic
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
@@ -113,6 +115,9 @@ struct ConvEpilogue {
 };
 // y = conv(x, w_fwd[Co][wtaps][Ci])
 int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* w_fwd, void* y, const ConvEpilogue& e);
+// patch-staged forms of the style network's end layers (patchconv.hip); conv_fprop routes to them when patch_conv_ok
+int patch_conv_ok(const ConvGeom& g, const ConvEpilogue& e);
+int patch_conv_fprop(hipStream_t s, const ConvGeom& g, const void* x, const void* w_fwd, void* y, const ConvEpilogue& e);
 // The BatchNorm whose backward consumes a dgrad's output (IgParams::bs_*): the dgrad epilogue masks dx with that BN's ReLU
 // and leaves the partial sums of g and g * xhat in slab[rows][2][C]; `rows` is set by conv_dgrad.
 struct DgradBnStat {

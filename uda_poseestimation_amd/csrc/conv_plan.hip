@@ -120,6 +120,12 @@ int conv_stat_rows(const ConvGeom& g) {
 }
 
 int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* w_fwd, void* y, const ConvEpilogue& e) {
+    if (patch_conv_ok(g, e)) {
+        const int tok = prof_before(s, 0, alg_flops(g));
+        const int rc = patch_conv_fprop(s, g, x, w_fwd, y, e);
+        prof_after(s, tok);
+        return rc;
+    }
     const TapPlan* tp = get_tap_plan(g, 0, s);
     if (!tp) return UDAPOSE_ERR_NOT_PREPARED;
     if (g.transposed && (g.reflect || g.upsample)) return UDAPOSE_ERR_UNSUPPORTED;
