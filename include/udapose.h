@@ -77,8 +77,9 @@ typedef struct {
                            * stride-1 layers on power-of-two maps with Co % 256 == 0 and Ci % 128 == 0 (layer3 / layer4, layer2's c3) */
     int igemm_big_min;    /* > 0: 128x128 tiles (2-stage ring) for single-class launches with Co % 128 == 0 whose 128x64 grid has at least this
                            * many work-groups - the style network's large maps, run on one stream (+13-18 % there); 0 (default): never */
-    int patch_conv;       /* 1 (default): the style network's 64 -> 3 and 3 -> 64 reflection-padded 3x3 convolutions run the patch-staged kernels
-                           * (input patch staged once, not once per tap); 0: the implicit GEMM for every layer */
+    int patch_conv;       /* reflection-padded 3x3 stride-1 convolutions (the style network) through the patch-staged kernels (input patch staged once,
+                           * not once per tap): 0 never (the implicit GEMM for every layer), 1 the 64 -> 3 and 3 -> 64 end layers, 2 (default)
+                           * the trunk layers too, 3 = 2 with 128 output channels per work-group in the 16-bit form */
     int pad0;
     void* timeline;
 } udapose_policy;

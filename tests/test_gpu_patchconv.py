@@ -108,3 +108,57 @@ def test_ci8_patch_conv_matches_torch_and_the_igemm(shape):
         e_ig = (y - y_ig).abs().max().item() / scale
         assert e < 2e-6 and e_ig < 2e-6, (relu, e, e_ig)
     print(f"ci8 patch conv {shape}: f16x2 err {e:.2e} * max vs fp64, {e_ig:.2e} vs the igemm")
+
+
+TRUNK = [
+    # N, H, W (input), Ci, Co, upsample
+    (2, 8, 64, 64, 64, False),
+    (1, 4, 64, 128, 128, False),
+    (2, 32, 32, 256, 128, False),          # 32-wide maps: the 4 x 32 tile
+    (1, 16, 32, 128, 64, True),            # folded nearest x2 upsample: 32 x 64 output
+    (1, 64, 64, 64, 64, True),             # 128 x 128 output, several tiles per row and column
+    (1, 6, 128, 64, 192, False),
+]
+
+
+@pytest.mark.parametrize("case,mode", [(c, 2) for c in TRUNK] + [(TRUNK[1], 3), (TRUNK[2], 3)], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else f"mode{v}")
+def test_trunk_patch_conv_matches_torch_and_the_igemm(case, mode):
+    """patch3x3_kernel (policy patch_conv = 2; 3: 128 output channels per work-group in the 16-bit form where Co % 128 == 0): the style
+    network's trunk layers, 16-bit and f16x2, bias + ReLU, with and without the folded upsample - against torch's convolution on the same
+    rounded operands and against the implicit GEMM."""
+    from uda_poseestimation_amd import _hip, ops
+    N, H, W, Ci, Co, up = case
+    g = torch.Generator().manual_seed(H * 3 + W + Ci + Co)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / np.sqrt(9 * Ci)
+    b = torch.randn(Co, generator=g)
+    d = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1, reflect=True, upsample=up, policy=_hip.policy(patch_conv=mode))
+    d_ig = ops.with_policy(d, _hip.policy(patch_conv=0))
+
+    def ref_of(xr, wr, relu):
+        xu = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+        return _ref(xu, wr, b, relu)
+    for et, tol in ((torch.bfloat16, 1.2e-2), (torch.float16, 2e-3)):
+        xr, wr = x.to(et).float(), w.to(et).float()
+        xs = xr.permute(0, 2, 3, 1).contiguous().to(et).cuda()
+        wp = ops.pack_weight(wr.cuda(), d, dtype=et)
+        for relu in (False, True):
+            y = ops.conv2d_fwd(xs, wp, d, bias=b.cuda(), relu=relu)
+            y_ig = ops.conv2d_fwd(xs, wp, d_ig, bias=b.cuda(), relu=relu)
+            ref = ref_of(xr, wr, relu)
+            scale = ref.abs().max().item()
+            assert tuple(y.shape) == tuple(ref.shape) and y.dtype == et
+            e = (y.cpu().double() - ref).abs().max().item() / scale
+            assert e < tol, (et, relu, e)
+            assert (y.float() - y_ig.float()).abs().max().item() <= tol * scale
+    xsp = ops.to_nhwc_split(x.cuda(), Ci)
+    wsp = ops.f32_to_split(w.cuda().permute(0, 2, 3, 1).contiguous())
+    for relu in (False, True):
+        y = ops.split_to_f32(ops.conv2d_fwd(xsp, wsp, d, bias=b.cuda(), relu=relu))
+        y_ig = ops.split_to_f32(ops.conv2d_fwd(xsp, wsp, d_ig, bias=b.cuda(), relu=relu))
+        ref = ref_of(x, w, relu)
+        scale = ref.abs().max().item()
+        e = (y.cpu().double() - ref).abs().max().item() / scale
+        e_ig = (y - y_ig).abs().max().item() / scale
+        assert e < 2e-6 and e_ig < 2e-6, (relu, e, e_ig)
+    print(f"trunk patch conv {case}: f16x2 err {e:.2e} * max vs fp64, {e_ig:.2e} vs the igemm")

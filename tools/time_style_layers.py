@@ -7,9 +7,12 @@ from uda_poseestimation_amd.lib.models import Style_net
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 from uda_poseestimation_amd import _hip
 TILE = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+PATCH = int(sys.argv[3]) if len(sys.argv) > 3 else None          # policy patch_conv override of the style network's own policy
 POL = _hip.policy(igemm_tile=TILE) if TILE >= 0 else None        # None: the style network's own policy
 dev = torch.device("cuda:0")
 Style_net.vgg.to(dev); Style_net.decoder.to(dev)
+if PATCH is not None:
+    Style_net._SeqRunner.policy_overrides = dict(Style_net._SeqRunner.policy_overrides, patch_conv=PATCH)
 net = Style_net.Net(torch.nn.Sequential(*list(Style_net.vgg.children())[:31]), Style_net.decoder).to(dev)
 img = torch.rand(N, 3, 256, 256, device=dev)
 def timeit(fn, n=5):

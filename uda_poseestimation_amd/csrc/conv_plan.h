@@ -37,8 +37,10 @@ struct Policy {
                                 // +16-19 % per layer alone (+40-55 % against the filter-row form on layer3 / layer4's 3x3), but the third class
                                 // launch and its 2 work-groups per CU cost the grouped launch +9 % (2.73 against 2.48 ms for both passes): OFF
     int igemm_big_min = 0;      // > 0: tile 4 (128x128, 2-stage ring) when Co % 128 == 0 and the 128x64 grid has >= this many work-groups
-    int patch_conv = 1;         // the style network's 64 -> 3 and 3 -> 64 reflection-padded 3x3 convolutions through the patch-staged kernels
-                                // (patchconv.hip: the input patch staged once instead of once per tap); 0: the igemm for every layer
+    int patch_conv = 2;         // reflection-padded 3x3 stride-1 convolutions (the style network) through the patch-staged kernels of patchconv.hip
+                                // (the input patch staged once instead of once per tap): 0 = never (the igemm for every layer), 1 = the 64 -> 3
+                                // and 3 -> 64 end layers only, 2 = the trunk layers too (128 pixels x 64 channels per work-group), 3 = 128
+                                // channels per work-group in the 16-bit form where Co % 128 == 0 (measured equal to 2)
     int igemm_q_tile = -1;      // tile id for launches whose 128x64 grid has 769..1024 work-groups (second round mostly empty); -1: heuristic
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line

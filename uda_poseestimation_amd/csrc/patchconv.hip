@@ -23,6 +23,8 @@ struct PcParams {
     int N, H, W, Co, relu, out_f32;
 };
 
+template <int U> struct IC { static constexpr int value = U; };
+
 __device__ __forceinline__ int reflect1(int v, int n) { return v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v); }
 
 // ---------------------------------------------------------------------------------------------------------------- Ci = 64, Co <= 16
@@ -356,10 +358,250 @@ int launch_ci8(const PcParams& p, hipStream_t s) {
     return udapose_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------- Ci >= 64, Co % 64 == 0
+// The style network's trunk layers.  Tile = 128 output pixels (TH x TW, TW = 64 or 32) x 64 output channels, four waves as 2 (pixels) x 2
+// (channels).  K runs over channel slices of 128 bytes per pixel (64 channels; split: 32 as [8 h][8 l] x 4) and, inside a slice, the nine
+// taps: the (TH + 2) x (TW + 2) patch of a slice is staged ONCE (next slice's patch in registers meanwhile) and only the 8 KB weight stage
+// of a tap moves per step (double-buffered through registers) - 11.8 KB of L2 -> LDS fill per 16 MFMAs and wave against 16 KB for the
+// igemm's 128x128 tile and 24 KB for its 128x64 tile, at 50 KB of LDS (three work-groups per CU).  The filter is the MFMA's row operand and
+// rows are assigned to channels as in patch3x3_ci8_kernel, so a lane owns one 16-byte chunk of a pixel's output row; rows are assembled in
+// LDS and stored as whole 128-byte (256-byte) segments.
+struct PgParams {
+    const void* x;
+    const void* w;
+    const float* bias;
+    void* y;
+    int N, Hi, Wi, Ho, Wo, Ci, Co, up, relu;
+};
+
+template <bool SP, int TW, int JB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JB > 2 ? 2 : 3))) void patch3x3_kernel(const PgParams p) {
+    constexpr int TH = 128 / TW, PW = TW + 2, PR = TH + 2, NPX = PR * PW;
+    constexpr int NCHA = NPX * 8, ITA = (NCHA + 255) / 256;
+    constexpr int BN = 32 * JB;                    // output channels per work-group: two wave columns of JB 16-channel blocks
+    constexpr int ESZ = SP ? 4 : 2, RC = BN * ESZ / 16;      // RC: 16-byte chunks per output row of the tile
+    constexpr int BW = BN * 8 / 256, BSTAGE = BN * 128;      // weight stage: chunks per thread, bytes
+    constexpr int KK = SP ? 1 : 2;                 // 32-deep MFMA steps per slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch = smem;
+    char* const bst = smem + NPX * 128;             // two weight stages of 64 rows x 128 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4, wm = wid >> 1, wn = wid & 1;
+    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH, n_tiles = p.Co / BN;
+    const uint32_t total = (uint32_t)tiles_x * tiles_y * p.N * n_tiles;
+    uint32_t t0 = xcd_remap(blockIdx.x, total);
+    const int n_tile = t0 % n_tiles; t0 /= n_tiles;
+    const int tx = t0 % tiles_x; t0 /= tiles_x;
+    const int ty = t0 % tiles_y;
+    const int n = t0 / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH, n0 = n_tile * BN;
+    const int S = p.Ci * ESZ / 128, G = S * 9;
+    const size_t rowb = (size_t)p.Ci * ESZ;          // bytes per input pixel / per (co, tap) weight row
+
+    // ---- loader state: byte offsets of this thread's patch chunks (reflection at the output resolution, then the folded upsample) and weight chunks
+    const char* xin = (const char*)p.x + (size_t)n * p.Hi * p.Wi * rowb;
+    unsigned offA[ITA];
+#pragma unroll
+    for (int i = 0; i < ITA; ++i) {
+        const int e = tid + i * 256;
+        const int px = e >> 3, ch = e & 7;
+        const int r = px / PW, c = px - r * PW;
+        const int yy = reflect1(y0 - 1 + r, p.Ho) >> p.up, xx = reflect1(x0 - 1 + c, p.Wo) >> p.up;
+        offA[i] = e < NCHA ? (unsigned)(((size_t)yy * p.Wi + xx) * rowb + ch * 16) : 0u;
+    }
+    const char* wrow[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) {
+        const int e = tid + i * 256;
+        wrow[i] = (const char*)p.w + (size_t)(n0 + (e >> 3)) * 9 * rowb + (e & 7) * 16;
+    }
+    u32x4 ra[ITA], rb[BW];
+    auto fetchA = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < ITA; ++i)
+            if (tid + i * 256 < NCHA) ra[i] = *(const u32x4*)(xin + offA[i] + sl * 128);
+    };
+    auto storeA = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            const int e = tid + i * 256;
+            if (e < NCHA) {
+                const int px = e >> 3, ch = e & 7;
+                *(u32x4*)(patch + px * 128 + ((ch ^ ((px >> 1) & 7)) << 4)) = ra[i];
+            }
+        }
+    };
+    auto fetchB = [&](int sl, int tp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < BW; ++i) rb[i] = *(const u32x4*)(wrow[i] + (size_t)tp * rowb + sl * 128);
+    };
+    auto storeB = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < BW; ++i) {
+            const int e = tid + i * 256;
+            const int row = e >> 3, ch = e & 7;
+            *(u32x4*)(bst + buf * BSTAGE + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = rb[i];
+        }
+    };
+
+    // ---- fragment addressing.  Filter rows: MFMA row i = (qq, r) of block jb <-> channel wn * 32 + qq * 8 + jb * 4 + r (patch3x3_ci8_kernel)
+    int wrow_l[JB], wsw[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        const int row = wn * (16 * JB) + (l15 >> 2) * (4 * JB) + jb * 4 + (l15 & 3);
+        wrow_l[jb] = row * 128;
+        wsw[jb] = (row >> 1) & 7;
+    }
+    int pp0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int m = wm * 64 + mb * 16 + l15;
+        pp0[mb] = (m / TW) * PW + (m % TW);
+    }
+    f32x4 acc[JB][4], acc2[SP ? JB : 1][SP ? 4 : 1];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            acc[jb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SP) acc2[jb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    // ---- prologue: patch of slice 0 and weight stage 0 in LDS, stage 1 and the patch of slice 1 in registers (G = 9 S >= 9)
+    fetchA(0);
+    fetchB(0, 0);
+    storeA();
+    storeB(0);
+    fetchB(0, 1);
+    if (S > 1) fetchA(1);
+    __syncthreads();
+    int sl = 0, tp = 0;
+    // (a second register set with stage g + 2 in flight as well changed nothing in the 16-bit form and cost the split form its third
+    // work-group per CU: the weight stages come from the L2 well within one step)
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) storeB((g + 1) & 1);         // (every wave left stage (g + 1) & 1 at the barrier that ended step g - 1)
+        if (g + 2 < G) {
+            int s2 = sl, t2 = tp + 2;
+            if (t2 >= 9) { t2 -= 9; ++s2; }
+            fetchB(s2, t2);
+        }
+        const char* B = bst + (g & 1) * BSTAGE;
+        const int toff = (tp / 3) * PW + tp % 3;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            u32x4 wa[JB], wb[SP ? JB : 1];
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) {
+                if constexpr (SP) {
+                    wa[jb] = *(const u32x4*)(B + wrow_l[jb] + (((2 * q) ^ wsw[jb]) << 4));
+                    wb[jb] = *(const u32x4*)(B + wrow_l[jb] + (((2 * q + 1) ^ wsw[jb]) << 4));
+                } else {
+                    wa[jb] = *(const u32x4*)(B + wrow_l[jb] + (((kk * 4 + q) ^ wsw[jb]) << 4));
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int pp = pp0[mb] + toff;
+                const char* prow = patch + pp * 128;
+                const int sw = (pp >> 1) & 7;
+                if constexpr (SP) {
+                    const half8 xh = *(const half8*)(prow + (((2 * q) ^ sw) << 4));
+                    const half8 xl = *(const half8*)(prow + (((2 * q + 1) ^ sw) << 4));
+#pragma unroll
+                    for (int jb = 0; jb < JB; ++jb) {
+                        const half8 ah = __builtin_bit_cast(half8, wa[jb]), al = __builtin_bit_cast(half8, wb[jb]);
+                        acc[jb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh, acc[jb][mb], 0, 0, 0);
+                        acc2[jb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl, acc2[jb][mb], 0, 0, 0);
+                        acc2[jb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, acc2[jb][mb], 0, 0, 0);
+                    }
+                } else {
+                    const elem8 xf = *(const elem8*)(prow + (((kk * 4 + q) ^ sw) << 4));
+#pragma unroll
+                    for (int jb = 0; jb < JB; ++jb) acc[jb][mb] = UDAPOSE_MFMA_16x16x32(__builtin_bit_cast(elem8, wa[jb]), xf, acc[jb][mb]);
+                }
+            }
+        }
+        __syncthreads();
+        if (++tp == 9) {
+            tp = 0; ++sl;
+            if (sl < S) {                            // slice boundary: the next slice's patch (in registers since the last boundary) replaces this one
+                storeA();
+                if (sl + 1 < S) fetchA(sl + 1);
+                __syncthreads();
+            }
+        }
+    }
+    // ---- epilogue: lane (pixel l15 of block mb, q) owns channels wn * 16 JB + q * 4 JB .. + 4 JB of its pixel = JB / 2 chunks (split: chunk pairs)
+    // of the pixel's BN-channel output row, assembled in LDS (the staging buffers are free: the loop ended with a barrier), then whole rows out
+    float bias_r[4 * JB];
+#pragma unroll
+    for (int e = 0; e < 4 * JB; ++e) bias_r[e] = p.bias ? p.bias[n0 + wn * (16 * JB) + q * (4 * JB) + e] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int m = wm * 64 + mb * 16 + l15;
+        char* row = smem + m * (RC * 16);
+#pragma unroll
+        for (int c2 = 0; c2 < JB / 2; ++c2) {
+            float v[8];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jb = c2 * 2 + j2;
+                    float t2 = acc[jb][mb][r];
+                    if constexpr (SP) t2 += acc2[jb][mb][r] * UDAPOSE_SP_INV;
+                    t2 += bias_r[jb * 4 + r];
+                    v[j2 * 4 + r] = p.relu ? (t2 > 0.f ? t2 : 0.f) : t2;
+                }
+            const int ci = (wn * 4 + q) * (JB / 2) + c2;          // 8-channel group of the row
+            if constexpr (SP) {
+                half8 h8, l8;
+                sp_split8(v, h8, l8);
+                const int sw = m & 15;
+                *(half8*)(row + (((2 * ci) ^ sw) << 4)) = h8;
+                *(half8*)(row + (((2 * ci + 1) ^ sw) << 4)) = l8;
+            } else {
+                elem8 o8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o8[r] = (elem_t)v[r];
+                *(elem8*)(row + ((ci ^ (RC == 16 ? (m & 15) : ((m >> 1) & 7))) << 4)) = o8;
+            }
+        }
+    }
+    __syncthreads();
+    char* yo = (char*)p.y + (((size_t)n * p.Ho + y0) * p.Wo + x0) * p.Co * ESZ + (size_t)n0 * ESZ;
+#pragma unroll
+    for (int it = 0; it < RC / 2; ++it) {
+        const int L = it * 256 + tid;
+        const int m = L / RC, c = L % RC;
+        const int sw = RC == 16 ? (m & 15) : ((m >> 1) & 7);
+        const int r = m / TW, cc = m % TW;
+        *(u32x4*)(yo + ((size_t)r * p.Wo + cc) * p.Co * ESZ + c * 16) = *(const u32x4*)(smem + m * (RC * 16) + ((c ^ sw) << 4));
+    }
+}
+
+template <bool SP, int TW, int JB>
+int launch_pg(const PgParams& p, hipStream_t s) {
+    constexpr int TH = 128 / TW, BN = 32 * JB, LDS = (TH + 2) * (TW + 2) * 128 + 2 * BN * 128;       // (the output rows reuse it)
+    static_assert(LDS >= 128 * BN * (SP ? 4 : 2), "epilogue rows fit the staging buffers");
+    static std::atomic<unsigned long long> attr_done{0};
+    static std::mutex attr_mu;
+    once_per_device(attr_done, attr_mu, [] {
+        (void)hipFuncSetAttribute((const void*)patch3x3_kernel<SP, TW, JB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    });
+    const long long total = (long long)(p.Wo / TW) * (p.Ho / TH) * p.N * (p.Co / BN);
+    if (total <= 0 || total > 0x7fffffffll) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL((patch3x3_kernel<SP, TW, JB>), dim3((unsigned)total), dim3(256), LDS, s, p);
+    return udapose_check_launch();
+}
+
 }  // namespace
 
 // 1 when conv_fprop hands this geometry / epilogue to a patch-staged kernel
+static int patch_trunk_ok(const ConvGeom& g, const ConvEpilogue& e);
 int patch_conv_ok(const ConvGeom& g, const ConvEpilogue& e) {
+    if (patch_trunk_ok(g, e)) return 1;
     if (!g.policy().patch_conv || g.transposed || g.upsample || !g.reflect || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return 0;
     if (e.f32 || e.res || e.stats || g.Wi % 64 != 0 || g.Hi < 2 || g.Wi < 2) return 0;
     if (g.Ci == 64 && g.Co <= 16 && e.out_f32 && g.Hi % 4 == 0) return 1;
@@ -367,9 +609,29 @@ int patch_conv_ok(const ConvGeom& g, const ConvEpilogue& e) {
     return 0;
 }
 
+// 1 when the geometry takes the trunk form (patch3x3_kernel): policy patch_conv >= 2
+static int patch_trunk_ok(const ConvGeom& g, const ConvEpilogue& e) {
+    if (g.policy().patch_conv < 2 || g.transposed || !g.reflect || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return 0;
+    if (e.f32 || e.res || e.stats || e.out_f32 || g.Ci < 64 || g.Ci % 64 || g.Co % 64) return 0;
+    const int Ho = g.Ho(), Wo = g.Wo();
+    if (Wo % 32 || Ho < 2 || Wo < 2) return 0;
+    const int TW = (Wo % 64 == 0) ? 64 : 32;
+    if (Ho % (128 / TW)) return 0;
+    if ((long long)g.Hi * g.Wi * g.Ci * (e.split ? 4 : 2) >= (1ll << 32)) return 0;       // (32-bit patch offsets per image)
+    return TW;
+}
+
 int patch_conv_fprop(hipStream_t s, const ConvGeom& g, const void* x, const void* w_fwd, void* y, const ConvEpilogue& e) {
     PcParams p{x, w_fwd, e.bias, y, g.N, g.Hi, g.Wi, g.Co, e.relu ? 1 : 0, e.out_f32 ? 1 : 0};
     if (g.Ci == 64 && g.Co <= 16) return e.split ? launch_co16<true, 4>(p, s) : launch_co16<false, 4>(p, s);
     if (g.Ci == 8 && g.Co == 64) return e.split ? launch_ci8<true>(p, s) : launch_ci8<false>(p, s);
+    if (const int TW = patch_trunk_ok(g, e)) {
+        PgParams q{x, w_fwd, e.bias, y, g.N, g.Hi, g.Wi, g.Ho(), g.Wo(), g.Ci, g.Co, g.upsample ? 1 : 0, e.relu ? 1 : 0};
+        // 128 output channels per work-group in the 16-bit form where Co allows (policy patch_conv >= 3; the split form's two accumulator
+        // sets keep it at 64)
+        const bool wide = !e.split && g.Co % 128 == 0 && g.policy().patch_conv >= 3;
+        if (TW == 64) return e.split ? launch_pg<true, 64, 2>(q, s) : (wide ? launch_pg<false, 64, 4>(q, s) : launch_pg<false, 64, 2>(q, s));
+        return e.split ? launch_pg<true, 32, 2>(q, s) : (wide ? launch_pg<false, 32, 4>(q, s) : launch_pg<false, 32, 2>(q, s));
+    }
     return UDAPOSE_ERR_UNSUPPORTED;
 }
