@@ -398,28 +398,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JB > 2 ? 2 
     const int S = p.Ci * ESZ / 128, G = S * 9;
     const size_t rowb = (size_t)p.Ci * ESZ;          // bytes per input pixel / per (co, tap) weight row
 
-    // ---- loader state: byte offsets of this thread's patch chunks (reflection at the output resolution, then the folded upsample) and weight chunks
+    // ---- loaders.  Patch chunk e of this thread: pixel e >> 3 of the patch (reflection at the output resolution, then the folded upsample),
+    // chunk e & 7 of the slice; its offset is recomputed at every fetch (once per nine steps) rather than held in ITA registers.  Weight
+    // chunk: row n0 + (e >> 3) of tap tp, as a 32-bit offset from the (scalar) tile base.
     const char* xin = (const char*)p.x + (size_t)n * p.Hi * p.Wi * rowb;
-    unsigned offA[ITA];
-#pragma unroll
-    for (int i = 0; i < ITA; ++i) {
-        const int e = tid + i * 256;
-        const int px = e >> 3, ch = e & 7;
-        const int r = px / PW, c = px - r * PW;
-        const int yy = reflect1(y0 - 1 + r, p.Ho) >> p.up, xx = reflect1(x0 - 1 + c, p.Wo) >> p.up;
-        offA[i] = e < NCHA ? (unsigned)(((size_t)yy * p.Wi + xx) * rowb + ch * 16) : 0u;
-    }
-    const char* wrow[BW];
+    const char* wbase = (const char*)p.w + (size_t)n0 * 9 * rowb;
+    unsigned wrow[BW];
 #pragma unroll
     for (int i = 0; i < BW; ++i) {
         const int e = tid + i * 256;
-        wrow[i] = (const char*)p.w + (size_t)(n0 + (e >> 3)) * 9 * rowb + (e & 7) * 16;
+        wrow[i] = (unsigned)((size_t)(e >> 3) * 9 * rowb + (e & 7) * 16);
     }
+    // Chunk swizzle of a weight stage.  A fragment read touches the 16 rows (qq, r) -> qq * 4 JB + jb * 4 + r, not 16 consecutive ones: the
+    // eight rows of one parity differ in bit 1 and in qq, so THOSE bits select the chunk permutation (the igemm's (row >> 1) & 7 maps rows
+    // r and r + 16 to the same bank group: 2-way conflicts on every filter read, a third of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT)
+    auto wswz = [](int row) __attribute__((always_inline)) { return ((row >> 1) & 1) | (((row / (4 * JB)) & 3) << 1); };
     u32x4 ra[ITA], rb[BW];
     auto fetchA = [&](int sl) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < ITA; ++i)
-            if (tid + i * 256 < NCHA) ra[i] = *(const u32x4*)(xin + offA[i] + sl * 128);
+        for (int i = 0; i < ITA; ++i) {
+            const int e = tid + i * 256;
+            if (e < NCHA) {
+                const int px = e >> 3, ch = e & 7;
+                const int r = px / PW, c = px - r * PW;
+                const int yy = reflect1(y0 - 1 + r, p.Ho) >> p.up, xx = reflect1(x0 - 1 + c, p.Wo) >> p.up;
+                ra[i] = *(const u32x4*)(xin + (unsigned)(((size_t)yy * p.Wi + xx) * rowb + ch * 16) + sl * 128);
+            }
+        }
     };
     auto storeA = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -427,37 +432,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JB > 2 ? 2 
             const int e = tid + i * 256;
             if (e < NCHA) {
                 const int px = e >> 3, ch = e & 7;
-                *(u32x4*)(patch + px * 128 + ((ch ^ ((px >> 1) & 7)) << 4)) = ra[i];
+                const int col = px % PW;
+                *(u32x4*)(patch + px * 128 + ((ch ^ ((col >> 1) & 7)) << 4)) = ra[i];
             }
         }
     };
     auto fetchB = [&](int sl, int tp) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < BW; ++i) rb[i] = *(const u32x4*)(wrow[i] + (size_t)tp * rowb + sl * 128);
+        for (int i = 0; i < BW; ++i) rb[i] = *(const u32x4*)(wbase + (size_t)tp * rowb + sl * 128 + wrow[i]);
     };
     auto storeB = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < BW; ++i) {
             const int e = tid + i * 256;
             const int row = e >> 3, ch = e & 7;
-            *(u32x4*)(bst + buf * BSTAGE + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = rb[i];
+            *(u32x4*)(bst + buf * BSTAGE + row * 128 + ((ch ^ wswz(row)) << 4)) = rb[i];
         }
     };
 
     // ---- fragment addressing.  Filter rows: MFMA row i = (qq, r) of block jb <-> channel wn * 32 + qq * 8 + jb * 4 + r (patch3x3_ci8_kernel)
-    int wrow_l[JB], wsw[JB];
+    // woff[jb][kk]: byte offset of this lane's filter fragment inside a weight stage (split: the h chunk; l = h ^ 16)
+    int woff[JB][KK];
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
         const int row = wn * (16 * JB) + (l15 >> 2) * (4 * JB) + jb * 4 + (l15 & 3);
-        wrow_l[jb] = row * 128;
-        wsw[jb] = (row >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) woff[jb][kk] = row * 128 + (((SP ? 2 * q : kk * 4 + q) ^ wswz(row)) << 4);
     }
-    int pp0[4];
+    // Patch fragments.  The chunk swizzle of the patch goes by the pixel's COLUMN, (col >> 1) & 7 (PW is even: column parity = pixel
+    // parity, so the 16 consecutive columns of a fragment read still fall into 16 bank groups), and a lane's column is l15 + 16 k + dx:
+    // its swizzle is (l15 >> 1) & 7 (variant A) or that + 1 (variant B: dx == 2, or dx == 1 on an odd l15) - two precomputed chunk
+    // offsets per K sub-step and ONE select per step, instead of a shift / and / xor chain per fragment read.
+    int pbase[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int m = wm * 64 + mb * 16 + l15;
-        pp0[mb] = (m / TW) * PW + (m % TW);
+        pbase[mb] = ((m / TW) * PW + (m % TW)) * 128;
     }
+    int cA[KK], cB[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int c = SP ? 2 * q : kk * 4 + q;
+        cA[kk] = (c ^ ((l15 >> 1) & 7)) << 4;
+        cB[kk] = (c ^ (((l15 >> 1) + 1) & 7)) << 4;
+    }
+    const bool odd = (l15 & 1) != 0;
     f32x4 acc[JB][4], acc2[SP ? JB : 1][SP ? 4 : 1];
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
@@ -487,27 +506,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JB > 2 ? 2 
             fetchB(s2, t2);
         }
         const char* B = bst + (g & 1) * BSTAGE;
-        const int toff = (tp / 3) * PW + tp % 3;
+        const int dx = tp % 3;
+        const char* ptap = patch + ((tp / 3) * PW + dx) * 128;       // (scalar)
+        const bool useB = dx == 2 || (dx == 1 && odd);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             u32x4 wa[JB], wb[SP ? JB : 1];
 #pragma unroll
             for (int jb = 0; jb < JB; ++jb) {
-                if constexpr (SP) {
-                    wa[jb] = *(const u32x4*)(B + wrow_l[jb] + (((2 * q) ^ wsw[jb]) << 4));
-                    wb[jb] = *(const u32x4*)(B + wrow_l[jb] + (((2 * q + 1) ^ wsw[jb]) << 4));
-                } else {
-                    wa[jb] = *(const u32x4*)(B + wrow_l[jb] + (((kk * 4 + q) ^ wsw[jb]) << 4));
-                }
+                wa[jb] = *(const u32x4*)(B + woff[jb][kk]);
+                if constexpr (SP) wb[jb] = *(const u32x4*)(B + (woff[jb][kk] ^ 16));
             }
+            const int csel = useB ? cB[kk] : cA[kk];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                const int pp = pp0[mb] + toff;
-                const char* prow = patch + pp * 128;
-                const int sw = (pp >> 1) & 7;
+                const char* prow = ptap + pbase[mb];
                 if constexpr (SP) {
-                    const half8 xh = *(const half8*)(prow + (((2 * q) ^ sw) << 4));
-                    const half8 xl = *(const half8*)(prow + (((2 * q + 1) ^ sw) << 4));
+                    const half8 xh = *(const half8*)(prow + csel);
+                    const half8 xl = *(const half8*)(prow + (csel ^ 16));
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) {
                         const half8 ah = __builtin_bit_cast(half8, wa[jb]), al = __builtin_bit_cast(half8, wb[jb]);
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JB > 2 ? 2 
                         acc2[jb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, acc2[jb][mb], 0, 0, 0);
                     }
                 } else {
-                    const elem8 xf = *(const elem8*)(prow + (((kk * 4 + q) ^ sw) << 4));
+                    const elem8 xf = *(const elem8*)(prow + csel);
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) acc[jb][mb] = UDAPOSE_MFMA_16x16x32(__builtin_bit_cast(elem8, wa[jb]), xf, acc[jb][mb]);
                 }
@@ -615,8 +631,11 @@ static int patch_trunk_ok(const ConvGeom& g, const ConvEpilogue& e) {
     if (e.f32 || e.res || e.stats || e.out_f32 || g.Ci < 64 || g.Ci % 64 || g.Co % 64) return 0;
     const int Ho = g.Ho(), Wo = g.Wo();
     if (Wo % 32 || Ho < 2 || Wo < 2) return 0;
-    const int TW = (Wo % 64 == 0) ? 64 : 32;
-    if (Ho % (128 / TW)) return 0;
+    // tile shape: 4 x 32 pixels (a 6 x 34 patch: 1.6 staged pixels per output pixel) where the height allows, else 2 x 64 (4 x 66: 2.1)
+    // (measured on the style network, N = 32: 2.85 against 2.89 ms per pass in the 16-bit form, 6.26 against 6.66 in the split form, whose
+    // 2 x 64 variant also spills)
+    const int TW = (Ho % 4 == 0) ? 32 : 64;
+    if (Wo % TW || Ho % (128 / TW)) return 0;
     if ((long long)g.Hi * g.Wi * g.Ci * (e.split ? 4 : 2) >= (1ll << 32)) return 0;       // (32-bit patch offsets per image)
     return TW;
 }
