@@ -55,6 +55,8 @@ int pw_f32_to_split(hipStream_t, const float*, void*, size_t);
 int pw_transpose_split(hipStream_t, const float*, void*, int, int, int);
 int pw_pack_strided_split(hipStream_t, const float*, void*, int, int, int, int, int, int, long, long, long, long);
 int pw_bn_apply_split(hipStream_t, const float*, const void*, void*, size_t, int, const float*, const float*, int);
+int pw_bn_train_fused_split(hipStream_t, const float*, const void*, void*, size_t, int, const float*, int, const float*, const float*, float*, float*,
+                            long long*, float, float, float*, int, int);
 int pw_maxpool3x3s2_fwd_split(hipStream_t, const void*, void*, unsigned char*, int, int, int, int);
 
 namespace {
@@ -336,6 +338,13 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
                                            beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
                                            upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked, mask);
+        if (took < 0) return took;
+        if (took) return UDAPOSE_OK;
+    }
+    if (training && n.f32 == 2 && !no_apply && !pre_bias) {
+        const int took = pw_bn_train_fused_split(s, (const float*)(act + c.y_off), res, act + b.z_off, b.npix, b.C, slab, conv_stat_rows(c.g), gamma, beta,
+                                                 upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
+                                                 upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked);
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }

@@ -503,7 +503,10 @@ __global__ void bn_bwd_apply_k(const DZ* __restrict__ dz, const elem_t* __restri
 // epilogue's partial-statistics slab ([rows][2][C], rows <= 128 since the igemm adds its wave rows itself: <= 64 KB of
 // L2-resident data, read as 16-byte vectors) in fp64 with a fixed order and derives scale / shift exactly as bn_finalize_k
 // does; the sp == 0 work-groups also write the saved statistics and the running-statistics update.  Then it streams its pixels.
-__global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const elem_t* __restrict__ y, const elem_t* __restrict__ res, elem_t* __restrict__ z,
+// (TY / TZ: element types of the pre-BN conv output and of the residual / output: elem_t, elem_t in the 16-bit modes; float, sp32 in the
+// f16x2 mode, whose convolutions leave y in fp32 and whose activations are split tensors)
+template <typename TY, typename TZ>
+__global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const TY* __restrict__ y, const TZ* __restrict__ res, TZ* __restrict__ z,
                                                         size_t npix, int C, const float* __restrict__ slab, int rows, double count,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -582,23 +585,25 @@ __global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const elem_t* __restrict
     for (size_t p = p0 + prow; p < p1; p += 32) {
         const size_t off = p * C + c0;
         float v[8], o[8];
-        ld8<elem_t>(y + off, v);
+        ld8<TY>(y + off, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = v[e] * sc[e] + sh[e];
         if (res) {
             float r8[8];
-            ld8<elem_t>(res + off, r8);
+            ld8<TZ>(res + off, r8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += r8[e];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (relu && o[e] < 0.f) ? 0.f : o[e];
-        st8<elem_t>(z + off, o);
-        if (mask) {
-            unsigned mb = 0u;
+        st8<TZ>(z + off, o);
+        if constexpr (sizeof(TZ) == sizeof(elem_t)) {
+            if (mask) {
+                unsigned mb = 0u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mb |= ((float)(elem_t)o[e] > 0.f ? 1u : 0u) << e;
-            mask[off >> 3] = (unsigned char)mb;
+                for (int e = 0; e < 8; ++e) mb |= ((float)(elem_t)o[e] > 0.f ? 1u : 0u) << e;
+                mask[off >> 3] = (unsigned char)mb;
+            }
         }
     }
 }
@@ -1154,8 +1159,25 @@ int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t*
     int P = (int)((npix + S - 1) / S);
     P = (P + 31) & ~31;
     S = (int)((npix + P - 1) / P);
-    hipLaunchKernelGGL(bn_apply_chunk_k, dim3(chunks, S), dim3(TPB), 0, s, y, res, z, npix, C, slab, rows, (double)npix, gamma, beta, eps, momentum, rm,
-                       rv, nbt, save, relu, P, mask);
+    hipLaunchKernelGGL((bn_apply_chunk_k<elem_t, elem_t>), dim3(chunks, S), dim3(TPB), 0, s, y, res, z, npix, C, slab, rows, (double)npix, gamma, beta, eps,
+                       momentum, rm, rv, nbt, save, relu, P, mask);
+    return udapose_check_launch() == UDAPOSE_OK ? 1 : UDAPOSE_ERR_LAUNCH;
+}
+// the same for the f16x2 mode: y fp32 (the split convolutions' pre-BN output), res / z split tensors.  On the teacher's forward - the
+// critical path of a step in the reference precision mix - this removes one launch (bn_finalize_k) per BatchNorm of layer3 / layer4 / deconv1.
+int pw_bn_train_fused_split(hipStream_t s, const float* y, const void* res, void* z, size_t npix, int C, const float* slab, int rows,
+                            const float* gamma, const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* save,
+                            int relu, int enabled) {
+    if (!enabled || C < 256 || C % 64 || npix > 8192 || npix < 1024 || rows > 128) return 0;
+    const int chunks = C / 64;
+    int S = (enabled > 1 ? enabled : 1024) / chunks;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    int P = (int)((npix + S - 1) / S);
+    P = (P + 31) & ~31;
+    S = (int)((npix + P - 1) / P);
+    hipLaunchKernelGGL((bn_apply_chunk_k<float, sp32>), dim3(chunks, S), dim3(TPB), 0, s, y, (const sp32*)res, (sp32*)z, npix, C, slab, rows, (double)npix,
+                       gamma, beta, eps, momentum, rm, rv, nbt, save, relu, P, (unsigned char*)nullptr);
     return udapose_check_launch() == UDAPOSE_OK ? 1 : UDAPOSE_ERR_LAUNCH;
 }
 // the same for every BN layer of a net in one launch: jobs[blockIdx.x], channels blockIdx.y*TPB..; save = act + save_off
