@@ -80,6 +80,13 @@ typedef struct {
     int patch_conv;       /* reflection-padded 3x3 stride-1 convolutions (the style network) through the patch-staged kernels (input patch staged once,
                            * not once per tap): 0 never (the implicit GEMM for every layer), 1 the 64 -> 3 and 3 -> 64 end layers, 2 (default)
                            * the trunk layers too, 3 = 2 with 128 output channels per work-group in the 16-bit form */
+    int wgrad_overlap;    /* > 0: the weight gradients of a backward pass go out STAGE BY STAGE on a side stream, each stage as soon as the
+                           * gradient chain has left its layers (udapose_net_backward_staged + udapose_net_wgrad_staged): stage 0 = head +
+                           * deconvolutions, then groups of this many bottleneck blocks counted from the top (or the cuts below) */
+    int wgrad_cap;        /* > 0: grouped weight-gradient launches are PERSISTENT grids of this many work-groups (256 = one per CU) pulling
+                           * table entries from per-XCD heads: bounded residency, so a launch can run under the gradient chain */
+    int wgrad_cut_lo, wgrad_cut_hi;   /* staged launches: bit b set = bottleneck block b (0 = layer1's first) is the LOWEST block of its stage;
+                           * 0 / 0 = every wgrad_overlap-th block counted from the top */
     int pad0;
     void* timeline;
 } udapose_policy;
@@ -239,6 +246,25 @@ int udapose_net_backward_phase(udapose_net_t net, void* stream, const float* dou
  * together and their weight gradients are exposed there; one grid of twice the size has half the tail. */
 int udapose_net_wgrad_pair(udapose_net_t net, void* stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a,
                            const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int part);
+/* Staged weight gradients (udapose_policy.wgrad_overlap > 0; round 4): the ONE `loss.backward()` of the reference's step
+ * (train_human.py:436) computes every layer's weight gradient as soon as that layer's output gradient exists; here the plan's
+ * layers are cut into stages in chain order (stage 0 = head + deconvolutions, then groups of bottleneck blocks from the top, the
+ * stem with the last), and
+ *   udapose_net_backward_staged  runs the gradient chain of the whole backward on `stream` (= udapose_net_backward_phase(part 0,
+ *                                phase 1)) and records the plan's stage events of `slot` (0..3: one per concurrent pass of a step)
+ *                                as the chain leaves each stage;
+ *   udapose_net_wgrad_staged     enqueues on the side stream `wg_stream`, stage by stage: wait for the stage's event of pass A (and
+ *                                of pass B when act_b != NULL: the two passes of one plan share every launch), then that stage's
+ *                                grouped weight gradients.  Every stage but the last is a PERSISTENT grid of udapose_policy.wgrad_cap
+ *                                work-groups (bounded residency: the chain kernels of the layers below keep their CU slots).
+ * The caller joins wg_stream into the stream of the optimizer step.  Gradients are bit-identical to the unstaged backward for layers
+ * that reduce inside one work-group; layers split over pixels accumulate with fp32 atomics in either form (order not fixed).
+ * Both need udapose_net_bind_grads for the gradient placement (it builds the stage tables, events and head counters). */
+int udapose_net_num_stages(udapose_net_t net);
+int udapose_net_backward_staged(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
+                                void* act, void* ws, void* const* h_grads, float beta, int slot);
+int udapose_net_wgrad_staged(udapose_net_t net, void* wg_stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a, int slot_a,
+                             const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int slot_b);
 long long udapose_net_grad_split_param(udapose_net_t net);
 
 /* ---------------------------------------------------------------- heat-map losses and decode (fp32 NCHW rows [R=B*K][HW]) */

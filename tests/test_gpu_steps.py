@@ -519,6 +519,39 @@ def test_merged_weight_gradient_launch_is_bit_identical():
     assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
 
 
+@pytest.mark.parametrize("pol", [dict(wgrad_overlap=1, wgrad_cap=8), dict(wgrad_overlap=2, wgrad_cap=256), dict(wgrad_overlap=3, wgrad_cap=0),
+                                 dict(wgrad_overlap=1, wgrad_cap=64, wgrad_cut_lo=0b010101)])
+def test_staged_persistent_weight_gradients_are_bit_identical(pol):
+    """udapose_net_backward_staged + udapose_net_wgrad_staged (policy wgrad_overlap / wgrad_cap): the weight gradients launched stage by
+    stage on a side stream behind the events the gradient chain records, as persistent residency-capped grids that pull their table
+    entries (per-XCD heads, stealing, self-resetting counters), against the one grouped launch after the chain: same tables entries,
+    same tile kernels - bit-identical parameters, eagerly and over several replays of the captured step (the counters must have
+    reset themselves), for caps far below and above the entry count and for an explicit cut mask."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=8)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    res = {}
+    for staged in (False, True):
+        stu, tea = _tiny(K, layers=(1, 2, 3, 1), seed=5).cuda(), _tiny(K, layers=(1, 2, 3, 1), seed=5).cuda()
+        if staged:
+            stu.policy.update(pol)
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
+        tr.train_step(*args)
+        assert not stu._pending_wg
+        if staged:
+            hd = stu._last_hd
+            assert hd.staged and hd.L.udapose_net_num_stages(hd.h) >= 3
+        gs = GraphedTrainStep(tr, *args, warmup=1)
+        for _ in range(4):
+            out = gs.step(*args)
+        assert torch.isfinite(out["loss_all"])
+        res[staged] = [p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
+    assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
+
+
 @pytest.mark.parametrize("seed", [123, 4, 14])       # both directions drawn | t2s only | s2t only
 def test_config2_eager_step_matches_whole_step_oracle(seed):
     """BASELINE.json configs[2]'s whole step - AdaIN style transfer in both directions (drawn with probability 0.7

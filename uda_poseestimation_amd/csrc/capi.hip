@@ -83,6 +83,9 @@ int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
 int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
 int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int, int);
 int net_wgrad_pair(void*, hipStream_t, const void*, void*, void* const*, float, const void*, void*, void* const*, float, int);
+int net_num_stages(void*);
+int net_wgrad_staged(void*, hipStream_t, const void*, void*, void* const*, float, int, const void*, void*, void* const*, float, int);
+int net_backward_staged(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int);
 
 static Policy from_c(const udapose_policy& c) {
     Policy p;
@@ -90,7 +93,7 @@ static Policy from_c(const udapose_policy& c) {
     p.igemm_tap0 = c.igemm_tap0; p.wgrad_tile = c.wgrad_tile; p.wgrad_ksplit = c.wgrad_ksplit; p.wgrad_fastgeo = c.wgrad_fastgeo;
     p.wgrad_group = c.wgrad_group; p.wgrad_stages = c.wgrad_stages > 0 ? c.wgrad_stages : 128; p.wgrad_group_stem = c.wgrad_group_stem;
     p.bn_bwd_fused = c.bn_bwd_fused; p.bn_fwd_chunked = c.bn_fwd_chunked; p.bn_bwd_chunked = c.bn_bwd_chunked;
-    p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.igemm_wg_min = c.igemm_wg_min; p.wgrad_row3 = c.wgrad_row3; p.bn3_mask = c.bn3_mask; p.stem_fused = c.stem_fused; p.debug_sync = c.debug_sync; p.igemm_q_tile = c.igemm_q_tile; p.exp0 = c.exp0; p.wgrad_big = c.wgrad_big; p.igemm_big_min = c.igemm_big_min; p.patch_conv = c.patch_conv; p.timeline = (unsigned long long*)c.timeline;
+    p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.igemm_wg_min = c.igemm_wg_min; p.wgrad_row3 = c.wgrad_row3; p.bn3_mask = c.bn3_mask; p.stem_fused = c.stem_fused; p.debug_sync = c.debug_sync; p.igemm_q_tile = c.igemm_q_tile; p.exp0 = c.exp0; p.wgrad_big = c.wgrad_big; p.igemm_big_min = c.igemm_big_min; p.patch_conv = c.patch_conv; p.wgrad_overlap = c.wgrad_overlap; p.wgrad_cap = c.wgrad_cap; p.wgrad_cut_lo = c.wgrad_cut_lo; p.wgrad_cut_hi = c.wgrad_cut_hi; p.timeline = (unsigned long long*)c.timeline;
     return p;
 }
 static void to_c(const Policy& p, udapose_policy* c) {
@@ -98,7 +101,7 @@ static void to_c(const Policy& p, udapose_policy* c) {
     c->igemm_tap0 = p.igemm_tap0; c->wgrad_tile = p.wgrad_tile; c->wgrad_ksplit = p.wgrad_ksplit; c->wgrad_fastgeo = p.wgrad_fastgeo;
     c->wgrad_group = p.wgrad_group; c->wgrad_stages = p.wgrad_stages; c->wgrad_group_stem = p.wgrad_group_stem;
     c->bn_bwd_fused = p.bn_bwd_fused; c->bn_fwd_chunked = p.bn_fwd_chunked; c->bn_bwd_chunked = p.bn_bwd_chunked;
-    c->bn_bwd_pre_legacy = p.bn_bwd_pre_legacy; c->igemm_wg_min = p.igemm_wg_min; c->wgrad_row3 = p.wgrad_row3; c->bn3_mask = p.bn3_mask; c->stem_fused = p.stem_fused; c->debug_sync = p.debug_sync; c->igemm_q_tile = p.igemm_q_tile; c->exp0 = p.exp0; c->wgrad_big = p.wgrad_big; c->igemm_big_min = p.igemm_big_min; c->patch_conv = p.patch_conv; c->pad0 = 0; c->timeline = p.timeline;
+    c->bn_bwd_pre_legacy = p.bn_bwd_pre_legacy; c->igemm_wg_min = p.igemm_wg_min; c->wgrad_row3 = p.wgrad_row3; c->bn3_mask = p.bn3_mask; c->stem_fused = p.stem_fused; c->debug_sync = p.debug_sync; c->igemm_q_tile = p.igemm_q_tile; c->exp0 = p.exp0; c->wgrad_big = p.wgrad_big; c->igemm_big_min = p.igemm_big_min; c->patch_conv = p.patch_conv; c->wgrad_overlap = p.wgrad_overlap; c->wgrad_cap = p.wgrad_cap; c->wgrad_cut_lo = p.wgrad_cut_lo; c->wgrad_cut_hi = p.wgrad_cut_hi; c->pad0 = 0; c->timeline = p.timeline;
 }
 // a convolution descriptor and the policy it names, as the host-side geometry (the policy lives as long as this object)
 struct Geom {
@@ -279,6 +282,17 @@ int udapose_net_backward_phase(udapose_net_t n, void* stream, const float* dout,
                                void* ws, void* const* grads, float beta, int part, int phase) {
     if (!n) return UDAPOSE_ERR_ARG;
     return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part, phase);
+}
+int udapose_net_num_stages(udapose_net_t n) { return n ? net_num_stages(n) : 0; }
+int udapose_net_backward_staged(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act, void* ws,
+                                void* const* grads, float beta, int slot) {
+    if (!n || !dout || !params || !wpack || !act || !ws || !grads) return UDAPOSE_ERR_ARG;
+    return net_backward_staged(n, S(stream), dout, params, wpack, act, ws, grads, beta, slot);
+}
+int udapose_net_wgrad_staged(udapose_net_t n, void* wg_stream, const void* act_a, void* ws_a, void* const* grads_a, float beta_a, int slot_a,
+                             const void* act_b, void* ws_b, void* const* grads_b, float beta_b, int slot_b) {
+    if (!n || !act_a || !ws_a || !grads_a || (act_b && (!ws_b || !grads_b))) return UDAPOSE_ERR_ARG;
+    return net_wgrad_staged(n, S(wg_stream), act_a, ws_a, grads_a, beta_a, slot_a, act_b, ws_b, grads_b, beta_b, slot_b);
 }
 long long udapose_net_grad_split_param(udapose_net_t n) { return net_grad_split_param(n); }
 int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* const* params_s, void* const* grads, void* const* exp_avg,

@@ -42,6 +42,13 @@ struct Policy {
                                 // and 3 -> 64 end layers only, 2 = the trunk layers too (128 pixels x 64 channels per work-group), 3 = 128
                                 // channels per work-group in the 16-bit form where Co % 128 == 0 (measured equal to 2)
     int igemm_q_tile = -1;      // tile id for launches whose 128x64 grid has 769..1024 work-groups (second round mostly empty); -1: heuristic
+    int wgrad_overlap = 0;      // > 0: the weight gradients of a backward pass are launched STAGE BY STAGE on a side stream, each stage as soon as
+                                // the gradient chain has left its layers (net_backward_staged / net_wgrad_staged): stage 0 = head + deconvolutions,
+                                // then groups of this many bottleneck blocks from the top (or the cuts of wgrad_cut_lo / hi)
+    int wgrad_cap = 0;          // > 0: grouped weight-gradient launches are PERSISTENT grids of this many work-groups (256 = one per CU) that
+                                // pull table entries, so that a launch running under the gradient chain leaves the chain kernels their slots
+    int wgrad_cut_lo = 0, wgrad_cut_hi = 0;   // staged launches: bit b set = block b (0 = first block of layer1) is the LOWEST block of its stage
+                                // (0 / 0: every wgrad_overlap-th block counted from the top)
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null
@@ -104,7 +111,8 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
 // the x / dy / dw fields of the table entries are byte offsets from the three bases
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr,
-                       const void* x_base2 = nullptr, const void* dy_base2 = nullptr, void* dw_base2 = nullptr);
+                       const void* x_base2 = nullptr, const void* dy_base2 = nullptr, void* dw_base2 = nullptr, int cap = 0,
+                       unsigned int* ctr = nullptr);   // cap > 0 (with 9 zeroed counter words `ctr`): persistent grid of `cap` work-groups
 
 struct ConvEpilogue {
     const elem_t* res = nullptr;

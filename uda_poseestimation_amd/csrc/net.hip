@@ -146,6 +146,18 @@ struct Net {
     // batched deferred running-statistics update: device job table, rebuilt when the buffer pointers change
     BnRunJob* d_runjobs = nullptr; int n_runjobs = 0; const void* runjobs_key = nullptr;
     unsigned long long wg_tick = 0;
+    // staged weight gradients (Policy::wgrad_overlap): the backward's layers cut into stages in chain order.  Stage k's grouped
+    // launches need only the dy buffers the chain has written by the time it leaves the stage's lowest layer: the chain records
+    // ev[slot][k] there (slot = which of the step's concurrent passes) and net_wgrad_staged makes the side stream wait for it.
+    struct WgStage { int head_up, hi, lo, stem; };       // blocks hi..lo (hi < lo: none)
+    std::vector<WgStage> stages;
+    static constexpr int EV_SLOTS = 4, EV_MAX = 40;
+    hipEvent_t ev[EV_SLOTS][EV_MAX] = {};
+    int rec_slot = -1;                                   // >= 0 while net_backward_staged runs its chain
+    // persistent grouped launches (Policy::wgrad_cap): a ring of self-resetting head-counter sets (16 words each), one per launch
+    // in flight; a captured launch keeps the set it was given at capture
+    unsigned int* d_ctr = nullptr; int ctr_next = 0;
+    static constexpr int CTR_SETS = 128;
 };
 struct PackJobH { const float* src; elem_t* dst; int A, T, B, kind; long long n; };
 
@@ -377,6 +389,8 @@ void net_destroy(void* h) {
     for (auto& g : n->wg_groups)
         for (int t = 0; t < WG_CLASSES; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
     for (auto& g : n->wg_groups) if (g.d_zero) (void)hipFree(g.d_zero);
+    if (n->d_ctr) (void)hipFree(n->d_ctr);
+    for (auto& row : n->ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     delete n;
 }
 void net_set_policy(void* h, const Policy& p) { ((Net*)h)->policy = p; }
@@ -623,8 +637,46 @@ DgradBnStat bn_stat_of(const Net& n, const ConvL& c, const BnL& b, const void* c
 // the rest of the backward
 inline int split_block(const Net& n) { return n.layers[0] + n.layers[1]; }
 
+// which layers a `part` of the grouped weight gradients covers: 0 all, 1 / 2 the data-parallel cut, 16 + k = stage k of the staged form
+#define WG_PART_STAGE0 16
+struct PartSel { bool head_up; int hi, lo; bool stem; };
+PartSel part_sel(const Net& n, int part) {
+    const int nb = (int)n.blocks.size(), split = split_block(n);
+    if (part >= WG_PART_STAGE0) {
+        const Net::WgStage& st = n.stages[part - WG_PART_STAGE0];
+        return PartSel{st.head_up != 0, st.hi, st.lo, st.stem != 0};
+    }
+    if (part == 1) return PartSel{true, nb - 1, split, false};
+    if (part == 2) return PartSel{false, split - 1, 0, true};
+    return PartSel{true, nb - 1, 0, true};
+}
+// stage plan of the staged form: stage 0 = head + deconvolutions; then the bottleneck blocks from the top, a new stage after
+// every block whose bit is set in the cut mask (default: every wgrad_overlap-th); the last stage takes the stem
+void plan_stages(Net& n) {
+    n.stages.clear();
+    const int nb = (int)n.blocks.size();
+    if (n.policy.wgrad_overlap <= 0 || nb < 1 || nb > 64) return;
+    unsigned long long cut = ((unsigned long long)(unsigned)n.policy.wgrad_cut_hi << 32) | (unsigned)n.policy.wgrad_cut_lo;
+    if (!cut) {
+        int cnt = 0;
+        for (int b = nb - 1; b >= 0; --b)
+            if (++cnt == n.policy.wgrad_overlap) { cut |= 1ull << b; cnt = 0; }
+    }
+    cut |= 1ull;                                        // (block 0 always ends a stage)
+    n.stages.push_back(Net::WgStage{1, -1, 0, 0});
+    int hi = nb - 1;
+    for (int b = nb - 1; b >= 0; --b)
+        if ((cut >> b) & 1ull) {
+            if ((int)n.stages.size() >= Net::EV_MAX - 1) { n.stages.back().lo = 0; hi = -1; break; }     // (more cuts than events: the rest joins the last stage)
+            n.stages.push_back(Net::WgStage{0, hi, b, 0});
+            hi = b - 1;
+        }
+    n.stages.back().stem = 1;
+}
+
 int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int part) {
-    const bool upper = part != 2, lower = part != 1;
+    const PartSel sel = part_sel(n, part);
+    const bool upper = sel.head_up, lower = sel.stem;
     std::vector<WgParams> tab[WG_CLASSES];
     struct Unit { int prob, z, nblk; long load; };
     std::vector<Unit> units[WG_CLASSES];
@@ -683,8 +735,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         }
     }
     if (upper) for (int i = 2; i >= 0; --i) CK(add(n.up[i]));
-    for (int bi = (int)n.blocks.size() - 1; bi >= 0; --bi) {
-        if (bi >= split_block(n) ? !upper : !lower) continue;
+    for (int bi = sel.hi; bi >= sel.lo; --bi) {
         Block& b = n.blocks[bi];
         CK(add(b.c3)); CK(add(b.c2));
         if (b.has_ds) CK(add(b.cd));
@@ -748,7 +799,21 @@ int bind_wg_groups(Net& n, void* const* grads) {
     // 3 parts x 2 accumulate modes per gradient placement (a few KB of device tables each).  Tables are never evicted or rebuilt
     // in place: launches captured in a hipGraph hold their device pointers, and a process only ever uses a handful of
     // gradient placements (two per-pass buffers per network).
-    for (const int part : {0, 1, 2})
+    std::vector<int> parts = {0, 1, 2};
+    if (n.policy.wgrad_overlap > 0) {
+        if (n.stages.empty()) {
+            plan_stages(n);
+            for (int sl = 0; sl < Net::EV_SLOTS; ++sl)
+                for (size_t k = 0; k < n.stages.size(); ++k)
+                    if (!n.ev[sl][k] && hipEventCreateWithFlags(&n.ev[sl][k], hipEventDisableTiming) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        }
+        for (size_t k = 0; k < n.stages.size(); ++k) parts.push_back(WG_PART_STAGE0 + (int)k);
+    }
+    if (n.policy.wgrad_cap > 0 && !n.d_ctr) {
+        if (hipMalloc((void**)&n.d_ctr, Net::CTR_SETS * 16 * sizeof(unsigned int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemset(n.d_ctr, 0, Net::CTR_SETS * 16 * sizeof(unsigned int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    }
+    for (const int part : parts)
         for (const float beta : {0.f, 1.f}) {
             if (find_wg_group(n, grads, beta, part)) continue;
             n.wg_groups.emplace_back();
@@ -759,10 +824,18 @@ int bind_wg_groups(Net& n, void* const* grads) {
         }
     return UDAPOSE_OK;
 }
-int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta, int part) {
+// the head-counter set of the next persistent launch (null: the one-work-group-per-entry grid)
+unsigned int* next_ctr(Net& n, int cap) {
+    if (cap <= 0 || !n.d_ctr) return nullptr;
+    unsigned int* c = n.d_ctr + (size_t)n.ctr_next * 16;
+    n.ctr_next = (n.ctr_next + 1) % Net::CTR_SETS;
+    return c;
+}
+// cap: > 0 = persistent grid of that many work-groups (staged launches running under the gradient chain); 0 = one work-group per entry
+int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta, int part, int cap = 0) {
     Net::WgGroup* G = find_wg_group(n, grads, beta, part);
     if (!G) return UDAPOSE_ERR_NOT_PREPARED;
-    const bool with_stem = part != 1 && n.policy.wgrad_group_stem;
+    const bool with_stem = part_sel(n, part).stem && n.policy.wgrad_group_stem;
     G->last_use = ++n.wg_tick;
     if (G->d_zero) {
         CK(pw_zero_multi(s, G->d_zero, G->n_zero, grads[0]));
@@ -776,7 +849,8 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);
-        const int rc = wgrad_group_launch(s, t, G->d_tab[t], G->d_blk[t], G->per_xcd[t], act, ws, grads[0]);
+        const int rc = wgrad_group_launch(s, t, G->d_tab[t], G->d_blk[t], G->per_xcd[t], act, ws, grads[0], nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          cap, next_ctr(n, cap));
         conv_prof_after(s, tok);
         CK(rc);
     }
@@ -789,17 +863,17 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
 // launch per tile class: the step's two student passes end at about the same time and their weight-gradient launches are fully
 // exposed there; one grid of twice the size has half the tail (measured on the launches alone: 2498 us for 64 images against 2 x 1353).
 int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const* gradsA, float betaA, const char* actB, char* wsB,
-                void* const* gradsB, float betaB, int part) {
+                void* const* gradsB, float betaB, int part, int cap = 0) {
     Net::WgGroup* GA = find_wg_group(n, gradsA, betaA, part);
     Net::WgGroup* GB = find_wg_group(n, gradsB, betaB, part);
     if (!GA || !GB) return UDAPOSE_ERR_NOT_PREPARED;
     bool same = true;
     for (int t = 0; t < WG_CLASSES; ++t) same = same && GA->per_xcd[t] == GB->per_xcd[t];
     if (!same) {        // (different table shapes: two launches)
-        CK(run_wg_group(s, n, actA, wsA, gradsA, betaA, part));
-        return run_wg_group(s, n, actB, wsB, gradsB, betaB, part);
+        CK(run_wg_group(s, n, actA, wsA, gradsA, betaA, part, cap));
+        return run_wg_group(s, n, actB, wsB, gradsB, betaB, part, cap);
     }
-    const bool with_stem = part != 1 && n.policy.wgrad_group_stem;
+    const bool with_stem = part_sel(n, part).stem && n.policy.wgrad_group_stem;
     const ConvGeom& sg = n.stem.g;
     const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
     struct { Net::WgGroup* G; char* ws; void* const* grads; } side[2] = {{GA, wsA, gradsA}, {GB, wsB, gradsB}};
@@ -816,7 +890,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
         if (n.policy.exp0 & (1 << t)) continue;          // (tuning: skip this tile class - timing experiments only)
         const int tok = conv_prof_before(s, 2, GA->flops[t] + GB->flops[t]);
         const int rc = wgrad_group_launch(s, t, GA->d_tab[t], GA->d_blk[t], GA->per_xcd[t], actA, wsA, gradsA[0], GB->d_tab[t], GB->d_blk[t], actB, wsB,
-                                          gradsB[0]);
+                                          gradsB[0], cap, next_ctr(n, cap));
         conv_prof_after(s, tok);
         CK(rc);
     }
@@ -835,7 +909,45 @@ int net_wgrad_pair(void* h, hipStream_t s, const void* actA, void* wsA, void* co
     Net& n = *(Net*)h;
     if (part < 0 || part > 2 || n.f32 || !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
     DbgSyncScope dbg(n.policy.debug_sync);
-    return run_wg_pair(s, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, part);
+    // (wgrad_cap without wgrad_overlap: the end-of-chain launches themselves as persistent grids - dynamic scheduling only)
+    return run_wg_pair(s, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, part,
+                       n.policy.wgrad_overlap > 0 ? 0 : n.policy.wgrad_cap);
+}
+
+// Staged weight gradients (Policy::wgrad_overlap > 0, round 4).  net_backward_staged = the gradient chain of the whole backward
+// (phase 1) on `s`, recording the plan's stage events of `slot` as the chain leaves each stage.  net_wgrad_staged then enqueues, on
+// the side stream `sw`, stage after stage: wait for that stage's event of pass A (and of pass B), launch the stage's grouped weight
+// gradients (of both passes in one grid).  Every stage but the last runs as a persistent grid of Policy::wgrad_cap work-groups
+// (the chain kernels of the layers below keep their CU slots); the last stage starts when the chains have ended and takes the
+// whole chip.  The caller joins `sw` into the stream that runs the optimizer.  Inside a stream capture the waits become graph
+// edges, so the order in which the host enqueues chains and stages does not matter; eagerly the chains must be enqueued first.
+int net_num_stages(void* h) { return (int)((Net*)h)->stages.size(); }
+int net_wgrad_staged(void* h, hipStream_t sw, const void* actA, void* wsA, void* const* gradsA, float betaA, int slotA, const void* actB, void* wsB,
+                     void* const* gradsB, float betaB, int slotB) {
+    Net& n = *(Net*)h;
+    if (n.f32 || !n.policy.wgrad_group || n.stages.empty() || slotA < 0 || slotA >= Net::EV_SLOTS || slotB >= Net::EV_SLOTS) return UDAPOSE_ERR_ARG;
+    DbgSyncScope dbg(n.policy.debug_sync);
+    const int ns = (int)n.stages.size();
+    for (int k = 0; k < ns; ++k) {
+        if (hipStreamWaitEvent(sw, n.ev[slotA][k], 0) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (actB && hipStreamWaitEvent(sw, n.ev[slotB][k], 0) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        const int cap = k + 1 < ns ? n.policy.wgrad_cap : 0;
+        if (actB) CK(run_wg_pair(sw, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, WG_PART_STAGE0 + k, cap));
+        else CK(run_wg_group(sw, n, (const char*)actA, (char*)wsA, gradsA, betaA, WG_PART_STAGE0 + k, cap));
+    }
+    return UDAPOSE_OK;
+}
+int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack_, void* act_, void* ws_,
+                 void* const* grads, float beta, int part, int phase);
+int net_backward_staged(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack, void* act, void* ws,
+                        void* const* grads, float beta, int slot) {
+    Net& n = *(Net*)h;
+    if (slot < 0 || slot >= Net::EV_SLOTS || n.stages.empty()) return UDAPOSE_ERR_ARG;
+    if (!find_wg_group(n, grads, beta, WG_PART_STAGE0)) return UDAPOSE_ERR_NOT_PREPARED;
+    n.rec_slot = slot;
+    const int rc = net_backward(h, s, dout_nchw, params, wpack, act, ws, grads, beta, 0, 1);
+    n.rec_slot = -1;
+    return rc;
 }
 
 // grads[i] (fp32, same physical layout as params[i]) = beta*grads[i] + d loss / d params[i]; beta in {0,1}
@@ -910,6 +1022,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         pool.put(dz);
         dz = dx;
     }
+    if (n.rec_slot >= 0 && hipEventRecord(n.ev[n.rec_slot][0], s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;     // stage 0: head + deconvolutions
     } else {
         // part 2 resumes where part 1 stopped: the gradient entering block split-1 sits in the pool buffer part 1 ended on
         // (the buffer sequence is a function of the plan alone), masked for that block's bn3 with its sums in the slab
@@ -924,6 +1037,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     }
     // bottlenecks, last to first
     const int bi_hi = part == 2 ? split - 1 : (int)n.blocks.size() - 1, bi_lo = part == 1 ? split : 0;
+    int next_stage = 1;
     for (int bi = bi_hi; bi >= bi_lo; --bi) {
         Block& b = n.blocks[bi];
         // bn3 (+ReLU of the block output): g = masked dz feeds the skip branch (written in place unless the producing dgrad
@@ -952,6 +1066,11 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         if (dxd) pool.put(dxd);
         pool.put(dz);
         dz = dxin;
+        // staged weight gradients: the chain has left stage `next_stage` (every dy of its layers is enqueued): mark it
+        if (n.rec_slot >= 0 && next_stage + 1 < (int)n.stages.size() && n.stages[next_stage].lo == bi) {
+            if (hipEventRecord(n.ev[n.rec_slot][next_stage], s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+            ++next_stage;
+        }
     }
     if (part == 1) {
         for (int i = 0; i < 6; ++i) if ((char*)dz == ws + pool.off[i]) n.split_dz_idx = i;      // (the same value on every pass)
@@ -979,6 +1098,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 2, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
     }
+    if (n.rec_slot >= 0 && hipEventRecord(n.ev[n.rec_slot][n.stages.size() - 1], s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;   // last stage (stem included)
     if (grouped && phase == 0) CK(run_wg_group(s, n, act, ws, grads, beta, part));
     // backbone.fc is not part of the forward: zero gradient when overwriting
     if (beta == 0.f && part == 0) {

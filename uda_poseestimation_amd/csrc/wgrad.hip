@@ -448,7 +448,9 @@ template <int U> struct WIC { static constexpr int value = U; };
 template <int N, typename F> __device__ __forceinline__ void w_static_for(F&& f) {
     if constexpr (N > 0) { w_static_for<N - 1>(f); f(WIC<N - 1>{}); }
 }
-template <int RT, int CT, int WR, int WC, int NS, int PX>
+// (TAG: a second call site of one specialization fails to compile in hipcc 7.2's host pass - "substitution failure" - so each
+// calling kernel instantiates its own copy)
+template <int RT, int CT, int WR, int WC, int NS, int PX, int TAG = 0>
 __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
                                                  const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
     struct {
@@ -868,6 +870,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 1
     }
 }
 
+// Persistent, residency-capped form of the grouped launch (round 4): the grid is `cap` work-groups (1-2 per CU) instead of one per
+// table entry, and every work-group PULLS entries until the table is drained.  A launch of this form can run on a side stream
+// UNDER the latency-bound gradient chain of the layers below it without flooding the CUs: it holds at most cap / 256 work-groups'
+// worth of LDS and wave slots per CU, whatever the table's size (the one-work-group-per-entry grid put four 32 KB work-groups
+// on every CU for ~130 us each and starved the chain kernels: profiles/r2_ab_runs.txt, r3_ab_runs.txt).
+// Scheduling: one head counter per XCD list (ctr[0..7]; the guide's `dequeue` row: 0.3-1.3 us per pull with sharded heads
+// against units of 20-130 us).  A work-group starts on the list of the XCD it actually runs on (HW_REG_XCC_ID: the tiles that
+// re-read one pixel range share that L2) and, once that list is empty, steals from the next ones, so every list is drained
+// wherever the dispatcher placed the grid - placement is a speed matter only.  Exit: every work-group leaves after ONE failed
+// pull on each of the 8 lists (bounded: the heads only grow).  The counters reset themselves: the last work-group to leave
+// (ctr[8] counts leavers) zeroes all nine words, so a captured launch replays without a memset node.
+template <int RT, int CT, int WR, int WC, int NS, int PX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 128 * 128 ? 2 : 4))) void wgrad_persist_kernel(
+    const WgParams* __restrict__ tabA, const WgGroupBlk* __restrict__ blkA, const uint32_t per_xcd, const char* x_baseA, const char* dy_baseA,
+    char* dw_baseA, const WgParams* __restrict__ tabB, const WgGroupBlk* __restrict__ blkB, const char* x_baseB, const char* dy_baseB,
+    char* dw_baseB, unsigned int* __restrict__ ctr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned int s_slot;
+    const uint32_t nslots = tabB ? 2u * per_xcd : per_xcd;           // entries per XCD list (pair launch: the two passes interleaved)
+    // (s_getreg HW_REG_XCC_ID: id 20, offset 0, 4 bits)
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    for (uint32_t hop = 0; hop < 8u; ++hop) {
+        const uint32_t lst = (xcc + hop) & 7u;
+        while (true) {
+            __syncthreads();                                          // (the previous unit's last LDS reads, and s_slot's readers)
+            if (threadIdx.x == 0) s_slot = atomicAdd(&ctr[lst], 1u);
+            __syncthreads();
+            uint32_t slot = s_slot;
+            if (slot >= nslots) break;
+            const WgParams* tab = tabA; const WgGroupBlk* blk = blkA;
+            const char* x_base = x_baseA; const char* dy_base = dy_baseA; char* dw_base = dw_baseA;
+            if (tabB) {
+                if (slot & 1u) { tab = tabB; blk = blkB; x_base = x_baseB; dy_base = dy_baseB; dw_base = dw_baseB; }
+                slot >>= 1;
+            }
+            const WgGroupBlk b = blk[lst * per_xcd + slot];
+            if (b.prob < 0) continue;
+            const WgParams& p = tab[b.prob];
+            const uint32_t gx = (uint32_t)(p.r_tiles * p.c_tiles), gxy = gx * (uint32_t)p.total_taps;
+            const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
+            const uint32_t by = bxy / gx, bx = bxy - by * gx;
+            bool done = false;
+            if constexpr (RT == 64 && CT == 64 && PX == 64) {
+                if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base); done = true; }
+            }
+            if (!done) {
+                if constexpr (RT != CT) {
+                    wgrad_fast2_body<RT, CT, WR, WC, NS, PX, 1>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+                } else {
+                    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX, 1>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+                    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+                    else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+                }
+            }
+        }
+    }
+    // leave: the last of the grid's work-groups resets the heads (every other work-group has made its last pull by then)
+    if (threadIdx.x == 0) {
+        const unsigned int left = atomicAdd(&ctr[8], 1u);
+        if (left == gridDim.x - 1u) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicExch(&ctr[k], 0u);
+        }
+    }
+}
+
+template <int RT, int CT, int WR, int WC, int NS, int PX>
+int launch_wd_persist(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
+                      hipStream_t stream, const WgParams* d_tab2, const WgGroupBlk* d_blk2, const void* x_base2, const void* dy_base2,
+                      void* dw_base2, int cap, unsigned int* ctr) {
+    using C = WdCfg<RT, CT, WR, WC, NS, PX>;
+    constexpr int LDS = (RT == 64 && CT == 64 && PX == 64 && Row3Cfg::lds_bytes(NS) > C::LDS_BYTES) ? Row3Cfg::lds_bytes(NS) : C::LDS_BYTES;
+    static std::atomic<unsigned long long> attr_done{0};
+    static std::mutex attr_mu;
+    once_per_device(attr_done, attr_mu, [] {
+        (void)hipFuncSetAttribute((const void*)wgrad_persist_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    });
+    const long total = 8L * per_xcd * (d_tab2 ? 2 : 1);
+    const int grid = (int)(total < cap ? total : cap);
+    hipLaunchKernelGGL((wgrad_persist_kernel<RT, CT, WR, WC, NS, PX>), dim3(grid), dim3(256), LDS, stream, d_tab, d_blk, (uint32_t)per_xcd,
+                       (const char*)x_base, (const char*)dy_base, (char*)dw_base, d_tab2, d_blk2, (const char*)x_base2, (const char*)dy_base2,
+                       (char*)dw_base2, ctr);
+    return udapose_check_launch();
+}
+
 template <int RT, int CT, int WR, int WC, int NS, int PX>
 int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
                     hipStream_t stream, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr, const void* x_base2 = nullptr,
@@ -1032,12 +1119,17 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
 
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base, const WgParams* d_tab2, const WgGroupBlk* d_blk2, const void* x_base2,
-                       const void* dy_base2, void* dw_base2) {
+                       const void* dy_base2, void* dw_base2, int cap, unsigned int* ctr) {
     if (per_xcd <= 0) return UDAPOSE_OK;
     // 32-pixel stages for the 128x128 tile (32 KB of LDS, 128 VGPRs: four resident work-groups per CU instead of two with
     // 64-pixel stages) and a 2-stage ring of 64-pixel stages for the 64x64 tile (35 KB with the filter-row form's reserve: four per
     // CU; round 1 ran three stages = three per CU, with the buffer-load loader two measure -4.5 % alone and -0.05 ms in the step):
     // occupancy beats prefetch depth here as in the igemm (a 3-stage ring for the 128x128 tile: +40 % alone)
+    if (cap > 0 && ctr) {       // persistent, residency-capped grid (wgrad_persist_kernel)
+        if (tile == 2) return launch_wd_persist<256, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
+        if (tile == 0) return launch_wd_persist<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
+        return launch_wd_persist<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
+    }
     if (tile == 2) return launch_wd_group<256, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
     if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
     return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);

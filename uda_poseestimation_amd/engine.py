@@ -328,6 +328,8 @@ class MeanTeacherTrainer:
         if self._side is None or self._side[0].device != x_s.device:
             pr = self.stream_priority
             self._side = (torch.cuda.Stream(device=x_s.device, priority=pr), torch.cuda.Stream(device=x_s.device, priority=pr))
+        if getattr(self, "_wg_stream", None) is None or self._wg_stream.device != x_s.device:
+            self._wg_stream = torch.cuda.Stream(device=x_s.device)      # staged weight gradients (policy wgrad_overlap): created outside capture
         s_tea, s_stu = self._side if self.concurrent else (main, main)
         occl = self._occl if self.occlude_rate > -1 else None
         student.prepare(x_s)                # bf16 weight packs refreshed on `main` before the branches fork
@@ -426,7 +428,7 @@ class MeanTeacherTrainer:
         student.split_backward = False
         if merge:
             student.merge_wgrad = False
-            student.finish_wgrad()
+            student.finish_wgrad(getattr(self, "_wg_stream", None))
         if overlap:
             student.finish_grads(part=1)    # the suffix of both passes is final: sum it ...
             if not torch.cuda.is_current_stream_capturing():

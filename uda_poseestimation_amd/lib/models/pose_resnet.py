@@ -80,6 +80,8 @@ class _NetHandle:
         self.wpack_version = None
         # (the backward can be cut at layer3's first block, and its weight gradients are grouped launches)
         self.grouped = int((policy or {}).get("wgrad_group", 1)) != 0
+        # staged weight gradients (udapose_policy.wgrad_overlap): stage by stage on a side stream under the gradient chain
+        self.staged = self.grouped and int((policy or {}).get("wgrad_overlap", 0)) > 0 and precision in ('bf16', 'fp16')
         self.can_split = L.udapose_net_grad_split_param(h) >= 0 and self.grouped
         self.act_nograd = None
         self._fin = weakref.finalize(self, L.udapose_net_destroy, h)
@@ -466,9 +468,16 @@ class PoseResNet(nn.Module):
                   "net_backward part 1")
             self._pending_lower.append((hd, act, ws, gptrs, beta, cur, side))       # (keeps the arenas alive until part 2 has run)
         elif self.merge_wgrad and hd.grouped:
-            check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 1),
-                  "net_backward gradient chain")
-            self._pending_wg.append((hd, act, ws, gptrs, beta, cur))          # (keeps the arenas alive until the weight gradients have run)
+            if hd.staged and len(self._pending_wg) < 2:
+                # the chain records the plan's stage events of this pass's slot; finish_wgrad() launches every stage behind its event
+                slot = len(self._pending_wg)
+                check(hd.L.udapose_net_backward_staged(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, slot),
+                      "net_backward gradient chain (staged)")
+                self._pending_wg.append((hd, act, ws, gptrs, beta, cur, slot))
+            else:
+                check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 1),
+                      "net_backward gradient chain")
+                self._pending_wg.append((hd, act, ws, gptrs, beta, cur, -1))      # (keeps the arenas alive until the weight gradients have run)
         else:
             check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not
@@ -478,24 +487,42 @@ class PoseResNet(nn.Module):
             if p.requires_grad and id(p) not in nograd:
                 p.grad = v
 
-    def finish_wgrad(self):
+    def finish_wgrad(self, wg_stream=None):
         """Launch the grouped weight gradients of the backward passes that ran with merge_wgrad, on the current stream (the caller
-        has made it wait for the streams those passes ran on): two pending passes of one plan go out as ONE launch per tile class."""
+        has made it wait for the streams those passes ran on): two pending passes of one plan go out as ONE launch per tile class.
+        Staged plans (policy wgrad_overlap): every stage goes to `wg_stream` behind the event its gradient chain recorded, as a
+        residency-capped persistent grid that runs UNDER the rest of the chain; the current stream then waits for `wg_stream`."""
         pend, self._pending_wg = self._pending_wg, []
         if not pend:
             return
         s = _hip.stream()
         cur = torch.cuda.current_stream()
         pa, ba, params = self._pointers()
-        if len(pend) == 2 and pend[0][0] is pend[1][0]:
-            (hd, actA, wsA, gA, bA, _), (_, actB, wsB, gB, bB, _) = pend
+        staged = all(q[6] >= 0 for q in pend) and all(q[0] is pend[0][0] for q in pend) and len(pend) <= 2
+        if staged:
+            if wg_stream is None:
+                raise RuntimeError("finish_wgrad: a staged plan (policy wgrad_overlap) needs the weight-gradient side stream")
+            hd, actA, wsA, gA, bA, _, slA = pend[0]
+            if len(pend) == 2:
+                _, actB, wsB, gB, bB, _, slB = pend[1]
+                check(hd.L.udapose_net_wgrad_staged(hd.h, wg_stream.cuda_stream, ptr(actA), ptr(wsA), gA, bA, slA, ptr(actB), ptr(wsB), gB, bB, slB),
+                      "net_wgrad_staged")
+            else:
+                check(hd.L.udapose_net_wgrad_staged(hd.h, wg_stream.cuda_stream, ptr(actA), ptr(wsA), gA, bA, slA, None, None, None, 0.0, 0),
+                      "net_wgrad_staged")
+            for q in pend:
+                q[1].record_stream(wg_stream)
+                q[2].record_stream(wg_stream)
+            cur.wait_stream(wg_stream)
+        elif len(pend) == 2 and pend[0][0] is pend[1][0] and pend[0][6] < 0 and pend[1][6] < 0:
+            (hd, actA, wsA, gA, bA, _, _), (_, actB, wsB, gB, bB, _, _) = pend
             check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0), "net_wgrad_pair")
         else:
-            for hd, act, ws, gptrs, beta, _ in pend:
+            for hd, act, ws, gptrs, beta, _, _ in pend:
                 check(hd.L.udapose_net_backward_phase(hd.h, s, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 2), "net_backward weight gradients")
-        for _, act, ws, _, _, _ in pend:
-            act.record_stream(cur)
-            ws.record_stream(cur)
+        for q in pend:
+            q[1].record_stream(cur)
+            q[2].record_stream(cur)
 
     def _side_stream_for(self, cur, device):
         """The side stream paired with `cur` (one per stream a backward runs on).  Streams are only CREATED outside a capture
