@@ -60,28 +60,111 @@ def measured_traffic_per_step(eager_steps=9):
         return None
 
 
-def cpu_baseline(n, arch_layers, seconds_budget=25.0):
-    """CPU oracle step (kind 'port'): PoseResNet-101 mean-teacher step on `n` images, fp32, all host cores."""
+def host_cpu_share():
+    """Cores this process may actually use: the affinity mask, cut by the cgroup's CPU quota when one is set (a GPU box hands each
+    lease a share of the host; running more threads than that share only oversubscribes it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(path).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, int(q / p + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(n, arch_layers, seconds_budget=30.0):
+    """CPU oracle step (kind 'port'): PoseResNet-101 mean-teacher step on `n` images per domain, fp32, in the CPU's best configuration
+    found inside the budget: the thread count is swept on a short probe (one student forward + backward on 2 images) over
+    {8, 16, 32, 64, the process's CPU share, all logical CPUs}, then the whole step is timed with the best count at batch `n`
+    (default 8: SURVEY.md's own 8-core probe ran 0.9 img/s there; N = 2 on every logical CPU of the box, round 3's setting, read
+    0.32 img/s - oversubscribed threads on a tiny batch)."""
+    from oracle.losses_ref import joints_mse_ref
     from oracle.pose_resnet_ref import PoseResNetRef
     from oracle.step_ref import train_step_ref
     from uda_poseestimation_amd import synthetic
+    t_start = time.time()
+    n = n if n > 0 else 8
     torch.manual_seed(0)
     stu, tea = PoseResNetRef(arch_layers, 16), PoseResNetRef(arch_layers, 16)
     tea.load_state_dict(stu.state_dict())
     opt = torch.optim.Adam(stu.parameters(), lr=1e-4)
     b = synthetic.mean_teacher_batch(n, seed=0)
+    share, logical = host_cpu_share(), (os.cpu_count() or 1)
+    # (candidates up to twice the share: far more threads than cores only oversubscribes, and one such probe can eat the whole budget)
+    cands = sorted({c for c in (8, 16, 32, 64, share, logical) if 1 <= c <= min(logical, max(2 * share, 8))})
+    probe = {}
+    xs, ls, ws = b["x_s"][:2], b["label_s"][:2], b["weight_s"][:2]
+    for c in cands:
+        torch.set_num_threads(c)
+        best = None
+        for it in range(2):                     # (first pass: primitive creation / allocator warm-up)
+            t0 = time.time()
+            stu.zero_grad()
+            joints_mse_ref(stu(xs), ls, ws).backward()
+            dt = time.time() - t0
+            best = dt if best is None or it > 0 else best
+        probe[c] = best
+        print(f"cpu_baseline probe: {c} threads {best:.2f} s", file=sys.stderr, flush=True)
+        if time.time() - t_start > 0.3 * seconds_budget:
+            break
+    stu.zero_grad()
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     times = []
-    t_start = time.time()
-    for it in range(3):
+    for it in range(5):
         t0 = time.time()
         train_step_ref(stu, tea, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"], b["aug_param_tea"])
         times.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget:
+        print(f"cpu_baseline step {it}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
+        if time.time() - t_start + times[-1] > seconds_budget:      # (no room for another iteration)
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": n / best, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(n / best, 3), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"PoseResNet-101 mean-teacher step (student fwd+bwd on 2x{n}, teacher fwd on {n}, losses, Adam, EMA) fp32 "
-                      f"oracle/step_ref.py, {len(times)} iteration(s), best of the non-first: {best:.2f} s/step"}
+                      f"oracle/step_ref.py, batch {n}, {threads} threads (CPU share {share}, {logical} logical CPUs; probe s per 2-image fwd+bwd by threads: "
+                      + ", ".join(f"{c}: {t:.2f}" for c, t in probe.items()) + f"), {len(times)} iteration(s), best"
+                      + (" of the non-first (times fall over the first iterations: " + ", ".join(f"{t:.1f}" for t in times) + " s)" if len(times) > 1 else "") + f": {best:.2f} s/step"}
+
+
+def other_config_rate(arch, dev, N, K, S, sigma, dtype, precision, steps=20, warmup=3):
+    """The SAME step (BASELINE.json configs[1] shape) in another precision configuration, timed as `steps` hipGraph replays between
+    two synchronisations AFTER the headline's timed region (never part of `value`): the configurations that meet north_star's 1e-3
+    heat-map bar on a trained network - fp16 everywhere, and the reference's own mix (train_human.py:346-358,414: fp16 student under
+    the loss scaler, fp32-grade teacher) - next to the bf16 headline."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    import uda_poseestimation_amd.lib.models as models
+    torch.manual_seed(0)
+    student = models.__dict__[arch](num_keypoints=K, pretrained_backbone=False).to(dev)
+    teacher = models.__dict__[arch](num_keypoints=K, pretrained_backbone=False).to(dev)
+    trainer = MeanTeacherTrainer(student, teacher, lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=sigma, image_size=S,
+                                 heatmap_size=S // 4, precision=(precision or dtype))
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=0)
+    g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    graphed = GraphedTrainStep(trainer, g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    for _ in range(warmup):
+        out = graphed.step(None, None, None, None, None, g["aug_param_stu"], g["aug_param_tea"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = graphed.step(None, None, None, None, None, g["aug_param_stu"], g["aug_param_tea"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = float(out["loss_all"])
+    res = {"images_per_sec": round(N * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "loss_finite": loss == loss,
+           "student": student._last_hd.precision, "teacher": teacher._last_hd.precision}
+    del graphed, trainer, student, teacher, g
+    torch.cuda.empty_cache()
+    return res
 
 
 def spawn_ranks(n):
@@ -164,7 +247,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=0, help="batch of the CPU baseline step (0: 8, or what fits the time budget)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed extra legs (fp16 / reference precision mix rates)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -353,6 +437,17 @@ def main():
         sync_ms.append((time.perf_counter() - t_a) * 1e3)
     sync_ms.sort()
     ms_synced = sync_ms[len(sync_ms) // 2] if sync_ms else None
+    # The same loop with the read-back DEFERRED by one step (GraphedTrainStep.step_async: losses + device PCK of step i are read from a
+    # pinned double buffer while step i+1 is already queued): what a loop that logs every iteration costs with this engine
+    ms_deferred, last_metrics = None, None
+    if not args.eager and host is None and getattr(graphed, "metrics", False):
+        nd = min(args.steps, 40)
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for i in range(nd):
+            last_metrics = graphed.step_async(None, None, None, None, None, g["aug_param_stu"], g["aug_param_tea"])
+        last_metrics = graphed.flush_metrics()
+        ms_deferred = (time.perf_counter() - t_a) / nd * 1e3
     # Roofline sample, UNTIMED, after the timed region: one eager step on ONE stream with HIP events recorded on the launch
     # stream around every convolution launch (events cannot be placed inside a replayed graph; single-stream so that the
     # per-launch durations are comparable with rocprofv3's, which serialises).  A dry run first creates the profiler's event
@@ -399,6 +494,8 @@ def main():
             "metric": f"images/sec (student+teacher step) {S}x{S} b={N}", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "ms_per_step_synced": round(ms_synced, 3) if ms_synced is not None else None,
+            "ms_per_step_deferred_readback": round(ms_deferred, 3) if ms_deferred is not None else None,
+            "pck_source_batch": (round(last_metrics["acc_s"], 4) if last_metrics else None),
             "spinup_s": args.spinup, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": ("fp16 (student) + f16x2 fp32-grade (teacher, style)" if args.precision == "reference" else
                       ("fp16 (student) + exact fp32 MFMA (teacher, style)" if args.precision == "reference_fp32" else args.dtype)), "data": "synthetic",
@@ -436,6 +533,25 @@ def main():
                                            "peak_TBps": 8.0, "note": "whole-step HBM traffic of the conv / BN / weight-gradient kernels (PMC passes under "
                                            "profiles/) over this run's step time: the step is bound by bytes and by latency-bound launch chains, "
                                            "not by the MFMA pipes"}
+        # the parity-compliant configurations of the same step, driver-visible (untimed extras after the headline's timed region)
+        headline_cfg = (args.arch, S, K, N, args.dtype, args.precision) == ("pose_resnet101", 256, 16, 32, "bf16", None)
+        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune):
+            try:
+                del graphed
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            oc = {}
+            for tag, dt_, pr_ in (("fp16", "fp16", None), ("reference_mix", "fp16", "reference")):
+                print(f"other_configs: {tag} ...", file=sys.stderr, flush=True)
+                oc[tag] = other_config_rate(args.arch, dev, N, K, S, sigma, dt_, pr_)
+            oc["fp16"]["heatmap_error_vs_fp32_oracle"] = ("trained PoseResNet-101, train-mode BN, 256x256: max|dy| 8.6e-4 (bar 1e-3), arg-max identical 32/32 "
+                                                          "(tests/test_gpu_trained.py::test_trained_like_forward_parity_all_precisions)")
+            oc["reference_mix"]["heatmap_error_vs_fp32_oracle"] = ("teacher (f16x2) 5.5e-7 on the trained network, 3.6e-5 at the reference initialisation; "
+                                                                   "student (fp16) 8.6e-4; arg-max identical 32/32 (same test; tests/test_gpu_f16x2.py)")
+            oc["note"] = ("the headline (bf16, BASELINE.json configs[1]) is at 5.6e-3 = 0.6 % of max|y| from the fp32 oracle on the same trained network "
+                          "(arg-max identical 32/32): the configurations that meet the ABSOLUTE 1e-3 bar are these two")
+            res["other_configs"] = oc
         if not args.no_cpu_baseline and world == 1:     # (the CPU leg runs on rank 0 of the ONE-rank run only; N > 1 lines carry null)
             res["cpu_baseline"] = cpu_baseline(args.cpu_images, layers)
         elif world > 1:

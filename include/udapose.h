@@ -343,8 +343,10 @@ int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, flo
 
 /* ---------------------------------------------------------------- gradient all-reduce in bf16 on the wire (data parallel,
  * the 212 MB fp32 student-gradient buffer): pack = one rounding of the fp32 bucket to bf16 (zero padded to n_padded, a
- * multiple of the world size); after an all-to-all every rank holds the W ranks' copies of its shard: shard_mean adds them in fp32,
- * divides by W and writes the averaged shard in bf16; after the all-gather unpack widens the bucket back to fp32. */
+ * multiple of the world size); after an all-to-all every rank holds the W ranks' copies of its shard: shard_mean adds them in fp32
+ * (rank order), multiplies by 1/W and ROUNDS THE MEAN to bf16 for the all-gather - an averaged element therefore carries two bf16
+ * roundings, one per contribution and one of the mean (all-gathering the mean in fp32 would cost 6 instead of 4 bytes per element and rank
+ * on the wire); unpack widens the bucket back to fp32.  tests/test_gpu_hotpath.py emulates W = 2, 3, 8 ranks on one GPU. */
 int udapose_comm_pack_bf16(void* stream, const float* src, long long n, void* dst_bf16, long long n_padded);
 int udapose_comm_shard_mean(void* stream, const void* shards_bf16, int world, long long m, void* out_bf16);
 int udapose_comm_unpack_bf16(void* stream, const void* src_bf16, float* dst, long long n);
@@ -370,6 +372,9 @@ int udapose_adain_alpha_dev(void* stream, const void* content, const void* style
  * theta [N][nstage][6] = the inverse affine matrices in application order; backward != 0: src = d(out), dst = d(in). */
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage,
                            int backward);
+/* mean of k re-warped teacher heat-map tensors (train_human.py:361-372 with `--k` > 1: `torch.mean(recons, dim=0)` per sample): h_views = HOST
+ * array of k (1..8) device pointers to fp32 tensors of n elements; dst[i] = (v0[i] + v1[i] + ...) / k, added in view order in fp32. */
+int udapose_mean_views(void* stream, const float* const* h_views, int k, float* dst, size_t n);
 /* the loop's matrices on the device, in double precision, from the collated aug_param of lib/transforms/keypoint_detection.py:139:
  * params[n] = (angle, tx, ty, shear_x, shear_y, scale), angles in degrees (6 doubles per sample).  theta_fwd [N][3][6] (may be NULL):
  * translate by (tx, ty) / ratio | rotate by angle and scale | shear - the three warps of train_human.py:366-368,421-423;
@@ -418,6 +423,14 @@ int udapose_aug_resized_crop_u8(void* stream, const unsigned char* src, unsigned
 int udapose_aug_to_tensor(void* stream, const unsigned char* img, float* out, int N, int HW, const float* mean3, const float* std3);
 int udapose_gaussian_labels(void* stream, const double* kp, const float* vis, float* target, float* weight, int R, int Hh, int Wh,
                             double stride_x, double stride_y, const float* patch, int rad);
+/* draw_labelmap_ori (lib/datasets/util.py:326-363), the animal pipelines' label generator as their datasets call it
+ * (lib/datasets/real_animal_all_mt.py:274-283, animal_pose_mt.py:169-177,200-205; BASELINE.json configs[4]): pt [R][2] float32 = the 0-based
+ * centres the datasets pass (`tpts[i] - 1`), truncated to int32 inside; vis [R] = pts[:, 2]; gate [R] uint8 = the datasets' `tpts[i, 1] > 0`
+ * test (0: the row keeps vis and an empty map) -> target [R][Hh][Wh] fp32, weight [R] = vis * (whole stamp inside the map) where the
+ * gate is open.  r3 = float32(3 * sigma); patch = the reference's (6 sigma + 1)^2 float64 stamp, 'Gaussian' or 'Cauchy', rounded to
+ * float32 by the caller (psize = its side). */
+int udapose_draw_labelmap_ori(void* stream, const float* pt, const float* vis, const unsigned char* gate, float* target, float* weight, int R,
+                              int Hh, int Wh, float r3, const float* patch, int psize);
 
 /* measurement: HIP events around every conv launch between begin and end (process-wide recorder, mutex-guarded) */
 void udapose_prof_begin(void);

@@ -1,7 +1,8 @@
 """CPU restatement of one training step of the reference loop (oracle / CPU baseline, test-only).
 
   * pretrain_step_ref  <- train_human.py:262-289 (source-only: forward, JointsMSE, backward, Adam)
-  * train_step_ref     <- train_human.py:326-440 (k=1, no style, no occlusion: BASELINE.json configs[1])
+  * train_step_ref     <- train_human.py:326-440 (no style, no occlusion: BASELINE.json configs[1]; x_t_tea / aug_param_tea may be
+                          LISTS of k teacher views, :358-372: the re-warped maps are averaged per sample)
   * train_step_full_ref <- the same iteration with the AdaIN style passes (:345-356) and the adaptive occlusion (:374-412) in the
     reference's order of host random draws: BASELINE.json configs[2]
 Plain torch fp32 on the host; autocast/GradScaler of the reference are CUDA-only and are not restated (fp32 is the
@@ -75,8 +76,15 @@ def train_step_full_ref(student, teacher, optimizer, x_s, label_s, weight_s, x_t
         if style is not None and t2s_freq > rng.rand():
             a_t2s = rng.uniform(*t2s_alpha)
             x_t_tea = _clamp(style_forward_ref(style[0], style[1], x_t_tea_ori, x_s_ori, a_t2s))
-        y_t_tea = teacher(x_t_tea)
-        y_t_tea_recon = _recon(y_t_tea, aug_param_tea, ratio)
+        if isinstance(x_t_tea, (list, tuple)):
+            # k teacher views (`--k`, train_human.py:358-372): one teacher forward per view, each re-warped with its own aug_param,
+            # `torch.mean(recons, dim=0)` per sample (style t2s above applies to every view in the reference; k > 1 is restated without style)
+            assert style is None and len(x_t_tea) == len(aug_param_tea)
+            recs = [_recon(teacher(xv), ap, ratio) for xv, ap in zip(x_t_tea, aug_param_tea)]
+            y_t_tea_recon = torch.mean(torch.stack(recs), dim=0)
+        else:
+            y_t_tea = teacher(x_t_tea)
+            y_t_tea_recon = _recon(y_t_tea, aug_param_tea, ratio)
         occluded = []
         if occlude_rate > -1:
             x_t_stu, occluded = occlude_ref(x_t_stu, y_t_tea_recon, aug_param_stu, ratio, image_size, occlude_rate, occlude_thresh,

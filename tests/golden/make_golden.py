@@ -24,6 +24,42 @@ def load_by_path(name, rel):
     return mod
 
 
+def labelmap():
+    """draw_labelmap_ori (lib/datasets/util.py:326-363) as the animal `_mt` datasets call it (real_animal_all_mt.py:274-283): for every
+    (sigma, type, map size) a set of seeded key points - interior, borders on both sides of the whole-patch-inside rule, negative
+    fractions that int32 truncation pulls to 0 - through the reference's own function -> labelmap.npz."""
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    ref_dutil = load_by_path("ref_dutil", "lib/datasets/util.py")
+    rs = np.random.RandomState(5)
+    out, cases = {}, []
+    for ci, (sigma, typ, res) in enumerate([(1.0, "Gaussian", 64), (2, "Gaussian", 64), (1.0, "Cauchy", 96), (1.0, "Gaussian", 96), (1.5, "Gaussian", 64),
+                                            (2, "Cauchy", 64)]):
+        K = 40
+        pts = rs.uniform(-6, res + 6, size=(K, 3)).astype(np.float32)
+        r = int(3 * sigma)
+        edge = [(r + 1, r + 1), (r + 0.999, r + 1.5), (r + 1.0, res - r - 1.0), (res - r - 1.0, r + 1), (res - r - 0.001, r + 1), (res - r, res - r),
+                (0.5, 10), (r + 1, 0.2), (res - r - 1 + 0.9999, res - r - 1 + 0.5), (res / 2, res / 2)]
+        for k, (x, y) in enumerate(edge):
+            pts[k, 0], pts[k, 1] = x, y                      # (1-based: the loop below subtracts 1 as the datasets do)
+        pts[:, 2] = (rs.rand(K) > 0.2).astype(np.float32)
+        gate = rs.rand(K) > 0.15                             # `tpts[i, 1] > 0` before the transform
+        target = torch.zeros(K, res, res)
+        weight = torch.from_numpy(pts[:, 2].copy()).view(K, 1)
+        tp = torch.from_numpy(pts.copy())
+        for i in range(K):
+            if gate[i]:
+                target[i], vis = ref_dutil.draw_labelmap_ori(target[i], tp[i] - 1, sigma, type=typ)
+                weight[i, 0] *= vis
+        cases.append((float(sigma), typ, res))
+        out[f"pts{ci}"], out[f"gate{ci}"], out[f"target{ci}"], out[f"weight{ci}"] = pts, gate, target.numpy(), weight.numpy()
+    out["sigmas"] = np.array([c[0] for c in cases])
+    out["types"] = np.array([c[1] for c in cases])
+    out["sizes"] = np.array([c[2] for c in cases])
+    np.savez_compressed(os.path.join(OUT, "labelmap.npz"), **out)
+    drawn = [int((out[f"target{ci}"].reshape(40, -1).max(1) > 0).sum()) for ci in range(len(cases))]
+    print("labelmap.npz written; stamps drawn per case:", drawn)
+
+
 def main():
     sys.path.insert(0, REF)
     import utils as ref_utils                      # reference utils.py
@@ -164,4 +200,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "labelmap":      # (round 4: only the new fixture; the others stay byte for byte)
+        labelmap()
+    else:
+        main()
+        labelmap()

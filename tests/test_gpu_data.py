@@ -185,3 +185,30 @@ def test_resized_crop_bit_exact_with_pil():
         w_ref = R.affine_view_ref(base[i][0], base[i][1], *prm[i])[0]
         t_ref = R.to_tensor_normalize_ref(R.color_jitter_ref(w_ref, *jit[i]), D.IMAGENET_MEAN, D.IMAGENET_STD)
         assert torch.equal(x_s[i].cpu(), t_ref), f"student view {i} from the raw image differs from the PIL chain"
+
+
+def test_draw_labelmap_ori_device_bit_exact_with_reference_golden_and_oracle():
+    """udapose_draw_labelmap_ori (data_gpu.TargetViewPipeline.labels_animal) = the animal datasets' label loop over draw_labelmap_ori
+    (lib/datasets/util.py:326-363; BASELINE.json configs[4]'s labels): bit-exact against the reference's own outputs (labelmap.npz)
+    for Gaussian / Cauchy, sigma 1.0 / 2 / 1.5, 64x64 / 96x96, and against the oracle on a configs[4]-shaped batch (N=8, K=18, 96x96)."""
+    import os
+    from oracle.mean_teacher_ref import animal_labels_ref
+    from uda_poseestimation_amd import data_gpu as D
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "labelmap.npz"))
+    pipe = D.TargetViewPipeline(image_size=384, heatmap_size=96, sigma=1.0)
+    dev = torch.device("cuda")
+    for ci, (sg, typ, res) in enumerate(zip(z["sigmas"], z["types"], z["sizes"])):
+        sg = int(sg) if float(sg).is_integer() and sg >= 2 else float(sg)
+        pts = z[f"pts{ci}"]
+        t, w = pipe.labels_animal(pts[None], pts[None, :, 2], z[f"gate{ci}"][None], dev, sigma=sg, label_type=str(typ), out_res=int(res))
+        assert np.array_equal(t[0].cpu().numpy(), z[f"target{ci}"]), (ci, sg, typ)
+        assert np.array_equal(w[0].cpu().numpy(), z[f"weight{ci}"]), (ci, sg, typ)
+    rs = np.random.RandomState(11)
+    N, K, R = 8, 18, 96
+    tp = rs.uniform(-4, R + 4, (N, K, 3)).astype(np.float32)
+    vis = (rs.rand(N, K) > 0.1).astype(np.float32)
+    gate = rs.rand(N, K) > 0.1
+    t, w = pipe.labels_animal(tp, vis, gate, dev)
+    for n in range(N):
+        tr, wr = animal_labels_ref(tp[n], vis[n], gate[n], R, 1.0, "Gaussian")
+        assert np.array_equal(t[n].cpu().numpy(), tr) and np.array_equal(w[n].cpu().numpy(), wr), n

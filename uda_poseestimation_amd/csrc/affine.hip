@@ -180,3 +180,23 @@ int affine_warp_chain(hipStream_t s, const float* src, float* dst, const float* 
     }
     return udapose_check_launch();
 }
+
+// mean over k re-warped teacher views (train_human.py:361-372 with --k > 1: `torch.mean(recons, dim=0)`): the k values of an element
+// are added in view order in fp32 and divided by k, as ATen's mean over the leading dimension does for a handful of rows
+struct ViewPtrs { const float* p[8]; };
+__global__ void mean_views_k(ViewPtrs v, int k, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float a = v.p[0][i];
+        for (int j = 1; j < k; ++j) a += v.p[j][i];
+        dst[i] = a / (float)k;
+    }
+}
+int affine_mean_views(hipStream_t s, const float* const* srcs, int k, float* dst, size_t n) {
+    if (k < 1 || k > 8 || !srcs || !dst) return UDAPOSE_ERR_ARG;
+    ViewPtrs v;
+    for (int j = 0; j < 8; ++j) v.p[j] = j < k ? srcs[j] : nullptr;
+    for (int j = 0; j < k; ++j) if (!v.p[j]) return UDAPOSE_ERR_ARG;
+    size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(mean_views_k, dim3((unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g))), dim3(256), 0, s, v, k, dst, n);
+    return udapose_check_launch();
+}

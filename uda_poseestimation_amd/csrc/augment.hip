@@ -118,6 +118,31 @@ __global__ void gaussian_labels_k(const double* __restrict__ kp, const float* __
         t[i] = (draw && gx >= 0 && gx < size && gy >= 0 && gy < size) ? patch[gy * size + gx] : 0.f;
     }
 }
+// draw_labelmap_ori (lib/datasets/util.py:326-363), the label generator of the animal `_mt` datasets (call loop:
+// lib/datasets/real_animal_all_mt.py:274-283, animal_pose_mt.py:169-177,200-205): row r's centre is pt[r] truncated to int32
+// (`pt.to(torch.int32)`), the stamp's corners are int(centre -+ r3 (+ 1)) with the sums in float32 (an int32 tensor and a Python
+// float), and the stamp is drawn - weight kept - only when ALL of it lies inside the map (any part outside: zeros, weight 0).
+// gate[r] = the caller's `tpts[i, 1] > 0` test of the un-transformed key point: closed rows keep their visibility weight and an
+// empty map.  patch = the reference's (6 sigma + 1)^2 float64 stamp (Gaussian or Cauchy) rounded to float32 by the caller.
+__global__ void draw_labelmap_ori_k(const float* __restrict__ pt, const float* __restrict__ vis, const unsigned char* __restrict__ gate,
+                                    float* __restrict__ target, float* __restrict__ weight, int Hh, int Wh, float r3,
+                                    const float* __restrict__ patch, int psize) {
+    const size_t r = blockIdx.x;
+    const int cx = (int)pt[r * 2], cy = (int)pt[r * 2 + 1];
+    const int ulx = (int)((float)cx - r3), uly = (int)((float)cy - r3);
+    const int brx = (int)(((float)cx + r3) + 1.0f), bry = (int)(((float)cy + r3) + 1.0f);
+    const bool inside = !(brx >= Wh || bry >= Hh || ulx < 0 || uly < 0);
+    const bool open = gate[r] != 0;
+    if (threadIdx.x == 0) weight[r] = open ? vis[r] * (inside ? 1.0f : 0.0f) : vis[r];
+    const bool draw = open && inside;
+    const int nx = min(brx - ulx, psize), ny = min(bry - uly, psize);
+    float* t = target + r * (size_t)Hh * Wh;
+    for (int i = threadIdx.x; i < Hh * Wh; i += TPB) {
+        const int y = i / Wh, x = i - y * Wh;
+        const int gx = x - ulx, gy = y - uly;
+        t[i] = (draw && gx >= 0 && gx < nx && gy >= 0 && gy < ny) ? patch[gy * psize + gx] : 0.f;
+    }
+}
 // PIL's ImageFilter.GaussianBlur (lib/transforms/keypoint_detection.py:216-225; libImaging BoxBlur.c): three passes of a box blur
 // per direction, every pass in 8.24 fixed point with replicated edges:
 //   out[x] = (sum_{k=-r..r} in[x+k] * ww + (in[x-r-1] + in[x+r+1]) * fw + 2^23) >> 24     (32-bit unsigned arithmetic)
@@ -251,5 +276,11 @@ int aug_gaussian_labels(hipStream_t s, const double* kp, const float* vis, float
                         double stride_y, const float* patch, int rad) {
     if (R <= 0 || Hh <= 0 || Wh <= 0 || rad < 0 || !patch) return UDAPOSE_ERR_ARG;
     hipLaunchKernelGGL(gaussian_labels_k, dim3(R), dim3(TPB), 0, s, kp, vis, target, weight, Hh, Wh, stride_x, stride_y, patch, rad);
+    return udapose_check_launch();
+}
+int aug_draw_labelmap_ori(hipStream_t s, const float* pt, const float* vis, const unsigned char* gate, float* target, float* weight, int R, int Hh,
+                          int Wh, float r3, const float* patch, int psize) {
+    if (R <= 0 || Hh <= 0 || Wh <= 0 || psize <= 0 || !patch || !pt || !vis || !gate) return UDAPOSE_ERR_ARG;
+    hipLaunchKernelGGL(draw_labelmap_ori_k, dim3(R), dim3(TPB), 0, s, pt, vis, gate, target, weight, Hh, Wh, r3, patch, psize);
     return udapose_check_launch();
 }

@@ -53,8 +53,10 @@ int aug_gaussian_blur_u8(hipStream_t, unsigned char*, unsigned char*, const unsi
 int aug_resized_crop_u8(hipStream_t, const unsigned char*, unsigned char*, unsigned char*, const int*, const int*, const int*, int, int, int, int, int);
 int aug_to_tensor(hipStream_t, const unsigned char*, float*, int, int, const float*, const float*);
 int aug_gaussian_labels(hipStream_t, const double*, const float*, float*, float*, int, int, int, double, double, const float*, int);
+int aug_draw_labelmap_ori(hipStream_t, const float*, const float*, const unsigned char*, float*, float*, int, int, int, float, const float*, int);
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int affine_recon_thetas(hipStream_t, const double*, int, double, float*, float*);
+int affine_mean_views(hipStream_t, const float* const*, int, float*, size_t);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
 int occlusion_pick(hipStream_t, const float*, const int*, const float*, int, int, int, double, int, float, float, int, int*, unsigned char*);
 int select_rows(hipStream_t, float*, const float*, const float*, const unsigned char*, int, size_t);
@@ -414,6 +416,9 @@ int udapose_recon_thetas(void* stream, const double* params, int N, double ratio
     if (!params || (!theta_fwd && !theta_back)) return UDAPOSE_ERR_ARG;
     return affine_recon_thetas(S(stream), params, N, ratio, theta_fwd, theta_back);
 }
+int udapose_mean_views(void* stream, const float* const* h_views, int k, float* dst, size_t n) {
+    return affine_mean_views(S(stream), h_views, k, dst, n);
+}
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage, int backward) {
     return affine_warp_chain(S(stream), src, dst, theta, N, C, H, W, nstage, backward);
 }
@@ -443,6 +448,11 @@ int udapose_gaussian_labels(void* stream, const double* kp, const float* vis, fl
                             double stride_x, double stride_y, const float* patch, int rad) {
     if (!kp || !vis || !target || !weight) return UDAPOSE_ERR_ARG;
     return aug_gaussian_labels(S(stream), kp, vis, target, weight, R, Hh, Wh, stride_x, stride_y, patch, rad);
+}
+int udapose_draw_labelmap_ori(void* stream, const float* pt, const float* vis, const unsigned char* gate, float* target, float* weight, int R,
+                              int Hh, int Wh, float r3, const float* patch, int psize) {
+    if (!target || !weight) return UDAPOSE_ERR_ARG;
+    return aug_draw_labelmap_ori(S(stream), pt, vis, gate, target, weight, R, Hh, Wh, r3, patch, psize);
 }
 void udapose_prof_begin(void) { prof_begin(); }
 int udapose_prof_end(double* h_out9) { return prof_end(h_out9); }

@@ -312,6 +312,35 @@ class TargetViewPipeline:
                                             ptr(c["patch"]), c["rad"]), "gaussian_labels")
         return target, weight
 
+    def labels_animal(self, tpts, visible, gate, device, sigma=None, label_type="Gaussian", out_res=None):
+        """The animal `_mt` datasets' label loop (lib/datasets/real_animal_all_mt.py:274-283 -> draw_labelmap_ori, lib/datasets/util.py:326-363)
+        for a batch: tpts [N,K,2+] float32 = the transformed key points as `transform(pts + 1, ...)` returns them (1-based; the datasets pass
+        `tpts - 1`), visible [N,K] = pts[:, 2], gate [N,K] bool = `tpts[i, 1] > 0` of the UN-transformed points
+        -> (target [N,K,R,R], weight [N,K,1]) on the device.  The stamp is built as the reference builds it (float64, Gaussian or Cauchy)."""
+        sigma = self.sigma if sigma is None else sigma
+        R = int(out_res or self.heatmap_size)
+        tp = np.ascontiguousarray(np.asarray(tpts, dtype=np.float32)[..., :2])
+        N, K, _ = tp.shape
+        size = 6 * sigma + 1
+        x = np.arange(0, size, 1, float)
+        y = x[:, np.newaxis]
+        x0 = y0 = size // 2
+        if label_type == "Gaussian":
+            g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+        elif label_type == "Cauchy":
+            g = sigma / (((x - x0) ** 2 + (y - y0) ** 2 + sigma ** 2) ** 1.5)
+        else:
+            raise ValueError("label_type must be 'Gaussian' or 'Cauchy' (lib/datasets/util.py:349-352)")
+        patch = torch.from_numpy(np.ascontiguousarray(g, dtype=np.float32)).to(device, non_blocking=True)
+        pt = torch.from_numpy(tp - np.float32(1)).to(device, non_blocking=True)
+        vis = torch.from_numpy(np.ascontiguousarray(visible, dtype=np.float32).reshape(N * K)).to(device, non_blocking=True)
+        gt = torch.from_numpy(np.ascontiguousarray(np.asarray(gate).reshape(N * K), dtype=np.uint8)).to(device, non_blocking=True)
+        target = torch.empty(N, K, R, R, dtype=torch.float32, device=device)
+        weight = torch.empty(N, K, 1, dtype=torch.float32, device=device)
+        check(lib().udapose_draw_labelmap_ori(_hip.stream(), ptr(pt), ptr(vis), ptr(gt), ptr(target), ptr(weight), N * K, R, R,
+                                              float(np.float32(3 * sigma)), ptr(patch), int(g.shape[0])), "draw_labelmap_ori")
+        return target, weight
+
     # ------------------------------------------------------------------ one view of the whole batch
     def view(self, base_u8, keypoints, cfg, params=None, jitter=None, blur=None):
         """-> (image [N,3,H,W] fp32 normalised, key points [N,K,2], aug_param collated, target, weight)"""

@@ -44,7 +44,8 @@ class GradSync:
         self.model = model
         self._work = None
         # 'bf16': the buckets travel in bf16 (udapose_comm_*: one rounding per contribution, all-to-all of shards, fp32 accumulation on
-        # the shard's owner, all-gather of the averaged shards): half the bytes per xGMI link.  RCCL backend only.
+        # the shard's owner, the MEAN rounded to bf16 once more for the all-gather of the averaged shards): half the bytes per xGMI
+        # link, two bf16 roundings per averaged gradient element.  RCCL backend only.
         self.comm_dtype = comm_dtype
         self._cbuf = {}
         # timing (bench.py): HIP events around finish() on the current stream = what the step WAITS for communication
@@ -167,6 +168,9 @@ class MeanTeacherTrainer:
                  heatmap_size=64, use_sgd=False, style_net=None, recover=None, s2t_freq=0.5, t2s_freq=0.5, s2t_alpha=(0.0, 1.0),
                  t2s_alpha=(0.0, 1.0), rng=None, occlude_rate=-1.0, occlude_thresh=0.9, occlude_size=10, image_px=None, precision=None,
                  loss_scale_init=65536.0, loss_scale_interval=2000, grad_comm="fp32"):
+        # a single-device nn.DataParallel wrap (the reference's call form) is unwrapped: the engine drives the executor's own entry points
+        # (prepare / forward_deferred_bn / finish_wgrad ...), which live on the module
+        student, teacher = getattr(student, "module", student), getattr(teacher, "module", teacher)
         self.student, self.teacher = student, teacher
         self.criterion, self.con_criterion = JointsMSELoss(), ConsLoss()
         # precision: None keeps what the networks are set to (a new PoseResNet is 'auto': a differentiable forward outside
@@ -176,18 +180,27 @@ class MeanTeacherTrainer:
         #   in fp32 - here the fp32-grade 'f16x2' mode (three fp16 MFMAs per K step; heat-maps within ~4e-5 of the fp32 oracle).
         # 'bf16' / 'fp16': student AND teacher in that 16-bit type (BASELINE.json's benched configuration is 'bf16'; the style
         #   network keeps its own setting).
+        # (the networks may arrive wrapped in a single-device nn.DataParallel, as in the reference: attributes go to the modules)
+        stu_m, tea_m = getattr(student, "module", student), getattr(teacher, "module", teacher)
         if precision in ("reference", "reference_fp32"):
             # ('reference_fp32': the same mix with the EXACT fp32 MFMA forms for the teacher and the style network - the slow way to the
             # same numbers, kept for A/B timing of the f16x2 mode)
             hi = "f16x2" if precision == "reference" else "fp32"
-            student.precision, teacher.precision = "fp16", hi
+            stu_m.precision, tea_m.precision = "fp16", hi
             sn = getattr(style_net, "module", style_net)
             if sn is not None and hasattr(sn, "precision"):
                 sn.precision = hi
         elif precision is not None:
-            student.precision = precision
-            teacher.precision = precision
-        scaled = getattr(student, "precision", "bf16") == "fp16"
+            stu_m.precision = precision
+            tea_m.precision = precision
+        # Loss scaling is decided ONCE, here, from what the student can run: 'fp16', or 'auto' (which resolves to fp16 whenever the step
+        # runs under torch.autocast, the reference's call form) get the device-side GradScaler; a scaled bf16 step is exact (powers of
+        # two), an unscaled fp16 step underflows silently - _check_scaler() refuses that combination at step time
+        sp = getattr(stu_m, "precision", "bf16")
+        scaled = sp in ("fp16", "auto")
+        # the teacher's fp32-grade plans live in the student's library build, so the fused optimizer tail hands both plans to one .so
+        if hasattr(tea_m, "aux_lib_kind"):
+            tea_m.aux_lib_kind = "fp16" if sp == "fp16" else "bf16"
         sc = dict(dynamic_loss_scale=True, init_scale=loss_scale_init, growth_interval=loss_scale_interval) if scaled else {}
         if use_sgd:
             self.stu_optimizer = fused_optim.FusedSGD(student.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, nesterov=True, **sc)
@@ -221,6 +234,14 @@ class MeanTeacherTrainer:
         self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
 
+    def _check_scaler(self):
+        """An fp16 student forward needs the loss scaler the optimizer was built with (or the caller's own GradScaler: then build the
+        trainer's optimizer yourself)."""
+        hd = getattr(getattr(self.student, "module", self.student), "_last_hd", None)
+        if hd is not None and hd.precision == "fp16" and getattr(self.stu_optimizer, "_scaler", None) is None:
+            raise RuntimeError("the student ran in fp16 but the trainer's optimizer has no dynamic loss scaling: fp16 heat-map gradients "
+                               "underflow without it - construct MeanTeacherTrainer with precision='fp16' / 'reference' / 'auto'")
+
     # ------------------------------------------------------------------ train_human.py:262-302
     def pretrain_step(self, x_s, label_s, weight_s, x_t=None):
         self.student.train()
@@ -230,6 +251,7 @@ class MeanTeacherTrainer:
             x_s = self.style_net(x_s, x_t, a, clamp=self.recover)[2]
         y_s = self.student(x_s)
         loss = self.criterion(y_s, label_s, weight_s)
+        self._check_scaler()
         overlap = self._overlap()
         self.student.split_backward = overlap
         self.stu_optimizer.scale_loss(loss).backward()          # (scaler.scale(loss).backward(), train_human.py:285; identity in bf16)
@@ -340,7 +362,7 @@ class MeanTeacherTrainer:
         with torch.cuda.stream(s_tea), torch.no_grad():
             y_t_teas = [teacher(x_t) for x_t in x_t_teas]
             recons = [warp.warp_chain(y, th) for y, th in zip(y_t_teas, thetas_tea)]
-            y_t_tea_recon = recons[0] if len(recons) == 1 else torch.stack(recons).mean(0)
+            y_t_tea_recon = warp.mean_views(recons)          # (k teacher views, train_human.py:361-372: one launch; k = 1: the view itself)
         if occl is not None:
             # the occlusion needs the teacher's re-warped heat-maps: the source-domain forward is issued first (it runs under
             # the teacher's), the target-domain branch waits for the teacher
@@ -416,6 +438,7 @@ class MeanTeacherTrainer:
         merge = (not overlap) and (not side) and self.merge_wgrad and hasattr(student, "finish_wgrad")
         student.merge_wgrad = bool(merge)
         loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
+        self._check_scaler()
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
             tea_mask, _, _ = mt.confidence_mask(st["y_t_tea_recon"], self.mask_ratio, None, gathered_activates, st["activates"])
@@ -512,7 +535,12 @@ class GraphedTrainStep:
     drew, or copies the original images, before the main graph.  Occlusion (train_human.py:374-412): the decisions are taken
     on the device from four uniform draws per sample (trainer.device_occlusion), inside the main graph."""
 
-    def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None):
+    def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None, metrics=True):
+        # metrics: the captured step also decodes y_s and computes PCK@0.05 against label_s on the device (the reference's per-iteration
+        # `accuracy(y_s, label_s)`, train_human.py:443) and gathers the losses + PCK into ONE small device vector: step_async() reads
+        # it back one step late through a pinned double buffer, so a loop that logs every iteration never drains the device
+        self.metrics = bool(metrics)
+        self._mvec, self._mpin, self._mev, self._mi, self._mk = None, None, [None, None], 0, 0
         self.styled = trainer.style_net is not None
         self.occl = trainer.occlude_rate > -1
         if self.occl and not trainer.device_occlusion:
@@ -602,6 +630,7 @@ class GraphedTrainStep:
                 if self.one_graph:
                     trainer._sync_grads()
                     trainer._update()
+                    self._capture_metrics()
         else:
             self.g_lb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
@@ -626,6 +655,7 @@ class GraphedTrainStep:
                 trainer.sync()
             with torch.cuda.graph(self.g_up, pool=self.g_fb.pool(), capture_error_mode=mode, **self._cap):
                 trainer._update()
+                self._capture_metrics()
         for m in (trainer.student, trainer.teacher):
             m._capture_token = None
             m.weights_changed()
@@ -636,6 +666,55 @@ class GraphedTrainStep:
             for m, hd, bwd in self._maintained:
                 m.packs_refreshed(hd, bwd)
         torch.cuda.synchronize()
+
+    def _capture_metrics(self):
+        """(inside the capture of the step's last graph) losses + device PCK of the source batch -> self._mvec = [loss_all, loss_s, loss_c,
+        avg_acc, cnt, acc[0..K-1]]: decode and PCK are the udapose_heatmap_argmax / udapose_pck launches of lib.keypoint_detection."""
+        if not self.metrics:
+            return
+        acc, avg_cnt, _ = kd.accuracy_device(self.out["y_s"], self.static["label_s"])
+        parts = [self.out["loss_all"].reshape(1), self.out["loss_s"].reshape(1), self.out["loss_c"].reshape(1), avg_cnt.reshape(2), acc.reshape(-1)]
+        self._mk = int(acc.numel())
+        self._mvec = torch.cat([p.float() for p in parts])
+        self.out["acc_s"], self.out["acc_avg_cnt"] = acc, avg_cnt
+
+    def _metrics_dict(self, v):
+        v = v.tolist()
+        return {"loss_all": v[0], "loss_s": v[1], "loss_c": v[2], "acc_s": v[3], "cnt_s": int(v[4]), "acc_per_keypoint": v[5:5 + self._mk]}
+
+    def step_async(self, *args, **kw):
+        """step() with the metric read-back DEFERRED by one step: replays this step, queues the copy of its metric vector into a pinned
+        slot behind it, and only then waits for the PREVIOUS step's slot - the device always has the next replay queued while the host
+        reads, so the reference's per-iteration logging (train_human.py:440-452) costs no device idle time (a synchronous read exposes
+        the ~0.75 ms launch latency of a 1270-node graph every step).  Returns the previous step's metrics as Python numbers (None on
+        the first call); flush_metrics() returns the last step's."""
+        if self._mvec is None:
+            raise RuntimeError("GraphedTrainStep(metrics=False) has no metric vector to read back")
+        if self._mpin is None:
+            self._mpin = [torch.empty(self._mvec.numel(), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.step(*args, **kw)
+        i = self._mi
+        self._mpin[i].copy_(self._mvec, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._mev[i] = ev
+        self._mi = 1 - i
+        prev = self._mev[1 - i]
+        if prev is None:
+            return None
+        prev.synchronize()
+        self._mev[1 - i] = None
+        return self._metrics_dict(self._mpin[1 - i])
+
+    def flush_metrics(self):
+        """Metrics of the most recent step_async() (waits for it)."""
+        last = 1 - self._mi
+        ev = self._mev[last]
+        if ev is None:
+            return None
+        ev.synchronize()
+        self._mev[last] = None
+        return self._metrics_dict(self._mpin[last])
 
     def _stage_aug(self, aug_param_stu=None, aug_param_tea=None):
         """The batch's raw aug_param values -> the static [2,N,6] float64 device buffer the captured udapose_recon_thetas launches

@@ -54,9 +54,12 @@ class Upsampling(nn.Sequential):
 class _NetHandle:
     """One executor plan (fixed N,H,W) plus its device work areas."""
 
-    def __init__(self, layers, K, N, H, W, device, precision='bf16', policy=None, deconv_bias=False):
-        # the library build whose element type is this plan's storage / MFMA type ('fp32' plans live in the bf16 build)
-        L = self.L = lib('fp16' if precision == 'fp16' else 'bf16')
+    def __init__(self, layers, K, N, H, W, device, precision='bf16', policy=None, deconv_bias=False, aux_lib='bf16'):
+        # the library build whose element type is this plan's storage / MFMA type.  'fp32' / 'f16x2' plans do not depend on the
+        # element type (both builds carry them): they live in the build `aux_lib` names - the STUDENT's build when this network is
+        # the teacher of a fused optimizer tail, which hands both plans to one library (ADVICE r3: a plan is only ever
+        # dereferenced by the .so that created it)
+        L = self.L = lib('fp16' if precision == 'fp16' else ('bf16' if precision == 'bf16' else aux_lib))
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
         check(L.udapose_net_create(arr, K, N, H, W, {'fp32': 1, 'f16x2': 2}.get(precision, 0) | (0x100 if deconv_bias else 0), C.byref(h)),
@@ -138,6 +141,7 @@ class PoseResNet(nn.Module):
         #         fp32 accumulation / BatchNorm statistics - heat-maps within ~4e-5 of the fp32 CPU oracle, 1.7x the exact mode's speed.
         # 'fp32': exact fp32 MFMA (v_mfma_f32_16x16x4_f32), forward only; 3x slower than bf16.
         self.precision = type(self).default_precision
+        self.aux_lib_kind = 'bf16'    # build that holds this module's 'fp32' / 'f16x2' plans (engine: the student's build, see _NetHandle)
         self._handles = {}
         self._ptr_cache = None
         self._flat_grad = None
@@ -197,7 +201,12 @@ class PoseResNet(nn.Module):
         # accept checkpoints saved from DataParallel wrappers ('module.' prefix, train_human.py:229-230)
         if any(k.startswith("module.") for k in state_dict):
             state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
-        return super().load_state_dict(state_dict, strict=strict, **kw)
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        if kw.get("assign"):
+            self._ptr_cache = None          # (Parameter objects were replaced: pointer / version caches are void)
+            self._to_channels_last()
+            self._handles = {}
+        return r
 
     def _pointers(self):
         params = list(self.parameters())
@@ -245,10 +254,12 @@ class PoseResNet(nn.Module):
         if differentiable is None:
             differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         prec = self.resolved_precision(differentiable)
-        key = (N, H, W, x.device.index, prec)
+        aux = self.aux_lib_kind if prec in ('fp32', 'f16x2') else None
+        key = (N, H, W, x.device.index, prec, aux)
         hd = self._handles.get(key)
         if hd is None:
-            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, prec, dict(self.policy), self._deconv_bias)
+            hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, prec, dict(self.policy), self._deconv_bias,
+                            aux_lib=(aux or 'bf16'))
             params = list(self.parameters())
             assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
             for i, p in enumerate(params):
@@ -276,6 +287,13 @@ class PoseResNet(nn.Module):
         # captured step asks four times per replay)
         plist = self._ptr_cache[3] if self._ptr_cache is not None else list(self.parameters())
         return (self._wepoch, sum(p._version for p in plist))
+
+    def __setattr__(self, name, value):
+        # a Parameter object replaced behind the cached parameter list (module.x = nn.Parameter(...), load_state_dict(assign=True))
+        # must not leave version_key() watching the old objects
+        if isinstance(value, (nn.Parameter, nn.Module)) and "_ptr_cache" in self.__dict__:
+            self.__dict__["_ptr_cache"] = None
+        super().__setattr__(name, value)
 
     def packs_refreshed(self, hd, with_bwd):
         """A kernel outside _pack (the fused optimizer tail) has just rewritten hd's packs from the current parameters."""

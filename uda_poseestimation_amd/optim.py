@@ -217,7 +217,9 @@ class FusedAdam(_FusedBase):
         if hd_s is None or hd_t is None or hd_s.precision not in ("bf16", "fp16"):
             return False
         t_split = hd_t.precision == "f16x2"
-        if not t_split and (hd_s.L is not hd_t.L or hd_t.precision != hd_s.precision):
+        # both plans are handed to ONE library (the student's): the teacher's must have been created by it (PoseResNet.aux_lib_kind puts an
+        # f16x2 teacher's plan into the student's build; a plan of the other .so is never dereferenced here - ADVICE r3)
+        if hd_s.L is not hd_t.L or (not t_split and hd_t.precision != hd_s.precision):
             return False
         if len(group["params"]) != len(ps) or any(a is not b for a, b in zip(group["params"], ps)):
             return False

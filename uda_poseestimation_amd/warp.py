@@ -132,6 +132,22 @@ def warp_chain(x, theta):
     return _WarpFn.apply(x, theta)
 
 
+def mean_views(views):
+    """Mean of k re-warped teacher heat-map tensors (train_human.py:361-372, `--k` > 1: `torch.mean(recons, dim=0)`): one launch, the k
+    values added in view order in fp32 and divided by k."""
+    import ctypes as C
+    if len(views) == 1:
+        return views[0]
+    if len(views) > 8:
+        raise NotImplementedError("at most 8 teacher views per step (the reference's --k defaults to 1)")
+    vs = [v.detach().float().contiguous() for v in views]
+    _hip.require_cuda(*vs)
+    out = torch.empty_like(vs[0])
+    arr = (C.c_void_p * len(vs))(*[v.data_ptr() for v in vs])
+    check(lib().udapose_mean_views(_hip.stream(), arr, len(vs), ptr(out), out.numel()), "mean_views")
+    return out
+
+
 def affine(img, angle, translate, scale, shear, interpolation=None, fill=None):
     """`torchvision.transforms.functional.affine` for CUDA tensors as the reference's loop calls it (train_human.py:366-368,
     388-390, 412, 421-423): img [C,H,W] or [N,C,H,W], nearest interpolation, zero fill, centre of rotation = image centre;
