@@ -87,7 +87,8 @@ typedef struct {
                            * table entries from per-XCD heads: bounded residency, so a launch can run under the gradient chain */
     int wgrad_cut_lo, wgrad_cut_hi;   /* staged launches: bit b set = bottleneck block b (0 = layer1's first) is the LOWEST block of its stage;
                            * 0 / 0 = every wgrad_overlap-th block counted from the top */
-    int pad0;
+    int eval_fold;        /* 1 (default): eval-mode network forwards (validate(), train_human.py:461-500) apply BatchNorm's running-statistics scale /
+                           * shift, the residual and the ReLU in the convolution's epilogue: no BN-apply launch, no pre-BN tensor; 0: conv + apply */
     void* timeline;
 } udapose_policy;
 void udapose_policy_default(udapose_policy* p);

@@ -452,7 +452,8 @@ def test_mean_teacher_step_with_two_teacher_views_matches_oracle():
     import uda_poseestimation_amd.lib.models.pose_resnet as pr
     vs = [torch.randn(3, 16, 32, 32, device="cuda") * (10.0 ** (i - 1)) for i in range(3)]
     for k in (2, 3):
-        assert torch.equal(warp.mean_views(vs[:k]), torch.mean(torch.stack(vs[:k]), dim=0))
+        # (the reference builds `recons` with torch.zeros(k, ...) - a CPU tensor - so its mean is ATen's CPU mean: sum in view order, divided by k)
+        assert torch.equal(warp.mean_views(vs[:k]).cpu(), torch.mean(torch.stack([v.cpu() for v in vs[:k]]), dim=0))
     assert warp.mean_views(vs[:1]) is vs[0]
     layers, K, N, S = [1, 1, 1, 1], 16, 4, 128
     torch.manual_seed(3)
@@ -474,13 +475,13 @@ def test_mean_teacher_step_with_two_teacher_views_matches_oracle():
     assert (mask_dev != mask_ref).sum().item() <= 1, (mask_dev != mask_ref).sum().item()       # (a confidence within rounding of the k-th value may flip)
     assert abs(float(out["loss_s"]) - float(ref["loss_s"])) <= 5e-3 * float(ref["loss_s"])
     assert abs(float(out["loss_c"]) - float(ref["loss_c"])) <= 2e-2 * float(ref["loss_c"]) + 1e-7
-    # ... and it is not the k = 1 step: the one-view oracle gives another consistency loss
+    # ... and it is not the k = 1 step: the one-view oracle selects other key points (the mask the device reproduced above is the two-view one)
     torch.manual_seed(3)
     r_s, r_t = PoseResNetRef(layers, K), PoseResNetRef(layers, K)
     r_t.load_state_dict(r_s.state_dict())
     one = train_step_ref(r_s, r_t, torch.optim.Adam(r_s.parameters(), lr=1e-4), b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"],
                          b["aug_param_stu"], b["aug_param_tea"], ratio=4.0)
-    assert abs(float(one["loss_c"]) - float(ref["loss_c"])) > 5e-2 * float(ref["loss_c"])
+    assert (one["tea_mask"].bool() != mask_ref).sum().item() >= 2 and not torch.equal(one["y_t_tea_recon"], ref["y_t_tea_recon"])
 
 
 def test_mean_teacher_step_animal_config_k18_float_sigma():
@@ -639,8 +640,9 @@ def test_comm_bf16_pack_shard_mean_unpack_emulating_w_ranks_on_one_gpu():
         want = (acc * (1.0 / W_)).to(torch.bfloat16).float()
         assert torch.equal(outp, want), (W_, n, (outp - want).abs().max().item())
         exact = torch.stack(gs).double().mean(0)
-        rel = ((outp.double() - exact).abs() / exact.abs().clamp_min(1e-30)).max().item()
-        assert rel < 2.0 ** -6, rel                            # (two bf16 roundings + W roundings of the inputs: < 3 x 2^-8)
+        # distance from the exact fp64 mean: every contribution rounded once (2^-9 of its size each) and the mean once more
+        bound = (torch.stack(gs).double().abs().mean(0) + exact.abs()) * 2.0 ** -8
+        assert bool(((outp.double() - exact).abs() <= bound + 1e-30).all())
 
 
 def test_two_rank_config3_step_style_and_occlusion_captured():

@@ -372,6 +372,44 @@ def test_poseresnet101_bf16_forward_backward_256_n2_vs_oracle(gamma3):
         print(f"  gradients {key:10s} worst rel err: bf16-storage emulation vs fp32 {ng:.3f} | device vs fp32 {eg:.3f} (min cosine {cs:.4f})")
 
 
+def test_eval_mode_bn_folded_into_the_conv_epilogue():
+    """Policy eval_fold (round 4, the default): in eval mode (validate(), train_human.py:461-500) every convolution's epilogue applies the
+    BatchNorm's running-statistics scale / shift, the residual and the ReLU from the fp32 accumulators and writes z itself - against the
+    conv -> y -> apply launches (eval_fold = 0): equal to the rounding of the dropped 16-bit y, closer to (never further from) the fp32
+    oracle, identical arg-max; in the fp32-grade f16x2 mode both forms sit at the oracle's level."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    ref, net = _pair((1, 2, 2, 1), 16, seed=9, gamma3=0.25)
+    g = torch.Generator().manual_seed(10)
+    with torch.no_grad():
+        for m in ref.modules():                      # non-trivial running statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(4, 3, 128, 96, generator=g)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        y_ref = ref(x)
+    out = {}
+    for prec in ("bf16", "f16x2"):
+        for fold in (0, 1):
+            net.precision = prec
+            net.policy, net._handles = {"eval_fold": fold}, {}
+            with torch.no_grad():
+                out[(prec, fold)] = net(x.cuda()).cpu()
+    scale = y_ref.abs().max().item()
+    e = {k: (v - y_ref).abs().max().item() for k, v in out.items()}
+    print("eval-mode fold: max|device - fp32 oracle| " + ", ".join(f"{k[0]} fold={k[1]}: {v:.2e}" for k, v in e.items()) + f" (max|y| {scale:.3f})")
+    assert (out[("bf16", 0)] - out[("bf16", 1)]).abs().max().item() <= 3e-2 * scale
+    assert e[("bf16", 1)] <= 1.2 * e[("bf16", 0)] + 1e-6 and e[("bf16", 1)] <= 2e-2 * scale
+    assert e[("f16x2", 1)] < 1e-5 * max(scale, 1.0) and e[("f16x2", 0)] < 1e-5 * max(scale, 1.0)
+    p0, _ = kd.get_max_preds(out[("f16x2", 1)].cuda())
+    p1, _ = kd.get_max_preds(y_ref.cuda())
+    assert torch.equal(p0, p1)
+
+
 def test_stem_fusion_is_bit_identical_to_separate_launches():
     """Policy stem_fused: BN apply + ReLU + max-pool in one sweep (z of the stem never stored) and the max-pool backward gathered
     inside the BN backward give exactly the outputs, running statistics and gradients of the separate launches - train mode with
@@ -386,7 +424,7 @@ def test_stem_fusion_is_bit_identical_to_separate_launches():
         net = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 1, 1], False, False)
         net.load_state_dict(base.state_dict())
         net = net.cuda().train()
-        net.policy, net._handles = {"stem_fused": fused}, {}
+        net.policy, net._handles = {"stem_fused": fused, "eval_fold": 0}, {}     # (eval_fold: its own test below; here conv -> y -> apply in eval too)
         y = net(x)
         y.backward(d)
         torch.cuda.synchronize()

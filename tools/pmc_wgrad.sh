@@ -1,7 +1,7 @@
 # Dev tool: SQ / TCC counters of one weight-gradient layer.  usage: bash tools/pmc_wgrad.sh "<one_wgrad.py args>" (program directly after --)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS=${1:-"2048 8 512 512 3 16 0"}
-rm -rf /tmp/pw1 /tmp/pw2 /tmp/pw3
+rm -rf /tmp/pw1 /tmp/pw2 /tmp/pw3 /tmp/pw4
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pw1 -- python3 tools/one_wgrad.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d /tmp/pw2 -- python3 tools/one_wgrad.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pw3 -- python3 tools/one_wgrad.py $ARGS > /dev/null 2>&1

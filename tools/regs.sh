@@ -1,6 +1,6 @@
 # Dev tool: VGPR / scratch use of every kernel of one source file.  usage: bash tools/regs.sh patchconv [-DUDAPOSE_ELEM_F16]
 F=${1:-igemm}; shift
-mkdir -p /tmp/regs && cd /root/repo/uda_poseestimation_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c $F.hip -o /tmp/regs/$F.o -save-temps=obj 2>&1 | grep -v "^$" | head -20
+mkdir -p /tmp/regs && cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}/uda_poseestimation_amd/csrc" && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c $F.hip -o /tmp/regs/$F.o -save-temps=obj 2>&1 | grep -v "^$" | head -20
 python3 - "$F" <<'PY'
 import re, glob, sys
 f = [x for x in glob.glob('/tmp/regs/%s-hip-amdgcn*.s' % sys.argv[1])][0]

@@ -49,6 +49,8 @@ struct Policy {
                                 // pull table entries, so that a launch running under the gradient chain leaves the chain kernels their slots
     int wgrad_cut_lo = 0, wgrad_cut_hi = 0;   // staged launches: bit b set = block b (0 = first block of layer1) is the LOWEST block of its stage
                                 // (0 / 0: every wgrad_overlap-th block counted from the top)
+    int eval_fold = 1;          // eval-mode forwards (validate()): BatchNorm's running-statistics scale / shift, the residual and the ReLU are applied in
+                                // the convolution's epilogue - z is written by the conv, no BN-apply launch, no pre-BN tensor (0: conv + apply launches)
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null
@@ -117,6 +119,7 @@ int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, cons
 struct ConvEpilogue {
     const elem_t* res = nullptr;
     const float* bias = nullptr;
+    const float* scale = nullptr;   // per-channel factor applied to the fp32 result before the bias (igemm path only; eval-mode BN folding)
     float* stats = nullptr;
     int relu = 0;
     int out_f32 = 0;

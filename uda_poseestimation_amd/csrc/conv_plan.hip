@@ -130,7 +130,7 @@ int conv_fprop(hipStream_t s, const ConvGeom& g, const elem_t* x, const elem_t* 
     if (!tp) return UDAPOSE_ERR_NOT_PREPARED;
     if (g.transposed && (g.reflect || g.upsample)) return UDAPOSE_ERR_UNSUPPORTED;
     IgParams p{};
-    p.x = x; p.w = w_fwd; p.y = y; p.res = e.res; p.bias = e.bias; p.stats = e.stats; p.taps = tp->d_taps;
+    p.x = x; p.w = w_fwd; p.y = y; p.res = e.res; p.bias = e.bias; p.scale = e.scale; p.stats = e.stats; p.taps = tp->d_taps;
     p.N = g.N; p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci;
     p.Ho = g.Ho(); p.Wo = g.Wo(); p.Co = g.Co;
     if (g.transposed) { p.Hg = g.Hi; p.Wg = g.Wi; p.s = 1; p.os = g.stride; }

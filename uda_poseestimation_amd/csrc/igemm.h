@@ -25,6 +25,8 @@ struct IgParams {
     void* y;                // NHWC [N, Ho, Wo, Co] bf16 (or fp32)
     const elem_t* res;      // optional residual, same shape as y (bf16), added before ReLU
     const float* bias;      // optional [Co]
+    const float* scale;     // optional [Co]: the fp32 result is multiplied by it before the bias (eval-mode BatchNorm folded into the conv:
+                            // y = conv * gamma * invstd + (beta - mean * gamma * invstd), net.hip conv_bn_fwd)
     float* stats;           // optional per-channel partial sums: [stat_rows][2][Co] fp32 (sum, sumsq of fp32 acc)
     const IgTap* taps;      // device tap table
     int N, Hi, Wi, Ci;

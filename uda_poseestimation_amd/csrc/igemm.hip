@@ -658,9 +658,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN >= 
             if (col < p.Co) p.stats[(srow * 2 + st) * p.Co + col] = t;
         }
     }
-    float bias[8];
+    float bias[8], scl[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = (p.bias && cbase + e < p.Co) ? p.bias[cbase + e] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+        bias[e] = (p.bias && cbase + e < p.Co) ? p.bias[cbase + e] : 0.f;
+        scl[e] = (p.scale && cbase + e < p.Co) ? p.scale[cbase + e] : 1.f;       // (x * 1 + b == x + b exactly: the unscaled form is unchanged)
+    }
     // BS (dgrad feeding a BatchNorm backward): per-lane coefficients of the consumer BN's 8 channels and the running partial
     // sums of g and g * xhat over this lane's rows
     float bmu[8], bis[8], bsc[8], bsh[8], bs1[8], bs2[8];
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN >= 
                 }
                 const size_t off = opix * p.Co + cbase;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bias[e];
+                for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], scl[e], bias[e]);
                 if (p.res) {
                     if constexpr (SP) {
                         const char* rp = (const char*)p.res + off * 4;

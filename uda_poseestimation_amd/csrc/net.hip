@@ -342,9 +342,20 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     // block outputs: the apply also saves the ReLU bit mask of z (1/16 of z's bytes) for the data gradients that mask with it
     unsigned char* mask = (b.mask_off && n.policy.bn3_mask && relu) ? (unsigned char*)(act + b.mask_off) : nullptr;
     const void* wptr = (n.f32 == 1 && !c.g.smallc() && !c.g.transposed) ? params[c.w_idx] : (const void*)(wpack + c.wf_off);
-    CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
     const float* gamma = (const float*)params[b.g_idx];
     const float* beta = (const float*)params[b.b_idx];
+    if (!training && !no_apply && !pre_bias && n.policy.eval_fold) {
+        // Eval mode (validate(), train_human.py:461-500): the BatchNorm is a per-channel affine map known BEFORE the convolution, so the
+        // conv's epilogue applies it from the fp32 accumulators - z = relu(conv * scale + shift (+ residual)) is written by the conv
+        // itself: no apply launch, no pre-BN tensor, one rounding less than conv -> y -> apply
+        CK(pw_bn_eval_coeff(s, b.C, gamma, beta, (const float*)buffers[b.rm_idx], (const float*)buffers[b.rv_idx], 1e-5f, scale, shift));
+        e.stats = nullptr;
+        e.scale = scale; e.bias = shift; e.relu = relu;
+        e.res = res;
+        e.out_f32 = 0;                    // (z has the plan's storage type: 16-bit, fp32, or the f16x2 split form)
+        return conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + b.z_off, e);
+    }
+    CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
     if (training && !n.f32 && !no_apply && !pre_bias) {
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,

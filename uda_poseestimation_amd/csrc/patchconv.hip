@@ -617,6 +617,7 @@ int launch_pg(const PgParams& p, hipStream_t s) {
 // 1 when conv_fprop hands this geometry / epilogue to a patch-staged kernel
 static int patch_trunk_ok(const ConvGeom& g, const ConvEpilogue& e);
 int patch_conv_ok(const ConvGeom& g, const ConvEpilogue& e) {
+    if (e.scale) return 0;                 // (per-channel scale: the igemm epilogue only)
     if (patch_trunk_ok(g, e)) return 1;
     if (!g.policy().patch_conv || g.transposed || g.upsample || !g.reflect || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return 0;
     if (e.f32 || e.res || e.stats || g.Wi % 64 != 0 || g.Hi < 2 || g.Wi < 2) return 0;

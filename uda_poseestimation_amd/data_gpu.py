@@ -188,11 +188,14 @@ class TargetViewPipeline:
     """Batched device pipeline for the `_mt` datasets' student / teacher views."""
 
     def __init__(self, image_size=256, heatmap_size=64, sigma=2, k=1, student=None, teacher=None, mean=IMAGENET_MEAN, std=IMAGENET_STD,
-                 rng=None, resize_scale=(0.6, 1.3)):
+                 rng=None, resize_scale=(0.6, 1.3), np_rng=None):
         self.image_size, self.heatmap_size, self.sigma, self.k = int(image_size), int(heatmap_size), sigma, int(k)
         self.stu, self.tea = student or ViewConfig(), teacher or ViewConfig()
         self.mean, self.std = tuple(mean), tuple(std)
         self.rng = rng if rng is not None else random
+        # the reference draws the blur radius from the GLOBAL np.random (lib/transforms/keypoint_detection.py:221), everything else of a view
+        # from python's `random`: two generators, so a seeded pipeline consumes each stream as the reference does (ADVICE r3)
+        self.np_rng = np_rng if np_rng is not None else np.random
         self.resize_scale = tuple(resize_scale)          # `--resize-scale` (train_human.py:523)
         self._dev = {}
         self._coef_cache = {}
@@ -352,7 +355,7 @@ class TargetViewPipeline:
         img = self.warp_images(base_u8, params)
         self.jitter_(img, [j[0] for j in jitter], [j[1] for j in jitter])
         if blur is None and cfg.blur > 0:
-            blur = [cfg.draw_blur(self.rng) for _ in range(N)]
+            blur = [cfg.draw_blur(self.np_rng) for _ in range(N)]
         if blur is not None:
             self.blur_(img, blur)                     # (after the colour jitter, before ToTensor: train_human.py:67-71)
         x = self.to_tensor(img)

@@ -528,8 +528,9 @@ class GraphedTrainStep:
     Data parallel: four graphs - forwards | losses + backward part 1 | backward part 2 | Adam + EMA - with the confidence
     all-gather after the first, the all-reduce of the finished gradient suffix launched after the second (it runs on the
     communicator's stream under the third) and the small prefix all-reduce after the third.
-    Inputs are copied into static device tensors before each replay; the re-warp matrices are computed on the host from
-    the batch's aug_param tuples exactly as in the eager step.
+    Inputs are copied into static device tensors before each replay; the re-warp matrices are computed INSIDE the captured step
+    (udapose_recon_thetas, double precision) from the batch's raw aug_param values, which the host packs into a pinned ring and
+    uploads with one asynchronous copy per step.
     Style transfer (train_human.py:345-358): each direction is its own small graph (content, style, alpha as a device scalar ->
     the step's effective input); the host draws the step's decisions in the reference's order and replays the direction(s) it
     drew, or copies the original images, before the main graph.  Occlusion (train_human.py:374-412): the decisions are taken

@@ -113,6 +113,7 @@ class _PoseNetFn(torch.autograd.Function):
 class PoseResNet(nn.Module):
     """Simple Baseline for key-point detection (pose_resnet.py:59-91) on the MI355X executor."""
     default_precision = 'auto'      # what a new module's `precision` starts as (see __init__)
+    _warned_bf16_fallback = False
 
     def __init__(self, backbone, upsampling, feature_dim, num_keypoints, finetune=False):
         super().__init__()
@@ -245,6 +246,12 @@ class PoseResNet(nn.Module):
             return prec
         if torch.is_autocast_enabled():
             return 'bf16' if torch.get_autocast_dtype('cuda') == torch.bfloat16 else 'fp16'
+        if differentiable and not PoseResNet._warned_bf16_fallback:
+            PoseResNet._warned_bf16_fallback = True
+            import warnings
+            warnings.warn("PoseResNet(precision='auto'): a differentiable forward OUTSIDE torch.autocast runs in bf16 here (the reference would run "
+                          "fp32: there is no fp32 backward on this path; its scripts always train under autocast, train_human.py:280,414). Set "
+                          ".precision explicitly ('bf16' / 'fp16') to silence this.", stacklevel=3)
         return 'bf16' if differentiable else 'f16x2'
 
     def _handle(self, x, differentiable=None):
