@@ -235,6 +235,8 @@ def main():
                     "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
     ap.add_argument("--wgrad-side", action="store_true", help="tuning: the upper part's weight gradients on a side stream under the lower "
                     "part's gradient chain instead of after the whole chain (measured slower: profiles/r2_ab_runs.txt)")
+    ap.add_argument("--early-source-bwd", action="store_true", help="tuning: the source pass's gradient chain starts right after its own forward")
+    ap.add_argument("--wgrad-streams", type=int, default=1, help="tuning: side streams of the staged weight gradients (--policy wgrad_overlap=N)")
     ap.add_argument("--no-merge-wgrad", action="store_true", help="tuning: each pass launches its own grouped weight gradients")
     ap.add_argument("--two-graphs", action="store_true", help="tuning: the optimizer tail as its own graph on one rank too")
     ap.add_argument("--force-overlap", action="store_true", help="tuning: the data-parallel backward (two parts, gradient sums per part) without a "
@@ -348,6 +350,8 @@ def main():
     trainer.stream_priority = args.stream_priority
     if args.no_merge_wgrad:
         trainer.merge_wgrad = False
+    trainer.early_source_backward = bool(args.early_source_bwd)
+    trainer.wgrad_streams = args.wgrad_streams
     if args.two_graphs:
         trainer.single_graph = False
     if args.force_overlap:
@@ -535,7 +539,7 @@ def main():
                                            "not by the MFMA pipes"}
         # the parity-compliant configurations of the same step, driver-visible (untimed extras after the headline's timed region)
         headline_cfg = (args.arch, S, K, N, args.dtype, args.precision) == ("pose_resnet101", 256, 16, 32, "bf16", None)
-        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune):
+        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune or args.early_source_bwd):
             try:
                 del graphed
             except NameError:

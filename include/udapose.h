@@ -254,18 +254,20 @@ int udapose_net_wgrad_pair(udapose_net_t net, void* stream, const void* act_a, v
  *   udapose_net_backward_staged  runs the gradient chain of the whole backward on `stream` (= udapose_net_backward_phase(part 0,
  *                                phase 1)) and records the plan's stage events of `slot` (0..3: one per concurrent pass of a step)
  *                                as the chain leaves each stage;
- *   udapose_net_wgrad_staged     enqueues on the side stream `wg_stream`, stage by stage: wait for the stage's event of pass A (and
+ *   udapose_net_wgrad_staged     enqueues on the side streams (host array of n_streams handles; stage k goes to stream k mod n_streams:
+ *                                one stream = stages strictly in order, several = lagging stages run beside each other), stage by
+ *                                stage: wait for the stage's event of pass A (and
  *                                of pass B when act_b != NULL: the two passes of one plan share every launch), then that stage's
  *                                grouped weight gradients.  Every stage but the last is a PERSISTENT grid of udapose_policy.wgrad_cap
  *                                work-groups (bounded residency: the chain kernels of the layers below keep their CU slots).
- * The caller joins wg_stream into the stream of the optimizer step.  Gradients are bit-identical to the unstaged backward for layers
+ * The caller joins every side stream into the stream of the optimizer step.  Gradients are bit-identical to the unstaged backward for layers
  * that reduce inside one work-group; layers split over pixels accumulate with fp32 atomics in either form (order not fixed).
  * Both need udapose_net_bind_grads for the gradient placement (it builds the stage tables, events and head counters). */
 int udapose_net_num_stages(udapose_net_t net);
 int udapose_net_backward_staged(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
                                 void* act, void* ws, void* const* h_grads, float beta, int slot);
-int udapose_net_wgrad_staged(udapose_net_t net, void* wg_stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a, int slot_a,
-                             const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int slot_b);
+int udapose_net_wgrad_staged(udapose_net_t net, void* const* h_wg_streams, int n_streams, const void* act_a, void* ws_a, void* const* h_grads_a,
+                             float beta_a, int slot_a, const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int slot_b);
 long long udapose_net_grad_split_param(udapose_net_t net);
 
 /* ---------------------------------------------------------------- heat-map losses and decode (fp32 NCHW rows [R=B*K][HW]) */

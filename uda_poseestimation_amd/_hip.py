@@ -96,7 +96,7 @@ _SIGS = {
     "udapose_net_backward_phase": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]),
     "udapose_net_num_stages": (ci, [vp]),
     "udapose_net_backward_staged": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci]),
-    "udapose_net_wgrad_staged": (ci, [vp, vp, vp, vp, vp, cf, ci, vp, vp, vp, cf, ci]),
+    "udapose_net_wgrad_staged": (ci, [vp, vp, ci, vp, vp, vp, cf, ci, vp, vp, vp, cf, ci]),
     "udapose_net_wgrad_pair": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, cf, ci]),
     "udapose_net_grad_split_param": (ll, [vp]),
     "udapose_net_bind_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -86,7 +86,7 @@ int net_forward(void*, hipStream_t, const float*, const void* const*, void* cons
 int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int, int);
 int net_wgrad_pair(void*, hipStream_t, const void*, void*, void* const*, float, const void*, void*, void* const*, float, int);
 int net_num_stages(void*);
-int net_wgrad_staged(void*, hipStream_t, const void*, void*, void* const*, float, int, const void*, void*, void* const*, float, int);
+int net_wgrad_staged(void*, void* const*, int, const void*, void*, void* const*, float, int, const void*, void*, void* const*, float, int);
 int net_backward_staged(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int);
 
 static Policy from_c(const udapose_policy& c) {
@@ -291,10 +291,10 @@ int udapose_net_backward_staged(udapose_net_t n, void* stream, const float* dout
     if (!n || !dout || !params || !wpack || !act || !ws || !grads) return UDAPOSE_ERR_ARG;
     return net_backward_staged(n, S(stream), dout, params, wpack, act, ws, grads, beta, slot);
 }
-int udapose_net_wgrad_staged(udapose_net_t n, void* wg_stream, const void* act_a, void* ws_a, void* const* grads_a, float beta_a, int slot_a,
-                             const void* act_b, void* ws_b, void* const* grads_b, float beta_b, int slot_b) {
-    if (!n || !act_a || !ws_a || !grads_a || (act_b && (!ws_b || !grads_b))) return UDAPOSE_ERR_ARG;
-    return net_wgrad_staged(n, S(wg_stream), act_a, ws_a, grads_a, beta_a, slot_a, act_b, ws_b, grads_b, beta_b, slot_b);
+int udapose_net_wgrad_staged(udapose_net_t n, void* const* wg_streams, int n_streams, const void* act_a, void* ws_a, void* const* grads_a, float beta_a,
+                             int slot_a, const void* act_b, void* ws_b, void* const* grads_b, float beta_b, int slot_b) {
+    if (!n || !wg_streams || n_streams < 1 || !act_a || !ws_a || !grads_a || (act_b && (!ws_b || !grads_b))) return UDAPOSE_ERR_ARG;
+    return net_wgrad_staged(n, wg_streams, n_streams, act_a, ws_a, grads_a, beta_a, slot_a, act_b, ws_b, grads_b, beta_b, slot_b);
 }
 long long udapose_net_grad_split_param(udapose_net_t n) { return net_grad_split_param(n); }
 int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* const* params_s, void* const* grads, void* const* exp_avg,

@@ -933,13 +933,17 @@ int net_wgrad_pair(void* h, hipStream_t s, const void* actA, void* wsA, void* co
 // whole chip.  The caller joins `sw` into the stream that runs the optimizer.  Inside a stream capture the waits become graph
 // edges, so the order in which the host enqueues chains and stages does not matter; eagerly the chains must be enqueued first.
 int net_num_stages(void* h) { return (int)((Net*)h)->stages.size(); }
-int net_wgrad_staged(void* h, hipStream_t sw, const void* actA, void* wsA, void* const* gradsA, float betaA, int slotA, const void* actB, void* wsB,
-                     void* const* gradsB, float betaB, int slotB) {
+int net_wgrad_staged(void* h, void* const* sws, int nsw, const void* actA, void* wsA, void* const* gradsA, float betaA, int slotA, const void* actB,
+                     void* wsB, void* const* gradsB, float betaB, int slotB) {
     Net& n = *(Net*)h;
-    if (n.f32 || !n.policy.wgrad_group || n.stages.empty() || slotA < 0 || slotA >= Net::EV_SLOTS || slotB >= Net::EV_SLOTS) return UDAPOSE_ERR_ARG;
+    if (n.f32 || !n.policy.wgrad_group || n.stages.empty() || slotA < 0 || slotA >= Net::EV_SLOTS || slotB >= Net::EV_SLOTS || nsw < 1 || !sws)
+        return UDAPOSE_ERR_ARG;
     DbgSyncScope dbg(n.policy.debug_sync);
     const int ns = (int)n.stages.size();
     for (int k = 0; k < ns; ++k) {
+        // stage k on side stream k mod nsw: with one stream the stages run in order (a capped stage that lags delays every later one);
+        // with several, lagging stages pile up beside each other and the residency of the weight gradients grows as the chain proceeds
+        hipStream_t sw = (hipStream_t)sws[k % nsw];
         if (hipStreamWaitEvent(sw, n.ev[slotA][k], 0) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         if (actB && hipStreamWaitEvent(sw, n.ev[slotB][k], 0) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         const int cap = k + 1 < ns ? n.policy.wgrad_cap : 0;

@@ -233,6 +233,10 @@ class MeanTeacherTrainer:
         self.single_graph = True            # one rank: the optimizer tail is captured into the step's graph (one launch per step)
         self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
+        # one rank: start the SOURCE-domain pass's gradient chain as soon as its own forward has finished (loss_s does not depend on the
+        # teacher), beside the teacher's and the target-domain forwards; its weight gradients still go out with the other pass's at the
+        # end.  Same gradients (the two passes own separate buffers; d(loss_s + lambda * loss_c) = d loss_s + lambda * d loss_c).
+        self.early_source_backward = False
 
     def _check_scaler(self):
         """An fp16 student forward needs the loss scaler the optimizer was built with (or the caller's own GradScaler: then build the
@@ -350,8 +354,9 @@ class MeanTeacherTrainer:
         if self._side is None or self._side[0].device != x_s.device:
             pr = self.stream_priority
             self._side = (torch.cuda.Stream(device=x_s.device, priority=pr), torch.cuda.Stream(device=x_s.device, priority=pr))
-        if getattr(self, "_wg_stream", None) is None or self._wg_stream.device != x_s.device:
-            self._wg_stream = torch.cuda.Stream(device=x_s.device)      # staged weight gradients (policy wgrad_overlap): created outside capture
+        if getattr(self, "_wg_stream", None) is None or self._wg_stream[0].device != x_s.device:
+            # staged weight gradients (policy wgrad_overlap): side streams, created outside capture (wgrad_streams = 1: stages in order)
+            self._wg_stream = [torch.cuda.Stream(device=x_s.device) for _ in range(max(1, int(getattr(self, "wgrad_streams", 1))))]
         s_tea, s_stu = self._side if self.concurrent else (main, main)
         occl = self._occl if self.occlude_rate > -1 else None
         student.prepare(x_s)                # bf16 weight packs refreshed on `main` before the branches fork
@@ -384,6 +389,13 @@ class MeanTeacherTrainer:
             y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
         if occl is None:
             y_s = student(x_s)
+        loss_s_early = None
+        if self.early_source_backward and not self._overlap() and self.merge_wgrad and hasattr(student, "finish_wgrad") \
+                and not getattr(student, "wgrad_side_stream", False):
+            student.split_backward, student.merge_wgrad = False, True
+            loss_s_early = self.criterion(y_s, label_s, weight_s)
+            self._check_scaler()
+            self.stu_optimizer.scale_loss(loss_s_early).backward()        # (the source pass's chain, on `main`, under the other branches' forwards)
         main.wait_stream(s_stu)
         student.apply_deferred_bn()         # (x_s first, then x_t_stu: the reference's call order, train_human.py:414-417)
         for t in (y_t_stu, y_t_stu_recon, x_t_stu):
@@ -394,7 +406,7 @@ class MeanTeacherTrainer:
         with torch.no_grad():
             activates = mt.heatmap_activations(y_t_tea_recon)    # BEFORE rectify (train_human.py:427)
         return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
-                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu}
+                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu, "loss_s_early": loss_s_early}
 
     def _overlap(self):
         on = self.overlap_allreduce
@@ -437,7 +449,8 @@ class MeanTeacherTrainer:
         # one rank: the two passes' grouped weight gradients go out as ONE launch after both gradient chains (finish_wgrad)
         merge = (not overlap) and (not side) and self.merge_wgrad and hasattr(student, "finish_wgrad")
         student.merge_wgrad = bool(merge)
-        loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
+        early = st.get("loss_s_early")
+        loss_s = early.detach() if early is not None else self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         self._check_scaler()
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
@@ -445,7 +458,8 @@ class MeanTeacherTrainer:
             y_t_tea_rect = mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
         loss_c = self.con_criterion(st["y_t_stu_recon"], y_t_tea_rect, tea_mask=tea_mask)
         loss_all = loss_s + self.lambda_c * loss_c
-        self.stu_optimizer.scale_loss(loss_all).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
+        # (with the source pass's chain already enqueued by _forward_part only the consistency term is left to differentiate)
+        self.stu_optimizer.scale_loss(loss_all if early is None else self.lambda_c * loss_c).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
         student.split_backward = False

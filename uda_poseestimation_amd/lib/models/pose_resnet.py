@@ -528,17 +528,20 @@ class PoseResNet(nn.Module):
             if wg_stream is None:
                 raise RuntimeError("finish_wgrad: a staged plan (policy wgrad_overlap) needs the weight-gradient side stream")
             hd, actA, wsA, gA, bA, _, slA = pend[0]
+            streams = list(wg_stream) if isinstance(wg_stream, (list, tuple)) else [wg_stream]
+            sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
             if len(pend) == 2:
                 _, actB, wsB, gB, bB, _, slB = pend[1]
-                check(hd.L.udapose_net_wgrad_staged(hd.h, wg_stream.cuda_stream, ptr(actA), ptr(wsA), gA, bA, slA, ptr(actB), ptr(wsB), gB, bB, slB),
+                check(hd.L.udapose_net_wgrad_staged(hd.h, sarr, len(streams), ptr(actA), ptr(wsA), gA, bA, slA, ptr(actB), ptr(wsB), gB, bB, slB),
                       "net_wgrad_staged")
             else:
-                check(hd.L.udapose_net_wgrad_staged(hd.h, wg_stream.cuda_stream, ptr(actA), ptr(wsA), gA, bA, slA, None, None, None, 0.0, 0),
+                check(hd.L.udapose_net_wgrad_staged(hd.h, sarr, len(streams), ptr(actA), ptr(wsA), gA, bA, slA, None, None, None, 0.0, 0),
                       "net_wgrad_staged")
-            for q in pend:
-                q[1].record_stream(wg_stream)
-                q[2].record_stream(wg_stream)
-            cur.wait_stream(wg_stream)
+            for st in streams[:hd.L.udapose_net_num_stages(hd.h)]:
+                for q in pend:
+                    q[1].record_stream(st)
+                    q[2].record_stream(st)
+                cur.wait_stream(st)
         elif len(pend) == 2 and pend[0][0] is pend[1][0] and pend[0][6] < 0 and pend[1][6] < 0:
             (hd, actA, wsA, gA, bA, _, _), (_, actB, wsB, gB, bB, _, _) = pend
             check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0), "net_wgrad_pair")
