@@ -36,12 +36,19 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (/opt/skills/gu
 FWD_GFLOP_PER_IMAGE = 24.165       # PoseResNet-101, K=16, 256x256 forward
 
 
+def _pmc_traffic_file():
+    """The newest committed PMC summary (profiles/r<N>_pmc_hbm_traffic.txt)."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.txt")))
+    return fs[-1] if fs else os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.txt")
+
+
 def measured_traffic_per_igemm_launch():
     """HBM bytes per igemm launch from the committed PMC passes (profiles/r3_pmc_hbm_traffic.txt: separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this benchmark; FETCH_SIZE doubled per the gfx950 note)."""
     try:
         import ast
-        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.txt")).read().strip())
+        d = ast.literal_eval(open(_pmc_traffic_file()).read().strip())
         n, f = d["fetch"]["igemm"]
         _, w = d["write"]["igemm"]
         return (2.0 * f + w) * 1024.0 / n
@@ -54,7 +61,7 @@ def measured_traffic_per_step(eager_steps=9):
     (9 eager steps in the profiled run: `--eager --steps 3 --warmup 1` = 1 + 3 timed + 3 synchronised-loop + 2 roofline steps): what the whole step moves, next to the per-launch figure of the dominant kernel."""
     try:
         import ast
-        d = ast.literal_eval(open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.txt")).read().strip())
+        d = ast.literal_eval(open(_pmc_traffic_file()).read().strip())
         return {fam: (2.0 * d["fetch"][fam][1] + d["write"][fam][1]) * 1024.0 / eager_steps for fam in ("igemm", "bn", "wgrad")}
     except Exception:
         return None
@@ -476,7 +483,7 @@ def main():
         dist.all_gather(every_t, mine)
         rank_ms = [[round(float(e[0]), 3), round(float(e[1]), 3)] for e in every_t]
     loss = float(out["loss_all"])
-    assert loss == loss, "loss is NaN"
+    assert loss == loss or tune.get("exp0"), "loss is NaN"        # (exp0: timing experiments that skip work on purpose)
     in_sync = None
     if world > 1:
         # data-parallel invariant (outside the timed region): every rank holds the same student and teacher after the run
@@ -524,7 +531,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic_per_igemm_launch(),
                          "traffic_note": "HBM bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                         "(profiles/r3_pmc_hbm_traffic.txt), not collected live",
+                                         f"(profiles/{os.path.basename(_pmc_traffic_file())}), not collected live",
                          "launches_per_step": int(ig_l), "avg_launch_us": round(ig_ms * 1e3 / max(ig_l, 1), 2),
                          "flops_per_launch_avg": ig_fl / max(ig_l, 1), "kernel_ms_per_step": round(ig_ms, 3),
                          "wgrad": {"launches_per_step": int(wl), "kernel_ms_per_step": round(ms_w, 3),

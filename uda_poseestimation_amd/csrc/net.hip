@@ -356,6 +356,8 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         return conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + b.z_off, e);
     }
     CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
+    if (training && !n.f32 && !no_apply && !pre_bias && (((n.policy.exp0 & 8) && b.npix <= 8192 && b.C >= 256) || (n.policy.exp0 & 16)))
+        return UDAPOSE_OK;      // TIMING EXPERIMENT ONLY (wrong results): what the step would gain if these BN launches cost nothing (r4_ab_runs.txt)
     if (training && !n.f32 && !no_apply && !pre_bias) {
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
