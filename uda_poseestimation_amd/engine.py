@@ -387,15 +387,28 @@ class MeanTeacherTrainer:
                                                                         self.occlude_rate, self.occlude_thresh, self.occlude_size, self.occl_rng)
             y_t_stu = student.forward_deferred_bn(x_t_stu)     # separate forwards: separate BN statistics per domain
             y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
-        if occl is None:
+        loss_s_early, s_src = None, None
+        early = (self.early_source_backward and occl is None and self.concurrent and not self._overlap() and self.merge_wgrad
+                 and hasattr(student, "finish_wgrad") and not getattr(student, "wgrad_side_stream", False))
+        if early:
+            # the source pass on a stream of its own: forward, JointsMSE and its gradient chain run to the end without waiting for the
+            # other branches (loss_s does not depend on the teacher), while `main` goes on to the consistency loss - an in-order
+            # stream that carried both would put the whole source chain in front of the target pass's backward
+            if getattr(self, "_src_stream", None) is None or self._src_stream.device != x_s.device:
+                self._src_stream = torch.cuda.Stream(device=x_s.device, priority=self.stream_priority)
+            s_src = self._src_stream
+            s_src.wait_stream(main)
+            with torch.cuda.stream(s_src):
+                y_s = student(x_s)
+                src_fwd_done = torch.cuda.Event()
+                src_fwd_done.record(s_src)
+                student.split_backward, student.merge_wgrad = False, True
+                loss_s_early = self.criterion(y_s, label_s, weight_s)
+                self._check_scaler()
+                self.stu_optimizer.scale_loss(loss_s_early).backward()
+            main.wait_event(src_fwd_done)    # (the source forward's own running-statistics update comes before the deferred one below)
+        elif occl is None:
             y_s = student(x_s)
-        loss_s_early = None
-        if self.early_source_backward and not self._overlap() and self.merge_wgrad and hasattr(student, "finish_wgrad") \
-                and not getattr(student, "wgrad_side_stream", False):
-            student.split_backward, student.merge_wgrad = False, True
-            loss_s_early = self.criterion(y_s, label_s, weight_s)
-            self._check_scaler()
-            self.stu_optimizer.scale_loss(loss_s_early).backward()        # (the source pass's chain, on `main`, under the other branches' forwards)
         main.wait_stream(s_stu)
         student.apply_deferred_bn()         # (x_s first, then x_t_stu: the reference's call order, train_human.py:414-417)
         for t in (y_t_stu, y_t_stu_recon, x_t_stu):
@@ -406,7 +419,7 @@ class MeanTeacherTrainer:
         with torch.no_grad():
             activates = mt.heatmap_activations(y_t_tea_recon)    # BEFORE rectify (train_human.py:427)
         return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
-                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu, "loss_s_early": loss_s_early}
+                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu, "loss_s_early": loss_s_early, "s_src": s_src}
 
     def _overlap(self):
         on = self.overlap_allreduce
@@ -462,6 +475,10 @@ class MeanTeacherTrainer:
         self.stu_optimizer.scale_loss(loss_all if early is None else self.lambda_c * loss_c).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
+        if st.get("s_src") is not None:
+            main.wait_stream(st["s_src"])       # ... and the early source pass on its own
+            for t in (st["y_s"], early):
+                t.record_stream(main)
         student.split_backward = False
         if merge:
             student.merge_wgrad = False
