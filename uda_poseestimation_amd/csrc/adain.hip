@@ -197,3 +197,5 @@ int adain_launch_split(hipStream_t s, const void* content, const void* style, vo
                        alpha_dev, stats_out);
     return udapose_check_launch();
 }
+
+UDAPOSE_SP_SAT_READER(sp_sat_read_adain)

@@ -57,6 +57,10 @@ int aug_draw_labelmap_ori(hipStream_t, const float*, const float*, const unsigne
 int affine_warp_chain(hipStream_t, const float*, float*, const float*, int, int, int, int, int, int);
 int affine_recon_thetas(hipStream_t, const double*, int, double, float*, float*);
 int affine_mean_views(hipStream_t, const float* const*, int, float*, size_t);
+unsigned long long sp_sat_read_adain(int);
+unsigned long long sp_sat_read_igemm(int);
+unsigned long long sp_sat_read_patchconv(int);
+unsigned long long sp_sat_read_pointwise(int);
 int patch_paste(hipStream_t, float*, const int*, int, int, int, int, int);
 int occlusion_pick(hipStream_t, const float*, const int*, const float*, int, int, int, double, int, float, float, int, int*, unsigned char*);
 int select_rows(hipStream_t, float*, const float*, const float*, const unsigned char*, int, size_t);
@@ -415,6 +419,16 @@ int udapose_select_rows(void* stream, float* dst, const float* a, const float* b
 int udapose_recon_thetas(void* stream, const double* params, int N, double ratio, float* theta_fwd, float* theta_back) {
     if (!params || (!theta_fwd && !theta_back)) return UDAPOSE_ERR_ARG;
     return affine_recon_thetas(S(stream), params, N, ratio, theta_fwd, theta_back);
+}
+int udapose_split_saturations(int reset, unsigned long long* count) {
+    if (!count) return UDAPOSE_ERR_ARG;
+    unsigned long long t = 0;
+    for (unsigned long long v : {sp_sat_read_adain(reset), sp_sat_read_igemm(reset), sp_sat_read_patchconv(reset), sp_sat_read_pointwise(reset)}) {
+        if (v == ~0ull) return UDAPOSE_ERR_LAUNCH;
+        t += v;
+    }
+    *count = t;
+    return UDAPOSE_OK;
 }
 int udapose_mean_views(void* stream, const float* const* h_views, int k, float* dst, size_t n) {
     return affine_mean_views(S(stream), h_views, k, dst, n);

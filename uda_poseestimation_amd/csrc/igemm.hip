@@ -1071,3 +1071,5 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream, const Policy& pol) {
         default: return UDAPOSE_ERR_ARG;
     }
 }
+
+UDAPOSE_SP_SAT_READER(sp_sat_read_igemm)

@@ -655,3 +655,5 @@ int patch_conv_fprop(hipStream_t s, const ConvGeom& g, const void* x, const void
     }
     return UDAPOSE_ERR_UNSUPPORTED;
 }
+
+UDAPOSE_SP_SAT_READER(sp_sat_read_patchconv)

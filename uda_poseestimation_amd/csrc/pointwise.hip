@@ -1409,3 +1409,5 @@ int pw_plane_sum(hipStream_t s, const float* x, float* out, int N, int C, int HW
     hipLaunchKernelGGL(plane_sum_k, dim3(C), dim3(1024), 0, s, x, out, N, C, HW, beta);
     return udapose_check_launch();
 }
+
+UDAPOSE_SP_SAT_READER(sp_sat_read_pointwise)

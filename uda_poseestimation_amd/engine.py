@@ -550,6 +550,11 @@ def validate(batches, model, criterion=None):
         return [], float("nan")
     avg = torch.where(acc_cnt > 0, acc_sum / acc_cnt.clamp(min=1), torch.zeros_like(acc_sum))     # AverageMeter.avg starts at 0
     out = torch.cat([avg, (loss_sum / max(n_seen, 1)).reshape(1)]).cpu().tolist()                 # the one read-back
+    sat = mt.split_saturations(reset=True)          # (the evaluation forward runs the fp32-grade f16x2 mode under 'auto': its range is fp16's)
+    if sat:
+        import warnings
+        warnings.warn(f"validate(): {sat} f16x2 stores saturated at |x| = 65504 (or were NaN) since the last check - activations outside fp16's "
+                      "range; run the model with precision='fp32' (exact, slower) to rule the format out")
     return out[:-1], out[-1]
 
 

@@ -156,3 +156,17 @@ def confidence_mask(recon, mask_ratio, tea_mask=None, gathered_activates=None, a
     tm = None if tea_mask is None else tea_mask.detach().float().contiguous()
     check(lib().udapose_kth_mask(_hip.stream(), ptr(pool), ptr(tm), pool.numel(), k, ptr(thr), ptr(mask), ptr(act), B * K), "kth_mask")
     return mask.bool(), act, thr
+
+
+def split_saturations(reset=True):
+    """How many f16x2 ('fp32-grade' mode) stores since the last reset hit a value outside fp16's range (|v| > 65504 saturates; NaN) - the
+    teacher / validate() / style-network forwards of the reference's precision mix.  Sums both library builds; synchronises the device."""
+    import ctypes as C
+    from . import _hip
+    total = 0
+    for kind in ("bf16", "fp16"):
+        if kind in _hip._libs or kind == "bf16":
+            c = C.c_ulonglong(0)
+            check(_hip.lib(kind).udapose_split_saturations(int(bool(reset)), C.byref(c)), "split_saturations")
+            total += int(c.value)
+    return total
