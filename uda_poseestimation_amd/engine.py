@@ -462,6 +462,8 @@ class MeanTeacherTrainer:
         # one rank: the two passes' grouped weight gradients go out as ONE launch after both gradient chains (finish_wgrad)
         merge = (not overlap) and (not side) and self.merge_wgrad and hasattr(student, "finish_wgrad")
         student.merge_wgrad = bool(merge)
+        if getattr(self, "_metrics_cb", None) is not None:
+            self._metrics_cb(st)                # (GraphedTrainStep: decode + PCK of the source batch on an idle side stream, under the backward)
         early = st.get("loss_s_early")
         loss_s = early.detach() if early is not None else self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         self._check_scaler()
@@ -577,7 +579,7 @@ class GraphedTrainStep:
         # `accuracy(y_s, label_s)`, train_human.py:443) and gathers the losses + PCK into ONE small device vector: step_async() reads
         # it back one step late through a pinned double buffer, so a loop that logs every iteration never drains the device
         self.metrics = bool(metrics)
-        self._mvec, self._mpin, self._mev, self._mi, self._mk = None, None, [None, None], 0, 0
+        self._mvec, self._mpin, self._mev, self._mi, self._mk, self._macc = None, None, [None, None], 0, 0, None
         self.styled = trainer.style_net is not None
         self.occl = trainer.occlude_rate > -1
         if self.occl and not trainer.device_occlusion:
@@ -658,16 +660,21 @@ class GraphedTrainStep:
         # one rank, nothing eager between backward and the optimizer: the update is captured into the same graph (one launch per step)
         self.one_graph = (not self.split) and (not _dist_on()) and trainer.single_graph
         if not self.split:
-            with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
-                self._thetas()
-                self.out = trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
-                                                     st["theta_stu"], [st["theta_tea"]])
-                if trainer.student._pending_lower:      # (overlap forced on one rank: both backward parts in the one graph)
-                    trainer._backward_lower()
-                if self.one_graph:
-                    trainer._sync_grads()
-                    trainer._update()
-                    self._capture_metrics()
+            if self.one_graph and self.metrics:
+                trainer._metrics_cb = self._metrics_side
+            try:
+                with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
+                    self._thetas()
+                    self.out = trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
+                                                         st["theta_stu"], [st["theta_tea"]])
+                    if trainer.student._pending_lower:      # (overlap forced on one rank: both backward parts in the one graph)
+                        trainer._backward_lower()
+                    if self.one_graph:
+                        trainer._sync_grads()
+                        trainer._update()
+                        self._capture_metrics()
+            finally:
+                trainer._metrics_cb = None
         else:
             self.g_lb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
@@ -709,11 +716,32 @@ class GraphedTrainStep:
         avg_acc, cnt, acc[0..K-1]]: decode and PCK are the udapose_heatmap_argmax / udapose_pck launches of lib.keypoint_detection."""
         if not self.metrics:
             return
-        acc, avg_cnt, _ = kd.accuracy_device(self.out["y_s"], self.static["label_s"])
+        if self._macc is not None:          # computed on the side stream while the backward ran: join it
+            torch.cuda.current_stream().wait_stream(self._macc[2])
+            acc, avg_cnt = self._macc[0], self._macc[1]
+            for t in (acc, avg_cnt):
+                t.record_stream(torch.cuda.current_stream())
+        else:
+            acc, avg_cnt, _ = kd.accuracy_device(self.out["y_s"], self.static["label_s"])
         parts = [self.out["loss_all"].reshape(1), self.out["loss_s"].reshape(1), self.out["loss_c"].reshape(1), avg_cnt.reshape(2), acc.reshape(-1)]
         self._mk = int(acc.numel())
         self._mvec = torch.cat([p.float() for p in parts])
         self.out["acc_s"], self.out["acc_avg_cnt"] = acc, avg_cnt
+
+    def _metrics_side(self, st):
+        """(inside the one-graph capture, called by the trainer before the losses) the metric's decode + PCK launches on the teacher's
+        stream, which is idle from here on: they run under the backward instead of behind the optimizer tail (pck_k alone is a 24 us
+        single-work-group kernel)."""
+        t = self.t
+        side = t._side[0] if (t._side is not None and t.concurrent) else None
+        if side is None:
+            return
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            acc, avg_cnt, _ = kd.accuracy_device(st["y_s"], self.static["label_s"])
+        st["y_s"].record_stream(side)
+        self._macc = (acc, avg_cnt, side)
 
     def _metrics_dict(self, v):
         v = v.tolist()
