@@ -172,3 +172,34 @@ def test_data_parallel_helpers_gloo_world2():
         assert g0 == 1.5                                           # (1 + 2) / 2
         assert allact == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 100.0, 101.0, 102.0, 103.0, 104.0, 105.0]
         assert thr == 5.0                                          # k = 6 of 12: identical on both ranks (global statistic)
+
+
+def test_oracle_step_with_a_one_view_list_equals_the_single_view_form():
+    """oracle/step_ref.py (train_human.py:358-372): k teacher views as lists; a one-element list is the k = 1 step, and two identical views
+    average to the same maps (mean of equal tensors), so all three give one loss."""
+    import torch
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_ref
+    from uda_poseestimation_amd import synthetic
+    b = synthetic.mean_teacher_batch(2, num_keypoints=16, image_size=64, heatmap_size=16, seed=1)
+    outs = []
+    for views in ("scalar", "one", "two"):
+        torch.manual_seed(0)
+        s_, t_ = PoseResNetRef([1, 1, 1, 1], 16), PoseResNetRef([1, 1, 1, 1], 16)
+        t_.load_state_dict(s_.state_dict())
+        opt = torch.optim.Adam(s_.parameters(), lr=1e-4)
+        xt = b["x_t_tea"] if views == "scalar" else [b["x_t_tea"]] * (1 if views == "one" else 2)
+        ap = b["aug_param_tea"] if views == "scalar" else [b["aug_param_tea"]] * (1 if views == "one" else 2)
+        o = train_step_ref(s_, t_, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], xt, b["aug_param_stu"], ap, ratio=4.0)
+        outs.append((float(o["loss_s"]), float(o["loss_c"]), o["tea_mask"].clone()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+    # (two views: the teacher's train-mode BN sees each view separately, running statistics aside the maps are the same)
+    assert abs(outs[2][1] - outs[0][1]) <= 1e-6 * abs(outs[0][1]) + 1e-12 and torch.equal(outs[0][2], outs[2][2])
+
+
+def test_bench_cpu_share_is_bounded_by_the_affinity_mask():
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    n = m.host_cpu_share()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
