@@ -89,6 +89,9 @@ typedef struct {
                            * 0 / 0 = every wgrad_overlap-th block counted from the top */
     int eval_fold;        /* 1 (default): eval-mode network forwards (validate(), train_human.py:461-500) apply BatchNorm's running-statistics scale /
                            * shift, the residual and the ReLU in the convolution's epilogue: no BN-apply launch, no pre-BN tensor; 0: conv + apply */
+    int bn_xcd_rows;      /* 1 (default): the BatchNorm apply kernels give XCD k the k-th eighth of the pixel rows - what the implicit GEMMs' work-groups on
+                           * XCD k wrote and will read - so activations cross the conv <-> BatchNorm kernel boundaries through one L2; 0: interleaved */
+    int pad0;
     void* timeline;
 } udapose_policy;
 void udapose_policy_default(udapose_policy* p);

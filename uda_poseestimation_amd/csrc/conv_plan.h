@@ -51,6 +51,10 @@ struct Policy {
                                 // (0 / 0: every wgrad_overlap-th block counted from the top)
     int eval_fold = 1;          // eval-mode forwards (validate()): BatchNorm's running-statistics scale / shift, the residual and the ReLU are applied in
                                 // the convolution's epilogue - z is written by the conv, no BN-apply launch, no pre-BN tensor (0: conv + apply launches)
+    int bn_xcd_rows = 1;        // BatchNorm apply kernels (forward and backward, chunked and streaming forms): XCD k processes the k-th eighth of the pixel
+                                // rows, the rows the implicit GEMMs' work-groups on XCD k produce and consume (each XCD owns a contiguous range of
+                                // m-tiles there), so activations cross the conv <-> BatchNorm kernel boundaries through that XCD's L2
+                                // (tools/probe/l2_handoff.hip: 17.9 against 6.7 TB/s); bit-identical results, -0.06..-0.15 ms per step (r4_ab_runs.txt)
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null

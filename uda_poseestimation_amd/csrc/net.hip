@@ -23,7 +23,7 @@ int pw_unpack_strided(hipStream_t, const float*, float*, int, int, int, int, int
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
                    float*, float*, const float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
-int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int, unsigned char*);
+int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int, unsigned char*, int);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
               float*, float*, float*, float*, float, const float*, int);
@@ -362,14 +362,14 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
                                            beta, upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
-                                           upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked, mask);
+                                           upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked | (n.policy.bn_xcd_rows ? (1 << 30) : 0), mask);
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }
     if (training && n.f32 == 2 && !no_apply && !pre_bias) {
         const int took = pw_bn_train_fused_split(s, (const float*)(act + c.y_off), res, act + b.z_off, b.npix, b.C, slab, conv_stat_rows(c.g), gamma, beta,
                                                  upd ? (float*)buffers[b.rm_idx] : nullptr, upd ? (float*)buffers[b.rv_idx] : nullptr,
-                                                 upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked);
+                                                 upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, save, relu, n.policy.bn_fwd_chunked | (n.policy.bn_xcd_rows ? (1 << 30) : 0));
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }
@@ -384,7 +384,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         return pw_bn_apply_split(s, (const float*)(act + c.y_off), res, act + b.z_off, b.npix * b.C, b.C, scale, shift, relu);
     if (n.f32)
         return pw_bn_apply_f32(s, (const float*)(act + c.y_off), (const float*)res, (float*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu);
-    return pw_bn_apply(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu, mask);
+    return pw_bn_apply(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, b.C, scale, shift, relu, mask, n.policy.bn_xcd_rows >= 2);
 }
 
 }  // namespace
@@ -595,7 +595,8 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     elem_t* dy = (elem_t*)(ws + c.dy_off);
     if (pre)
         CK(pw_bn_bwd_pre(s, dz, dz_f32, (const elem_t*)(act + c.y_off), dy, b.npix, b.C, (const float*)params[b.g_idx], save, save + b.C, pre->slab,
-                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, n.policy.bn_bwd_chunked, n.policy.bn_bwd_pre_legacy));
+                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, n.policy.bn_bwd_chunked | (n.policy.bn_xcd_rows ? (1 << 30) : 0) | (n.policy.bn_xcd_rows >= 2 ? (1 << 29) : 0),
+                         n.policy.bn_bwd_pre_legacy));
     else
         CK(pw_bn_bwd(s, dz, dz_f32, (const elem_t*)(act + b.z_off), (const elem_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx],
                      save, save + b.C, relu, slab, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, (const float*)params[b.b_idx],

@@ -302,14 +302,29 @@ __global__ void bn_eval_coeff_k(int C, const float* __restrict__ gamma, const fl
 // (TY: storage of the conv output y; T: storage of the residual and of z - the f16x2 mode keeps y in fp32 and z split)
 template <typename T, typename TY = T>
 __global__ void bn_apply_k(const TY* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, size_t n8, int C,
-                           const float* __restrict__ scale, const float* __restrict__ shift, int relu, unsigned char* __restrict__ mask = nullptr) {
+                           const float* __restrict__ scale, const float* __restrict__ shift, int relu, unsigned char* __restrict__ mask = nullptr,
+                           int xcd = 0) {
     const int G = C >> 3;
     // the launcher keeps gridDim.x * TPB a multiple of G (G is a power of two <= TPB, or the grid is one block per G-aligned
     // stride), so a thread's channel group never changes: its coefficients are loaded once
     const int c0 = (int)(((size_t)blockIdx.x * TPB + threadIdx.x) % G) * 8;
     const f32x4 sa = *(const f32x4*)(scale + c0), sb = *(const f32x4*)(scale + c0 + 4);
     const f32x4 ha = *(const f32x4*)(shift + c0), hb = *(const f32x4*)(shift + c0 + 4);
-    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+    // xcd (launcher: TPB % G == 0, gridDim.x % 8 == 0): work-group b runs on XCD b mod 8 (round-robin dealing), and XCD k takes the
+    // k-th EIGHTH of the pixel rows - the rows the implicit GEMM's work-groups on XCD k wrote just before and will read next (each
+    // XCD owns a contiguous range of m-tiles there): y comes from, and z stays in, that XCD's L2 (tools/probe/l2_handoff.hip)
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x, iend = n8, istep = (size_t)gridDim.x * TPB;
+    if (xcd) {
+        const size_t rows = n8 / G, per = (rows + 7) / 8;
+        const unsigned x = blockIdx.x & 7u, local = blockIdx.x >> 3, nb = gridDim.x >> 3;
+        const unsigned RB = TPB / G;
+        size_t rend = (size_t)(x + 1) * per;
+        if (rend > rows) rend = rows;
+        i = ((size_t)x * per + (size_t)local * RB + threadIdx.x / G) * G + threadIdx.x % G;
+        iend = rend * G;
+        istep = (size_t)nb * RB * G;
+    }
+    for (; i < iend; i += istep) {
         float v[8];
         ld8<TY>(y + i * 8, v);
         float o[8];
@@ -511,10 +526,18 @@ __global__ __launch_bounds__(TPB) void bn_apply_chunk_k(const TY* __restrict__ y
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                         long long* __restrict__ nbt, float* __restrict__ save, int relu, int P,
-                                                        unsigned char* __restrict__ mask) {
+                                                        unsigned char* __restrict__ mask, int xcd) {
     __shared__ double part[8][128];
     __shared__ float scs[64], shs[64];
-    const int chunk = blockIdx.x, sp = blockIdx.y;
+    // xcd: the (chunk, pixel range) pairs are dealt so that XCD k gets the k-th EIGHTH of the pixel rows (all chunks of it) - the rows
+    // the implicit GEMMs' work-groups on XCD k produced and will consume (igemm.hip: each XCD owns a contiguous range of m-tiles):
+    // y is then read from, and z left in, that XCD's L2 (tools/probe/l2_handoff.hip: 17.9 against 6.7 TB/s across a kernel boundary)
+    int chunk = blockIdx.x, sp = blockIdx.y;
+    if (xcd) {
+        const uint32_t w = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        sp = (int)(w / gridDim.x);
+        chunk = (int)(w - (uint32_t)sp * gridDim.x);
+    }
     {
         const int q = threadIdx.x & 31, rg = threadIdx.x >> 5;          // 16-byte column quad (16 per statistic), row group
         const float* base = slab + (size_t)(q >> 4) * C + chunk * 64 + (q & 15) * 4;
@@ -739,7 +762,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_chunk_k(const DZ* __restrict
 template <typename DZ>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_k(const DZ* __restrict__ g, const elem_t* __restrict__ y, elem_t* __restrict__ dy, size_t n8,
                                                           int C, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          const float* __restrict__ coef) {
+                                                          const float* __restrict__ coef, int xcd = 0) {
     const int G = C >> 3;
     const int c0 = (int)(((size_t)blockIdx.x * TPB + threadIdx.x) % G) * 8;
     float mu[8], is[8], ca[8], cb[8], cc[8];
@@ -748,7 +771,18 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_k(const DZ* __restrict__
     load8<float>(coef + c0, ca);
     load8<float>(coef + C + c0, cb);
     load8<float>(coef + 2 * C + c0, cc);
-    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (size_t)gridDim.x * TPB) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x, iend = n8, istep = (size_t)gridDim.x * TPB;
+    if (xcd) {      // (XCD k <- the k-th eighth of the pixel rows, as in bn_apply_k)
+        const size_t rows = n8 / G, per = (rows + 7) / 8;
+        const unsigned x = blockIdx.x & 7u, local = blockIdx.x >> 3, nb = gridDim.x >> 3;
+        const unsigned RB = TPB / G;
+        size_t rend = (size_t)(x + 1) * per;
+        if (rend > rows) rend = rows;
+        i = ((size_t)x * per + (size_t)local * RB + threadIdx.x / G) * G + threadIdx.x % G;
+        iend = rend * G;
+        istep = (size_t)nb * RB * G;
+    }
+    for (; i < iend; i += istep) {
         float d[8];
         load8<DZ>(g + i * 8, d);
         const elem8 yy = *(const elem8*)(y + i * 8);
@@ -771,10 +805,15 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_pre_chunk_k(const DZ* __rest
                                                                 size_t npix, int C, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ slab, int rows, int P, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, float beta_acc) {
+                                                                float* __restrict__ dbeta, float beta_acc, int xcd) {
     __shared__ double part[8][128];
     __shared__ double tot[2][64];
-    const int chunk = blockIdx.x, sp = blockIdx.y;
+    int chunk = blockIdx.x, sp = blockIdx.y;
+    if (xcd) {      // (XCD k <- the k-th eighth of the pixel rows, as in bn_apply_chunk_k)
+        const uint32_t w = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        sp = (int)(w / gridDim.x);
+        chunk = (int)(w - (uint32_t)sp * gridDim.x);
+    }
     {
         const int q = threadIdx.x & 31, rg = threadIdx.x >> 5;          // 16-byte column quad (16 per statistic), row group
         const float* base = slab + (size_t)(q >> 4) * C + chunk * 64 + (q & 15) * 4;
@@ -1151,6 +1190,8 @@ int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t*
     // layer3 / layer4 / the first deconv (<= 8 K pixels, <= 128 slab rows): measured -0.1 ms per step; with the 32 K-pixel
     // layers included the 128-byte row segments of the chunked layout cost what the saved launches gain
     // (enabled: Policy::bn_fwd_chunked)
+    const int xcd = (enabled >> 30) & 1;                   // (policy bit 30: XCD-aligned pixel ranges)
+    enabled &= ~(1 << 30);
     if (!enabled || C < 256 || C % 64 || npix > 8192 || npix < 1024 || rows > 128) return 0;
     const int chunks = C / 64;
     int S = (enabled > 1 ? enabled : 1024) / chunks;      // (policy value > 1: the target work-group count; tuning)
@@ -1160,7 +1201,7 @@ int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t*
     P = (P + 31) & ~31;
     S = (int)((npix + P - 1) / P);
     hipLaunchKernelGGL((bn_apply_chunk_k<elem_t, elem_t>), dim3(chunks, S), dim3(TPB), 0, s, y, res, z, npix, C, slab, rows, (double)npix, gamma, beta, eps,
-                       momentum, rm, rv, nbt, save, relu, P, mask);
+                       momentum, rm, rv, nbt, save, relu, P, mask, xcd);
     return udapose_check_launch() == UDAPOSE_OK ? 1 : UDAPOSE_ERR_LAUNCH;
 }
 // the same for the f16x2 mode: y fp32 (the split convolutions' pre-BN output), res / z split tensors.  On the teacher's forward - the
@@ -1168,6 +1209,8 @@ int pw_bn_train_fused(hipStream_t s, const elem_t* y, const elem_t* res, elem_t*
 int pw_bn_train_fused_split(hipStream_t s, const float* y, const void* res, void* z, size_t npix, int C, const float* slab, int rows,
                             const float* gamma, const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* save,
                             int relu, int enabled) {
+    const int xcd = (enabled >> 30) & 1;
+    enabled &= ~(1 << 30);
     if (!enabled || C < 256 || C % 64 || npix > 8192 || npix < 1024 || rows > 128) return 0;
     const int chunks = C / 64;
     int S = (enabled > 1 ? enabled : 1024) / chunks;
@@ -1177,7 +1220,7 @@ int pw_bn_train_fused_split(hipStream_t s, const float* y, const void* res, void
     P = (P + 31) & ~31;
     S = (int)((npix + P - 1) / P);
     hipLaunchKernelGGL((bn_apply_chunk_k<float, sp32>), dim3(chunks, S), dim3(TPB), 0, s, y, (const sp32*)res, (sp32*)z, npix, C, slab, rows, (double)npix,
-                       gamma, beta, eps, momentum, rm, rv, nbt, save, relu, P, (unsigned char*)nullptr);
+                       gamma, beta, eps, momentum, rm, rv, nbt, save, relu, P, (unsigned char*)nullptr, xcd);
     return udapose_check_launch() == UDAPOSE_OK ? 1 : UDAPOSE_ERR_LAUNCH;
 }
 // the same for every BN layer of a net in one launch: jobs[blockIdx.x], channels blockIdx.y*TPB..; save = act + save_off
@@ -1232,9 +1275,12 @@ static int bn_apply_grid(size_t n8, int C) {
     return g;
 }
 int pw_bn_apply(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, size_t n, int C, const float* scale, const float* shift, int relu,
-                unsigned char* mask) {
+                unsigned char* mask, int xcd) {
     if (C % 8 || n % 8) return UDAPOSE_ERR_ARG;
-    hipLaunchKernelGGL(bn_apply_k<elem_t>, dim3(bn_apply_grid(n / 8, C)), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu, mask);
+    const int grid = bn_apply_grid(n / 8, C), G = C / 8;
+    // (XCD-aligned rows: needs whole rows per block pass, a grid that is a multiple of the 8 XCDs and enough rows to give every XCD work)
+    const int ok = xcd && (TPB % G) == 0 && (grid % 8) == 0 && (n / 8 / G) >= (size_t)8 * (TPB / G);
+    hipLaunchKernelGGL(bn_apply_k<elem_t>, dim3(grid), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu, mask, ok);
     return udapose_check_launch();
 }
 // f16x2 mode: y fp32 (the conv epilogue's fp32 output), residual and z split
@@ -1307,6 +1353,8 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
                   int legacy) {
     const int G = C / 8;
     if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
+    const int xcd = (chunked >> 30) & 1, xcd_stream = (chunked >> 29) & 1;     // (bit 30: XCD-aligned pixel ranges in the chunked form; bit 29: in the streaming form too)
+    chunked &= ~(3 << 29);
     if (chunked && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
         const int chunks = C / 64;
         int S = (chunked > 1 ? chunked : 1024) / chunks;
@@ -1318,10 +1366,10 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
         const dim3 grid(chunks, S);
         if (g_is_f32)
             hipLaunchKernelGGL(bn_bwd_apply_pre_chunk_k<float>, grid, dim3(TPB), 0, s, (const float*)g, y, dy, npix, C, mean, invstd, gamma, slab, rows, P,
-                               dgamma, dbeta, beta_acc);
+                               dgamma, dbeta, beta_acc, xcd);
         else
             hipLaunchKernelGGL(bn_bwd_apply_pre_chunk_k<elem_t>, grid, dim3(TPB), 0, s, (const elem_t*)g, y, dy, npix, C, mean, invstd, gamma, slab, rows, P,
-                               dgamma, dbeta, beta_acc);
+                               dgamma, dbeta, beta_acc, xcd);
         return udapose_check_launch();
     }
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
@@ -1335,10 +1383,11 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
         return udapose_check_launch();
     }
     const int grid = bn_apply_grid(npix * G, C);
+    const int ok = xcd_stream && (TPB % G) == 0 && (grid % 8) == 0 && npix >= (size_t)8 * (TPB / G);
     if (g_is_f32)
-        hipLaunchKernelGGL(bn_bwd_apply_pre_k<float>, dim3(grid), dim3(TPB), 0, s, (const float*)g, y, dy, npix * G, C, mean, invstd, coef);
+        hipLaunchKernelGGL(bn_bwd_apply_pre_k<float>, dim3(grid), dim3(TPB), 0, s, (const float*)g, y, dy, npix * G, C, mean, invstd, coef, ok);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_pre_k<elem_t>, dim3(grid), dim3(TPB), 0, s, (const elem_t*)g, y, dy, npix * G, C, mean, invstd, coef);
+        hipLaunchKernelGGL(bn_bwd_apply_pre_k<elem_t>, dim3(grid), dim3(TPB), 0, s, (const elem_t*)g, y, dy, npix * G, C, mean, invstd, coef, ok);
     return udapose_check_launch();
 }
 int pw_maxpool3x3s2_fwd(hipStream_t s, const elem_t* x, elem_t* y, unsigned char* idx, int N, int H, int W, int C) {
