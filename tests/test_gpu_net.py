@@ -410,6 +410,40 @@ def test_eval_mode_bn_folded_into_the_conv_epilogue():
     assert torch.equal(p0, p1)
 
 
+def test_xcd_aligned_batchnorm_kernels_are_bit_identical():
+    """Policy bn_xcd_rows (round 4, default 1): the channel-chunked BatchNorm kernels give XCD k all channel chunks of the k-th eighth of the
+    pixel rows (the implicit GEMMs' own XCD mapping, so activations cross the kernel boundaries through one L2); 2: the streaming apply
+    kernels too.  Only WHICH work-group computes what changes: outputs, running statistics and every gradient are bit for bit those of
+    the interleaved order (0), on a network whose layer3 / layer4 take the chunked kernels (>= 1024 pixels, >= 256 channels) and whose
+    layer1 / layer2 take the streaming ones."""
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    torch.manual_seed(11)
+    base = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 2, 1], False, False)
+    x = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(12)).cuda()
+    d = torch.randn(4, 16, 64, 64, generator=torch.Generator().manual_seed(13)).cuda()
+    res = {}
+    for mode in (0, 1, 2):
+        net = pr._pose_resnet("t", 16, pr.Bottleneck_default, [1, 1, 2, 1], False, False)
+        net.load_state_dict(base.state_dict())
+        net = net.cuda().train()
+        # (wgrad_stages = 512: no weight gradient of this size is split over pixels, so none is accumulated by atomics in arrival order -
+        # except the stem's, which always is and is compared to rounding below)
+        net.policy, net._handles = {"bn_xcd_rows": mode, "wgrad_stages": 512}, {}
+        y = net(x)
+        y.backward(d)
+        torch.cuda.synchronize()
+        res[mode] = (y.detach().clone(), {n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None}, [b.clone() for b in net.buffers()])
+    for mode in (1, 2):
+        assert torch.equal(res[0][0], res[mode][0])
+        for n_, g0 in res[0][1].items():
+            g1 = res[mode][1][n_]
+            if n_ == "backbone.conv1.weight":
+                assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item() + 1e-12, n_
+            else:
+                assert torch.equal(g0, g1), (mode, n_)
+        assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[mode][2]))
+
+
 def test_stem_fusion_is_bit_identical_to_separate_launches():
     """Policy stem_fused: BN apply + ReLU + max-pool in one sweep (z of the stem never stored) and the max-pool backward gathered
     inside the BN backward give exactly the outputs, running statistics and gradients of the separate launches - train mode with
