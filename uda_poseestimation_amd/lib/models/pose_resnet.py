@@ -135,6 +135,10 @@ class PoseResNet(nn.Module):
         #         forward that keeps no backward state (the teacher under no_grad, validate(): train_human.py:346-358,461-500 run in
         #         fp32) takes the fp32-grade 'f16x2' mode; a differentiable forward outside autocast takes 'bf16' (there is no fp32
         #         backward: the reference's scripts always train under autocast).
+        #         (memory: every (N, H, W, precision) a module is called with owns an executor plan - weight packs, a workspace and, for no-grad
+        #         forwards, one activation arena: 88 MB per image at 256x256 in the 16-bit modes, twice that in f16x2 - so an 'auto' student
+        #         that is also evaluated under no_grad holds a second, f16x2 plan of its batch size: 5.6 GB at N = 32; `del model._handles[key]`
+        #         or `model._handles.clear()` releases plans that are no longer needed.)
         # 'bf16': bf16 storage + MFMA, fp32 accumulation (training and inference; BASELINE.json's benched precision).
         # 'fp16': fp16 storage + MFMA (v_mfma_f32_16x16x32_f16), fp32 accumulation - the reference's autocast dtype
         #         (train_human.py:280,414); gradients need loss scaling (GradScaler, or optim.FusedAdam(dynamic_loss_scale=True)).
