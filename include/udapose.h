@@ -345,6 +345,10 @@ int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void*
  * update: S *= backoff on found_inf, S *= growth after `interval` clean steps; clears found_inf, refreshes 1/S. */
 int udapose_grad_scaler_check(void* stream, const long long* g, const long long* sizes, const int* blk_tensor, const long long* blk_off,
                               int nblocks, float* dev_state);
+/* the same check over g + g2, g2 = the second per-pass gradient buffer at grad2_delta_bytes from the first (the sum the fused optimizer tail
+ * forms itself, udapose_net_fused_update's grad2_delta_bytes): no separate axpy in front of the check (round 4) */
+int udapose_grad_scaler_check2(void* stream, const long long* g, const long long* sizes, const int* blk_tensor, const long long* blk_off,
+                               int nblocks, float* dev_state, long long grad2_delta_bytes);
 int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, float backoff, int interval);
 
 /* ---------------------------------------------------------------- gradient all-reduce in bf16 on the wire (data parallel,

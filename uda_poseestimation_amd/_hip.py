@@ -43,6 +43,7 @@ _SIGS = {
     "udapose_version": (ci, []),
     "udapose_elem_kind": (ci, []),
     "udapose_grad_scaler_check": (ci, [vp, vp, vp, vp, vp, ci, vp]),
+    "udapose_grad_scaler_check2": (ci, [vp, vp, vp, vp, vp, ci, vp, ll]),
     "udapose_grad_scaler_update": (ci, [vp, vp, cf, cf, ci]),
     "udapose_policy_default": (None, [vp]),
     "udapose_conv_prepare": (ci, [vp]),

@@ -41,7 +41,7 @@ int opt_adam(hipStream_t, const long long*, const long long*, const long long*, 
              float, float, float, float, float, int, float, float*);
 int opt_sgd(hipStream_t, const long long*, const long long*, const long long*, const long long*, const int*, const long long*, int, float, float, float,
             int, int, float, float*);
-int opt_grad_check(hipStream_t, const long long*, const long long*, const int*, const long long*, int, float*);
+int opt_grad_check(hipStream_t, const long long*, const long long*, const int*, const long long*, int, float*, long long);
 int opt_scaler_update(hipStream_t, float*, float, float, int);
 int comm_pack_bf16(hipStream_t, const float*, long long, void*, long long);
 int comm_shard_mean(hipStream_t, const void*, int, long long, void*);
@@ -368,7 +368,11 @@ int udapose_sgd_multi(void* stream, const long long* p, const long long* g, cons
     return opt_sgd(S(stream), p, g, buf, sizes, bt, bo, nb, lr, mom, wd, nesterov, first, gscale, dev_state);
 }
 int udapose_grad_scaler_check(void* stream, const long long* g, const long long* sizes, const int* bt, const long long* bo, int nb, float* dev_state) {
-    return opt_grad_check(S(stream), g, sizes, bt, bo, nb, dev_state);
+    return opt_grad_check(S(stream), g, sizes, bt, bo, nb, dev_state, 0);
+}
+int udapose_grad_scaler_check2(void* stream, const long long* g, const long long* sizes, const int* bt, const long long* bo, int nb, float* dev_state,
+                               long long grad2_delta_bytes) {
+    return opt_grad_check(S(stream), g, sizes, bt, bo, nb, dev_state, grad2_delta_bytes);
 }
 int udapose_grad_scaler_update(void* stream, float* dev_state, float growth, float backoff, int interval) {
     return opt_scaler_update(S(stream), dev_state, growth, backoff, interval);

@@ -121,7 +121,9 @@ __global__ void sgd_k(MtTable t, float lr, float momentum, float wd, int nestero
 }
 // ---- dynamic loss scaling (torch.cuda.amp.GradScaler, train_human.py:260,285-287,324,436-440) on the device
 // found_inf: operand b = the gradient tensors; any non-finite value raises state[5] (every writer stores the same 1.0f)
-__global__ void grad_check_k(MtTable t, float* __restrict__ state) {
+// g2 (round 4): byte distance to a second per-pass gradient buffer whose sum with the first is still pending (the fused tail adds the two
+// itself): the check then looks at g + g2, the value the optimizer sweep will form - no separate 0.64 GB axpy in front of the check
+__global__ void grad_check_k(MtTable t, float* __restrict__ state, long long g2) {
     const int ti = t.blk_tensor[blockIdx.x];
     const long long off = t.blk_off[blockIdx.x];
     const float* g = (const float*)t.b[ti];
@@ -129,7 +131,8 @@ __global__ void grad_check_k(MtTable t, float* __restrict__ state) {
     const long long end = off + CHUNK < n ? off + CHUNK : n;
     bool bad = false;
     for (long long i = off + threadIdx.x; i < end; i += TPB) {
-        const float v = g[i];
+        float v = g[i];
+        if (g2) v += *(const float*)((const char*)(g + i) + g2);
         bad = bad || !(fabsf(v) <= 3.4028234e38f);        // inf or nan
     }
     if (bad) state[5] = 1.f;
@@ -260,11 +263,11 @@ int opt_tail(hipStream_t s, const void* d_jobs, const int* blk_job, const int* b
     return udapose_check_launch();
 }
 int opt_grad_check(hipStream_t s, const long long* g, const long long* sizes, const int* blk_tensor, const long long* blk_off, int nblocks,
-                   float* dev_state) {
-    if (!dev_state) return UDAPOSE_ERR_ARG;
+                   float* dev_state, long long grad2_delta) {
+    if (!dev_state || grad2_delta % 4) return UDAPOSE_ERR_ARG;
     MtTable t{nullptr, g, nullptr, nullptr, sizes, blk_tensor, blk_off};
     if (nblocks <= 0) return UDAPOSE_OK;
-    hipLaunchKernelGGL(grad_check_k, dim3(nblocks), dim3(TPB), 0, s, t, dev_state);
+    hipLaunchKernelGGL(grad_check_k, dim3(nblocks), dim3(TPB), 0, s, t, dev_state, grad2_delta);
     return udapose_check_launch();
 }
 int opt_scaler_update(hipStream_t s, float* dev_state, float growth, float backoff, int interval) {

@@ -92,10 +92,12 @@ class _FusedBase(torch.optim.Optimizer):
         sc = self.loss_scale()
         return loss if sc is None else loss * sc
 
-    def _pre_sweep(self, t, ent):
+    def _pre_sweep(self, t, ent, grad2_delta=0):
+        """found-inf sweep of the loss scaler; grad2_delta: byte distance to a second per-pass gradient buffer whose sum is still pending
+        (the fused tail adds it itself): the check then looks at g + g2."""
         if self._scaler is not None:
-            check(lib().udapose_grad_scaler_check(_hip.stream(), ptr(t.ptrs[1]), ptr(t.sizes), ptr(t.blk_t), ptr(t.blk_o), t.nblocks, ptr(ent[0])),
-                  "grad_scaler_check")
+            check(lib().udapose_grad_scaler_check2(_hip.stream(), ptr(t.ptrs[1]), ptr(t.sizes), ptr(t.blk_t), ptr(t.blk_o), t.nblocks, ptr(ent[0]),
+                                                   int(grad2_delta)), "grad_scaler_check")
 
     def _post_sweep(self, ent):
         if self._scaler is not None:
@@ -252,11 +254,10 @@ class FusedAdam(_FusedBase):
         b1, b2 = group["betas"]
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()
-        if self._scaler is not None and hasattr(student, "finish_grads"):
-            student.finish_grads()              # (the inf / nan check of the loss scaler reads the summed gradients)
-        self._pre_sweep(tab, ent)
-        # a pending sum of the two passes' gradient buffers is taken in the sweep itself (no separate axpy over 220 MB)
+        # a pending sum of the two passes' gradient buffers is taken in the sweep itself (no separate axpy over 220 MB) - and by the loss
+        # scaler's inf / nan check in front of it, which looks at g + g2 (round 4: the fp16 step used to force the sum first)
         delta = student.pending_grad_sum(take=True) if hasattr(student, "pending_grad_sum") else 0
+        self._pre_sweep(tab, ent, delta)
         check(hd_s.L.udapose_net_fused_update(hd_s.h, hd_t.h, _hip.stream(), pa_s, ga, ma, pa_t, ptr(hd_s.wpack), ptr(hd_t.wpack), float(group["lr"]),
                                               float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(group["step"]),
                                               float(group.get("grad_scale", 1.0)), ptr(ent[0]), float(ema.alpha), float(1.0 - ema.alpha), 1,
