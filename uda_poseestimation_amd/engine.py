@@ -802,7 +802,9 @@ class GraphedTrainStep:
         self._aug_ev[i], self._aug_last = ev, pin
 
     def _thetas(self):
-        """Launch the matrix kernels (captured: at the head of the step's first graph) from the static aug buffer."""
+        """Launch the matrix kernels (captured: at the head of the step's first graph) from the static aug buffer.  (Round 4 tried them on a
+        stream of their own, beside the forwards: no measurable gain, and the earlier start of the three branches changed the arrival order
+        of the stem's fp32 atomics often enough to break the bit-for-bit twins of tests/test_gpu_steps.py; reverted.)"""
         st, r = self.static, self.t.ratio
         warp.thetas_from_packed(st["aug"][0], r, want_fwd=True, want_back=self.occl, fwd=st["theta_stu"], back=st.get("theta_back"))
         warp.thetas_from_packed(st["aug"][1], r, fwd=st["theta_tea"])
