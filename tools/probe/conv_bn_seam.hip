@@ -464,6 +464,22 @@ static void run_forms(Ctx& c) {
         hipGraphExec_t ge = graph_of(st, [&]() { for (const Layer& L : c.hl) { if (L.N == 1024) launch_gemm<128, 64, 2, W4>(L, st); else launch_gemm<64, 64, 3, W4>(L, st); } });
         time_it(c, "  conv launches alone (c1/c2 64x64 x512, c3 128x64 x1024)", [&]() { hipGraphLaunch(ge, st); }, 4, c.bar, 0);
         hipGraphExecDestroy(ge);
+        for (int kind = 0; kind < 3; ++kind)
+            for (int form = 0; form < 2; ++form) {
+                // one layer kind repeated (the methodology of tools/tune_conv.py: the same launch back to back)
+                ge = graph_of(st, [&]() {
+                    for (int r = 0; r < c.n_layers; ++r) {
+                        const Layer& L = c.hl[kind];
+                        if (kind == 2) { if (form) launch_gemm<128, 256, 2, W4>(L, st); else launch_gemm<128, 64, 2, W4>(L, st); }
+                        else if (form) launch_gemm<128, 64, 2, W4>(L, st); else launch_gemm<64, 64, 3, W4>(L, st);
+                    }
+                });
+                char name[160];
+                snprintf(name, sizeof name, "  conv %s alone, %s", kind == 0 ? "c1 1024->256" : kind == 1 ? "c2 3x3 256" : "c3 256->1024",
+                         kind == 2 ? (form ? "128x256 x256" : "128x64 x1024") : (form ? "128x64 x256" : "64x64 x512"));
+                time_it(c, name, [&]() { hipGraphLaunch(ge, st); }, 3, c.bar, 0);
+                hipGraphExecDestroy(ge);
+            }
         ge = graph_of(st, [&]() { for (const Layer& L : c.hl) bn(L, M_ROWS / 128); });
         time_it(c, "  BatchNorm launches alone", [&]() { hipGraphLaunch(ge, st); }, 4, c.bar, 0);
         hipGraphExecDestroy(ge);
