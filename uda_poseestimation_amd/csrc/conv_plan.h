@@ -55,6 +55,7 @@ struct Policy {
                                 // rows, the rows the implicit GEMMs' work-groups on XCD k produce and consume (each XCD owns a contiguous range of
                                 // m-tiles there), so activations cross the conv <-> BatchNorm kernel boundaries through that XCD's L2
                                 // (tools/probe/l2_handoff.hip: 17.9 against 6.7 TB/s); bit-identical results, -0.06..-0.15 ms per step (r4_ab_runs.txt)
+    int igemm_ns3_k = 0;        // 64x64 igemm tiles: 3-stage ring from this K on, 2-stage below (0 = 2048)
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null

@@ -988,7 +988,9 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
     if (pol.igemm_big_min > 0 && nclass == 1 && Co % 128 == 0 && b12864 >= pol.igemm_big_min) return 4;
     if (pol.igemm_q_tile >= 0 && b12864 > 768 && b12864 <= 1024) return pol.igemm_q_tile;
     if (b12864 >= pol.igemm_wg_min) return 6;
-    return K >= 1024 ? 9 : 5;
+    // (round 4: the 3-stage ring from K = 2048 on, not 1024 - layer3's c1 and the data gradient of its c3, K = 1024, replayed alone from a graph take 8.6 us
+    //  with two stages against 9.8 with three, tools/time_l3_convs.py; whole step -0.03 .. -0.14 ms on two boxes, two stages for every K +0.07: r4_ab_runs.txt)
+    return K >= (pol.igemm_ns3_k > 0 ? pol.igemm_ns3_k : 2048) ? 9 : 5;
 }
 
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
