@@ -130,7 +130,22 @@ __global__ void grad_check_k(MtTable t, float* __restrict__ state, long long g2)
     const long long n = t.sizes[ti];
     const long long end = off + CHUNK < n ? off + CHUNK : n;
     bool bad = false;
-    for (long long i = off + threadIdx.x; i < end; i += TPB) {
+    long long i0 = off;
+    // 16-byte loads where the chunk allows it (a pure streaming read of 4 - 8 bytes per parameter, 0.44 GB for PoseResNet-101's two buffers: with
+    // 4-byte loads it ran at about half the rate); the scalar loop takes what is left (tensor tails, unaligned small tensors)
+    if (((uintptr_t)(g + off) & 15) == 0 && (g2 & 15) == 0) {
+        const long long n4 = (end - off) >> 2;
+        for (long long q = threadIdx.x; q < n4; q += TPB) {
+            f32x4 v = *(const f32x4*)(g + off + q * 4);
+            if (g2) {
+                const f32x4 w = *(const f32x4*)((const char*)(g + off + q * 4) + g2);
+                v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+            }
+            bad = bad || !(fabsf(v[0]) <= 3.4028234e38f) || !(fabsf(v[1]) <= 3.4028234e38f) || !(fabsf(v[2]) <= 3.4028234e38f) || !(fabsf(v[3]) <= 3.4028234e38f);
+        }
+        i0 = off + n4 * 4;
+    }
+    for (long long i = i0 + threadIdx.x; i < end; i += TPB) {
         float v = g[i];
         if (g2) v += *(const float*)((const char*)(g + i) + g2);
         bad = bad || !(fabsf(v) <= 3.4028234e38f);        // inf or nan
