@@ -257,6 +257,8 @@ def main():
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
     ap.add_argument("--cpu-images", type=int, default=0, help="batch of the CPU baseline step (0: 8, or what fits the time budget)")
+    ap.add_argument("--dp-segments", action="store_true", help="tuning: after the timed region, 20 more steps with HIP events between the parts of the "
+                    "data-parallel step (graphs and collectives); device ms per part on stderr")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed extra legs (fp16 / reference precision mix rates)")
     args = ap.parse_args()
 
@@ -437,6 +439,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     comm_exposed_ms = trainer.sync.exposed_ms()
+    if args.dp_segments and not args.eager:
+        graphed.profile_segments = True
+        for i in range(20):
+            step()
+        print("dp segments (device ms per part, mean of 20 steps):", graphed.segment_ms(), file=sys.stderr, flush=True)
+        graphed.profile_segments = False
     trainer.sync.profile = False
     # The synchronous-loop rate (untimed extra, after the timed region): one torch.cuda.synchronize() per step, as a loop that reads
     # the loss / PCK of every iteration on the host forces (train_human.py:443 moves y_s to the CPU each iteration)

@@ -781,6 +781,27 @@ class GraphedTrainStep:
         self._mev[last] = None
         return self._metrics_dict(self._mpin[last])
 
+    profile_segments = False        # bench.py --dp-segments: HIP events between the parts of a step (device time per part, after a synchronize)
+
+    def _seg_mark(self, name):
+        if not self.profile_segments:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.__dict__.setdefault("_seg_events", []).append((name, e))
+
+    def segment_ms(self):
+        """Mean device time of each part of the step since the last call: {part: ms} (the parts of one step are consecutive events)."""
+        ev = self.__dict__.pop("_seg_events", [])
+        torch.cuda.synchronize()
+        tot, cnt = {}, {}
+        for (n0, e0), (n1, e1) in zip(ev, ev[1:]):
+            if n1 == "start":
+                continue
+            tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
+            cnt[n1] = cnt.get(n1, 0) + 1
+        return {k: round(tot[k] / cnt[k], 3) for k in tot}
+
     def _stage_aug(self, aug_param_stu=None, aug_param_tea=None):
         """The batch's raw aug_param values -> the static [2,N,6] float64 device buffer the captured udapose_recon_thetas launches
         read (a ring of pinned host buffers and one asynchronous copy: nothing here waits for the device)."""
@@ -921,22 +942,31 @@ class GraphedTrainStep:
                     with torch.enable_grad() if bwd else torch.no_grad():
                         m.prepare(self.static["x_s"])
         self._draw_and_style()
+        seg = self._seg_mark            # (profile_segments: an event after each part of the data-parallel step; a no-op otherwise)
+        seg("start")
         if self.one_graph:
             self.t.stu_optimizer.sync_hyper()    # lr scheduler / loss scale -> device state read by the captured sweep
         self.g_fb.replay()
+        seg("forwards")
         if self.split:
             g = gather_activates(self.fwd_state["activates"])
             self.gathered.copy_(g if g is not None else self.fwd_state["activates"].reshape(-1))
+            seg("gather")
             self.g_lb.replay()
+            seg("losses+backward1")
         if self.g_lb2 is not None:
             self.t.sync.start_upper()            # suffix (94 %) on the communicator's stream ...
             self.g_lb2.replay()                  # ... under backward part 2
+            seg("backward2")
             self.t.sync.finish()
+            seg("finish")
         else:
             self.t.sync()
+            seg("allreduce")
         if not self.one_graph:
             self.t.stu_optimizer.sync_hyper()    # lr scheduler / loss scale -> device state read by the captured sweep
             self.g_up.replay()
+            seg("update")
         # the replayed Adam / EMA kernels changed both networks' parameters behind torch's back: every executor plan (other
         # batch sizes, validate(), fp32 mode) must re-pack its bf16 weights before its next forward
         self.t.student.weights_changed()
