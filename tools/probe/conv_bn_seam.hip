@@ -143,7 +143,7 @@ __device__ __forceinline__ void conv_tile(const Layer& L, int m0, int n0, char* 
 
 // one slab row per m-tile: column sums and sums of squares of the fp32 accumulators
 template <int BM, int BN, int NS, bool W4>
-__device__ __forceinline__ void tile_stats(const Layer& L, int m_tile, int n0, char* smem, const f32x4 (&acc)[BM / 32][BN / 32]) {
+__device__ __forceinline__ void tile_stats(const Layer& L, int m_tile, int n0, char* smem, const f32x4 (&acc)[BM / 32][BN / 32], bool coherent = false) {
     using C = Cfg<BM, BN, NS, W4>;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1, l15 = lane & 15;
     float* red = (float*)(smem + C::LDS - 4096);       // [2 wm][2][BN] floats <= 4 KB for BN <= 256
@@ -165,7 +165,11 @@ __device__ __forceinline__ void tile_stats(const Layer& L, int m_tile, int n0, c
     __syncthreads();
     for (int t = threadIdx.x; t < 2 * BN; t += 256) {
         const int which = t / BN, col = t - which * BN;
-        L.slab[((size_t)m_tile * 2 + which) * L.N + n0 + col] = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
+        const float v = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
+        float* dst = L.slab + ((size_t)m_tile * 2 + which) * L.N + n0 + col;
+        // (the last-arriver forms publish the row with device-coherent write-through stores: visible to another XCD without writing the L2 back)
+        if (coherent) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = v;
     }
 }
 
@@ -347,6 +351,7 @@ struct LayerN {
     float* sc_out; float* sh_out;             // [N] written by the last-arriving work-group of each n-tile (null: this layer's BatchNorm is a launch)
     unsigned int* ticket;                     // [n_tiles][32] arrival counters, monotonic (m_tiles arrivals per launch and n-tile)
     bf16* zside;                              // [M][Kc] the transformed input kept for a backward pass (null: not kept)
+    int fence_release;                        // 1: iteration-1 form (plain slab stores + a release fence per work-group); 0: write-through slab stores, no fence
 };
 
 template <int BM, int BN>
@@ -446,7 +451,9 @@ __device__ __forceinline__ void finalize_last(const LayerN& P, int n_tile, int n
     __shared__ int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // (design iteration 1 ran an agent-scope release fence here in every work-group - an L2 write-back each: +13 us per launch at 512 work-groups, +26 at
+        //  1024.  Iteration 2: the slab row was stored write-through (tile_stats, coherent) and __syncthreads has waited for those stores: no fence.)
+        if (P.fence_release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const unsigned int t = __hip_atomic_fetch_add(&P.ticket[n_tile * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = ((t + 1u) % (unsigned int)(M_ROWS / BM)) == 0u;
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256) void gemm_n_k(const LayerN P) {
     f32x4 acc[C::MI][C::NJ];
     if constexpr (XF) conv_tile_rs<BM, BN>(P, m_tile * BM, n_tile * BN, n_tile, smem, acc);
     else conv_tile<BM, BN, NS>(P.L, m_tile * BM, n_tile * BN, smem, acc);
-    tile_stats<BM, BN, NS, false>(P.L, m_tile, n_tile * BN, smem, acc);
+    tile_stats<BM, BN, NS, false>(P.L, m_tile, n_tile * BN, smem, acc, P.sc_out != nullptr && !P.fence_release);
     store_tile<BM, BN, NS, false, false>(P.L.y, P.L.N, m_tile * BM, n_tile * BN, smem, acc, nullptr, nullptr);
     if (P.sc_out) finalize_last<BM, BN>(P, n_tile, n_tile * BN, smem);
 }
@@ -622,10 +629,10 @@ static void run_forms(Ctx& c) {
         auto chain_N = [&](int nblocks, bool keep) {
             for (int b = 0; b < nblocks; ++b) {
                 const Layer &l1 = c.hl[3 * b], &l2 = c.hl[3 * b + 1], &l3 = c.hl[3 * b + 2];
-                LayerN p1{l1, nullptr, nullptr, sc1, sh1, tick, nullptr};
-                LayerN p2{l2, sc1, sh1, sc2, sh2, tick + 16 * 32, keep ? (bf16*)l1.z : nullptr};
+                LayerN p1{l1, nullptr, nullptr, sc1, sh1, tick, nullptr, 0};
+                LayerN p2{l2, sc1, sh1, sc2, sh2, tick + 16 * 32, keep ? (bf16*)l1.z : nullptr, 0};
                 p2.L.x = (const bf16*)l1.y;                   // the raw output of c1
-                LayerN p3{l3, sc2, sh2, nullptr, nullptr, nullptr, keep ? (bf16*)l2.z : nullptr};
+                LayerN p3{l3, sc2, sh2, nullptr, nullptr, nullptr, keep ? (bf16*)l2.z : nullptr, 0};
                 p3.L.x = (const bf16*)l2.y;
                 launch_gemm_n<64, 64, 3, false>(p1, st);
                 launch_gemm_n<64, 64, 2, true>(p2, st);
@@ -644,6 +651,21 @@ static void run_forms(Ctx& c) {
             double md = 0; size_t nz = 0;
             for (size_t i = 0; i < ref.size(); ++i) { md = fmax(md, fabs((double)(float)ref[i] - (double)(float)got[i])); nz += (float)got[i] != 0.f; }
             printf("# check N (normalize on load) vs two launches after one block: max |dz| %.5f, %zu non-zero of %zu\n", md, nz, ref.size());
+        }
+        for (int fin = 0; fin < 3; ++fin) {
+            // what the arrival ticket + last-arriver finalize costs a plain conv launch (c1, 64x64 x512 and c3-shaped 128x64 x1024, repeated back to back)
+            for (int kind = 0; kind < 3; kind += 2) {
+                hipGraphExec_t ge = graph_of(st, [&]() {
+                    for (int r = 0; r < c.n_layers; ++r) {
+                        LayerN p{c.hl[kind], nullptr, nullptr, fin ? sc1 : nullptr, fin ? sh1 : nullptr, tick, nullptr, fin == 2};
+                        if (kind == 0) launch_gemm_n<64, 64, 3, false>(p, st); else launch_gemm_n<128, 64, 2, false>(p, st);
+                    }
+                });
+                char name[160];
+                snprintf(name, sizeof name, "  conv %s alone, %s", kind == 0 ? "c1 1024->256 64x64 x512" : "c3 256->1024 128x64 x1024", fin == 0 ? "plain (slab only)" : fin == 1 ? "ticket + last-arriver finalize, write-through slab row, no fence" : "ticket + last-arriver finalize, release fence per work-group");
+                time_it(c, name, [&]() { hipGraphLaunch(ge, st); }, 3, c.bar, 0);
+                hipGraphExecDestroy(ge);
+            }
         }
         for (int keep = 1; keep >= 0; --keep) {
             hipGraphExec_t ge = graph_of(st, [&]() { chain_N(c.n_layers / 3, keep != 0); });
