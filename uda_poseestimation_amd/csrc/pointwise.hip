@@ -1355,6 +1355,8 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
     if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
     const int xcd = (chunked >> 30) & 1, xcd_stream = (chunked >> 29) & 1;     // (bit 30: XCD-aligned pixel ranges in the chunked form; bit 29: in the streaming form too)
     chunked &= ~(3 << 29);
+    const int skip_finalize = (chunked >> 28) & 1;      // TIMING EXPERIMENT ONLY (policy exp0 & 64, wrong results): the ceiling of removing the finalize launch
+    chunked &= ~(1 << 28);
     if (chunked && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
         const int chunks = C / 64;
         int S = (chunked > 1 ? chunked : 1024) / chunks;
@@ -1372,7 +1374,8 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
                                dgamma, dbeta, beta_acc, xcd);
         return udapose_check_launch();
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
+    if (!skip_finalize)
+        hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + FIN_C - 1) / FIN_C), dim3(FIN_T), 0, s, slab, rows, C, (double)npix, gamma, invstd, dgamma, dbeta, beta_acc, coef);
     if (legacy) {
         if (g_is_f32)
             hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(grid_for(npix * G)), dim3(TPB), 0, s, (const float*)g, (const elem_t*)nullptr, y, dy, (elem_t*)nullptr,
