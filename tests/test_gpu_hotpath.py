@@ -10,6 +10,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (the two-rank tests must not collide when test modules run side by side)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 
 @pytest.fixture(autouse=True)
 def _bf16_unless_stated(monkeypatch):
@@ -540,7 +547,7 @@ def test_two_rank_step_on_one_gpu_gloo(arch, batch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, UDAPOSE_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533" if batch == 4 else "29535", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--spinup", "0.7", "--arch", arch, "--batch", str(batch), "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -570,7 +577,7 @@ def test_two_rank_synced_gradient_is_the_mean_of_the_rank_gradients(tmp_path):
     import dp_rank_worker as W
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "tests", "helpers", "dp_rank_worker.py"), str(tmp_path)]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -697,8 +704,8 @@ def test_one_rank_rccl_step():
     common = [os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--spinup", "0", "--arch", "pose_resnet50", "--batch", "4",
               "--no-cpu-baseline"]
     res = {}
-    rccl_env = {"UDAPOSE_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"}
-    for tag, extra, flags in (("rccl", rccl_env, []), ("plain", {}, []), ("rccl_bf16", dict(rccl_env, MASTER_PORT="29543"), ["--grad-comm", "bf16"])):
+    rccl_env = {"UDAPOSE_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
+    for tag, extra, flags in (("rccl", rccl_env, []), ("plain", {}, []), ("rccl_bf16", dict(rccl_env, MASTER_PORT=str(_free_port())), ["--grad-comm", "bf16"])):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         out = subprocess.run([sys.executable] + common + flags, cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, tag + out.stdout[-2000:] + out.stderr[-4000:]

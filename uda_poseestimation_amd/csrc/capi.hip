@@ -101,10 +101,14 @@ static Policy from_c(const udapose_policy& c) {
     p.wgrad_group = c.wgrad_group; p.wgrad_stages = c.wgrad_stages > 0 ? c.wgrad_stages : 128; p.wgrad_group_stem = c.wgrad_group_stem;
     p.bn_bwd_fused = c.bn_bwd_fused; p.bn_fwd_chunked = c.bn_fwd_chunked; p.bn_bwd_chunked = c.bn_bwd_chunked;
     p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.igemm_wg_min = c.igemm_wg_min; p.wgrad_row3 = c.wgrad_row3; p.bn3_mask = c.bn3_mask; p.stem_fused = c.stem_fused; p.debug_sync = c.debug_sync; p.igemm_q_tile = c.igemm_q_tile; p.exp0 = c.exp0; p.wgrad_big = c.wgrad_big; p.igemm_big_min = c.igemm_big_min; p.patch_conv = c.patch_conv; p.wgrad_overlap = c.wgrad_overlap; p.wgrad_cap = c.wgrad_cap; p.wgrad_cut_lo = c.wgrad_cut_lo; p.wgrad_cut_hi = c.wgrad_cut_hi; p.eval_fold = c.eval_fold; p.bn_xcd_rows = c.bn_xcd_rows; p.igemm_ns3_k = c.igemm_ns3_k; p.timeline = (unsigned long long*)c.timeline;
+#ifdef UDAPOSE_TIMING_EXPERIMENTS
     if (p.exp0) {       // exp0 switches on timing experiments that SKIP work (wrong gradients / activations): never silent
         static bool warned = false;
         if (!warned) { warned = true; fprintf(stderr, "udapose: policy.exp0 = %d - a timing experiment is active, results are NOT valid\n", p.exp0); }
     }
+#else
+    p.exp0 = 0;         // the work-skipping branches are not in this build (make EXTRA=-DUDAPOSE_TIMING_EXPERIMENTS); udapose_net_set_policy refuses the value
+#endif
     return p;
 }
 static void to_c(const Policy& p, udapose_policy* c) {
@@ -186,7 +190,7 @@ int udapose_bn_eval_coeff(void* stream, int C, const float* gamma, const float* 
     return pw_bn_eval_coeff(S(stream), C, gamma, beta, rm, rv, eps, scale, shift);
 }
 int udapose_bn_apply(void* stream, const void* y, const void* res, void* z, size_t numel, int C, const float* scale, const float* shift, int relu) {
-    return pw_bn_apply(S(stream), CB16(y), CB16(res), B16(z), numel, C, scale, shift, relu, nullptr, default_policy().bn_xcd_rows);
+    return pw_bn_apply(S(stream), CB16(y), CB16(res), B16(z), numel, C, scale, shift, relu, nullptr, default_policy().bn_xcd_rows >= 2);
 }
 int udapose_bn_bwd_rows(size_t npix) { return pw_bn_bwd_rows(npix); }
 int udapose_bn_bwd(void* stream, const void* dz, int dz_is_f32, const void* z, const void* y, void* dy, void* gout, size_t npix, int C,
@@ -241,6 +245,9 @@ int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
 int udapose_net_set_policy(udapose_net_t n, const udapose_policy* p) {
     if (!n || !p) return UDAPOSE_ERR_ARG;
+#ifndef UDAPOSE_TIMING_EXPERIMENTS
+    if (p->exp0) return UDAPOSE_ERR_UNSUPPORTED;     // timing experiments that skip work exist only in builds made with -DUDAPOSE_TIMING_EXPERIMENTS
+#endif
     net_set_policy(n, from_c(*p));
     return UDAPOSE_OK;
 }

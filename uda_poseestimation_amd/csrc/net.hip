@@ -356,8 +356,10 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         return conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + b.z_off, e);
     }
     CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
+#ifdef UDAPOSE_TIMING_EXPERIMENTS
     if (training && !n.f32 && !no_apply && !pre_bias && (((n.policy.exp0 & 8) && b.npix <= 8192 && b.C >= 256) || (n.policy.exp0 & 16)))
         return UDAPOSE_OK;      // TIMING EXPERIMENT ONLY (wrong results): what the step would gain if these BN launches cost nothing (r4_ab_runs.txt)
+#endif
     if (training && !n.f32 && !no_apply && !pre_bias) {
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
@@ -373,9 +375,12 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }
+#ifdef UDAPOSE_TIMING_EXPERIMENTS
     if (training && (n.policy.exp0 & 32) && !n.f32) {
         // TIMING EXPERIMENT ONLY (wrong results): the finalize launch of the layers the one-launch form does not take, skipped (r4_ab_runs.txt)
-    } else if (training)
+    } else
+#endif
+    if (training)
         CK(pw_bn_finalize(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, upd ? (float*)buffers[b.rm_idx] : nullptr,
                           upd ? (float*)buffers[b.rv_idx] : nullptr, upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, scale, shift,
                           save, save + b.C, pre_bias));
@@ -597,7 +602,11 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     elem_t* dy = (elem_t*)(ws + c.dy_off);
     if (pre)
         CK(pw_bn_bwd_pre(s, dz, dz_f32, (const elem_t*)(act + c.y_off), dy, b.npix, b.C, (const float*)params[b.g_idx], save, save + b.C, pre->slab,
-                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, n.policy.bn_bwd_chunked | (n.policy.bn_xcd_rows ? (1 << 30) : 0) | (n.policy.bn_xcd_rows >= 2 ? (1 << 29) : 0) | ((n.policy.exp0 & 64) ? (1 << 28) : 0),
+                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, n.policy.bn_bwd_chunked | (n.policy.bn_xcd_rows ? (1 << 30) : 0) | (n.policy.bn_xcd_rows >= 2 ? (1 << 29) : 0) 
+#ifdef UDAPOSE_TIMING_EXPERIMENTS
+                         | ((n.policy.exp0 & 64) ? (1 << 28) : 0)
+#endif
+                         ,
                          n.policy.bn_bwd_pre_legacy));
     else
         CK(pw_bn_bwd(s, dz, dz_f32, (const elem_t*)(act + b.z_off), (const elem_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx],
@@ -903,7 +912,9 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     }
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!GA->per_xcd[t]) continue;
+#ifdef UDAPOSE_TIMING_EXPERIMENTS
         if (n.policy.exp0 & (1 << t)) continue;          // (tuning: skip this tile class - timing experiments only)
+#endif
         const int tok = conv_prof_before(s, 2, GA->flops[t] + GB->flops[t]);
         const int rc = wgrad_group_launch(s, t, GA->d_tab[t], GA->d_blk[t], GA->per_xcd[t], actA, wsA, gradsA[0], GB->d_tab[t], GB->d_blk[t], actB, wsB,
                                           gradsB[0], cap, next_ctr(n, cap));

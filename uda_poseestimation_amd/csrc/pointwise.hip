@@ -1355,7 +1355,11 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
     if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
     const int xcd = (chunked >> 30) & 1, xcd_stream = (chunked >> 29) & 1;     // (bit 30: XCD-aligned pixel ranges in the chunked form; bit 29: in the streaming form too)
     chunked &= ~(3 << 29);
+#ifdef UDAPOSE_TIMING_EXPERIMENTS
     const int skip_finalize = (chunked >> 28) & 1;      // TIMING EXPERIMENT ONLY (policy exp0 & 64, wrong results): the ceiling of removing the finalize launch
+#else
+    const int skip_finalize = 0;
+#endif
     chunked &= ~(1 << 28);
     if (chunked && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
         const int chunks = C / 64;

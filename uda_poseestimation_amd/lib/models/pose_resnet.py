@@ -349,6 +349,11 @@ class PoseResNet(nn.Module):
         x = x.contiguous()
         hd = self._handle(x, differentiable=save)
         self._last_hd = hd            # the plan of the most recent forward (the fused optimizer tail keeps ITS packs fresh)
+        if save and not self.training:
+            # eval-mode BatchNorm is folded into the convolutions' epilogues (policy eval_fold): such a forward writes neither the pre-BN
+            # tensors nor the batch statistics a backward would read, and there is no eval-mode BN backward on this path
+            raise RuntimeError("PoseResNet: a differentiable forward in eval() mode is not supported (no eval-mode BatchNorm backward on this "
+                               "path; the reference trains in train() mode and evaluates under torch.no_grad())")
         if save and hd.precision in ('fp32', 'f16x2'):
             raise RuntimeError(f"precision={hd.precision!r} is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
         pa, ba, params = self._pointers()

@@ -221,7 +221,17 @@ class FusedAdam(_FusedBase):
         t_split = hd_t.precision == "f16x2"
         # both plans are handed to ONE library (the student's): the teacher's must have been created by it (PoseResNet.aux_lib_kind puts an
         # f16x2 teacher's plan into the student's build; a plan of the other .so is never dereferenced here - ADVICE r3)
+        if hd_s.L is not hd_t.L and t_split and hasattr(teacher, "aux_lib_kind") and teacher.aux_lib_kind != hd_s.precision:
+            # an 'auto' student resolved to the other build than the one the teacher's f16x2 plan was created in (the engine guesses the
+            # build before the first forward): move the teacher's fp32-grade plans into the student's build - the next teacher forward
+            # creates its plan there, and the one-launch tail applies from the following step on
+            teacher.aux_lib_kind = hd_s.precision
         if hd_s.L is not hd_t.L or (not t_split and hd_t.precision != hd_s.precision):
+            if not getattr(self, "_warned_tail_lib", False):
+                self._warned_tail_lib = True
+                import warnings
+                warnings.warn("fused optimizer tail refused: the student's and the teacher's plans live in different library builds "
+                              f"({hd_s.precision} / {hd_t.precision}); falling back to Adam + EMA + pack launches for this step")
             return False
         if len(group["params"]) != len(ps) or any(a is not b for a, b in zip(group["params"], ps)):
             return False
