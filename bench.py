@@ -280,6 +280,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=0, help="batch of the CPU baseline step (0: 8, or what fits the time budget)")
     ap.add_argument("--dp-segments", action="store_true", help="tuning: after the timed region, 20 more steps with HIP events between the parts of the "
                     "data-parallel step (graphs and collectives); device ms per part on stderr")
+    ap.add_argument("--arena-teacher", action="store_true", help="tuning: no-grad forwards keep the bump-allocated 2.8 GB arena instead of the forward-only "
+                    "plan's six rotating scratch buffers (A/B of round 5's default)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed extra legs (fp16 / reference precision mix rates)")
     args = ap.parse_args()
 
@@ -331,6 +333,9 @@ def main():
     from uda_poseestimation_amd import _hip, synthetic
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
     import uda_poseestimation_amd.lib.models as models
+    if args.arena_teacher:
+        from uda_poseestimation_amd.lib.models.pose_resnet import PoseResNet
+        PoseResNet.fwd_only_plans = False
     if args.precision in ("reference", "reference_fp32"):
         args.dtype = "fp16"                # (the student's element type: the library the roofline sample's profiler hooks live in)
     lib = _hip.lib(args.dtype)
@@ -572,7 +577,7 @@ def main():
             res["roofline"]["hbm_frac"] = round(tot / (ms * 1e-3) / 8e12, 4)       # whole-step HBM bytes / step time / 8 TB/s
         # the parity-compliant configurations of the same step, driver-visible (untimed extras after the headline's timed region)
         headline_cfg = (args.arch, S, K, N, args.dtype, args.precision) == ("pose_resnet101", 256, 16, 32, "bf16", None)
-        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune or args.early_source_bwd):
+        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune or args.early_source_bwd or args.arena_teacher):
             try:
                 del graphed
             except NameError:

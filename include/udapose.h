@@ -203,6 +203,10 @@ typedef void* udapose_net_t;
  * element type with fp32 accumulation, forward and backward. */
 /* bit 8 of `fp32` (value | 0x100): the three deconvolutions carry a bias parameter (`deconv_with_bias=True`, lib/models/pose_resnet.py:
  * 15,41,96) - parameter order weight, bias, then the BatchNorm's, as in the reference's Upsampling. */
+/* bit 9 of `fp32` (value | 0x200): a FORWARD-ONLY plan (the teacher's forwards under torch.no_grad(), train_human.py:346-372, and
+ * validate(), :461-500): nothing is kept for a backward, so the pre- and post-BatchNorm tensors of all layers rotate through five
+ * scratch buffers laid out by liveness (udapose_net_act_bytes: ~0.3 GB instead of 2.8 GB at N = 32, 256x256) and stay resident
+ * in the L2s / the Infinity Cache; udapose_net_backward* and udapose_net_bind_grads return UDAPOSE_ERR_UNSUPPORTED on such a plan. */
 int udapose_net_create(const int layers[4], int num_keypoints, int N, int H, int W, int fp32, udapose_net_t* out);
 void udapose_net_destroy(udapose_net_t net);
 int udapose_net_num_params(udapose_net_t net);

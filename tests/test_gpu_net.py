@@ -554,3 +554,50 @@ def test_deconv_with_bias_matches_oracle():
         elif name.startswith("upsampling") or name.startswith("head"):
             cos = torch.nn.functional.cosine_similarity(p_n.grad.cpu().flatten(), p_r.grad.flatten(), dim=0).item()
             assert cos > 0.9, (name, cos)          # (bf16 gradients of a random-init train-mode-BN network: 0.92-1.0, as without the bias)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16x2", "fp32"])
+def test_forward_only_plan_is_bit_identical_to_the_arena_plan(precision, monkeypatch):
+    """Round 5: no-grad forwards - the teacher (train_human.py:346-372, train-mode BN) and validate() (:461-500,
+    eval mode) - run a forward-only plan whose y / z tensors rotate through six scratch buffers laid out by liveness instead of a
+    bump-allocated arena.  Same kernels, other addresses: heat-maps, running statistics and the deferred-statistics path must be bit
+    for bit those of the arena plan; a plan of this kind is ~10x smaller and refuses a backward."""
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    outs = {}
+    for fo in (False, True):
+        monkeypatch.setattr(pr.PoseResNet, "fwd_only_plans", fo)
+        _, net = _pair((2, 2, 3, 2), 16, seed=5)
+        net.precision = precision
+        torch.manual_seed(11)
+        x = torch.randn(4, 3, 128, 160, device="cuda")
+        with torch.no_grad():
+            net.train()
+            y_tr = net(x).clone()
+            y_tr2 = net(x * 0.5).clone()                # (a second call: the scratch buffers are reused, nothing stale may survive)
+            y_df = net.forward_deferred_bn(x).clone()
+            net.apply_deferred_bn()
+            net.eval()
+            y_ev = net(x).clone()
+        hd = net._last_hd
+        assert hd.fwd_only == fo
+        bufs = {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+        outs[fo] = (y_tr, y_tr2, y_df, y_ev, bufs, hd.act_bytes)
+    for a, b in zip(outs[False][:4], outs[True][:4]):
+        assert torch.equal(a, b)
+    for k, v in outs[False][4].items():
+        assert torch.equal(v, outs[True][4][k]), k
+    assert outs[True][5] * 4 < outs[False][5], (outs[True][5], outs[False][5])
+
+
+def test_forward_only_plan_refuses_backward():
+    import ctypes as C
+    from uda_poseestimation_amd import _hip
+    L = _hip.lib("bf16")
+    h = C.c_void_p()
+    arr = (C.c_int * 4)(1, 1, 1, 1)
+    _hip.check(L.udapose_net_create(arr, 16, 2, 64, 64, 0x200, C.byref(h)), "net_create")
+    try:
+        g = (C.c_void_p * 1)(None)
+        assert L.udapose_net_bind_grads(h, g) != 0
+    finally:
+        L.udapose_net_destroy(h)

@@ -996,6 +996,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
 int igemm_stat_rows(int M, int Co, int nclass, int tile) {
     switch (tile) {
         case 2: case 5: case 7: case 9: case 10: case 12: return nclass * ((M + 63) / 64);       // one row per m-tile (wave rows added in-kernel)
+        case 13: case 14: return nclass * ((M + 255) / 256);
         default: return nclass * ((M + 127) / 128);
     }
 }
@@ -1018,6 +1019,7 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream, const Policy& pol) {
         // f16x2 launches take the plain (or lean 1x1) form of three tiles: 128x64 / 64x64 with the ring depth of the bf16 choice
         switch (tile) {
             case 3: case 4: case 5: case 6: case 9: break;
+            case 13: case 14: tile = 4; break;
             case 0: case 1: case 8: case 11: tile = 6; break;
             case 2: case 7: case 10: case 12: tile = 9; break;
             default: return UDAPOSE_ERR_ARG;
@@ -1034,6 +1036,11 @@ int igemm_launch(IgParams& p, int tile, hipStream_t stream, const Policy& pol) {
         case 7: return launch_cfg<64, 64, 2, 2, 4, true>(p, stream, pol);
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream, pol);
         case 9: return launch_cfg<64, 64, 2, 2, 3>(p, stream, pol);
+        // 256x128 work-group tiles, 128x64 per wave (round 5): half the L2 -> LDS bytes and half the LDS fragment reads per FLOP of the
+        // 128x64 tile (87 against 43 FLOP per filled byte; 0.375 against 0.75 ds_read_b128 per MFMA); 96 / 144 KB of LDS = ONE
+        // work-group per CU, 128 accumulator registers per lane (2 waves per SIMD budget)
+        case 13: return launch_cfg<256, 128, 2, 2, 2>(p, stream, pol);
+        case 14: return launch_cfg<256, 128, 2, 2, 3>(p, stream, pol);
         case 10: {
             // 3x3 stride-1 same-size form (tile id given by igemm_pick_tile only when h3_ok): re-checked here
             const bool ok = !(p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_REFLECT | IG_FLAG_UPSAMPLE)) && p.nclass == 1 && p.cls[0].ntaps == 9 &&

@@ -104,6 +104,11 @@ struct Net {
     int f32 = 0;            // 1: fp32 storage + exact fp32 MFMA (forward only: the reference's teacher / validate() precision)
                             // 2: f16x2 split storage (common.h), three fp16 MFMAs per K step: the FAST fp32-grade mode (forward only);
                             //    conv inputs (z, pooled map, image) and weight packs are split tensors, pre-BN conv outputs y are fp32
+    int fwd_only = 0;       // forward-only plan (mode bit 9; the teacher's no-grad forwards, validate()): nothing is kept for a backward, so the
+                            // pre-BN outputs y and the post-BN outputs z of all layers rotate through SIX scratch buffers (y | block input | block
+                            // output | bn1 output | bn2 output | downsample output) instead of a bump-allocated arena - layer after layer rewrites the same
+                            // few MB, which stay resident in the L2s / the Infinity Cache (round 5; the arena form streams 2.8 GB per forward to HBM)
+    struct Scratch { size_t need[6] = {0, 0, 0, 0, 0, 0}, off[6] = {0, 0, 0, 0, 0, 0}; bool sizing = false; } sc;     // (forward-only plans: build())
     int deconv_bias = 0;    // Upsampling(bias=True) (pose_resnet.py:15,41,96 `deconv_with_bias`): every ConvTranspose2d has a bias parameter
     size_t es = 2;          // bytes per activation element
     int n_params = 0, n_buffers = 0;
@@ -164,7 +169,13 @@ struct PackJobH { const float* src; elem_t* dst; int A, T, B, kind; long long n;
 size_t act_alloc(Net& n, size_t bytes) { size_t o = n.act_bytes; n.act_bytes = align_up(o + bytes); return o; }
 size_t wp_alloc(Net& n, size_t bytes) { size_t o = n.wpack_bytes; n.wpack_bytes = align_up(o + bytes); return o; }
 
-void add_conv(Net& n, ConvL& c, int Hi, int Wi, int Ci, int Co, int K, int stride, int pad, int transposed, size_t in_off, bool need_bwd_pack) {
+// forward-only plans: named scratch slots, each as large as its largest tenant (sized in a dry pass of the layout)
+enum { SC_Y = 0, SC_A, SC_B, SC_MID, SC_MID2, SC_DS, SC_COUNT };
+size_t sc_take(Net& n, int slot, size_t bytes) {
+    if (n.sc.sizing) { n.sc.need[slot] = std::max(n.sc.need[slot], align_up(bytes)); return 0; }
+    return n.sc.off[slot];
+}
+void add_conv(Net& n, ConvL& c, int Hi, int Wi, int Ci, int Co, int K, int stride, int pad, int transposed, size_t in_off, bool need_bwd_pack, int y_slot = -1) {
     c.g = ConvGeom{n.N, Hi, Wi, Ci, Co, K, K, stride, pad, transposed, 0, 0};
     c.w_idx = n.n_params++;
     n.param_numel.push_back((long long)Co * (Ci == 8 ? 3 : Ci) * K * K);
@@ -173,36 +184,46 @@ void add_conv(Net& n, ConvL& c, int Hi, int Wi, int Ci, int Co, int K, int strid
     // fp32 mode reads plain-conv weights straight from the fp32 master ([Co][taps][Ci] is its physical layout)
     if (n.f32 != 1 || c.g.smallc() || transposed) c.wf_off = wp_alloc(n, welems * n.es);
     if (need_bwd_pack && !n.f32) c.wb_off = wp_alloc(n, welems * 2);
-    c.y_off = act_alloc(n, (size_t)n.N * c.g.Ho() * c.g.Wo() * Co * n.es);
+    const size_t ybytes = (size_t)n.N * c.g.Ho() * c.g.Wo() * Co * n.es;
+    c.y_off = (n.fwd_only && y_slot >= 0) ? sc_take(n, y_slot, ybytes) : act_alloc(n, ybytes);
 }
-void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true) {
+void add_bn(Net& n, BnL& b, int C, size_t npix, bool alloc_z = true, int z_slot = -1) {
     b.C = C;
     b.g_idx = n.n_params++; n.param_numel.push_back(C);
     b.b_idx = n.n_params++; n.param_numel.push_back(C);
     b.rm_idx = n.n_buffers++; b.rv_idx = n.n_buffers++; b.nbt_idx = n.n_buffers++;
     b.save_off = act_alloc(n, (size_t)3 * C * 4);
     b.npix = npix;
-    if (alloc_z) b.z_off = act_alloc(n, npix * C * n.es);
+    if (alloc_z) b.z_off = (n.fwd_only && z_slot >= 0) ? sc_take(n, z_slot, npix * C * n.es) : act_alloc(n, npix * C * n.es);
 }
 
 Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
     Net* np = new Net();
     Net& n = *np;
-    const int f32 = mode & 0xff;          // (mode: low byte = precision 0 / 1 / 2, bit 8 = the deconvolutions carry a bias)
+    const int f32 = mode & 0xff;          // (mode: low byte = precision 0 / 1 / 2, bit 8 = the deconvolutions carry a bias, bit 9 = forward-only plan)
     n.deconv_bias = (mode >> 8) & 1;
     n.f32 = f32 == 2 ? 2 : (f32 ? 1 : 0);
     n.es = f32 ? 4 : 2;
     for (int i = 0; i < 4; ++i) n.layers[i] = layers[i];
     n.K = K; n.N = N; n.H = H; n.W = W;
-    n.x8_off = act_alloc(n, (size_t)N * H * W * 8 * n.es);
+    n.fwd_only = (mode >> 9) & 1;
+    // The arena layout.  Differentiable plans: every tensor its own range (the backward reads them all).  Forward-only plans: the
+    // SAME walk with the y / z tensors mapped onto six scratch slots by liveness - one live pre-BN output at a time (SC_Y), the
+    // block's input and output ping-pong between SC_A and SC_B (the input is the residual: live until bn3), bn1 / bn2 outputs
+    // in SC_MID / SC_MID2, the downsample branch's output waits in SC_DS for bn3.  The walk runs twice:
+    // a dry pass on a copy sizes each slot by its largest tenant, the second assigns the offsets.
+    auto layout = [&](Net& n) {
+    const bool fo = n.fwd_only != 0;
+    n.x8_off = fo ? sc_take(n, SC_DS, (size_t)N * H * W * 8 * n.es) : act_alloc(n, (size_t)N * H * W * 8 * n.es);
     // stem: conv 7x7 s2 p3 (3 -> padded 8 input channels), bn, relu, maxpool 3x3 s2 p1
-    add_conv(n, n.stem, H, W, 8, 64, 7, 2, 3, 0, n.x8_off, false);
+    add_conv(n, n.stem, H, W, 8, 64, 7, 2, 3, 0, n.x8_off, false, SC_Y);
     n.Hs = n.stem.g.Ho(); n.Ws = n.stem.g.Wo();
-    add_bn(n, n.stem_bn, 64, (size_t)N * n.Hs * n.Ws);
+    add_bn(n, n.stem_bn, 64, (size_t)N * n.Hs * n.Ws, true, SC_B);
     n.Hp = (n.Hs + 2 - 3) / 2 + 1; n.Wp = (n.Ws + 2 - 3) / 2 + 1;
-    n.pool_off = act_alloc(n, (size_t)N * n.Hp * n.Wp * 64 * n.es);
-    n.poolidx_off = act_alloc(n, (size_t)N * n.Hp * n.Wp * 64);
+    n.pool_off = fo ? sc_take(n, SC_A, (size_t)N * n.Hp * n.Wp * 64 * n.es) : act_alloc(n, (size_t)N * n.Hp * n.Wp * 64 * n.es);
+    n.poolidx_off = fo ? sc_take(n, SC_MID, (size_t)N * n.Hp * n.Wp * 64) : act_alloc(n, (size_t)N * n.Hp * n.Wp * 64);      // (written, never read, by a forward-only plan)
     size_t cur = n.pool_off;
+    int cur_slot = SC_A;
     int Hc = n.Hp, Wc = n.Wp, Cc = 64;
     const int planes[4] = {64, 128, 256, 512};
     for (int L = 0; L < 4; ++L)
@@ -210,32 +231,34 @@ Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
             n.blocks.emplace_back();
             Block& b = n.blocks.back();
             const int P = planes[L], stride = (bi == 0 && L > 0) ? 2 : 1;
+            const int out_slot = cur_slot == SC_A ? SC_B : SC_A;
             b.in_off = cur;
             b.npix_in = (size_t)N * Hc * Wc;
             b.has_ds = (bi == 0);
             // parameter order follows torchvision Bottleneck: conv1,bn1,conv2,bn2,conv3,bn3,(downsample.0, downsample.1)
-            add_conv(n, b.c1, Hc, Wc, Cc, P, 1, 1, 0, 0, cur, true);
-            add_bn(n, b.b1, P, (size_t)N * Hc * Wc);
-            add_conv(n, b.c2, Hc, Wc, P, P, 3, stride, 1, 0, b.b1.z_off, true);
+            add_conv(n, b.c1, Hc, Wc, Cc, P, 1, 1, 0, 0, cur, true, SC_Y);
+            add_bn(n, b.b1, P, (size_t)N * Hc * Wc, true, SC_MID);
+            add_conv(n, b.c2, Hc, Wc, P, P, 3, stride, 1, 0, b.b1.z_off, true, SC_Y);
             const int Ho = b.c2.g.Ho(), Wo = b.c2.g.Wo();
-            add_bn(n, b.b2, P, (size_t)N * Ho * Wo);
-            add_conv(n, b.c3, Ho, Wo, P, P * 4, 1, 1, 0, 0, b.b2.z_off, true);
-            add_bn(n, b.b3, P * 4, (size_t)N * Ho * Wo);
-            if (!n.f32) b.b3.mask_off = act_alloc(n, (size_t)N * Ho * Wo * (P * 4) / 8);
+            add_bn(n, b.b2, P, (size_t)N * Ho * Wo, true, SC_MID2);     // (its own slot: with eval_fold conv2 reads z1 and writes z2 in one launch)
+            add_conv(n, b.c3, Ho, Wo, P, P * 4, 1, 1, 0, 0, b.b2.z_off, true, SC_Y);
+            add_bn(n, b.b3, P * 4, (size_t)N * Ho * Wo, true, out_slot);
+            if (!n.f32 && !fo) b.b3.mask_off = act_alloc(n, (size_t)N * Ho * Wo * (P * 4) / 8);     // (the ReLU bit mask is the backward's)
             if (b.has_ds) {
-                add_conv(n, b.cd, Hc, Wc, Cc, P * 4, 1, stride, 0, 0, cur, true);
-                add_bn(n, b.bd, P * 4, (size_t)N * Ho * Wo);
+                add_conv(n, b.cd, Hc, Wc, Cc, P * 4, 1, stride, 0, 0, cur, true, SC_Y);
+                add_bn(n, b.bd, P * 4, (size_t)N * Ho * Wo, true, SC_DS);
                 b.zd_off = b.bd.z_off;
             }
-            cur = b.b3.z_off; Hc = Ho; Wc = Wo; Cc = P * 4;
+            cur = b.b3.z_off; cur_slot = out_slot; Hc = Ho; Wc = Wo; Cc = P * 4;
         }
     n.fc_w_idx = n.n_params++; n.param_numel.push_back(1000LL * 2048);
     n.fc_b_idx = n.n_params++; n.param_numel.push_back(1000);
     for (int i = 0; i < 3; ++i) {
-        add_conv(n, n.up[i], Hc, Wc, Cc, 256, 4, 2, 1, 1, cur, true);
+        add_conv(n, n.up[i], Hc, Wc, Cc, 256, 4, 2, 1, 1, cur, true, SC_Y);
         if (n.deconv_bias) { n.up[i].bias_idx = n.n_params++; n.param_numel.push_back(256); }      // (.parameters() order: weight, bias, then the BN)
         Hc = n.up[i].g.Ho(); Wc = n.up[i].g.Wo(); Cc = 256;
-        add_bn(n, n.up_bn[i], 256, (size_t)N * Hc * Wc);
+        cur_slot = cur_slot == SC_A ? SC_B : SC_A;
+        add_bn(n, n.up_bn[i], 256, (size_t)N * Hc * Wc, true, cur_slot);
         cur = n.up_bn[i].z_off;
     }
     // head: 1x1 conv with bias -> fp32
@@ -245,8 +268,18 @@ Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
     n.head.in_off = cur;
     n.head.wf_off = wp_alloc(n, (size_t)K * 256 * n.es);
     n.head.wb_off = wp_alloc(n, (size_t)256 * 64 * 2);      // [256][1][64] zero-padded for dgrad
-    n.head_out_off = act_alloc(n, (size_t)N * Hc * Wc * K * 4);
+    n.head_out_off = fo ? sc_take(n, SC_Y, (size_t)N * Hc * Wc * K * 4) : act_alloc(n, (size_t)N * Hc * Wc * K * 4);
     n.Hout = Hc; n.Wout = Wc;
+    return Hc * 65536 + Wc;
+    };
+    if (n.fwd_only) {
+        Net dry = n;
+        dry.sc.sizing = true;
+        (void)layout(dry);
+        for (int k = 0; k < SC_COUNT; ++k) { n.sc.need[k] = dry.sc.need[k]; n.sc.off[k] = act_alloc(n, dry.sc.need[k]); }
+    }
+    const int hw_out = layout(n);
+    const int Hc = hw_out >> 16, Wc = hw_out & 0xffff;
 
     // transient workspace: BN stat slabs, coefficient vectors, gradient ping-pong buffers
     size_t max_slab = 0, max_act = 0;
@@ -264,6 +297,14 @@ Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
     n.ws_slab = o; o = align_up(o + max_slab);
     n.ws_slabf = o; o = align_up(o + max_slab);     // partial sums written by dgrad epilogues (the downsample BN keeps ws_slab)
     n.ws_coef = o; o = align_up(o + (size_t)3 * 2048 * 4 + 2 * 2048 * 4);
+    if (n.fwd_only) {           // (no backward: statistics slabs and coefficient vectors only)
+        n.ws_bytes = o;
+        n.stem.g.pol = &n.policy;
+        for (auto& b : n.blocks) { b.c1.g.pol = b.c2.g.pol = b.c3.g.pol = b.cd.g.pol = &n.policy; }
+        for (int i = 0; i < 3; ++i) n.up[i].g.pol = &n.policy;
+        n.head.g.pol = &n.policy;
+        return np;
+    }
     n.gbuf_bytes = align_up(2 * max_act);   // x2: the deconv-stage gradients are fp32
     for (int i = 0; i < 6; ++i) { n.ws_gbuf[i] = o; o += n.gbuf_bytes; }
     n.ws_dyhead = o; o = align_up(o + (size_t)N * Hc * Wc * 64 * 2);
@@ -398,7 +439,7 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
 
 // ============================================================================ public (C++) entry points
 void* net_create(const int layers[4], int K, int N, int H, int W, int mode) {
-    if (K < 1 || K > 64 || N < 1 || H % 32 || W % 32 || (mode & 0xff) > 2 || (mode >> 9)) return nullptr;
+    if (K < 1 || K > 64 || N < 1 || H % 32 || W % 32 || (mode & 0xff) > 2 || (mode >> 10)) return nullptr;
     return build(layers, K, N, H, W, mode);
 }
 void net_destroy(void* h) {
@@ -996,12 +1037,12 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     if (part < 0 || part > 2 || phase < 0 || phase > 2) return UDAPOSE_ERR_ARG;
     if (phase != 0 && !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
     if (phase == 2) {
-        if (n.f32) return UDAPOSE_ERR_UNSUPPORTED;
+        if (n.f32 || n.fwd_only) return UDAPOSE_ERR_UNSUPPORTED;
         DbgSyncScope dbg2(n.policy.debug_sync);
         return run_wg_group(s, n, (const char*)act_, (char*)ws_, grads, beta, part);
     }
     DbgSyncScope dbg(n.policy.debug_sync);
-    if (n.f32) return UDAPOSE_ERR_UNSUPPORTED;   // fp32 mode is forward-only (teacher / validate precision)
+    if (n.f32 || n.fwd_only) return UDAPOSE_ERR_UNSUPPORTED;   // fp32 / f16x2 modes and forward-only plans keep nothing for a backward
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
@@ -1151,6 +1192,7 @@ int net_apply_running(void* h, hipStream_t s, const void* act_, void* const* buf
 int net_bind_grads(void* h, void* const* grads) {
     Net& n = *(Net*)h;
     if (n.f32) return UDAPOSE_OK;
+    if (n.fwd_only) return UDAPOSE_ERR_UNSUPPORTED;
     return bind_wg_groups(n, grads);
 }
 // index (in .parameters() order) of the first parameter whose gradient is final when net_backward part 1 has run: the first

@@ -54,7 +54,7 @@ class Upsampling(nn.Sequential):
 class _NetHandle:
     """One executor plan (fixed N,H,W) plus its device work areas."""
 
-    def __init__(self, layers, K, N, H, W, device, precision='bf16', policy=None, deconv_bias=False, aux_lib='bf16'):
+    def __init__(self, layers, K, N, H, W, device, precision='bf16', policy=None, deconv_bias=False, aux_lib='bf16', fwd_only=False):
         # the library build whose element type is this plan's storage / MFMA type.  'fp32' / 'f16x2' plans do not depend on the
         # element type (both builds carry them): they live in the build `aux_lib` names - the STUDENT's build when this network is
         # the teacher of a fused optimizer tail, which hands both plans to one library (ADVICE r3: a plan is only ever
@@ -62,8 +62,11 @@ class _NetHandle:
         L = self.L = lib('fp16' if precision == 'fp16' else ('bf16' if precision == 'bf16' else aux_lib))
         h = C.c_void_p()
         arr = (C.c_int * 4)(*layers)
-        check(L.udapose_net_create(arr, K, N, H, W, {'fp32': 1, 'f16x2': 2}.get(precision, 0) | (0x100 if deconv_bias else 0), C.byref(h)),
-              "net_create")
+        # fwd_only (mode bit 9): a plan for no-grad forwards - the teacher, validate() - whose y / z tensors rotate through six scratch
+        # buffers instead of a 2.8 GB arena (udapose.h); it refuses a backward
+        self.fwd_only = bool(fwd_only)
+        check(L.udapose_net_create(arr, K, N, H, W, {'fp32': 1, 'f16x2': 2}.get(precision, 0) | (0x100 if deconv_bias else 0) | (0x200 if fwd_only else 0),
+                                   C.byref(h)), "net_create")
         self.h = h
         self.precision = precision
         if policy:
@@ -114,6 +117,7 @@ class PoseResNet(nn.Module):
     """Simple Baseline for key-point detection (pose_resnet.py:59-91) on the MI355X executor."""
     default_precision = 'auto'      # what a new module's `precision` starts as (see __init__)
     _warned_bf16_fallback = False
+    fwd_only_plans = True           # no-grad forwards (teacher, validate()) run forward-only plans: y / z in six rotating scratch buffers
 
     def __init__(self, backbone, upsampling, feature_dim, num_keypoints, finetune=False):
         super().__init__()
@@ -266,11 +270,12 @@ class PoseResNet(nn.Module):
             differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         prec = self.resolved_precision(differentiable)
         aux = self.aux_lib_kind if prec in ('fp32', 'f16x2') else None
-        key = (N, H, W, x.device.index, prec, aux)
+        fo = bool(PoseResNet.fwd_only_plans) and not differentiable
+        key = (N, H, W, x.device.index, prec, aux, fo)
         hd = self._handles.get(key)
         if hd is None:
             hd = _NetHandle(self.backbone.layers_cfg, self.num_keypoints, N, H, W, x.device, prec, dict(self.policy), self._deconv_bias,
-                            aux_lib=(aux or 'bf16'))
+                            aux_lib=(aux or 'bf16'), fwd_only=fo)
             params = list(self.parameters())
             assert hd.n_params == len(params) and hd.n_buffers == len(list(self.buffers())), "executor/module parameter mismatch"
             for i, p in enumerate(params):
@@ -347,13 +352,14 @@ class PoseResNet(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        hd = self._handle(x, differentiable=save)
-        self._last_hd = hd            # the plan of the most recent forward (the fused optimizer tail keeps ITS packs fresh)
         if save and not self.training:
             # eval-mode BatchNorm is folded into the convolutions' epilogues (policy eval_fold): such a forward writes neither the pre-BN
-            # tensors nor the batch statistics a backward would read, and there is no eval-mode BN backward on this path
-            raise RuntimeError("PoseResNet: a differentiable forward in eval() mode is not supported (no eval-mode BatchNorm backward on this "
-                               "path; the reference trains in train() mode and evaluates under torch.no_grad())")
+            # tensors nor the batch statistics a backward would read, and there is no eval-mode BN backward on this path.
+            # An eval-mode forward outside torch.no_grad() (a validation loop that forgot it) therefore keeps NO backward state; a later
+            # .backward() raises in _PoseNetFn.backward ("backward without saved activations") instead of reading unwritten memory
+            save = False
+        hd = self._handle(x, differentiable=save)
+        self._last_hd = hd            # the plan of the most recent forward (the fused optimizer tail keeps ITS packs fresh)
         if save and hd.precision in ('fp32', 'f16x2'):
             raise RuntimeError(f"precision={hd.precision!r} is forward-only (run it under torch.no_grad(), as the reference does for the teacher)")
         pa, ba, params = self._pointers()
