@@ -272,9 +272,17 @@ def main():
     ap.add_argument("--stream-priority", type=int, default=0, help="tuning: priority of the three branch streams (-1 = high; side streams stay 0)")
     ap.add_argument("--no-sum-in-tail", action="store_true", help="tuning: a separate launch adds the two passes' gradient buffers")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
-    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="data parallel: wire format of the gradient buckets (bf16: one "
+    ap.add_argument("--dp-form", default="auto", choices=["auto", "fixed"], help="data parallel (world > 1): 'auto' times 5 steps of each form - {two gradient "
+                    "buckets, the first under backward part 2 | one bucket after the whole backward} x {fp32, bf16 on the wire} - during spin-up, "
+                    "all ranks agree on the fastest (rank 0's choice, broadcast) and the timed region runs it; 'fixed' (or an explicit --grad-comm / "
+                    "--one-bucket) runs the form the flags name")
+    ap.add_argument("--grad-comm", default=None, choices=["fp32", "bf16"], help="data parallel: wire format of the gradient buckets (bf16: one "
                     "rounding per contribution, all-to-all + fp32 accumulation on the shard's owner + all-gather: half the bytes per xGMI link)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-capture-comm", action="store_true", help="data parallel: keep the collectives eager between four graphs instead of capturing "
+                    "them into the step's one graph (round 5's default with RCCL)")
+    ap.add_argument("--one-bucket", action="store_true", help="data parallel: the whole backward with one merged weight-gradient tail, then ONE "
+                    "all-reduce of the flat gradient buffer (no overlap with backward part 2)")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
     ap.add_argument("--cpu-images", type=int, default=0, help="batch of the CPU baseline step (0: 8, or what fits the time budget)")
@@ -284,6 +292,9 @@ def main():
                     "plan's six rotating scratch buffers (A/B of round 5's default)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed extra legs (fp16 / reference precision mix rates)")
     args = ap.parse_args()
+    dp_auto = args.dp_form == "auto" and args.grad_comm is None and not args.one_bucket and not args.eager and not args.split_graphs
+    if args.grad_comm is None:
+        args.grad_comm = "fp32"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus))            # (nothing above this line touches the GPU)
@@ -382,6 +393,8 @@ def main():
         trainer.single_graph = False
     if args.force_overlap:
         trainer.overlap_allreduce = True
+    if args.one_bucket:
+        trainer.overlap_allreduce = False
     if args.no_sum_in_tail:
         trainer.sum_grads_in_tail = False
     # configs[2] captured: the occlusion decisions are taken on the device (four uniform draws per sample, no read-back);
@@ -393,13 +406,52 @@ def main():
     def eager_step():
         return trainer.train_step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
 
+    dp_choice = None
     if args.eager:
         step = eager_step
     else:
         # the whole step (~2500 kernels) is captured once into hipGraphs; every replay recomputes the re-warp matrices from
         # the batch's aug_param tuples on the host and copies them (and the batch, if it changed) into the static inputs
-        graphed = GraphedTrainStep(trainer, g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"],
-                                   g["aug_param_tea"], split=(True if args.split_graphs else None))
+        def build_graphed():
+            return GraphedTrainStep(trainer, g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"],
+                                    g["aug_param_tea"], split=(True if args.split_graphs else None),
+                                    capture_comm=(False if args.no_capture_comm else None))
+
+        if dp_auto and dist.is_initialized() and (world > 1 or force_dist):
+            # the ONE scaling run the driver may get should not depend on a guess about xGMI: every form is captured and timed (5 steps between
+            # barrier + synchronize brackets, MAX over ranks), rank 0 picks the fastest and broadcasts the choice
+            forms = [("two_buckets_fp32", True, "fp32"), ("one_bucket_fp32", False, "fp32"), ("two_buckets_bf16", True, "bf16"), ("one_bucket_bf16", False, "bf16")]
+            if dist.get_backend() != "nccl":
+                forms = forms[:2]                       # (bf16 on the wire needs RCCL)
+            timings, built = {}, {}
+            for name, overlap, wire in forms:
+                trainer.overlap_allreduce, trainer.sync.comm_dtype = overlap, wire
+                gr = build_graphed()
+                for _ in range(2):
+                    gr.step(None, None, None, None, None, g["aug_param_stu"], g["aug_param_tea"])
+                dist.barrier(); torch.cuda.synchronize()
+                t_a = time.perf_counter()
+                for _ in range(5):
+                    gr.step(None, None, None, None, None, g["aug_param_stu"], g["aug_param_tea"])
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t_a], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                timings[name] = round(float(tt.item()) / 5 * 1e3, 3)
+                built[name] = gr
+            pick = torch.tensor([min(range(len(forms)), key=lambda i: timings[forms[i][0]])], device=dev, dtype=torch.int64)
+            dist.broadcast(pick, 0)
+            name, overlap, wire = forms[int(pick.item())]
+            trainer.overlap_allreduce, trainer.sync.comm_dtype = overlap, wire
+            args.grad_comm = wire
+            graphed = built.pop(name)
+            built.clear()
+            gr = None            # (every graph that captured RCCL launches must be gone before the process group is destroyed: see the end of main)
+            torch.cuda.empty_cache()
+            dp_choice = {"chosen": name, "ms_per_step_5_steps": timings}
+            if rank == 0:
+                print(f"dp form: {dp_choice}", file=sys.stderr, flush=True)
+        else:
+            graphed = build_graphed()
 
         host = {k: v.cpu().pin_memory() for k, v in g.items() if torch.is_tensor(v)} if args.host_inputs else None
 
@@ -527,6 +579,21 @@ def main():
         ig_l, ig_ms, ig_fl = fl + dl, ms_f + ms_d, fp_f + fp_d
         achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         layers = {"pose_resnet101": [3, 4, 23, 3], "pose_resnet50": [3, 4, 6, 3]}[args.arch]
+        if args.eager:
+            launch_desc = "eager"
+        else:
+            if world > 1 or args.split_graphs or force_dist:
+                if getattr(graphed, "capture_comm", False):
+                    what = ("1 hipGraph with the RCCL collectives captured inside (confidence all-gather, gradient all-reduce "
+                            + ("in two buckets, the first under backward part 2)" if trainer._overlap() else "in one bucket after the whole backward)"))
+                elif graphed.g_lb2 is not None:
+                    what = "4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)"
+                else:
+                    what = "3 hipGraphs around the two RCCL collectives"
+            else:
+                what = "1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs"
+            launch_desc = (("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + what
+                           + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)")
         res = {
             "metric": f"images/sec (student+teacher step) {S}x{S} b={N}", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -545,9 +612,10 @@ def main():
                                         + (", style network" if args.config2 else "") + (" in the fp32-grade f16x2 mode" if args.precision == "reference" else
                                                                                           " in the exact-fp32 MFMA mode") + "; NOT the metric"}
                           if args.precision else {})},
-            "loss": loss, "launch": "eager" if args.eager else ("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + (("4 hipGraphs around the RCCL collectives (gradient all-reduce in two buckets, the first under backward part 2)" if graphed.g_lb2 is not None else "3 hipGraphs around the two RCCL collectives") if (world > 1 or args.split_graphs or force_dist) else ("1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs")) + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)",
+            "loss": loss, "launch": launch_desc,
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "grad_comm": args.grad_comm if dist.is_initialized() else None,
+            "dp_form": dp_choice,
             "comm_exposed_ms_per_step": round(comm_exposed_ms, 3) if comm_exposed_ms is not None else None,
             "rank_ms_per_step_min_max": ([min(r[0] for r in rank_ms), max(r[0] for r in rank_ms)] if rank_ms else None),
             "rank_comm_exposed_ms": ([r[1] for r in rank_ms] if rank_ms else None),
@@ -611,9 +679,18 @@ def main():
         elif world > 1:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
+    if os.environ.get("UDAPOSE_BENCH_DEBUG_EXIT"):
+        import faulthandler
+        faulthandler.dump_traceback_later(25, exit=True)
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
+        # graphs that hold captured RCCL launches go first: RCCL's communicator teardown waits for every graph that captured its kernels to be
+        # destroyed (measured: destroy_process_group() hangs for ever with one such graph still referenced)
+        graphed = built = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -548,7 +548,7 @@ def test_two_rank_step_on_one_gpu_gloo(arch, batch):
     env = dict(os.environ, UDAPOSE_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--spinup", "0.7", "--arch", arch, "--batch", str(batch), "--no-cpu-baseline"]
+           "--spinup", "0.7", "--arch", arch, "--batch", str(batch), "--no-cpu-baseline", "--dp-form", "fixed"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -661,7 +661,7 @@ def test_two_rank_config3_step_style_and_occlusion_captured():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(UDAPOSE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config2", "--steps", "3", "--warmup", "1", "--spinup", "0",
-           "--arch", "pose_resnet50", "--batch", "4", "--no-cpu-baseline"]
+           "--arch", "pose_resnet50", "--batch", "4", "--no-cpu-baseline", "--dp-form", "fixed"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -688,6 +688,8 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["replicas_in_sync"] is True
+    # (no form named: both gloo forms - two buckets | one bucket - were timed during spin-up and the ranks agreed on one)
+    assert d["dp_form"]["chosen"] in ("two_buckets_fp32", "one_bucket_fp32") and len(d["dp_form"]["ms_per_step_5_steps"]) == 2
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], cwd=root,
                          env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)
@@ -705,20 +707,29 @@ def test_one_rank_rccl_step():
               "--no-cpu-baseline"]
     res = {}
     rccl_env = {"UDAPOSE_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
-    for tag, extra, flags in (("rccl", rccl_env, []), ("plain", {}, []), ("rccl_bf16", dict(rccl_env, MASTER_PORT=str(_free_port())), ["--grad-comm", "bf16"])):
+    for tag, extra, flags in (("rccl", rccl_env, ["--dp-form", "fixed"]), ("plain", {}, []),
+                              ("rccl_bf16", dict(rccl_env, MASTER_PORT=str(_free_port())), ["--grad-comm", "bf16"]),
+                              ("rccl_auto", dict(rccl_env, MASTER_PORT=str(_free_port())), [])):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         out = subprocess.run([sys.executable] + common + flags, cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, tag + out.stdout[-2000:] + out.stderr[-4000:]
         lines = [l for l in out.stdout.splitlines() if l.strip()]
         assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]     # ONE JSON line, RCCL's banner goes to stderr
         res[tag] = json.loads(lines[0])
-    assert "4 hipGraphs" in res["rccl"]["launch"] and "1 hipGraph" in res["plain"]["launch"]
+    # round 5: over RCCL the collectives are captured INTO the step's graph (one launch per step, as on one rank without a group), and with
+    # no form named on the command line the bench times the four forms during spin-up and reports its choice
+    assert "1 hipGraph with the RCCL collectives captured" in res["rccl"]["launch"] and "1 hipGraph (" in res["plain"]["launch"]
+    dpf = res["rccl_auto"]["dp_form"]
+    assert dpf["chosen"] in dpf["ms_per_step_5_steps"] and len(dpf["ms_per_step_5_steps"]) == 4 and res["plain"]["dp_form"] is None
+    assert res["rccl"]["dp_form"] is None and res["rccl_auto"]["loss"] == res["rccl_auto"]["loss"]
     assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
     assert res["rccl"]["rccl_ranks"] == 1 and res["plain"]["rccl_ranks"] == 0
     a, b = res["rccl"]["loss"], res["plain"]["loss"]
     assert a == a and abs(a - b) <= 1e-3 * abs(b) + 1e-9, (a, b)
     # one SCALE line diagnoses itself: the time the compute stream waited in the communication calls is reported
-    assert res["rccl"]["grad_comm"] == "fp32" and res["rccl"]["comm_exposed_ms_per_step"] is not None and res["plain"]["grad_comm"] is None
+    # (the eager four-graph form - rccl_bf16 below: the bf16 suffix exchange cannot be captured - still reports what the compute stream waited)
+    assert res["rccl"]["grad_comm"] in ("fp32", "bf16") and res["plain"]["grad_comm"] is None
+    assert res["rccl_bf16"]["comm_exposed_ms_per_step"] is not None
     # gradient buckets in bf16 on the wire (all-to-all of shards, fp32 accumulation on the owner, all-gather): one bf16 rounding of the
     # gradients at world size 1 - the same training step to the precision of that rounding
     c = res["rccl_bf16"]["loss"]

@@ -487,8 +487,8 @@ class MeanTeacherTrainer:
             student.finish_wgrad(getattr(self, "_wg_stream", None))
         if overlap:
             student.finish_grads(part=1)    # the suffix of both passes is final: sum it ...
-            if not torch.cuda.is_current_stream_capturing():
-                self.sync.start_upper()     # ... and send it off (a captured step issues the collective between its graphs)
+            if not torch.cuda.is_current_stream_capturing() or getattr(self, "capture_comm", False):
+                self.sync.start_upper()     # ... and send it off (a captured step issues the collective between its graphs, or captures it: capture_comm)
         elif student._pending_lower:
             self._backward_lower(grads_part=0)      # weight gradients of the upper part on side streams | the lower part
         else:
@@ -574,7 +574,8 @@ class GraphedTrainStep:
     drew, or copies the original images, before the main graph.  Occlusion (train_human.py:374-412): the decisions are taken
     on the device from four uniform draws per sample (trainer.device_occlusion), inside the main graph."""
 
-    def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None, metrics=True):
+    def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None, metrics=True,
+                 capture_comm=None):
         # metrics: the captured step also decodes y_s and computes PCK@0.05 against label_s on the device (the reference's per-iteration
         # `accuracy(y_s, label_s)`, train_human.py:443) and gathers the losses + PCK into ONE small device vector: step_async() reads
         # it back one step late through a pinned double buffer, so a loop that logs every iteration never drains the device
@@ -633,6 +634,13 @@ class GraphedTrainStep:
                 trainer._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if _dist_on() and dist.get_backend() == "nccl":
+            # RCCL's watchdog thread polls the end events of the EAGER collectives issued so far (the warm-up steps'); on this HIP an
+            # event query fails with hipErrorCapturedEvent once the communicator's stream has joined a capture, even for an event that
+            # was recorded before it - and the watchdog then takes the process down.  Everything is complete here (synchronize above):
+            # give the watchdog (100 ms poll) time to retire those works before any collective is captured.
+            import time
+            time.sleep(0.7)
         style_mode = "thread_local" if _dist_on() else "global"
         if self.styled:
             for which in ("enc", "s2t", "t2s"):
@@ -643,7 +651,20 @@ class GraphedTrainStep:
                 self.g_style[which] = g
         # Data parallel: the confidence all-gather sits between the forwards and the losses, the gradient all-reduce between
         # backward and the optimizer; both stay eager, so the step is cut into three graphs around them.
-        self.split = _dist_on() if split is None else bool(split)
+        # capture_comm (round 5; default: on with the RCCL backend): the step's collectives - confidence all-gather, gradient all-reduce
+        # buckets - are captured INTO the step's graph (RCCL launches are stream-ordered kernels: capturable), so the data-parallel step is
+        # ONE graph launch like the one-rank step instead of four graphs with eager collectives between them.  If the capture raises
+        # (a collective backend that cannot be captured), the four-graph form below is built instead.
+        if capture_comm is None:
+            capture_comm = (_dist_on() and dist.get_backend() == "nccl" and split is None
+                            and os.environ.get("UDAPOSE_CAPTURE_COMM", "1") == "1")
+        self.capture_comm = bool(capture_comm) and _dist_on()
+        if self.capture_comm and trainer.sync.comm_dtype == "bf16" and trainer._overlap():
+            # the bf16 exchange of the suffix runs on a side stream that hands over to the communicator's stream and waits for it again:
+            # a fork that waits back on a non-origin stream brings hipStreamEndCapture down on this ROCm (tools/capture_fork_patterns.py)
+            self.capture_comm = False
+        trainer.capture_comm = self.capture_comm
+        self.split = (_dist_on() and not self.capture_comm) if split is None else bool(split)
         # hyper-parameters that are kernel ARGUMENTS of the captured launches stay what they were at capture: step() checks
         # them.  (lr / grad_scale are read from device memory and follow the optimizer's param_groups, see optim.py.)
         self._frozen = self._frozen_hyper()
@@ -658,8 +679,25 @@ class GraphedTrainStep:
         self.overlap = trainer._overlap()
         self.g_lb2 = None
         # one rank, nothing eager between backward and the optimizer: the update is captured into the same graph (one launch per step)
-        self.one_graph = (not self.split) and (not _dist_on()) and trainer.single_graph
-        if not self.split:
+        self.one_graph = (not self.split) and (self.capture_comm or not _dist_on()) and trainer.single_graph
+        if not self.split and self.capture_comm:
+            try:
+                self._capture_one(trainer, st, mode)
+            except Exception as e:      # (the backend refused the capture: fall back to eager collectives between four graphs)
+                import warnings
+                warnings.warn(f"GraphedTrainStep: capturing the collectives into the step's graph failed ({type(e).__name__}: {e}); "
+                              "using the four-graph form with eager collectives")
+                trainer.capture_comm = False
+                self.capture_comm = False
+                trainer._metrics_cb = None
+                trainer.student._pending_lower, trainer.student._pending_wg = [], []
+                torch.cuda.synchronize()
+                self.g_fb = torch.cuda.CUDAGraph()
+                self.split = True
+                self.one_graph = False
+        if not self.split and self.capture_comm:
+            pass
+        elif not self.split:
             if self.one_graph and self.metrics:
                 trainer._metrics_cb = self._metrics_side
             try:
@@ -693,7 +731,9 @@ class GraphedTrainStep:
         if self.one_graph:
             self.g_up = None
         else:
-            if self.g_lb2 is not None:
+            if self.capture_comm:
+                pass                        # (the collectives are inside g_fb)
+            elif self.g_lb2 is not None:
                 trainer.sync.finish()
             else:
                 trainer.sync()
@@ -710,6 +750,33 @@ class GraphedTrainStep:
             for m, hd, bwd in self._maintained:
                 m.packs_refreshed(hd, bwd)
         torch.cuda.synchronize()
+
+    def release(self):
+        """Destroy the captured graphs.  With capture_comm the graphs hold RCCL launches, and RCCL's communicator teardown waits for every
+        such graph to be gone: call this (or drop every reference to the object) BEFORE torch.distributed.destroy_process_group(), which
+        otherwise never returns (measured on RCCL 2.26 / ROCm 7.0)."""
+        self.g_fb = self.g_lb = self.g_lb2 = self.g_up = None
+        self.g_style = {}
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+
+    def _capture_one(self, trainer, st, mode):
+        """The whole data-parallel step - forwards, all-gather, losses, backward part 1, the suffix's all-reduce under backward part 2, the
+        prefix's all-reduce, Adam + EMA + packs - captured into self.g_fb."""
+        if self.one_graph and self.metrics:
+            trainer._metrics_cb = self._metrics_side
+        try:
+            with torch.cuda.graph(self.g_fb, capture_error_mode=mode, **self._cap):
+                self._thetas()
+                self.out = trainer._forward_backward(st["x_s_in"], st["label_s"], st["weight_s"], st["x_t_stu"], [st["x_t_tea_in"]],
+                                                     st["theta_stu"], [st["theta_tea"]])
+                trainer._sync_grads()
+                if self.one_graph:
+                    trainer._update()
+                    self._capture_metrics()
+        finally:
+            trainer._metrics_cb = None
 
     def _capture_metrics(self):
         """(inside the capture of the step's last graph) losses + device PCK of the source batch -> self._mvec = [loss_all, loss_s, loss_c,
@@ -960,7 +1027,7 @@ class GraphedTrainStep:
             seg("backward2")
             self.t.sync.finish()
             seg("finish")
-        else:
+        elif not self.one_graph and not self.capture_comm:
             self.t.sync()
             seg("allreduce")
         if not self.one_graph:
