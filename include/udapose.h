@@ -255,6 +255,12 @@ int udapose_net_backward_phase(udapose_net_t net, void* stream, const float* dou
  * together and their weight gradients are exposed there; one grid of twice the size has half the tail. */
 int udapose_net_wgrad_pair(udapose_net_t net, void* stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a,
                            const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int part);
+/* The same in two phases (round 5): phase 1 = the clearing launches and the tile classes that hold the 1x1 convolutions of layer2-4, the
+ * deconvolutions and the strided convolutions (60 % of the parameters); phase 2 = the remaining class (3x3 convolutions, layer1, head, stem).
+ * Between the two a caller starts udapose_net_fused_update_part(part 1) - the optimizer sweep of the parameters phase 1 completed - on another
+ * stream: the HBM-bound sweep runs beside phase 2's LDS-fill-bound launch instead of behind it.  phase 0 = udapose_net_wgrad_pair. */
+int udapose_net_wgrad_pair_phase(udapose_net_t net, void* stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a,
+                                 const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int part, int phase);
 /* Staged weight gradients (udapose_policy.wgrad_overlap > 0; round 4): the ONE `loss.backward()` of the reference's step
  * (train_human.py:436) computes every layer's weight gradient as soon as that layer's output gradient exists; here the plan's
  * layers are cut into stages in chain order (stage 0 = head + deconvolutions, then groups of bottleneck blocks from the top, the
@@ -340,6 +346,14 @@ int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void*
                              void* const* h_exp_avg, void* const* h_params_t, void* wpack_s, void* wpack_t, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha,
                              float one_minus_alpha, int do_adam, long long grad2_delta_bytes);
+/* The sweep in two parts (round 5; `stu_optimizer.step(); tea_optimizer.step()` of train_human.py:437-438 still once per step): part 1 = the
+ * convolution weights whose gradients udapose_net_wgrad_pair_phase(phase 1) completed (and the step counter's tick), part 2 = every other
+ * parameter and the two odd packs; parts 1 + 2 run the blocks of part 0 = udapose_net_fused_update, each exactly once.  The split follows the
+ * weight-gradient tables of udapose_net_bind_grads: call udapose_net_bind_update after it. */
+int udapose_net_fused_update_part(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* h_params_s, void* const* h_grads,
+                                  void* const* h_exp_avg, void* const* h_params_t, void* wpack_s, void* wpack_t, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha,
+                                  float one_minus_alpha, int do_adam, long long grad2_delta_bytes, int part);
 /* grad2_delta_bytes != 0: the gradient is h_grads[i] + the tensor grad2_delta_bytes behind it (the second per-pass gradient buffer
  * of a step whose two backward passes ran on different streams; a multiple of 16): the sum udapose_axpy_f32 would have written
  * first, taken in the same sweep.  h_grads itself is left holding the first pass's share. */

@@ -494,6 +494,40 @@ def test_gradient_buffers_summed_inside_the_fused_tail_are_bit_identical_to_the_
     assert stu.pending_grad_sum() == 0 and not torch.equal(part, stu.head.weight.grad)
 
 
+def test_split_optimizer_tail_beside_the_second_weight_gradient_phase_is_bit_identical():
+    """Round 5: the step's serial end - `loss.backward()`'s weight gradients, `stu_optimizer.step()`,
+    `tea_optimizer.step()` (train_human.py:436-438) - with the optimizer sweep of the parameters the FIRST weight-gradient phase completed
+    running on a side stream beside the second phase (udapose_net_wgrad_pair_phase, udapose_net_fused_update_part).  Same kernels on the same
+    blocks, each exactly once: parameters, moments and teacher bit-identical to the one-launch tail, eagerly and captured; both block
+    lists are non-empty on this network (otherwise the test would prove nothing)."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=12)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    res = {}
+    for split in (False, True):
+        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=7).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=7).cuda()
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
+        tr.split_tail = split
+        seen = []
+        orig = tr.stu_optimizer.fused_tail_step
+        tr.stu_optimizer.fused_tail_step = lambda *a, part=0, _o=orig, _s=seen: (_s.append(part), _o(*a, part=part))[1]
+        for _ in range(2):
+            tr.train_step(*args)
+        assert tr.fused_last and not stu._pending_wg
+        assert seen == ([1, 2, 1, 2] if split else [0, 0]), seen
+        gs = GraphedTrainStep(tr, *args, warmup=1)
+        for _ in range(3):
+            out = gs.step(*args)
+        assert torch.isfinite(out["loss_all"])
+        st = tr.stu_optimizer.state
+        res[split] = ([p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
+                      + [st[p]["exp_avg"].clone() for p in stu.parameters() if p in st] + [st[p]["exp_avg_sq"].clone() for p in stu.parameters() if p in st])
+    assert len(res[False]) == len(res[True]) and all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
+
+
 def test_merged_weight_gradient_launch_is_bit_identical():
     """udapose_net_wgrad_pair: both passes' grouped weight gradients as one launch per tile class (engine.merge_wgrad) against each
     pass launching its own - same tables, same kernels, bit-identical parameters; eager and captured, and with gradient accumulation

@@ -99,9 +99,11 @@ _SIGS = {
     "udapose_net_backward_staged": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci]),
     "udapose_net_wgrad_staged": (ci, [vp, vp, ci, vp, vp, vp, cf, ci, vp, vp, vp, cf, ci]),
     "udapose_net_wgrad_pair": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, cf, ci]),
+    "udapose_net_wgrad_pair_phase": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, cf, ci, ci]),
     "udapose_net_grad_split_param": (ll, [vp]),
     "udapose_net_bind_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "udapose_net_fused_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, cf, cf, ci, ll]),
+    "udapose_net_fused_update_part": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, cf, cf, ci, ll, ci]),
     "udapose_joints_mse_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),
     "udapose_joints_mse_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
     "udapose_cons_loss_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),

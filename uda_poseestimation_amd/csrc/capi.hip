@@ -78,7 +78,7 @@ int net_bind_grads(void*, void* const*);
 long long net_grad_split_param(void*);
 int net_bind_update(void*, void*, void* const*, void* const*, void* const*, void* const*, void* const*, void*, void*);
 int net_fused_update(void*, void*, hipStream_t, void* const*, void* const*, void* const*, void* const*, void*, void*, float, float, float, float, float,
-                     int, float, float*, float, float, int, long long);
+                     int, float, float*, float, float, int, long long, int);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -89,7 +89,7 @@ void net_out_shape(void*, int*);
 int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
 int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
 int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int, int);
-int net_wgrad_pair(void*, hipStream_t, const void*, void*, void* const*, float, const void*, void*, void* const*, float, int);
+int net_wgrad_pair(void*, hipStream_t, const void*, void*, void* const*, float, const void*, void*, void* const*, float, int, int);
 int net_num_stages(void*);
 int net_wgrad_staged(void*, void* const*, int, const void*, void*, void* const*, float, int, const void*, void*, void* const*, float, int);
 int net_backward_staged(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int);
@@ -294,7 +294,12 @@ int udapose_net_backward_part(udapose_net_t n, void* stream, const float* dout, 
 int udapose_net_wgrad_pair(udapose_net_t n, void* stream, const void* act_a, void* ws_a, void* const* grads_a, float beta_a, const void* act_b,
                            void* ws_b, void* const* grads_b, float beta_b, int part) {
     if (!n || !act_a || !ws_a || !grads_a || !act_b || !ws_b || !grads_b) return UDAPOSE_ERR_ARG;
-    return net_wgrad_pair(n, S(stream), act_a, ws_a, grads_a, beta_a, act_b, ws_b, grads_b, beta_b, part);
+    return net_wgrad_pair(n, S(stream), act_a, ws_a, grads_a, beta_a, act_b, ws_b, grads_b, beta_b, part, 0);
+}
+int udapose_net_wgrad_pair_phase(udapose_net_t n, void* stream, const void* act_a, void* ws_a, void* const* grads_a, float beta_a, const void* act_b,
+                                 void* ws_b, void* const* grads_b, float beta_b, int part, int phase) {
+    if (!n || !act_a || !ws_a || !grads_a || !act_b || !ws_b || !grads_b) return UDAPOSE_ERR_ARG;
+    return net_wgrad_pair(n, S(stream), act_a, ws_a, grads_a, beta_a, act_b, ws_b, grads_b, beta_b, part, phase);
 }
 int udapose_net_backward_phase(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act,
                                void* ws, void* const* grads, float beta, int part, int phase) {
@@ -324,7 +329,15 @@ int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void*
                              int do_adam, long long grad2_delta_bytes) {
     if (!student || !teacher) return UDAPOSE_ERR_ARG;
     return net_fused_update(student, teacher, S(stream), params_s, grads, exp_avg, params_t, wpack_s, wpack_t, lr, beta1, beta2, eps, weight_decay,
-                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam, grad2_delta_bytes);
+                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam, grad2_delta_bytes, 0);
+}
+int udapose_net_fused_update_part(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* params_s, void* const* grads,
+                                  void* const* exp_avg, void* const* params_t, void* wpack_s, void* wpack_t, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha, float one_minus_alpha,
+                                  int do_adam, long long grad2_delta_bytes, int part) {
+    if (!student || !teacher) return UDAPOSE_ERR_ARG;
+    return net_fused_update(student, teacher, S(stream), params_s, grads, exp_avg, params_t, wpack_s, wpack_t, lr, beta1, beta2, eps, weight_decay,
+                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam, grad2_delta_bytes, part);
 }
 
 int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out) {

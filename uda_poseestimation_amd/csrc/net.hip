@@ -45,7 +45,7 @@ int pw_nchw_f32_to_nhwc_f32(hipStream_t, const float*, float*, int, int, int, in
 size_t opt_tail_job_bytes();
 int opt_chunk();
 void opt_tail_job_fill(void*, float*, const float*, float*, float*, float*, void*, void*, void*, void*, int, int, int, int, long long);
-int opt_tail(hipStream_t, const void*, const int*, const int*, int, float, float, float, float, float, int, float, float*, float, float, int, long long);
+int opt_tail(hipStream_t, const void*, const int*, const int*, int, float, float, float, float, float, int, float, float*, float, float, int, long long, int);
 int pw_transpose_f32(hipStream_t, const float*, float*, int, int, int);
 int pw_pack_strided_f32(hipStream_t, const float*, float*, int, int, int, int, int, int, long, long, long, long);
 int pw_bn_apply_f32(hipStream_t, const float*, const float*, float*, size_t, int, const float*, const float*, int);
@@ -135,6 +135,7 @@ struct Net {
     struct WgGroup {
         float k_beta = -1.f; int k_stages = 0; int k_part = 0;     // part: 0 all layers, 1 upper (head..layer3), 2 lower (layer2..stem)
         std::vector<std::pair<int, ptrdiff_t>> rel;      // (parameter index, byte offset of its gradient from grads[0]) the table assumes
+        std::vector<int> rel_cls;                        // tile class of the launch that computes rel[i]'s gradient
         // tile classes of the grouped launch: 0 = 128x128, 1 = 64x64 (and the filter-row form), 2 = 256x128 (128x64 per wave)
         WgParams* d_tab[WG_CLASSES] = {}; WgGroupBlk* d_blk[WG_CLASSES] = {}; int per_xcd[WG_CLASSES] = {};
         double flops[WG_CLASSES] = {};
@@ -144,7 +145,9 @@ struct Net {
     };
     std::deque<WgGroup> wg_groups;       // (stable addresses, never evicted: a captured hipGraph may reference any table built so far)
     // fused optimizer tail (Adam + EMA + weight packs of student and teacher in one sweep): device job table
-    struct UpdTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0;
+    // (block lists: [0, nblocks) all jobs; the same blocks reordered as EARLY part [0, n_early) - the conv weights whose gradients the first
+    //  weight-gradient phase (tile classes 0 and 2) completes - followed by the LATE part: net_fused_update's `part`)
+    struct UpdTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0; int n_early = 0;
                     const void* k_ps = nullptr; const void* k_pt = nullptr; const void* k_g = nullptr; const void* k_m = nullptr;
                     const void* k_ws = nullptr; const void* k_wt = nullptr; };
     UpdTab upd;
@@ -748,6 +751,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
     std::vector<Unit> units[WG_CLASSES];
     G.zero.clear();
     G.rel.clear();
+    G.rel_cls.clear();
     for (int t = 0; t < WG_CLASSES; ++t) G.flops[t] = 0.0;
     auto add_geom = [&](const ConvGeom& g, int w_idx, size_t dy_off, size_t in_off, int rows_valid) -> int {
         if (g.smallc()) return UDAPOSE_OK;
@@ -760,6 +764,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         const int t = wgrad_group_plan(p, beta != 0.f, n.policy.wgrad_stages, n.policy);
         if (t < 0) return UDAPOSE_ERR_UNSUPPORTED;
         const int prob = (int)tab[t].size();
+        G.rel_cls.push_back(t);
         tab[t].push_back(p);
         G.flops[t] += fl;
         const int nblk = p.r_tiles * p.c_tiles * p.total_taps;
@@ -928,14 +933,19 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
 // The grouped weight gradients of TWO passes of this plan (each with its own arenas, gradient tensors and accumulate mode) as ONE
 // launch per tile class: the step's two student passes end at about the same time and their weight-gradient launches are fully
 // exposed there; one grid of twice the size has half the tail (measured on the launches alone: 2498 us for 64 images against 2 x 1353).
+// phase (round 5): 0 = everything; 1 = the clearing launches and tile classes 0 / 2 (the 1x1 convolutions of layer2-4, the deconvolutions, the
+// strided convolutions: 60 % of the parameters); 2 = tile class 1 (the 3x3 convolutions in the filter-row form, layer1, head, stem) and the stem's
+// unpack.  Between the two the caller may start the optimizer sweep of the parameters phase 1 completed (net_fused_update part 1) on another
+// stream: an HBM-bound sweep beside an LDS-fill-bound launch.
 int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const* gradsA, float betaA, const char* actB, char* wsB,
-                void* const* gradsB, float betaB, int part, int cap = 0) {
+                void* const* gradsB, float betaB, int part, int cap = 0, int phase = 0) {
     Net::WgGroup* GA = find_wg_group(n, gradsA, betaA, part);
     Net::WgGroup* GB = find_wg_group(n, gradsB, betaB, part);
     if (!GA || !GB) return UDAPOSE_ERR_NOT_PREPARED;
     bool same = true;
     for (int t = 0; t < WG_CLASSES; ++t) same = same && GA->per_xcd[t] == GB->per_xcd[t];
     if (!same) {        // (different table shapes: two launches)
+        if (phase == 2) return UDAPOSE_OK;      // (phase 1 did everything)
         CK(run_wg_group(s, n, actA, wsA, gradsA, betaA, part, cap));
         return run_wg_group(s, n, actB, wsB, gradsB, betaB, part, cap);
     }
@@ -943,6 +953,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     const ConvGeom& sg = n.stem.g;
     const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
     struct { Net::WgGroup* G; char* ws; void* const* grads; } side[2] = {{GA, wsA, gradsA}, {GB, wsB, gradsB}};
+    if (phase != 2)
     for (auto& sd : side) {
         sd.G->last_use = ++n.wg_tick;
         if (sd.G->d_zero) CK(pw_zero_multi(s, sd.G->d_zero, sd.G->n_zero, sd.grads[0]));
@@ -953,6 +964,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     }
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!GA->per_xcd[t]) continue;
+        if ((phase == 1 && t == 1) || (phase == 2 && t != 1)) continue;
 #ifdef UDAPOSE_TIMING_EXPERIMENTS
         if (n.policy.exp0 & (1 << t)) continue;          // (tuning: skip this tile class - timing experiments only)
 #endif
@@ -962,7 +974,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
         conv_prof_after(s, tok);
         CK(rc);
     }
-    if (with_stem) {
+    if (with_stem && phase != 1) {
         const float betas[2] = {betaA, betaB};
         for (int k = 0; k < 2; ++k)
             CK(pw_unpack_strided(s, (const float*)(side[k].ws + n.ws_dwtmp), (float*)side[k].grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
@@ -973,13 +985,13 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
 }  // namespace
 
 int net_wgrad_pair(void* h, hipStream_t s, const void* actA, void* wsA, void* const* gradsA, float betaA, const void* actB, void* wsB,
-                   void* const* gradsB, float betaB, int part) {
+                   void* const* gradsB, float betaB, int part, int phase) {
     Net& n = *(Net*)h;
-    if (part < 0 || part > 2 || n.f32 || !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
+    if (part < 0 || part > 2 || phase < 0 || phase > 2 || n.f32 || !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
     DbgSyncScope dbg(n.policy.debug_sync);
     // (wgrad_cap without wgrad_overlap: the end-of-chain launches themselves as persistent grids - dynamic scheduling only)
     return run_wg_pair(s, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, part,
-                       n.policy.wgrad_overlap > 0 ? 0 : n.policy.wgrad_cap);
+                       n.policy.wgrad_overlap > 0 ? 0 : n.policy.wgrad_cap, phase);
 }
 
 // Staged weight gradients (Policy::wgrad_overlap > 0, round 4).  net_backward_staged = the gradient chain of the whole backward
@@ -1220,8 +1232,16 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
     char* wt_ = (char*)wpack_t_;
     const size_t jb = opt_tail_job_bytes();
     std::vector<char> jobs;
-    std::vector<int> bj, bs;
+    std::vector<int> bj, bs, bj_late, bs_late;
     std::vector<char> covered(n.n_params, 0);
+    // parameters whose weight gradient the FIRST phase of the pair launch completes (tile classes 0 / 2 of the whole-backward group): their blocks
+    // come first in the block lists, so that net_fused_update(part 1) can sweep them while phase 2 still runs
+    std::vector<char> early(n.n_params, 0);
+    for (auto& G : n.wg_groups)
+        if (G.k_part == 0 && G.rel.size() == G.rel_cls.size()) {
+            for (size_t i = 0; i < G.rel.size(); ++i) early[G.rel[i].first] = (G.rel_cls[i] != 1);
+            break;
+        }
     auto push = [&](int idx, void* sd, void* td, void* sx, void* tx, int A, int T, int B) -> int {
         const long long numel = n.param_numel[idx];
         const int adam = (h_m[idx] && h_v[idx] && grads[idx]) ? 1 : 0;
@@ -1234,7 +1254,8 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
                           (float*)params_t[idx], sd, td, sx, tx, A, T, B, adam, numel);
         const int j = (int)(jobs.size() / jb) - 1;
         const long nb = A ? (long)(A / 64) * (B / 64) * T : (long)((numel + opt_chunk() - 1) / opt_chunk());
-        for (long k = 0; k < nb; ++k) { bj.push_back(j); bs.push_back((int)k); }
+        const bool e = A && early[idx] && adam;
+        for (long k = 0; k < nb; ++k) { (e ? bj : bj_late).push_back(j); (e ? bs : bs_late).push_back((int)k); }
         covered[idx] = 1;
         return UDAPOSE_OK;
     };
@@ -1257,6 +1278,9 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
     for (int i = 0; i < n.n_params; ++i)
         if (!covered[i]) CK(push(i, nullptr, nullptr, nullptr, nullptr, 0, 0, 0));                   // BN vectors, head bias, backbone.fc
     Net::UpdTab& u = n.upd;
+    u.n_early = (int)bj.size();
+    bj.insert(bj.end(), bj_late.begin(), bj_late.end());
+    bs.insert(bs.end(), bs_late.begin(), bs_late.end());
     if (u.jobs) { (void)hipFree(u.jobs); (void)hipFree(u.blk_job); (void)hipFree(u.blk_sub); u.jobs = nullptr; }
     if (hipMalloc(&u.jobs, jobs.size()) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     if (hipMalloc((void**)&u.blk_job, bj.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
@@ -1271,14 +1295,20 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
 
 int net_fused_update(void* hs, void* ht, hipStream_t s, void* const* params_s, void* const* grads, void* const* h_m, void* const* params_t,
                      void* wpack_s_, void* wpack_t_, float lr, float beta1, float beta2, float eps, float wd, int step, float gscale,
-                     float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta) {
+                     float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta, int part) {
     Net& n = *(Net*)hs;
     const Net& nt = *(const Net*)ht;
     DbgSyncScope dbg(n.policy.debug_sync);
     const Net::UpdTab& u = n.upd;
+    if (part < 0 || part > 2) return UDAPOSE_ERR_ARG;
     if (!u.jobs || u.k_ps != params_s[0] || u.k_pt != params_t[0] || u.k_g != grads[0] || u.k_m != h_m[0] || u.k_ws != wpack_s_ || u.k_wt != wpack_t_)
         return UDAPOSE_ERR_NOT_PREPARED;
-    CK(opt_tail(s, u.jobs, u.blk_job, u.blk_sub, u.nblocks, lr, beta1, beta2, eps, wd, step, gscale, dev_state, alpha, oma, do_adam, grad2_delta));
+    // part 0: the whole sweep.  part 1: the EARLY blocks (conv weights whose gradients the first weight-gradient phase completed), with the step
+    // counter's tick; part 2: the rest, no tick, then the two odd packs.  Parts 1 + 2 = part 0, block for block (the same kernel on disjoint blocks).
+    const int b0 = part == 2 ? u.n_early : 0, b1 = part == 1 ? u.n_early : u.nblocks;
+    CK(opt_tail(s, u.jobs, u.blk_job + b0, u.blk_sub + b0, b1 - b0, lr, beta1, beta2, eps, wd, step, gscale, dev_state, alpha, oma, do_adam, grad2_delta,
+                part != 2));
+    if (part == 1) return UDAPOSE_OK;
     // the two packs that are not a cast or a per-tap transpose of a whole tensor: the stem's 3 -> 8 channel gather (both
     // networks) and the head's zero-padded dgrad pack (student)
     CK(pack_conv(s, n, n.stem, (const void* const*)params_s, (char*)wpack_s_, false));

@@ -266,13 +266,15 @@ void opt_tail_job_fill(void* dst, float* p, const float* g, float* m, float* v, 
     TailJob j{p, g, m, v, t, (elem_t*)sd, (elem_t*)td, (elem_t*)sx, (elem_t*)tx, A, T, B, adam, n};
     *(TailJob*)dst = j;
 }
+// tick: advance the device-side step counter / bias corrections in front of the sweep (once per optimizer step: a step whose sweep is
+// issued in two parts ticks with the first)
 int opt_tail(hipStream_t s, const void* d_jobs, const int* blk_job, const int* blk_sub, int nblocks, float lr, float beta1, float beta2, float eps,
-             float wd, int step, float gscale, float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta) {
-    if (nblocks <= 0) return UDAPOSE_OK;
+             float wd, int step, float gscale, float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta, int tick) {
     if (grad2_delta % 16) return UDAPOSE_ERR_ARG;
     double bc1 = 1.0, bc2 = 1.0;
-    if (dev_state) { if (do_adam) hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(1), 0, s, dev_state, beta1, beta2); }
+    if (dev_state) { if (do_adam && tick) hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(1), 0, s, dev_state, beta1, beta2); }
     else { bc1 = 1.0 - pow((double)beta1, (double)step); bc2 = 1.0 - pow((double)beta2, (double)step); }
+    if (nblocks <= 0) return UDAPOSE_OK;
     TailHyper h{lr, beta1, beta2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, alpha, oma, do_adam, grad2_delta};
     hipLaunchKernelGGL(opt_tail_k, dim3(nblocks), dim3(TPB), 0, s, (const TailJob*)d_jobs, blk_job, blk_sub, h, dev_state);
     return udapose_check_launch();

@@ -233,6 +233,11 @@ class MeanTeacherTrainer:
         self.single_graph = True            # one rank: the optimizer tail is captured into the step's graph (one launch per step)
         self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
+        # one rank, no loss scaling: the optimizer sweep's first part beside the weight gradients' second phase (_split_tail_ok).  OFF: measured
+        # +0.1 .. 0.2 ms per step (profiles/r5_ab_runs.txt section 5) - a weight-gradient launch fills every wave slot of the chip (4 work-groups x 4 waves
+        # at 128 registers per CU), so the sweep's waves only run where they displace it; bit-identical either way (tests/test_gpu_steps.py)
+        self.split_tail = False
+        self._early_tail = False
         # one rank: start the SOURCE-domain pass's gradient chain as soon as its own forward has finished (loss_s does not depend on the
         # teacher), beside the teacher's and the target-domain forwards; its weight gradients still go out with the other pass's at the
         # end.  Same gradients (the two passes own separate buffers; d(loss_s + lambda * loss_c) = d loss_s + lambda * d loss_c).
@@ -484,7 +489,21 @@ class MeanTeacherTrainer:
         student.split_backward = False
         if merge:
             student.merge_wgrad = False
-            student.finish_wgrad(getattr(self, "_wg_stream", None))
+            if self._split_tail_ok():
+                # Round 5: the serial end of the step - weight gradients, then the optimizer sweep - with the sweep's first part UNDER the weight
+                # gradients' second phase.  Phase 1 computes the gradients of 60 % of the parameters; their Adam + EMA + packs (HBM-bound,
+                # 6.9 TB/s) then run on a side stream beside phase 2 (LDS-fill-bound, ~1 TB/s of HBM); _update() issues the rest.
+                student.finish_wgrad(phase=1)
+                if getattr(self, "_tail_stream", None) is None or self._tail_stream.device != main.device:
+                    self._tail_stream = torch.cuda.Stream(device=main.device)
+                ts = self._tail_stream
+                ts.wait_stream(main)
+                with torch.cuda.stream(ts):
+                    self._early_tail = bool(self.stu_optimizer.fused_tail_step(student, self.teacher, self.tea_optimizer, part=1))
+                student.finish_wgrad(phase=2)
+                main.wait_stream(ts)
+            else:
+                student.finish_wgrad(getattr(self, "_wg_stream", None))
         if overlap:
             student.finish_grads(part=1)    # the suffix of both passes is final: sum it ...
             if not torch.cuda.is_current_stream_capturing() or getattr(self, "capture_comm", False):
@@ -502,6 +521,12 @@ class MeanTeacherTrainer:
         st = self._forward_part(x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea)
         return self._loss_backward_part(st, gather_activates(st["activates"]))
 
+    def _split_tail_ok(self):
+        """The optimizer sweep may start before the last weight gradients exist only when nothing has to look at ALL gradients first: one
+        rank (no all-reduce), no dynamic loss scaling (its found-inf check), the fused tail summing the two passes' buffers itself."""
+        return bool(self.split_tail and self._tail_sums_grads() and getattr(self.stu_optimizer, "_scaler", None) is None
+                    and hasattr(self.student, "can_phase_wgrad") and self.student.can_phase_wgrad())
+
     def _tail_sums_grads(self):
         return bool(self.fuse_tail and self.sum_grads_in_tail and not _dist_on() and hasattr(self.stu_optimizer, "fused_tail_step")
                     and hasattr(self.student, "pending_grad_sum"))
@@ -509,6 +534,10 @@ class MeanTeacherTrainer:
     def _update(self):
         # Adam, the EMA and the next forwards' weight packs of both networks in ONE sweep when the layout allows ...
         fuse = self.fuse_tail and hasattr(self.stu_optimizer, "fused_tail_step")
+        if getattr(self, "_early_tail", False):
+            self._early_tail = False
+            self.fused_last = bool(self.stu_optimizer.fused_tail_step(self.student, self.teacher, self.tea_optimizer, part=2))
+            return
         self.fused_last = bool(fuse and self.stu_optimizer.fused_tail_step(self.student, self.teacher, self.tea_optimizer))
         if not self.fused_last:
             if hasattr(self.student, "finish_grads"):

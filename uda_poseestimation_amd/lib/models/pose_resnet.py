@@ -527,11 +527,31 @@ class PoseResNet(nn.Module):
             if p.requires_grad and id(p) not in nograd:
                 p.grad = v
 
-    def finish_wgrad(self, wg_stream=None):
+    def can_phase_wgrad(self):
+        """True when the pending weight gradients are two unstaged passes of one plan: finish_wgrad(phase=1) / (phase=2) then issue the pair
+        launch in two phases (udapose_net_wgrad_pair_phase) with room for the early part of the optimizer sweep between them."""
+        pend = self._pending_wg
+        return len(pend) == 2 and pend[0][0] is pend[1][0] and pend[0][6] < 0 and pend[1][6] < 0
+
+    def finish_wgrad(self, wg_stream=None, phase=0):
         """Launch the grouped weight gradients of the backward passes that ran with merge_wgrad, on the current stream (the caller
         has made it wait for the streams those passes ran on): two pending passes of one plan go out as ONE launch per tile class.
         Staged plans (policy wgrad_overlap): every stage goes to `wg_stream` behind the event its gradient chain recorded, as a
-        residency-capped persistent grid that runs UNDER the rest of the chain; the current stream then waits for `wg_stream`."""
+        residency-capped persistent grid that runs UNDER the rest of the chain; the current stream then waits for `wg_stream`.
+        phase 1 / 2 (only when can_phase_wgrad()): the pair launch's two phases, see udapose_net_wgrad_pair_phase."""
+        if phase:
+            if not self.can_phase_wgrad():
+                raise RuntimeError("finish_wgrad(phase=...): needs two pending unstaged passes of one plan (can_phase_wgrad())")
+            (hd, actA, wsA, gA, bA, _, _), (_, actB, wsB, gB, bB, _, _) = self._pending_wg
+            check(hd.L.udapose_net_wgrad_pair_phase(hd.h, _hip.stream(), ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0, int(phase)),
+                  "net_wgrad_pair_phase")
+            if phase == 2:
+                cur = torch.cuda.current_stream()
+                for q in self._pending_wg:
+                    q[1].record_stream(cur)
+                    q[2].record_stream(cur)
+                self._pending_wg = []
+            return
         pend, self._pending_wg = self._pending_wg, []
         if not pend:
             return
