@@ -281,6 +281,8 @@ def main():
     ap.add_argument("--grad-comm", default=None, choices=["fp32", "bf16"], help="data parallel: wire format of the gradient buckets (bf16: one "
                     "rounding per contribution, all-to-all + fp32 accumulation on the shard's owner + all-gather: half the bytes per xGMI link)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--branch-graphs", action="store_true", help="tuning: the one-rank step as nine linear hipGraphs on three streams joined by events instead "
+                    "of ONE hipGraph with three branches (measured: no faster, and dependent on the stream -> hardware-queue lottery: profiles/r5_ab_runs.txt)")
     ap.add_argument("--no-capture-comm", action="store_true", help="data parallel: keep the collectives eager between four graphs instead of capturing "
                     "them into the step's one graph (round 5's default with RCCL)")
     ap.add_argument("--one-bucket", action="store_true", help="data parallel: the whole backward with one merged weight-gradient tail, then ONE "
@@ -419,7 +421,7 @@ def main():
         def build_graphed():
             return GraphedTrainStep(trainer, g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"],
                                     g["aug_param_tea"], split=(True if args.split_graphs else None),
-                                    capture_comm=(False if args.no_capture_comm else None))
+                                    capture_comm=(False if args.no_capture_comm else None), branch_graphs=bool(args.branch_graphs))
 
         if dp_auto and dist.is_initialized() and (world > 1 or force_dist):
             # the ONE scaling run the driver may get should not depend on a guess about xGMI: every form is captured and timed (5 steps between
@@ -595,7 +597,9 @@ def main():
                 else:
                     what = "3 hipGraphs around the two RCCL collectives"
             else:
-                what = "1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs"
+                what = ("linear hipGraphs on three streams (head | teacher forward | source forward | target forward | losses | two gradient chains | "
+                        "weight gradients + Adam + EMA + packs), joined by events" if getattr(graphed, "branch", False) else
+                        ("1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs"))
             launch_desc = (("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + what
                            + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)")
         res = {

@@ -92,7 +92,53 @@ def alone(stream, g, reps=30):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+# the same three chains as THREE BRANCHES OF ONE GRAPH (forked from / joined into the capture's origin stream: the product's form)
+def one_graph():
+    g = torch.cuda.CUDAGraph()
+    sides = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for net in nets:
+        net._capture_token = object()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        for i, (net, x) in enumerate(zip(nets, xs)):
+            bwd = mode == "fwdbwd" and i > 0
+            st = main if i == 0 else sides[i - 1]
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                if bwd:
+                    y = net(x); y.backward(torch.ones_like(y) * 1e-3)
+                else:
+                    with torch.no_grad():
+                        y = net(x)
+        for st in sides:
+            main.wait_stream(st)
+    for net in nets:
+        net._capture_token = None
+    return g
+
+
+def alone_g(g, reps=30):
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
 plain = [torch.cuda.Stream(device=dev) for _ in range(3)]
+# device spin-up: an idle MI355X needs seconds of load to reach its steady clocks (a cold first measurement reads 20-25 % slow)
+t_spin = time.perf_counter()
+while time.perf_counter() - t_spin < 6.0:
+    run(plain, reps=10)
+if "onegraph" in specs:
+    specs = [s_ for s_ in specs if s_ != "onegraph"]
+    g1 = one_graph()
+    for rnd in range(3):
+        print(f"{mode}: the three chains as three branches of ONE graph: {alone_g(g1):.3f} ms | as three separate graphs on three streams: {run(plain):.3f} ms", flush=True)
 print(f"{mode}: one chain alone on the chip: " + " ".join(f"{alone(plain[0], g):.2f}" for g in graphs) + " ms", flush=True)
 for rnd in range(2):
     for spec in specs:

@@ -154,6 +154,37 @@ class GradSync:
         self._tock(ev)
 
 
+def pick_concurrent_streams(device, n=3, candidates=10):
+    """`n` torch streams whose kernels demonstrably run side by side.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; the
+    package asks for 8) by a least-users rule that depends on every stream the process has created so far, and two streams on one queue
+    serialise (tools/probe_stream_pairs.py: with 4 queues a third of all pairs do).  So the choice is MEASURED: a short spin kernel on each
+    stream of a pair, started together - wall time ~T: concurrent, ~2T: same queue - over `candidates` fresh streams until `n` mutually
+    concurrent ones are found (falls back to the first `n` if there is no such set).  ~50 ms, once, at capture time."""
+    import itertools
+    import time
+    pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+    cycles = 400_000
+
+    def wall(ss):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for s_ in ss:
+            with torch.cuda.stream(s_):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    wall(pool[:1])
+    t1 = min(wall(pool[:1]) for _ in range(3))
+    ok = {}
+    for i, j in itertools.combinations(range(candidates), 2):
+        ok[(i, j)] = min(wall([pool[i], pool[j]]) for _ in range(2)) < 1.5 * t1
+    for comb in itertools.combinations(range(candidates), n):
+        if all(ok[p_] for p_ in itertools.combinations(comb, 2)):
+            return [pool[i] for i in comb], True
+    return pool[:n], False
+
+
 def gather_activates(act):
     """All ranks' [N_local, K] confidences -> flat global vector (for the global-batch k-th value, train_human.py:429)."""
     if not _dist_on():
@@ -604,7 +635,7 @@ class GraphedTrainStep:
     on the device from four uniform draws per sample (trainer.device_occlusion), inside the main graph."""
 
     def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None, metrics=True,
-                 capture_comm=None):
+                 capture_comm=None, branch_graphs=None):
         # metrics: the captured step also decodes y_s and computes PCK@0.05 against label_s on the device (the reference's per-iteration
         # `accuracy(y_s, label_s)`, train_human.py:443) and gathers the losses + PCK into ONE small device vector: step_async() reads
         # it back one step late through a pinned double buffer, so a loop that logs every iteration never drains the device
@@ -709,7 +740,18 @@ class GraphedTrainStep:
         self.g_lb2 = None
         # one rank, nothing eager between backward and the optimizer: the update is captured into the same graph (one launch per step)
         self.one_graph = (not self.split) and (self.capture_comm or not _dist_on()) and trainer.single_graph
-        if not self.split and self.capture_comm:
+        # branch_graphs (round 5, OFF): the one-rank step as nine linear graphs on three streams - head | teacher forward | source forward |
+        # target forward | metrics | loss section | the two gradient chains | weight gradients + optimizer tail - joined by events, instead
+        # of one graph with three branches.  Built to test whether hipGraph's own branch scheduling loses concurrency against plain
+        # streams: it does not (15.77-15.94 against 15.75-15.98 ms with three streams on distinct hardware queues; 29 ms with
+        # GPU_MAX_HW_QUEUES=8, where the host-side launches block: profiles/r5_ab_runs.txt section 6).  Kept as a measurement tool: every
+        # phase is its own graph, so tools/exp_branch_host.py reads the step's device timeline phase by phase.
+        branch_graphs = bool(branch_graphs)
+        self.branch = bool(branch_graphs) and (not self.split) and (not _dist_on())
+        if self.branch:
+            self.one_graph = True           # (no separate update graph: the tail is the last of the branch graphs)
+            self._capture_branches(trainer, st)
+        elif not self.split and self.capture_comm:
             try:
                 self._capture_one(trainer, st, mode)
             except Exception as e:      # (the backend refused the capture: fall back to eager collectives between four graphs)
@@ -724,7 +766,7 @@ class GraphedTrainStep:
                 self.g_fb = torch.cuda.CUDAGraph()
                 self.split = True
                 self.one_graph = False
-        if not self.split and self.capture_comm:
+        if self.branch or (not self.split and self.capture_comm):
             pass
         elif not self.split:
             if self.one_graph and self.metrics:
@@ -780,12 +822,140 @@ class GraphedTrainStep:
                 m.packs_refreshed(hd, bwd)
         torch.cuda.synchronize()
 
+    def _capture_branches(self, trainer, st):
+        """One linear graph per branch and phase; every graph has its private memory pool (the graphs of one phase replay concurrently),
+        and every tensor that crosses a graph boundary is kept referenced in self._keep (its address is what the consumers captured)."""
+        t = trainer
+        student, teacher = t.student, t.teacher
+        dev = st["x_s"].device
+        picked, self.streams_concurrent = pick_concurrent_streams(dev, 3)
+        S = self._bs = dict(zip(("main", "tea", "stu"), picked))
+        G = self._bg = {}
+        keep = self._keep = []
+        ev = self._bev = {k: torch.cuda.Event() for k in ("head", "tea", "tgt", "src", "met", "loss", "bwd_tgt")}
+
+        def cap(name, stream):
+            g = G[name] = torch.cuda.CUDAGraph()
+            return torch.cuda.graph(g, stream=stream, capture_error_mode="global")
+
+        student.train()
+        teacher.train()
+        occl = t._occl if t.occlude_rate > -1 else None
+        with cap("head", S["main"]):
+            self._thetas()
+            t.stu_optimizer.zero_grad()
+            student.prepare(st["x_s_in"])
+            with torch.no_grad():
+                teacher.prepare(st["x_t_tea_in"])
+        with cap("tea", S["tea"]):
+            with torch.no_grad():
+                y_t_tea = teacher(st["x_t_tea_in"])
+                recon = warp.warp_chain(y_t_tea, st["theta_tea"])
+                y_t_tea_recon = warp.mean_views([recon])
+        keep += [y_t_tea, recon, y_t_tea_recon]
+        with cap("src", S["main"]):
+            out_s, act_s, hd_s, ws_s = student._run_forward(st["x_s_in"], save=True)
+        keep += [out_s, act_s, ws_s]
+        with cap("tgt", S["stu"]):
+            x_t_stu = st["x_t_stu"]
+            if occl is not None:
+                with torch.no_grad():
+                    x_t_stu, t.occluded = warp.occlude_keypoints_device(x_t_stu, y_t_tea_recon, st["theta_stu"], occl[1], occl[2], t.ratio, t.image_px,
+                                                                        t.occlude_rate, t.occlude_thresh, t.occlude_size)
+            out_t, act_t, hd_t, ws_t = student._run_forward(x_t_stu, save=True, defer_bn=True)
+        keep += [x_t_stu, out_t, act_t, ws_t]
+        if self.metrics:
+            with cap("met", S["tea"]):
+                acc, avg_cnt, _ = kd.accuracy_device(out_s, st["label_s"])
+            keep += [acc, avg_cnt]
+        with cap("loss", S["main"]):
+            student.apply_deferred_bn()         # (x_s first, then x_t_stu: the reference's call order, train_human.py:414-417)
+            with torch.no_grad():
+                activates = mt.heatmap_activations(y_t_tea_recon)
+            # autograd is cut at the student's outputs: the loss section's own backward ends in dL/dy_s and dL/dy_t_stu, and the two
+            # gradient chains are enqueued from those (PoseResNet._run_backward: what _PoseNetFn.backward does)
+            y_s = out_s.detach().requires_grad_(True)
+            y_t = out_t.detach().requires_grad_(True)
+            y_t_stu_recon = warp.warp_chain(y_t, st["theta_stu"])
+            loss_s = t.criterion(y_s, st["label_s"], st["weight_s"])
+            t._check_scaler()
+            with torch.no_grad():
+                tea_mask, _, _ = mt.confidence_mask(y_t_tea_recon, t.mask_ratio, None, None, activates)
+                y_t_tea_rect = mt.rectify(y_t_tea_recon, sigma=t.sigma)
+            loss_c = t.con_criterion(y_t_stu_recon, y_t_tea_rect, tea_mask=tea_mask)
+            loss_all = loss_s + t.lambda_c * loss_c
+            t.stu_optimizer.scale_loss(loss_all).backward()
+            dy_s, dy_t = y_s.grad, y_t.grad
+        keep += [activates, y_s, y_t, y_t_stu_recon, loss_s, loss_c, loss_all, tea_mask, y_t_tea_rect, dy_s, dy_t]
+        student.split_backward, student.merge_wgrad = False, True
+        with cap("bwd_src", S["main"]):
+            student._run_backward(dy_s, act_s, hd_s, ws_s)
+        with cap("bwd_tgt", S["stu"]):
+            student._run_backward(dy_t, act_t, hd_t, ws_t)
+        student.merge_wgrad = False
+        self.out = {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": out_s, "tea_mask": tea_mask}
+        with cap("tail", S["main"]):
+            student.finish_wgrad(getattr(t, "_wg_stream", None))
+            student.finish_grads(defer=t._tail_sums_grads())
+            t._update()
+            if self.metrics:
+                parts = [self.out["loss_all"].reshape(1), self.out["loss_s"].reshape(1), self.out["loss_c"].reshape(1), avg_cnt.reshape(2), acc.reshape(-1)]
+                self._mk = int(acc.numel())
+                self._mvec = torch.cat([p_.float() for p_ in parts])
+                self.out["acc_s"], self.out["acc_avg_cnt"] = acc, avg_cnt
+        self._occl_branch = occl is not None
+
+    def _replay_branches(self):
+        S, G, ev = self._bs, self._bg, self._bev
+        cur = torch.cuda.current_stream()
+        main, tea, stu = S["main"], S["tea"], S["stu"]
+        main.wait_stream(cur)
+        with torch.cuda.stream(main):
+            G["head"].replay()
+            ev["head"].record(main)
+        tea.wait_event(ev["head"])
+        with torch.cuda.stream(tea):
+            G["tea"].replay()
+            ev["tea"].record(tea)
+        stu.wait_event(ev["head"])
+        if self._occl_branch:
+            stu.wait_event(ev["tea"])               # the occlusion reads the teacher's re-warped heat-maps
+        with torch.cuda.stream(stu):
+            G["tgt"].replay()
+            ev["tgt"].record(stu)
+        with torch.cuda.stream(main):
+            G["src"].replay()
+            ev["src"].record(main)
+        if "met" in G:
+            tea.wait_event(ev["src"])
+            with torch.cuda.stream(tea):
+                G["met"].replay()
+                ev["met"].record(tea)
+        main.wait_event(ev["tea"])
+        main.wait_event(ev["tgt"])
+        with torch.cuda.stream(main):
+            G["loss"].replay()
+            ev["loss"].record(main)
+        stu.wait_event(ev["loss"])
+        with torch.cuda.stream(stu):
+            G["bwd_tgt"].replay()
+            ev["bwd_tgt"].record(stu)
+        with torch.cuda.stream(main):
+            G["bwd_src"].replay()
+        main.wait_event(ev["bwd_tgt"])
+        if "met" in G:
+            main.wait_event(ev["met"])
+        with torch.cuda.stream(main):
+            G["tail"].replay()
+        cur.wait_stream(main)
+
     def release(self):
         """Destroy the captured graphs.  With capture_comm the graphs hold RCCL launches, and RCCL's communicator teardown waits for every
         such graph to be gone: call this (or drop every reference to the object) BEFORE torch.distributed.destroy_process_group(), which
         otherwise never returns (measured on RCCL 2.26 / ROCm 7.0)."""
         self.g_fb = self.g_lb = self.g_lb2 = self.g_up = None
         self.g_style = {}
+        self._bg = {}
         import gc
         gc.collect()
         torch.cuda.synchronize()
@@ -1042,7 +1212,10 @@ class GraphedTrainStep:
         seg("start")
         if self.one_graph:
             self.t.stu_optimizer.sync_hyper()    # lr scheduler / loss scale -> device state read by the captured sweep
-        self.g_fb.replay()
+        if self.branch:
+            self._replay_branches()
+        else:
+            self.g_fb.replay()
         seg("forwards")
         if self.split:
             g = gather_activates(self.fwd_state["activates"])
