@@ -18,3 +18,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _dev_switches():
+    """Bisecting aid (dev only): UDAPOSE_TEST_ARENA_TEACHER=1 runs the whole session with the bump-allocated arena for no-grad forwards
+    instead of the forward-only plans (round 5's default)."""
+    if os.environ.get("UDAPOSE_TEST_ARENA_TEACHER") == "1":
+        from uda_poseestimation_amd.lib.models.pose_resnet import PoseResNet
+        PoseResNet.fwd_only_plans = False
+    yield
