@@ -432,7 +432,19 @@ def main():
             timings, built = {}, {}
             for name, overlap, wire in forms:
                 trainer.overlap_allreduce, trainer.sync.comm_dtype = overlap, wire
-                gr = build_graphed()
+                gr, err = None, None
+                try:
+                    gr = build_graphed()
+                except Exception as e:          # (a form this stack cannot build on some rank is dropped on all of them)
+                    err = e
+                okt = torch.tensor([0.0 if gr is None else 1.0], device=dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if float(okt.item()) < 1.0:
+                    if rank == 0:
+                        print(f"dp form {name}: not available ({type(err).__name__ if err else 'another rank failed'}: {err})", file=sys.stderr, flush=True)
+                    timings[name] = None
+                    gr = None
+                    continue
                 for _ in range(2):
                     gr.step(None, None, None, None, None, g["aug_param_stu"], g["aug_param_tea"])
                 dist.barrier(); torch.cuda.synchronize()
@@ -444,7 +456,10 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 timings[name] = round(float(tt.item()) / 5 * 1e3, 3)
                 built[name] = gr
-            pick = torch.tensor([min(range(len(forms)), key=lambda i: timings[forms[i][0]])], device=dev, dtype=torch.int64)
+            if not built:
+                raise SystemExit("bench.py: no data-parallel form could be built")
+            pick = torch.tensor([min((i for i in range(len(forms)) if timings[forms[i][0]] is not None), key=lambda i: timings[forms[i][0]])],
+                                device=dev, dtype=torch.int64)
             dist.broadcast(pick, 0)
             name, overlap, wire = forms[int(pick.item())]
             trainer.overlap_allreduce, trainer.sync.comm_dtype = overlap, wire
@@ -664,12 +679,12 @@ def main():
                 print(f"other_configs: {tag} ...", file=sys.stderr, flush=True)
                 oc[tag] = other_config_rate(args.arch, dev, N, K, S, sigma, dt_, pr_)
             # (`cited`: the parity figures are quoted from the named tests' measurements, not computed by this run)
-            oc["fp16"]["heatmap_error_vs_fp32_oracle"] = {"cited": True, "text": "trained PoseResNet-101, train-mode BN, 256x256: max|dy| 8.6e-4 (bar 1e-3), arg-max identical 32/32 "
+            oc["fp16"]["heatmap_error_vs_fp32_oracle"] = {"cited": True, "text": "trained PoseResNet-101, train-mode BN, 256x256: max|dy| 8.6e-4 .. 1.13e-3 over device-trained instances (AT the 1e-3 bar, not under it with margin), arg-max identical 32/32 "
                                                           "(tests/test_gpu_trained.py::test_trained_like_forward_parity_all_precisions)"}
             oc["reference_mix"]["heatmap_error_vs_fp32_oracle"] = {"cited": True, "text": "teacher (f16x2) 5.5e-7 on the trained network, 3.6e-5 at the reference initialisation; "
-                                                                   "student (fp16) 8.6e-4; arg-max identical 32/32 (same test; tests/test_gpu_f16x2.py)"}
+                                                                   "student (fp16) 8.6e-4 .. 1.13e-3; arg-max identical 32/32 (same test; tests/test_gpu_f16x2.py)"}
             oc["note"] = ("the headline (bf16, BASELINE.json configs[1]) is at 5.6e-3 = 0.6 % of max|y| from the fp32 oracle on the same trained network "
-                          "(arg-max identical 32/32; cited from tests/test_gpu_trained.py): the configurations that meet the ABSOLUTE 1e-3 bar are fp16 and reference_mix")
+                          "(arg-max identical 32/32; cited from tests/test_gpu_trained.py): fp16 sits AT the absolute 1e-3 bar (0.86-1.13e-3), the reference mix's fp32-grade teacher is under it by three orders of magnitude")
             # BASELINE.json's other single-GPU configurations (the ones the reference actually trains: train_human.py:345-358,
             # train_animal.py:330-483), same harness: 20 graph replays each
             for tag, kw in (("configs[2]_bf16_style", dict(dtype="bf16", precision=None, config2=True)),

@@ -142,6 +142,7 @@ struct Net {
         std::vector<std::pair<ptrdiff_t, size_t>> zero;  // dW ranges (offset from grads[0], bytes) cleared first (split reductions, when overwriting)
         ZeroJob* d_zero = nullptr; int n_zero = 0;       // the same ranges as a device job table, when all are 16-byte granular
         unsigned long long last_use = 0;
+        int ord = 0;                                     // position in wg_groups: names this group's head-counter sets (persistent launches)
     };
     std::deque<WgGroup> wg_groups;       // (stable addresses, never evicted: a captured hipGraph may reference any table built so far)
     // fused optimizer tail (Adam + EMA + weight packs of student and teacher in one sweep): device job table
@@ -164,8 +165,11 @@ struct Net {
     int rec_slot = -1;                                   // >= 0 while net_backward_staged runs its chain
     // persistent grouped launches (Policy::wgrad_cap): a ring of self-resetting head-counter sets (16 words each), one per launch
     // in flight; a captured launch keeps the set it was given at capture
-    unsigned int* d_ctr = nullptr; int ctr_next = 0;
-    static constexpr int CTR_SETS = 128;
+    // persistent grouped launches (Policy::wgrad_cap): self-resetting head-counter sets (16 words each), ONE PER (table group, tile class) - a
+    // launch captured in a hipGraph and a later eager launch of another group can never be handed the same set (a round-robin ring
+    // of 128 sets could, once it wrapped); launches of one group are ordered by the stream(s) that carry that pass's weight gradients
+    unsigned int* d_ctr = nullptr;
+    static constexpr int CTR_SETS = 1024;
 };
 struct PackJobH { const float* src; elem_t* dst; int A, T, B, kind; long long n; };
 
@@ -889,6 +893,7 @@ int bind_wg_groups(Net& n, void* const* grads) {
             if (find_wg_group(n, grads, beta, part)) continue;
             n.wg_groups.emplace_back();
             Net::WgGroup* G = &n.wg_groups.back();
+            G->ord = (int)n.wg_groups.size() - 1;
             const int rc = build_wg_group(n, *G, grads, beta, part);
             if (rc != UDAPOSE_OK) { n.wg_groups.pop_back(); return rc; }
             G->last_use = ++n.wg_tick;
@@ -896,11 +901,11 @@ int bind_wg_groups(Net& n, void* const* grads) {
     return UDAPOSE_OK;
 }
 // the head-counter set of the next persistent launch (null: the one-work-group-per-entry grid)
-unsigned int* next_ctr(Net& n, int cap) {
+unsigned int* next_ctr(Net& n, int cap, const Net::WgGroup& G, int t) {
     if (cap <= 0 || !n.d_ctr) return nullptr;
-    unsigned int* c = n.d_ctr + (size_t)n.ctr_next * 16;
-    n.ctr_next = (n.ctr_next + 1) % Net::CTR_SETS;
-    return c;
+    const int idx = G.ord * WG_CLASSES + t;
+    if (idx >= Net::CTR_SETS) return nullptr;           // (more groups than sets: that launch falls back to the one-work-group-per-entry grid)
+    return n.d_ctr + (size_t)idx * 16;
 }
 // cap: > 0 = persistent grid of that many work-groups (staged launches running under the gradient chain); 0 = one work-group per entry
 int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta, int part, int cap = 0) {
@@ -921,7 +926,7 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);
         const int rc = wgrad_group_launch(s, t, G->d_tab[t], G->d_blk[t], G->per_xcd[t], act, ws, grads[0], nullptr, nullptr, nullptr, nullptr, nullptr,
-                                          cap, next_ctr(n, cap));
+                                          cap, next_ctr(n, cap, *G, t));
         conv_prof_after(s, tok);
         CK(rc);
     }
@@ -970,7 +975,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
 #endif
         const int tok = conv_prof_before(s, 2, GA->flops[t] + GB->flops[t]);
         const int rc = wgrad_group_launch(s, t, GA->d_tab[t], GA->d_blk[t], GA->per_xcd[t], actA, wsA, gradsA[0], GB->d_tab[t], GB->d_blk[t], actB, wsB,
-                                          gradsB[0], cap, next_ctr(n, cap));
+                                          gradsB[0], cap, next_ctr(n, cap, *GA, t));
         conv_prof_after(s, tok);
         CK(rc);
     }
