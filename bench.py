@@ -649,7 +649,7 @@ def main():
                          "bound_note": "priced against the dense MFMA peak as SURVEY.md 8(d) prescribes for the convolutions (>99 % of the FLOPs); the MEASURED "
                                        "limiter of these launches is neither roof: per-CU L2->LDS operand fill (137-146 GB/s per CU, shared by the step's three "
                                        "streams) and launch-chain latency (MFMA pipe 4-22 % busy, 44-80 % of wave cycles in s_waitcnt / s_barrier: "
-                                       "profiles/r4_pmc_sq_by_shape.txt, r4_probes.txt); hbm_frac is the same launches priced against HBM",
+                                       "profiles/r5_pmc_sq_by_shape.txt, r4_probes.txt, r5_ab_runs.txt); hbm_frac is the same launches priced against HBM",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic_per_igemm_launch(),
                          "traffic_note": "HBM bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
