@@ -155,8 +155,8 @@ class GradSync:
 
 
 def pick_concurrent_streams(device, n=3, candidates=10):
-    """`n` torch streams whose kernels demonstrably run side by side.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; the
-    package asks for 8) by a least-users rule that depends on every stream the process has created so far, and two streams on one queue
+    """`n` torch streams whose kernels demonstrably run side by side.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+    by a least-users rule that depends on every stream the process has created so far, and two streams on one queue
     serialise (tools/probe_stream_pairs.py: with 4 queues a third of all pairs do).  So the choice is MEASURED: a short spin kernel on each
     stream of a pair, started together - wall time ~T: concurrent, ~2T: same queue - over `candidates` fresh streams until `n` mutually
     concurrent ones are found (falls back to the first `n` if there is no such set).  ~50 ms, once, at capture time."""
