@@ -91,6 +91,10 @@ typedef struct {
                            * shift, the residual and the ReLU in the convolution's epilogue: no BN-apply launch, no pre-BN tensor; 0: conv + apply */
     int bn_xcd_rows;      /* 1 (default): the BatchNorm apply kernels give XCD k the k-th eighth of the pixel rows - what the implicit GEMMs' work-groups on
                            * XCD k wrote and will read - so activations cross the conv <-> BatchNorm kernel boundaries through one L2; 0: interleaved */
+    int wgrad_merge;      /* 1: the pair launch (udapose_net_wgrad_pair) reduces BOTH passes' pixels inside one work-group per (layer, tile, split) - pass A's
+                           * stages, then pass B's, one accumulator tile, one epilogue - into pass A's gradient tensors; pass B's buffer keeps only what its
+                           * gradient chain wrote (BatchNorm / bias gradients).  Half the output tiles, epilogues and split atomics (round 5; 0 = default) */
+    int pad1;
     int igemm_ns3_k;      /* 64x64 implicit-GEMM tiles take the 3-stage LDS ring from this reduction length on (K = taps x Ci), the 2-stage ring
                            * below it; 0 = the default, 2048 */
     void* timeline;

@@ -55,6 +55,8 @@ struct Policy {
                                 // rows, the rows the implicit GEMMs' work-groups on XCD k produce and consume (each XCD owns a contiguous range of
                                 // m-tiles there), so activations cross the conv <-> BatchNorm kernel boundaries through that XCD's L2
                                 // (tools/probe/l2_handoff.hip: 17.9 against 6.7 TB/s); bit-identical results, -0.06..-0.15 ms per step (r4_ab_runs.txt)
+    int wgrad_merge = 0;        // pair launch: one reduction over both passes' pixels per (layer, tile, split) unit (udapose.h)
+    int pad1 = 0;
     int igemm_ns3_k = 0;        // 64x64 igemm tiles: 3-stage ring from this K on, 2-stage below (0 = 2048)
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
@@ -119,7 +121,7 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr,
                        const void* x_base2 = nullptr, const void* dy_base2 = nullptr, void* dw_base2 = nullptr, int cap = 0,
-                       unsigned int* ctr = nullptr);   // cap > 0 (with 9 zeroed counter words `ctr`): persistent grid of `cap` work-groups
+                       unsigned int* ctr = nullptr, int merge = 0);   // cap > 0 (with 9 zeroed counter words `ctr`): persistent grid of `cap` work-groups
 
 struct ConvEpilogue {
     const elem_t* res = nullptr;

@@ -170,6 +170,10 @@ struct Net {
     // of 128 sets could, once it wrapped); launches of one group are ordered by the stream(s) that carry that pass's weight gradients
     unsigned int* d_ctr = nullptr;
     static constexpr int CTR_SETS = 1024;
+    // gradient placements (grads[0]) that have received convolution-weight gradients from a grouped launch: the merged pair launch
+    // (Policy::wgrad_merge) leaves pass B's buffer untouched and relies on its convolution-weight ranges being zero - it is only taken
+    // while pass B's placement has never been written by an unmerged launch
+    std::vector<const void*> wg_written;
 };
 struct PackJobH { const float* src; elem_t* dst; int A, T, B, kind; long long n; };
 
@@ -911,6 +915,7 @@ unsigned int* next_ctr(Net& n, int cap, const Net::WgGroup& G, int t) {
 int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta, int part, int cap = 0) {
     Net::WgGroup* G = find_wg_group(n, grads, beta, part);
     if (!G) return UDAPOSE_ERR_NOT_PREPARED;
+    if (std::find(n.wg_written.begin(), n.wg_written.end(), (const void*)grads[0]) == n.wg_written.end()) n.wg_written.push_back(grads[0]);
     const bool with_stem = part_sel(n, part).stem && n.policy.wgrad_group_stem;
     G->last_use = ++n.wg_tick;
     if (G->d_zero) {
@@ -958,8 +963,15 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     const ConvGeom& sg = n.stem.g;
     const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
     struct { Net::WgGroup* G; char* ws; void* const* grads; } side[2] = {{GA, wsA, gradsA}, {GB, wsB, gradsB}};
+    // merged pair launch (Policy::wgrad_merge): one unit per table entry reduces BOTH passes' pixels into pass A's gradient tensors; pass B's
+    // buffer receives no convolution-weight gradient from this call (its BatchNorm / bias gradients were written by its gradient chain)
+    auto written = [&](const void* g0) { return std::find(n.wg_written.begin(), n.wg_written.end(), g0) != n.wg_written.end(); };
+    const bool merge = n.policy.wgrad_merge && betaA == betaB && cap == 0 && phase == 0 && gradsA[0] != gradsB[0] && !written(gradsB[0]);
+    if (!written(gradsA[0])) n.wg_written.push_back(gradsA[0]);
+    if (!merge && !written(gradsB[0])) n.wg_written.push_back(gradsB[0]);
     if (phase != 2)
     for (auto& sd : side) {
+        if (merge && &sd == &side[1]) break;
         sd.G->last_use = ++n.wg_tick;
         if (sd.G->d_zero) CK(pw_zero_multi(s, sd.G->d_zero, sd.G->n_zero, sd.grads[0]));
         else
@@ -975,13 +987,13 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
 #endif
         const int tok = conv_prof_before(s, 2, GA->flops[t] + GB->flops[t]);
         const int rc = wgrad_group_launch(s, t, GA->d_tab[t], GA->d_blk[t], GA->per_xcd[t], actA, wsA, gradsA[0], GB->d_tab[t], GB->d_blk[t], actB, wsB,
-                                          gradsB[0], cap, next_ctr(n, cap, *GA, t));
+                                          gradsB[0], cap, next_ctr(n, cap, *GA, t), merge ? 1 : 0);
         conv_prof_after(s, tok);
         CK(rc);
     }
     if (with_stem && phase != 1) {
         const float betas[2] = {betaA, betaB};
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < (merge ? 1 : 2); ++k)
             CK(pw_unpack_strided(s, (const float*)(side[k].ws + n.ws_dwtmp), (float*)side[k].grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
                                  (long)sg.KH * sg.KW * 3, (long)sg.KW * 3, 3, 1, betas[k]));
     }

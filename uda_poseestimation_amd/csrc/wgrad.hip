@@ -232,9 +232,12 @@ struct WdCfg {
 };
 
 // One work-group: tile bx of dW tap `by`, pixel split bz of problem p.
+// (x_base2 / dy_base2 != 0, round 5: MERGED pair launch - the unit reduces pass A's stages and then pass B's into one accumulator tile and
+//  writes pass A's gradient: stage index st >= nsteps addresses the second pass's arenas)
 template <int RT, int CT, int WR, int WC, int NS, int PX = 64, bool FAST = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
-                                               const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
+                                               const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0,
+                                               const uintptr_t x_base2 = 0, const uintptr_t dy_base2 = 0) {
     // scalar copies of the fields used below (gp may live in global memory: read it once, up front, into SGPRs)
     struct {
         const elem_t* dy; const elem_t* x; float* dw; const IgTap* taps;
@@ -267,7 +270,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     const int ms0 = bz * per;
     int ms1 = ms0 + per;
     if (ms1 > ms_total) ms1 = ms_total;
-    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const int nsteps1 = ms1 > ms0 ? ms1 - ms0 : 0;
+    const bool merged = dy_base2 != 0;
+    const int nsteps = merged ? 2 * nsteps1 : nsteps1;
+    const elem_t* const dyA = p.dy; const elem_t* const xA = p.x;
+    const elem_t* const dyB = (const elem_t*)((uintptr_t)gp.dy + dy_base2); const elem_t* const xB = (const elem_t*)((uintptr_t)gp.x + x_base2);
     const char* zsrc = (const char*)g_wzero16;
 
     // Address generation is the issue-slot hog of this loop (measured 24 VALU instructions per MFMA when every row was
@@ -290,7 +297,9 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
     const int lgw = 31 - __builtin_clz((unsigned)(p.Wi > 0 ? p.Wi : 1));
     auto issue_stage = [&](int st, int buf) {
-        const int mb = (ms0 + st) * PX;
+        const bool second = st >= nsteps1;
+        const int mb = (ms0 + (second ? st - nsteps1 : st)) * PX;
+        p.dy = second ? dyB : dyA; p.x = second ? xB : xA;
         char* P = smem + buf * C::STAGE1;
         char* Q = P + C::P_BYTES;
         if constexpr (FAST) {
@@ -452,7 +461,8 @@ template <int N, typename F> __device__ __forceinline__ void w_static_for(F&& f)
 // calling kernel instantiates its own copy)
 template <int RT, int CT, int WR, int WC, int NS, int PX, int TAG = 0>
 __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
-                                                 const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
+                                                 const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0,
+                                                 const uintptr_t x_base2 = 0, const uintptr_t dy_base2 = 0) {
     struct {
         const elem_t* dy; const elem_t* x; float* dw; const IgTap* taps;
         int Hi, Wi, Ci, Co, M, wtaps, flags, ksplit, c_tiles, rows_valid;
@@ -481,13 +491,17 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
     const int ms0 = bz * per;
     int ms1 = ms0 + per;
     if (ms1 > ms_total) ms1 = ms_total;
-    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const int nsteps1 = ms1 > ms0 ? ms1 - ms0 : 0;
+    const bool merged = dy_base2 != 0;
+    const int nsteps = merged ? 2 * nsteps1 : nsteps1;
     const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
     const int lgw = 31 - __builtin_clz((unsigned)p.Wi);
     // raw buffers over the two tensors; the x buffer starts at the tap's pixel offset (possibly in front of the tensor: every pixel
     // that would be read from outside the tensor is a tap outside the image and gets the out-of-range offset instead)
-    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Co * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (long long)toff * p.Ci * 2), 0, p.M * p.Ci * 2, 0x00020000);
+    // (merged pair launch: ONE descriptor pair, re-pointed at the second pass's tensors when the stage index crosses nsteps1 - a second pair
+    //  held alive through the loop pushed the kernel's scalar registers into scratch: 2.43 -> 3.54 ms for the pair launch)
+    __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Co * 2, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (long long)toff * p.Ci * 2), 0, p.M * p.Ci * 2, 0x00020000);
     int vd[P_PW], vx[Q_PW], rowl[Q_PW];
 #pragma unroll
     for (int i = 0; i < P_PW; ++i) {
@@ -506,8 +520,14 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
 
     auto issue_stage = [&](int st, auto ub) __attribute__((always_inline)) {
         constexpr int UB = decltype(ub)::value;
-        const int mb = (ms0 + st) * PX;
-        const int sd = (ms0 + st) * sd_step, sx = (ms0 + st) * sx_step;      // scalar byte offsets of the stage
+        const bool second = st >= nsteps1;                                   // (wave-uniform)
+        const int ls = second ? st - nsteps1 : st;
+        if (merged && st == nsteps1) {
+            rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)((uintptr_t)gp.dy + dy_base2), 0, p.M * p.Co * 2, 0x00020000);
+            rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)((uintptr_t)gp.x + x_base2) + (long long)toff * p.Ci * 2), 0, p.M * p.Ci * 2, 0x00020000);
+        }
+        const int mb = (ms0 + ls) * PX;
+        const int sd = (ms0 + ls) * sd_step, sx = (ms0 + ls) * sx_step;      // scalar byte offsets of the stage
         char* P = smem + UB * C::STAGE1;
         char* Q = P + C::P_BYTES;
 #pragma unroll
@@ -634,7 +654,8 @@ struct Row3Cfg {
 };
 template <int NS>
 __device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
-                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
+                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0,
+                                                const uintptr_t x_base2 = 0, const uintptr_t dy_base2 = 0) {
     using R = Row3Cfg;
     constexpr int PX = R::PX, LPS = 5;                                 // 2 dy pieces + 3 x-window pieces per wave and stage
     struct {
@@ -653,7 +674,11 @@ __device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32
     const int ms0 = bz * per;
     int ms1 = ms0 + per;
     if (ms1 > ms_total) ms1 = ms_total;
-    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const int nsteps1 = ms1 > ms0 ? ms1 - ms0 : 0;
+    const bool merged = dy_base2 != 0;
+    const int nsteps = merged ? 2 * nsteps1 : nsteps1;
+    const elem_t* const dyA = p.dy; const elem_t* const xA = p.x;
+    const elem_t* const dyB = (const elem_t*)((uintptr_t)gp.dy + dy_base2); const elem_t* const xB = (const elem_t*)((uintptr_t)gp.x + x_base2);
     const char* zsrc = (const char*)g_wzero16;
     char* const dump = smem + NS * R::STAGE1;
     const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
@@ -662,7 +687,9 @@ __device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32
     const int xoff0 = dyk * p.Wi - 1;                                  // x pixel of window row 0 relative to the stage's first pixel
 
     auto issue_stage = [&](int st, int buf) {
-        const int mb = (ms0 + st) * PX;
+        const bool second = st >= nsteps1;
+        const int mb = (ms0 + (second ? st - nsteps1 : st)) * PX;
+        p.dy = second ? dyB : dyA; p.x = second ? xB : xA;
         char* P = smem + buf * R::STAGE1;
         char* Q = P + R::P_BYTES;
 #pragma unroll
@@ -842,12 +869,15 @@ template <int RT, int CT, int WR, int WC, int NS, int PX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 128 * 128 ? 2 : 4))) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
                                                               const uint32_t per_xcd, const char* x_base, const char* dy_base, char* dw_base,
                                                               const WgParams* __restrict__ tab2, const WgGroupBlk* __restrict__ blk2,
-                                                              const char* x_base2, const char* dy_base2, char* dw_base2) {
+                                                              const char* x_base2, const char* dy_base2, char* dw_base2, const int merge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // PAIR launch (tab2 != null): the groups of TWO passes of one plan (same table shape, their own arenas and gradient buffers) in one
-    // grid, interleaved slot by slot - the second pass's heavy work-groups start beside the first's instead of behind its tail
+    // grid, interleaved slot by slot - the second pass's heavy work-groups start beside the first's instead of behind its tail.
+    // merge (round 5): ONE unit per table entry reduces both passes' pixels (the bodies' x_base2 / dy_base2) into pass A's gradient
     uint32_t slot = blockIdx.x >> 3;
-    if (tab2) {
+    uintptr_t mx = 0, md = 0;
+    if (tab2 && merge) { mx = (uintptr_t)x_base2; md = (uintptr_t)dy_base2; }
+    else if (tab2) {
         if (slot & 1u) { tab = tab2; blk = blk2; x_base = x_base2; dy_base = dy_base2; dw_base = dw_base2; }
         slot >>= 1;
     }
@@ -858,15 +888,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 1
     const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
     const uint32_t by = bxy / gx, bx = bxy - by * gx;
     if constexpr (RT == 64 && CT == 64 && PX == 64) {
-        if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base); return; }
+        if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md); return; }
     }
     if constexpr (RT != CT) {
         // (the 256x128 class holds fast-geometry layers only: wgrad_group_plan)
-        wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+        wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
     } else {
-    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
-    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
-    else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
+    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
+    else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
     }
 }
 
@@ -958,7 +988,7 @@ int launch_wd_persist(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xc
 template <int RT, int CT, int WR, int WC, int NS, int PX>
 int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
                     hipStream_t stream, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr, const void* x_base2 = nullptr,
-                    const void* dy_base2 = nullptr, void* dw_base2 = nullptr) {
+                    const void* dy_base2 = nullptr, void* dw_base2 = nullptr, int merge = 0) {
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     constexpr int LDS = (RT == 64 && CT == 64 && PX == 64 && Row3Cfg::lds_bytes(NS) > C::LDS_BYTES) ? Row3Cfg::lds_bytes(NS) : C::LDS_BYTES;
     static std::atomic<unsigned long long> attr_done{0};
@@ -966,9 +996,9 @@ int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd,
     once_per_device(attr_done, attr_mu, [] {
         (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd * (d_tab2 ? 2 : 1)), dim3(256), LDS, stream, d_tab, d_blk,
+    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd * ((d_tab2 && !merge) ? 2 : 1)), dim3(256), LDS, stream, d_tab, d_blk,
                        (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base, d_tab2, d_blk2, (const char*)x_base2,
-                       (const char*)dy_base2, (char*)dw_base2);
+                       (const char*)dy_base2, (char*)dw_base2, merge);
     return udapose_check_launch();
 }
 
@@ -1119,7 +1149,7 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
 
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base, const WgParams* d_tab2, const WgGroupBlk* d_blk2, const void* x_base2,
-                       const void* dy_base2, void* dw_base2, int cap, unsigned int* ctr) {
+                       const void* dy_base2, void* dw_base2, int cap, unsigned int* ctr, int merge) {
     if (per_xcd <= 0) return UDAPOSE_OK;
     // 32-pixel stages for the 128x128 tile (32 KB of LDS, 128 VGPRs: four resident work-groups per CU instead of two with
     // 64-pixel stages) and a 2-stage ring of 64-pixel stages for the 64x64 tile (35 KB with the filter-row form's reserve: four per
@@ -1130,7 +1160,7 @@ int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, cons
         if (tile == 0) return launch_wd_persist<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
         return launch_wd_persist<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
     }
-    if (tile == 2) return launch_wd_group<256, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
-    if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
-    return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
+    if (tile == 2) return launch_wd_group<256, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, merge);
+    if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, merge);
+    return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, merge);
 }
