@@ -94,7 +94,9 @@ typedef struct {
     int wgrad_merge;      /* 1: the pair launch (udapose_net_wgrad_pair) reduces BOTH passes' pixels inside one work-group per (layer, tile, split) - pass A's
                            * stages, then pass B's, one accumulator tile, one epilogue - into pass A's gradient tensors; pass B's buffer keeps only what its
                            * gradient chain wrote (BatchNorm / bias gradients).  Half the output tiles, epilogues and split atomics (round 5; 0 = default) */
-    int pad1;
+    int bn_fin_apply;     /* 1: the BatchNorm layers that run a finalize launch and a streaming apply launch (layer1, layer2, the last deconvolutions) run
+                           * ONE launch instead: the first C/8 blocks finalize and raise a counter, the others - the apply - wait for it with their first loads
+                           * already in flight (in-grid hand-off, self-resetting counters); bit-identical results (round 5) */
     int igemm_ns3_k;      /* 64x64 implicit-GEMM tiles take the 3-stage LDS ring from this reduction length on (K = taps x Ci), the 2-stage ring
                            * below it; 0 = the default, 2048 */
     void* timeline;

@@ -33,6 +33,8 @@ def masked_stream(lo, hi):
 
 torch.manual_seed(0)
 nets = [models.pose_resnet101(16, pretrained_backbone=False).to(dev).train() for _ in range(3)]
+for net in nets:        # (POL="field=int,field=int": dispatch-policy overrides for all three chains)
+    net.policy.update({k_: int(v_) for k_, v_ in (a_.split("=") for a_ in os.environ.get("POL", "").split(",") if a_)})
 xs = [torch.randn(32, 3, 256, 256, device=dev) for _ in range(3)]
 graphs = []
 side = torch.cuda.Stream(device=dev)

@@ -21,7 +21,7 @@ class Policy(C.Structure):
     given fields overridden; tests force code paths with it, bench.py's tuning flags run A/B comparisons through it."""
     _fields_ = [(k, C.c_int) for k in ("igemm_tile", "igemm_h3", "igemm_lean", "igemm_short_lds", "igemm_tap0", "wgrad_tile", "wgrad_ksplit",
                                        "wgrad_fastgeo", "wgrad_group", "wgrad_stages", "wgrad_group_stem", "bn_bwd_fused", "bn_fwd_chunked",
-                                       "bn_bwd_chunked", "bn_bwd_pre_legacy", "igemm_wg_min", "wgrad_row3", "bn3_mask", "stem_fused", "debug_sync", "igemm_q_tile", "exp0", "wgrad_big", "igemm_big_min", "patch_conv", "wgrad_overlap", "wgrad_cap", "wgrad_cut_lo", "wgrad_cut_hi", "eval_fold", "bn_xcd_rows", "wgrad_merge", "pad1", "igemm_ns3_k")] + [("timeline", C.c_void_p)]
+                                       "bn_bwd_chunked", "bn_bwd_pre_legacy", "igemm_wg_min", "wgrad_row3", "bn3_mask", "stem_fused", "debug_sync", "igemm_q_tile", "exp0", "wgrad_big", "igemm_big_min", "patch_conv", "wgrad_overlap", "wgrad_cap", "wgrad_cut_lo", "wgrad_cut_hi", "eval_fold", "bn_xcd_rows", "wgrad_merge", "bn_fin_apply", "igemm_ns3_k")] + [("timeline", C.c_void_p)]
 
 
 def policy(**overrides):

@@ -56,7 +56,7 @@ struct Policy {
                                 // m-tiles there), so activations cross the conv <-> BatchNorm kernel boundaries through that XCD's L2
                                 // (tools/probe/l2_handoff.hip: 17.9 against 6.7 TB/s); bit-identical results, -0.06..-0.15 ms per step (r4_ab_runs.txt)
     int wgrad_merge = 0;        // pair launch: one reduction over both passes' pixels per (layer, tile, split) unit (udapose.h)
-    int pad1 = 0;
+    int bn_fin_apply = 0;       // BatchNorm finalize + streaming apply as one launch with an in-grid hand-off (pointwise.hip bn_fin_apply_k)
     int igemm_ns3_k = 0;        // 64x64 igemm tiles: 3-stage ring from this K on, 2-stage below (0 = 2048)
     int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line

@@ -23,6 +23,8 @@ int pw_unpack_strided(hipStream_t, const float*, float*, int, int, int, int, int
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
                    float*, float*, const float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
+int pw_bn_finalize_apply(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
+                         float*, float*, const elem_t*, const elem_t*, elem_t*, size_t, int, unsigned char*, int, unsigned int*);
 int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int, unsigned char*, int);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
@@ -124,6 +126,7 @@ struct Net {
     int fc_w_idx = -1, fc_b_idx = -1;
     size_t act_bytes = 0, wpack_bytes = 0, ws_bytes = 0;
     // workspace carve (bytes)
+    size_t ws_sync = 0;
     size_t ws_slab = 0, ws_slabf = 0, ws_coef = 0, ws_gbuf[6] = {0, 0, 0, 0, 0, 0}, ws_dyhead = 0, ws_dwtmp = 0, ws_headbwd = 0;
     size_t gbuf_bytes = 0;
     int Hout = 0, Wout = 0;
@@ -308,6 +311,7 @@ Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
     n.ws_slab = o; o = align_up(o + max_slab);
     n.ws_slabf = o; o = align_up(o + max_slab);     // partial sums written by dgrad epilogues (the downsample BN keeps ws_slab)
     n.ws_coef = o; o = align_up(o + (size_t)3 * 2048 * 4 + 2 * 2048 * 4);
+    n.ws_sync = o; o = align_up(o + 64);             // hand-off counters of the one-launch finalize + apply (zeroed at the head of every forward)
     if (n.fwd_only) {           // (no backward: statistics slabs and coefficient vectors only)
         n.ws_bytes = o;
         n.stem.g.pol = &n.policy;
@@ -427,6 +431,12 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }
+    if (training && !n.f32 && !no_apply && !pre_bias && n.policy.bn_fin_apply)
+        // (the layers the channel-chunked form above did not take: finalize + streaming apply as ONE launch with an in-grid hand-off)
+        return pw_bn_finalize_apply(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, upd ? (float*)buffers[b.rm_idx] : nullptr,
+                                    upd ? (float*)buffers[b.rv_idx] : nullptr, upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, scale, shift,
+                                    save, save + b.C, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, relu, mask,
+                                    n.policy.bn_xcd_rows >= 2, (unsigned int*)(ws + n.ws_sync));
 #ifdef UDAPOSE_TIMING_EXPERIMENTS
     if (training && (n.policy.exp0 & 32) && !n.f32) {
         // TIMING EXPERIMENT ONLY (wrong results): the finalize launch of the layers the one-launch form does not take, skipped (r4_ab_runs.txt)
@@ -603,6 +613,7 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
+    if (training && !n.f32 && n.policy.bn_fin_apply && hipMemsetAsync(ws + n.ws_sync, 0, 64, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     if (n.f32 == 2) CK(pw_nchw_f32_to_nhwc_split(s, x_nchw, act + n.x8_off, n.N, 3, n.H * n.W, 8));
     else if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (elem_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
