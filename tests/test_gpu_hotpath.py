@@ -172,6 +172,42 @@ def test_warp_chain_matches_torchvision_restatement():
     assert rel < 5e-2, rel
 
 
+def test_captured_loss_section_backward_is_right_on_every_replay():
+    """The consistency branch of the loss section - re-warp (autograd), ConsLoss, backward to dL/dy_t - captured alone into a small
+    hipGraph and replayed with eager device work between the replays: every replay equals the eager result.  (With the re-warp's
+    backward clearing its output by hipMemsetAsync the third and later replays ran the clear AFTER the scatter on ROCm 7.2:
+    tools/probe/graph_memset_order.py; the clears are kernels now, csrc/common.h pw_zero.)"""
+    from uda_poseestimation_amd import synthetic, warp
+    from uda_poseestimation_amd.lib.models.loss import ConsLoss
+    torch.manual_seed(0)
+    N, K, H = 4, 16, 32
+    out_t = (torch.rand(N, K, H, H) * 0.3).cuda()
+    tea = torch.rand(N, K, H, H).cuda()
+    mask = (torch.rand(N, K) > 0.5).cuda()
+    theta = warp.recon_thetas(synthetic.aug_params(N, np.random.RandomState(2)), N, 4.0, "cuda")
+    con = ConsLoss()
+
+    def section():
+        y_t = out_t.detach().requires_grad_(True)
+        (con(warp.warp_chain(y_t, theta), tea, tea_mask=mask) * 1.0).backward()
+        return y_t.grad
+
+    want = section().cpu()
+    assert want.abs().max() > 0
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream, capture_error_mode="global"):
+        d_t = section()
+    for rep in range(6):
+        with torch.cuda.stream(stream):
+            g.replay()
+        torch.cuda.synchronize()
+        busy = (d_t * 2).abs().max().item()         # (eager allocations and launches between the replays)
+        err = (d_t.cpu() - want).abs().max().item()
+        assert err <= 1e-9 + 1e-4 * want.abs().max().item(), (rep, err, busy)
+
+
 def test_style_net_matches_reference_golden(golden_dir):
     """A10-A13 against the reference's own outputs (tests/golden/style.npz): bf16 fast mode with its stated error, fp32 mode
     (the reference's precision) within 1e-3 * max, content / Gram style losses of the full forward, module-level helpers."""

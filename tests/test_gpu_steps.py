@@ -675,6 +675,47 @@ def test_staged_persistent_weight_gradients_are_bit_identical(pol):
     assert abs(losses[True] - losses[False]) <= 5e-2 * abs(losses[False])
 
 
+@pytest.mark.parametrize("occlusion", [False, True], ids=["plain", "device_occlusion"])
+def test_branch_graph_step_tracks_the_one_graph_step(occlusion):
+    """Round 5: GraphedTrainStep(branch_graphs=True) - the mean-teacher step (train_human.py:326-444) as nine linear hipGraphs on three streams joined
+    by events (autograd cut at the student's outputs; the loss section's own backward yields dL/dy_s and dL/dy_t_stu; each gradient chain is
+    PoseResNet._run_backward) - against the one-graph step from identical state: the same kernels on the same data in another launch structure.
+    After one replay every parameter agrees to what the atomically accumulated gradients (stem, re-warp backward) allow - Adam's first update is
+    lr * sign-like, so a last-bit gradient difference moves a weight by at most ~2 lr per step - and the losses of that replay agree to 1e-3;
+    several more replays stay finite and close.  With the device-side occlusion the target chain waits for the teacher's."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=15)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    res = {}
+    for branch in (False, True):
+        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=13).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=13).cuda()
+        extra = dict(occlude_rate=0.5, occlude_thresh=0.0, occlude_size=6, rng=np.random.RandomState(3)) if occlusion else {}
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4, **extra)
+        tr.device_occlusion = occlusion
+        gs = GraphedTrainStep(tr, *args, warmup=1, branch_graphs=branch)
+        assert gs.branch == branch
+        out = gs.step(*args)
+        torch.cuda.synchronize()
+        first = (float(out["loss_all"]), float(out["loss_s"]), float(out["loss_c"]))
+        p1 = [p.detach().clone() for p in stu.parameters()]
+        for _ in range(3):
+            out = gs.step(*args)
+        m = gs.step_async(*args)
+        m = gs.flush_metrics()
+        assert m is not None and np.isfinite(m["loss_all"]) and len(m["acc_per_keypoint"]) == K
+        res[branch] = (first, p1, float(out["loss_all"]), [p.detach().clone() for p in tea.parameters()])
+    for a, c in zip(res[False][0], res[True][0]):
+        assert abs(a - c) <= 1e-3 * abs(a) + 1e-9, (res[False][0], res[True][0])
+    for a, c in zip(res[False][1], res[True][1]):
+        assert (a - c).abs().max().item() <= 5e-3
+    assert np.isfinite(res[True][2]) and abs(res[True][2] - res[False][2]) <= 0.1 * abs(res[False][2])
+    for a, c in zip(res[False][3], res[True][3]):
+        assert torch.isfinite(c).all() and (a - c).abs().max().item() <= 5e-3
+
+
 def test_deferred_metric_readback_returns_the_synchronous_loops_values():
     """GraphedTrainStep.step_async: losses and device PCK of step i read one step late from a pinned double buffer equal, number for
     number, what a loop that synchronises and reads after every step sees (train_human.py:440-452 logs every iteration); the PCK in

@@ -173,7 +173,7 @@ int affine_warp_chain(hipStream_t s, const float* src, float* dst, const float* 
     if (blocks > 4096) blocks = 4096;
     const int cgroups = C >= 16 ? 16 : (C >= 4 ? 4 : 1);
     if (backward) {
-        if (hipMemsetAsync(dst, 0, (size_t)N * C * H * W * sizeof(float), s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (pw_zero(s, dst, (size_t)N * C * H * W * sizeof(float)) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
         hipLaunchKernelGGL(warp_chain_k<true>, dim3(blocks, cgroups), dim3(TPB), 0, s, src, dst, theta, N, C, H, W, nstage);
     } else {
         hipLaunchKernelGGL(warp_chain_k<false>, dim3(blocks, cgroups), dim3(TPB), 0, s, src, dst, theta, N, C, H, W, nstage);

@@ -117,6 +117,12 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 // one BN layer of the batched running-statistics update (pw_bn_running_update_multi)
 struct BnRunJob { size_t save_off; float* rm; float* rv; long long* nbt; int C, pad; };
 
+// Clears `bytes` (a multiple of 4, 4-byte aligned) at p with a KERNEL.  Every clear on a capturable path goes through this instead of
+// hipMemsetAsync: on ROCm 7.2 a hipGraph memset node can be replayed out of order with the kernel node that depends on it (from the
+// third replay of a small captured graph on, with the runtime's default DEBUG_CLR_GRAPH_PACKET_CAPTURE=1: the clear lands AFTER the
+// scatter that follows it; tools/probe/graph_memset_order.py reproduces it with torch alone).  pointwise.hip.
+int pw_zero(hipStream_t s, void* p, size_t bytes);
+
 // one range of the multi-range clear (pw_zero_multi): byte offset from a base pointer, length in 16-byte units
 struct ZeroJob { long long off; long long n16; };
 

@@ -613,7 +613,7 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
-    if (training && !n.f32 && n.policy.bn_fin_apply && hipMemsetAsync(ws + n.ws_sync, 0, 64, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (training && !n.f32 && n.policy.bn_fin_apply && pw_zero(s, ws + n.ws_sync, 64) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     if (n.f32 == 2) CK(pw_nchw_f32_to_nhwc_split(s, x_nchw, act + n.x8_off, n.N, 3, n.H * n.W, 8));
     else if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (elem_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
@@ -679,7 +679,7 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     if (c.bias_idx >= 0 && beta == 0.f) {
         // bias in front of a training-mode BatchNorm: its gradient is the pixel sum of dy = gamma * invstd * (g - mean(g) - xhat * mean(g xhat)),
         // which is zero identically (autograd returns rounding noise around 0 there)
-        if (hipMemsetAsync(grads[c.bias_idx], 0, (size_t)c.g.Co * sizeof(float), s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (pw_zero(s, grads[c.bias_idx], (size_t)c.g.Co * sizeof(float)) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     }
     if (c.g.smallc() && grouped_wgrad && n.policy.wgrad_group_stem) {
         // (the stem's weight gradient joins the grouped launch in its row-tap form, run_wg_group)
@@ -933,11 +933,11 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
         CK(pw_zero_multi(s, G->d_zero, G->n_zero, grads[0]));
     } else {
         for (auto& z : G->zero)
-            if (hipMemsetAsync((char*)grads[0] + z.first, 0, z.second, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+            if (pw_zero(s, (char*)grads[0] + z.first, z.second) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     }
     const ConvGeom& sg = n.stem.g;
     const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
-    if (with_stem && hipMemsetAsync(ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+    if (with_stem && pw_zero(s, ws + n.ws_dwtmp, stem_tmp_bytes) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!G->per_xcd[t]) continue;
         const int tok = conv_prof_before(s, 2, G->flops[t]);
@@ -987,8 +987,8 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
         if (sd.G->d_zero) CK(pw_zero_multi(s, sd.G->d_zero, sd.G->n_zero, sd.grads[0]));
         else
             for (auto& z : sd.G->zero)
-                if (hipMemsetAsync((char*)sd.grads[0] + z.first, 0, z.second, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        if (with_stem && hipMemsetAsync(sd.ws + n.ws_dwtmp, 0, stem_tmp_bytes, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+                if (pw_zero(s, (char*)sd.grads[0] + z.first, z.second) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
+        if (with_stem && pw_zero(s, sd.ws + n.ws_dwtmp, stem_tmp_bytes) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     }
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!GA->per_xcd[t]) continue;
@@ -1188,8 +1188,8 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         for (int i = 0; i < 6; ++i) if ((char*)dz == ws + pool.off[i]) n.split_dz_idx = i;      // (the same value on every pass)
         if (grouped && phase == 0) CK(run_wg_group(s, n, act, ws, grads, beta, 1));
         if (beta == 0.f) {       // backbone.fc lies in part 1's suffix of the gradient buffer (not part of forward: zero)
-            if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-            if (hipMemsetAsync(grads[n.fc_b_idx], 0, (size_t)1000 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+            if (pw_zero(s, grads[n.fc_w_idx], (size_t)1000 * 2048 * 4) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
+            if (pw_zero(s, grads[n.fc_b_idx], (size_t)1000 * 4) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
         }
         return UDAPOSE_OK;
     }
@@ -1214,8 +1214,8 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     if (grouped && phase == 0) CK(run_wg_group(s, n, act, ws, grads, beta, part));
     // backbone.fc is not part of the forward: zero gradient when overwriting
     if (beta == 0.f && part == 0) {
-        if (hipMemsetAsync(grads[n.fc_w_idx], 0, (size_t)1000 * 2048 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        if (hipMemsetAsync(grads[n.fc_b_idx], 0, (size_t)1000 * 4, s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (pw_zero(s, grads[n.fc_w_idx], (size_t)1000 * 2048 * 4) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
+        if (pw_zero(s, grads[n.fc_b_idx], (size_t)1000 * 4) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     }
     return UDAPOSE_OK;
 }

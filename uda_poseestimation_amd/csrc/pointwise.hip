@@ -1379,6 +1379,27 @@ int pw_zero_multi(hipStream_t s, const ZeroJob* d_jobs, int njobs, void* base) {
     hipLaunchKernelGGL(zero_multi_k, dim3(njobs, 32), dim3(TPB), 0, s, d_jobs, (char*)base);
     return udapose_check_launch();
 }
+// one range cleared by a kernel (common.h: why not hipMemsetAsync): 16-byte stores over the aligned body, 4-byte stores over the ragged ends
+__global__ void zero_k(unsigned int* __restrict__ p, size_t head, size_t n16, size_t tail) {
+    const size_t t = (size_t)blockIdx.x * TPB + threadIdx.x, step = (size_t)gridDim.x * TPB;
+    if (t < head) p[t] = 0u;
+    u32x4* b = (u32x4*)(p + head);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = t; i < n16; i += step) b[i] = z;
+    if (t < tail) p[head + n16 * 4 + t] = 0u;
+}
+int pw_zero(hipStream_t s, void* p, size_t bytes) {
+    if (!bytes) return UDAPOSE_OK;
+    if (!p || (bytes & 3) || ((uintptr_t)p & 3)) return UDAPOSE_ERR_ARG;
+    size_t words = bytes / 4, head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    if (head > words) head = words;
+    const size_t n16 = (words - head) / 4, tail = (words - head) & 3;
+    size_t g = (n16 + TPB - 1) / TPB;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(zero_k, dim3((unsigned)g), dim3(TPB), 0, s, (unsigned int*)p, head, n16, tail);
+    return udapose_check_launch();
+}
 int pw_axpy(hipStream_t s, float* y, const float* x, size_t n) {
     const size_t n4 = n / 4;
     if (n4) hipLaunchKernelGGL(axpy_k, dim3(grid_for(n4)), dim3(TPB), 0, s, y, x, n4);

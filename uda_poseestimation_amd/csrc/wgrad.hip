@@ -1093,7 +1093,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
     if (ks > 1 && !accumulate) {
         const size_t n = (size_t)Rdim * p.wtaps * Cdim;
-        if (hipMemsetAsync(p.dw, 0, n * sizeof(float), stream) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (pw_zero(stream, p.dw, n * sizeof(float)) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     }
     if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
     if ((p.flags & WG_FLAG_FASTGEO) && !(p.flags & WG_FLAG_ROW3) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0) p.flags |= WG_FLAG_FAST2; else p.flags &= ~WG_FLAG_FAST2;
