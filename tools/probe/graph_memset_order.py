@@ -4,7 +4,9 @@ eager device work between the replays.  On this image (ROCm 7.2.0, torch 2.10) t
 done by a kernel (`zero`), every replay is right.  Nothing of the package is involved: torch + libamdhip64 only.  This is why every clear
 on a capturable path of csrc/ goes through pw_zero (common.h) instead of hipMemsetAsync.
 
-usage: python tools/probe/graph_memset_order.py [zero]        (prints |d - 1| per replay: 0 = right, 1 = the clear came last)
+`copy`: the same question for a memcpy node (dx.copy_(zeros): torch issues hipMemcpyAsync for a contiguous device-to-device copy).
+
+usage: python tools/probe/graph_memset_order.py [zero|copy]        (prints |d - 1| per replay: 0 = right, 1 = the clear came last)
 """
 import ctypes as C
 import sys
@@ -20,6 +22,8 @@ def clear_then_add(g):
     dx = torch.empty_like(g)
     if "zero" in sys.argv:
         dx.zero_()              # (a fill kernel)
+    elif "copy" in sys.argv:
+        dx.copy_(zeros)         # (a memcpy node)
     else:
         rc = hip.hipMemsetAsync(dx.data_ptr(), 0, dx.numel() * 4, torch.cuda.current_stream().cuda_stream)
         assert rc == 0
@@ -27,6 +31,7 @@ def clear_then_add(g):
     return dx
 
 
+zeros = torch.zeros(n, device=dev)
 for trial in range(3):
     stream = torch.cuda.Stream()
     gr = torch.cuda.CUDAGraph()
