@@ -273,6 +273,8 @@ def main():
     ap.add_argument("--no-sum-in-tail", action="store_true", help="tuning: a separate launch adds the two passes' gradient buffers")
     ap.add_argument("--split-tail", action="store_true", help="tuning: the optimizer sweep's first part (the parameters the first weight-gradient phase "
                     "completed) on a side stream beside the second weight-gradient phase (measured slower: profiles/r5_ab_runs.txt)")
+    ap.add_argument("--wgrad-classes-concurrent", action="store_true", help="tuning: the pair weight-gradient launch's two tile classes on two streams "
+                    "(profiles/r5_ab_runs.txt 11)")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
     ap.add_argument("--dp-form", default="auto", choices=["auto", "fixed"], help="data parallel (world > 1): 'auto' times 5 steps of each form - {two gradient "
                     "buckets, the first under backward part 2 | one bucket after the whole backward} x {fp32, bf16 on the wire} - during spin-up, "
@@ -390,6 +392,8 @@ def main():
         trainer.fuse_tail = False
     if args.split_tail:
         trainer.split_tail = True
+    if args.wgrad_classes_concurrent:
+        student.wgrad_classes_concurrent = True
     trainer.stream_priority = args.stream_priority
     if args.no_merge_wgrad:
         trainer.merge_wgrad = False
@@ -668,7 +672,7 @@ def main():
             res["roofline"]["hbm_frac"] = round(tot / (ms * 1e-3) / 8e12, 4)       # whole-step HBM bytes / step time / 8 TB/s
         # the parity-compliant configurations of the same step, driver-visible (untimed extras after the headline's timed region)
         headline_cfg = (args.arch, S, K, N, args.dtype, args.precision) == ("pose_resnet101", 256, 16, 32, "bf16", None)
-        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune or args.early_source_bwd or args.arena_teacher or args.split_tail):
+        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune or args.early_source_bwd or args.arena_teacher or args.split_tail or args.wgrad_classes_concurrent):
             try:
                 del graphed
             except NameError:

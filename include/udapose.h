@@ -264,7 +264,9 @@ int udapose_net_wgrad_pair(udapose_net_t net, void* stream, const void* act_a, v
 /* The same in two phases (round 5): phase 1 = the clearing launches and the tile classes that hold the 1x1 convolutions of layer2-4, the
  * deconvolutions and the strided convolutions (60 % of the parameters); phase 2 = the remaining class (3x3 convolutions, layer1, head, stem).
  * Between the two a caller starts udapose_net_fused_update_part(part 1) - the optimizer sweep of the parameters phase 1 completed - on another
- * stream: the HBM-bound sweep runs beside phase 2's LDS-fill-bound launch instead of behind it.  phase 0 = udapose_net_wgrad_pair. */
+ * stream: the HBM-bound sweep runs beside phase 2's LDS-fill-bound launch instead of behind it.  phase 0 = udapose_net_wgrad_pair.
+ * phase 3 = the clearing launches only, phase 4 = phase 1 without them: 3, then 2 on a second stream behind it and 4 on the first, runs the
+ * tile classes' grids side by side. */
 int udapose_net_wgrad_pair_phase(udapose_net_t net, void* stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a,
                                  const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int part, int phase);
 /* Staged weight gradients (udapose_policy.wgrad_overlap > 0; round 4): the ONE `loss.backward()` of the reference's step

@@ -624,6 +624,30 @@ def test_merged_weight_gradient_launch_is_bit_identical():
     assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
 
 
+def test_pair_launch_tile_classes_on_two_streams_give_the_same_step():
+    """PoseResNet.wgrad_classes_concurrent (off: measured +0.12 ms, profiles/r5_ab_runs.txt 11): the pair launch as clears | class 1 on a side
+    stream | classes 0 / 2 (udapose_net_wgrad_pair_phase 3 / 2 / 4).  Same kernels on the same tables: the parameters after captured steps agree
+    with the default form's (to the rounding of the fp32 atomics' arrival order)."""
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    N, K, S = 4, 16, 128
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=8)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    res = {}
+    for conc in (False, True):
+        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda()
+        stu.wgrad_classes_concurrent = conc
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
+        gs = GraphedTrainStep(tr, *args, warmup=1)
+        for _ in range(3):
+            out = gs.step(*args)
+        assert torch.isfinite(out["loss_all"]) and not stu._pending_wg
+        res[conc] = [p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
+    for a, c in zip(res[False], res[True]):
+        assert torch.allclose(a, c, rtol=1e-3, atol=2e-5), (a - c).abs().max()
+
+
 @pytest.mark.parametrize("pol", [dict(wgrad_overlap=1, wgrad_cap=8), dict(wgrad_overlap=2, wgrad_cap=256), dict(wgrad_overlap=3, wgrad_cap=0),
                                  dict(wgrad_overlap=1, wgrad_cap=64, wgrad_cut_lo=0b010101)])
 def test_staged_persistent_weight_gradients_are_bit_identical(pol):

@@ -958,6 +958,8 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
 // strided convolutions: 60 % of the parameters); 2 = tile class 1 (the 3x3 convolutions in the filter-row form, layer1, head, stem) and the stem's
 // unpack.  Between the two the caller may start the optimizer sweep of the parameters phase 1 completed (net_fused_update part 1) on another
 // stream: an HBM-bound sweep beside an LDS-fill-bound launch.
+// 3 = the clearing launches only; 4 = tile classes 0 / 2 only (no clears): with 2 on a second stream behind 3, the two classes' grids run
+// side by side (PoseResNet.wgrad_classes_concurrent).
 int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const* gradsA, float betaA, const char* actB, char* wsB,
                 void* const* gradsB, float betaB, int part, int cap = 0, int phase = 0) {
     Net::WgGroup* GA = find_wg_group(n, gradsA, betaA, part);
@@ -966,7 +968,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     bool same = true;
     for (int t = 0; t < WG_CLASSES; ++t) same = same && GA->per_xcd[t] == GB->per_xcd[t];
     if (!same) {        // (different table shapes: two launches)
-        if (phase == 2) return UDAPOSE_OK;      // (phase 1 did everything)
+        if (phase == 2 || phase == 4) return UDAPOSE_OK;      // (phase 1 / 3 did everything)
         CK(run_wg_group(s, n, actA, wsA, gradsA, betaA, part, cap));
         return run_wg_group(s, n, actB, wsB, gradsB, betaB, part, cap);
     }
@@ -980,7 +982,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     const bool merge = n.policy.wgrad_merge && betaA == betaB && cap == 0 && phase == 0 && gradsA[0] != gradsB[0] && !written(gradsB[0]);
     if (!written(gradsA[0])) n.wg_written.push_back(gradsA[0]);
     if (!merge && !written(gradsB[0])) n.wg_written.push_back(gradsB[0]);
-    if (phase != 2)
+    if (phase != 2 && phase != 4)
     for (auto& sd : side) {
         if (merge && &sd == &side[1]) break;
         sd.G->last_use = ++n.wg_tick;
@@ -992,7 +994,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
     }
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!GA->per_xcd[t]) continue;
-        if ((phase == 1 && t == 1) || (phase == 2 && t != 1)) continue;
+        if (phase == 3 || ((phase == 1 || phase == 4) && t == 1) || (phase == 2 && t != 1)) continue;
 #ifdef UDAPOSE_TIMING_EXPERIMENTS
         if (n.policy.exp0 & (1 << t)) continue;          // (tuning: skip this tile class - timing experiments only)
 #endif
@@ -1002,7 +1004,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
         conv_prof_after(s, tok);
         CK(rc);
     }
-    if (with_stem && phase != 1) {
+    if (with_stem && (phase == 0 || phase == 2)) {
         const float betas[2] = {betaA, betaB};
         for (int k = 0; k < (merge ? 1 : 2); ++k)
             CK(pw_unpack_strided(s, (const float*)(side[k].ws + n.ws_dwtmp), (float*)side[k].grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
@@ -1015,7 +1017,7 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
 int net_wgrad_pair(void* h, hipStream_t s, const void* actA, void* wsA, void* const* gradsA, float betaA, const void* actB, void* wsB,
                    void* const* gradsB, float betaB, int part, int phase) {
     Net& n = *(Net*)h;
-    if (part < 0 || part > 2 || phase < 0 || phase > 2 || n.f32 || !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
+    if (part < 0 || part > 2 || phase < 0 || phase > 4 || n.f32 || !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
     DbgSyncScope dbg(n.policy.debug_sync);
     // (wgrad_cap without wgrad_overlap: the end-of-chain launches themselves as persistent grids - dynamic scheduling only)
     return run_wg_pair(s, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, part,

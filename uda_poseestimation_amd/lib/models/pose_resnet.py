@@ -117,6 +117,7 @@ class PoseResNet(nn.Module):
     """Simple Baseline for key-point detection (pose_resnet.py:59-91) on the MI355X executor."""
     default_precision = 'auto'      # what a new module's `precision` starts as (see __init__)
     _warned_bf16_fallback = False
+    wgrad_classes_concurrent = False    # finish_wgrad: the pair launch's two tile classes on two streams (measured neutral, r5_ab_runs.txt 11)
     fwd_only_plans = True           # no-grad forwards (teacher, validate()) run forward-only plans: y / z in six rotating scratch buffers
 
     def __init__(self, backbone, upsampling, feature_dim, num_keypoints, finetune=False):
@@ -579,7 +580,22 @@ class PoseResNet(nn.Module):
                 cur.wait_stream(st)
         elif len(pend) == 2 and pend[0][0] is pend[1][0] and pend[0][6] < 0 and pend[1][6] < 0:
             (hd, actA, wsA, gA, bA, _, _), (_, actB, wsB, gB, bB, _, _) = pend
-            check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0), "net_wgrad_pair")
+            if self.wgrad_classes_concurrent and wg_stream is not None:
+                # the two tile classes' grids side by side (the second on `wg_stream` behind the clears): the tail of one launch is filled
+                # by the other's work-groups.  Measured (round 5): see profiles/r5_ab_runs.txt 11; off by default
+                sd = wg_stream[0] if isinstance(wg_stream, (list, tuple)) else wg_stream
+                pair = lambda st_, ph: check(hd.L.udapose_net_wgrad_pair_phase(hd.h, st_, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0, ph),
+                                             "net_wgrad_pair_phase")
+                pair(s, 3)
+                sd.wait_stream(cur)
+                pair(sd.cuda_stream, 2)
+                pair(s, 4)
+                cur.wait_stream(sd)
+                for q in pend:
+                    q[1].record_stream(sd)
+                    q[2].record_stream(sd)
+            else:
+                check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0), "net_wgrad_pair")
         else:
             for hd, act, ws, gptrs, beta, _, _ in pend:
                 check(hd.L.udapose_net_backward_phase(hd.h, s, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 2), "net_backward weight gradients")
