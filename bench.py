@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--no-sum-in-tail", action="store_true", help="tuning: a separate launch adds the two passes' gradient buffers")
     ap.add_argument("--split-tail", action="store_true", help="tuning: the optimizer sweep's first part (the parameters the first weight-gradient phase "
                     "completed) on a side stream beside the second weight-gradient phase (measured slower: profiles/r5_ab_runs.txt)")
+    ap.add_argument("--no-fuse-rectify", action="store_true", help="tuning: activations and rectify as two arg-max sweeps")
     ap.add_argument("--wgrad-classes-concurrent", action="store_true", help="tuning: the pair weight-gradient launch's two tile classes on two streams "
                     "(profiles/r5_ab_runs.txt 11)")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
@@ -394,6 +395,8 @@ def main():
         trainer.split_tail = True
     if args.wgrad_classes_concurrent:
         student.wgrad_classes_concurrent = True
+    if args.no_fuse_rectify:
+        trainer.fuse_rectify = False
     trainer.stream_priority = args.stream_priority
     if args.no_merge_wgrad:
         trainer.merge_wgrad = False

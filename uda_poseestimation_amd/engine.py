@@ -245,6 +245,7 @@ class MeanTeacherTrainer:
         self.s2t_freq, self.t2s_freq, self.s2t_alpha, self.t2s_alpha = s2t_freq, t2s_freq, s2t_alpha, t2s_alpha
         self.rng = rng if rng is not None else np.random   # the reference draws from the global np.random
         self._side = None
+        self.fuse_rectify = True    # activates and the rectified teacher heat-maps from one arg-max sweep (False: two launches, the reference's two calls)
         self.concurrent = True      # False: run the three branches back to back on the current stream (profiling)
         # adaptive key-point occlusion (train_human.py:374-412); rate <= -1 disables it like `--occlude-rate -1`
         self.occlude_rate, self.occlude_thresh, self.occlude_size = occlude_rate, occlude_thresh, occlude_size
@@ -453,8 +454,12 @@ class MeanTeacherTrainer:
         for t in y_t_teas + recons + [y_t_tea_recon]:
             t.record_stream(main)
         with torch.no_grad():
-            activates = mt.heatmap_activations(y_t_tea_recon)    # BEFORE rectify (train_human.py:427)
-        return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates,
+            # activates from the heat-maps BEFORE rectify (train_human.py:427); the rectified maps (:431) come out of the same arg-max sweep
+            if self.fuse_rectify:
+                activates, y_t_tea_rect = mt.activations_and_rectify(y_t_tea_recon, self.sigma)
+            else:
+                activates, y_t_tea_rect = mt.heatmap_activations(y_t_tea_recon), None
+        return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates, "y_t_tea_rect": y_t_tea_rect,
                 "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu, "loss_s_early": loss_s_early, "s_src": s_src}
 
     def _overlap(self):
@@ -506,7 +511,7 @@ class MeanTeacherTrainer:
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
             tea_mask, _, _ = mt.confidence_mask(st["y_t_tea_recon"], self.mask_ratio, None, gathered_activates, st["activates"])
-            y_t_tea_rect = mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
+            y_t_tea_rect = st["y_t_tea_rect"] if st.get("y_t_tea_rect") is not None else mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
         loss_c = self.con_criterion(st["y_t_stu_recon"], y_t_tea_rect, tea_mask=tea_mask)
         loss_all = loss_s + self.lambda_c * loss_c
         # (with the source pass's chain already enqueued by _forward_part only the consistency term is left to differentiate)
@@ -871,7 +876,7 @@ class GraphedTrainStep:
         with cap("loss", S["main"]):
             student.apply_deferred_bn()         # (x_s first, then x_t_stu: the reference's call order, train_human.py:414-417)
             with torch.no_grad():
-                activates = mt.heatmap_activations(y_t_tea_recon)
+                activates, y_t_tea_rect = mt.activations_and_rectify(y_t_tea_recon, t.sigma)
             # autograd is cut at the student's outputs: the loss section's own backward ends in dL/dy_s and dL/dy_t_stu, and the two
             # gradient chains are enqueued from those (PoseResNet._run_backward: what _PoseNetFn.backward does)
             y_s = out_s.detach().requires_grad_(True)
@@ -881,7 +886,6 @@ class GraphedTrainStep:
             t._check_scaler()
             with torch.no_grad():
                 tea_mask, _, _ = mt.confidence_mask(y_t_tea_recon, t.mask_ratio, None, None, activates)
-                y_t_tea_rect = mt.rectify(y_t_tea_recon, sigma=t.sigma)
             loss_c = t.con_criterion(y_t_stu_recon, y_t_tea_rect, tea_mask=tea_mask)
             loss_all = loss_s + t.lambda_c * loss_c
             t.stu_optimizer.scale_loss(loss_all).backward()

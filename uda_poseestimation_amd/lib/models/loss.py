@@ -70,7 +70,10 @@ class _ConsFn(torch.autograd.Function):
         R, HW = _rows(stu)
         K = stu.shape[1]
         s, t = _f32c(stu), _f32c(tea)
-        m = None if mask is None else (mask.detach() != 0).to(torch.uint8).reshape(-1).contiguous()
+        if mask is not None and mask.dtype == torch.bool and mask.is_contiguous():
+            m = mask.detach().view(torch.uint8).reshape(-1)        # (bool storage is 0 / 1: no conversion launches)
+        else:
+            m = None if mask is None else (mask.detach() != 0).to(torch.uint8).reshape(-1).contiguous()
         rows = torch.empty(R, dtype=torch.float32, device=s.device)
         mean = torch.empty((), dtype=torch.float32, device=s.device)
         v = cnt = None

@@ -143,6 +143,19 @@ def heatmap_activations(recon):
     return act
 
 
+def activations_and_rectify(recon, sigma):
+    """heatmap_activations(recon) and rectify(recon, sigma) from ONE sweep (the arg-max of a (b,k) plane gives both; the mean-teacher step
+    needs both from the teacher's re-warped heat-maps, train_human.py:427 and :431).  Returns (activates [B,K], rectified [B,K,H,W])."""
+    _hip.require_cuda(recon)
+    src = recon.detach().float().contiguous()
+    B, K, H, W = src.shape
+    patch, rad = _gauss_patch(sigma, src.device)
+    act = torch.empty(B, K, dtype=torch.float32, device=src.device)
+    out = torch.empty_like(src)
+    check(lib().udapose_heatmap_argmax(_hip.stream(), ptr(src), B * K, H, W, ptr(act), None, None, ptr(out), ptr(patch), rad), "amax + rectify")
+    return act, out.to(recon.dtype)
+
+
 def confidence_mask(recon, mask_ratio, tea_mask=None, gathered_activates=None, activates=None):
     """train_human.py:427-430 without the host round trip: activates = amax_{hw}(recon); thr = k-th smallest with
     k = int(mask_ratio * numel); mask = (tea_mask * activates) > thr.  `gathered_activates` (all ranks' activates,
@@ -155,7 +168,7 @@ def confidence_mask(recon, mask_ratio, tea_mask=None, gathered_activates=None, a
     thr = torch.empty((), dtype=torch.float32, device=act.device)
     tm = None if tea_mask is None else tea_mask.detach().float().contiguous()
     check(lib().udapose_kth_mask(_hip.stream(), ptr(pool), ptr(tm), pool.numel(), k, ptr(thr), ptr(mask), ptr(act), B * K), "kth_mask")
-    return mask.bool(), act, thr
+    return mask.view(torch.bool), act, thr        # (the kernel writes 0 / 1: a bool view, not a conversion launch)
 
 
 def split_saturations(reset=True):
