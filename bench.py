@@ -232,6 +232,38 @@ def spawn_ranks(n):
     return rc
 
 
+class _HangGuard:
+    """Data-parallel runs only.  A collective that never completes (a rank that died, a captured collective replayed out of step) would keep
+    the whole job waiting until the launcher's own limit - and collectives replayed from a hipGraph are invisible to torch.distributed's
+    watchdog and its timeout.  Every phase that issues collectives arms this timer with a generous bound for that phase; if it fires the rank
+    says which phase hung, dumps its Python stacks and exits (code 3; 0 when the JSON line is already out), so the job ends in minutes
+    with a message instead of hanging the node."""
+
+    def __init__(self):
+        self.timer, self.enabled = None, False
+
+    def arm(self, seconds, what, code=3):
+        self.cancel()
+        if not self.enabled:
+            return
+        import faulthandler
+        import threading
+
+        def fire():
+            sys.stderr.write(f"bench.py: '{what}' did not finish within {seconds:.0f} s on rank {os.environ.get('RANK', '0')} - giving up\n")
+            sys.stderr.flush()
+            faulthandler.dump_traceback(all_threads=True)
+            os._exit(code)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,6 +357,9 @@ def main():
     force_dist = os.environ.get("UDAPOSE_FORCE_DIST", "0") == "1"     # test hook: one-rank RCCL group, data-parallel code path
     # RCCL prints its version banner on stdout when the communicator is created (NCCL_DEBUG=VERSION in this image): stdout is
     # pointed at stderr while the process group comes up, so that rank 0's stdout carries the ONE JSON line and nothing else
+    guard = _HangGuard()
+    guard.enabled = world > 1 or force_dist
+    guard.arm(300, "process group / communicator creation")
     sys.stdout.flush()
     saved_out = os.dup(1)
     os.dup2(2, 1)
@@ -430,6 +465,7 @@ def main():
                                     g["aug_param_tea"], split=(True if args.split_graphs else None),
                                     capture_comm=(False if args.no_capture_comm else None), branch_graphs=bool(args.branch_graphs))
 
+        guard.arm(420, "capture / selection of the data-parallel form")
         if dp_auto and dist.is_initialized() and (world > 1 or force_dist):
             # the ONE scaling run the driver may get should not depend on a guess about xGMI: every form is captured and timed (5 steps between
             # barrier + synchronize brackets, MAX over ranks), rank 0 picks the fastest and broadcasts the choice
@@ -501,6 +537,7 @@ def main():
     # Every rank must run the SAME number of spin-up steps (each step issues collectives): the stop decision is rank 0's clock,
     # shared with a one-element all-reduce after every step (a rank-local clock test lets ranks disagree by one step at the
     # boundary, after which the collectives of the timed region no longer pair up).
+    guard.arm(240 + 2 * args.spinup + 0.5 * (args.warmup + args.steps), "spin-up, warm-up and the timed steps")
     t_spin = time.perf_counter()
     spin_ms = []
     go = torch.zeros(1, device=dev) if dist.is_initialized() else None
@@ -535,6 +572,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        guard.arm(300, "the untimed legs after the timed region")
+    else:
+        guard.cancel()          # (one rank: the other configurations and the CPU baseline follow, minutes of work without collectives that could pair wrongly)
     comm_exposed_ms = trainer.sync.exposed_ms()
     if args.dp_segments and not args.eager:
         graphed.profile_segments = True
@@ -712,6 +753,7 @@ def main():
     if os.environ.get("UDAPOSE_BENCH_DEBUG_EXIT"):
         import faulthandler
         faulthandler.dump_traceback_later(25, exit=True)
+    guard.arm(90, "process group teardown (the result line is already printed)", code=0)
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
@@ -722,6 +764,7 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         dist.destroy_process_group()
+    guard.cancel()
 
 
 if __name__ == "__main__":

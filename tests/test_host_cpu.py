@@ -203,3 +203,20 @@ def test_bench_cpu_share_is_bounded_by_the_affinity_mask():
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     n = m.host_cpu_share()
     assert 1 <= n <= len(os.sched_getaffinity(0))
+
+
+def test_bench_hang_guard_ends_a_rank_that_waits_for_ever():
+    """bench.py's _HangGuard (data-parallel runs): a phase that outlives its bound ends the process with the phase's name on stderr
+    (exit code 3; the given code when the result line is already out); a cancelled or disabled guard does nothing."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib.util, sys, time\n"
+            f"spec = importlib.util.spec_from_file_location('bench_mod', {os.path.join(root, 'bench.py')!r})\n"
+            "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+            "g = m._HangGuard(); g.arm(0.2, 'disabled'); time.sleep(0.5)\n"
+            "g.enabled = True; g.arm(0.2, 'cancelled'); g.cancel(); time.sleep(0.5)\n"
+            "g.arm(0.3, 'the phase that hangs', code=int(sys.argv[1])); time.sleep(30)\n")
+    for rc_want in (3, 0):
+        p = subprocess.run([sys.executable, "-c", code, str(rc_want)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == rc_want, (p.returncode, p.stderr[-400:])
+        assert "'the phase that hangs' did not finish" in p.stderr and "disabled" not in p.stderr and "cancelled" not in p.stderr
