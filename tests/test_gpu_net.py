@@ -212,6 +212,44 @@ def test_full_size_bf16_heatmaps_bounded_by_storage_noise_argmax_identical_on_cl
                   f"{32 - int(clear.sum())}/32 (tie / near-tie rate {(32 - int(clear.sum())) / 32:.3f})")
 
 
+@pytest.mark.parametrize("K,N,HW", [(21, 1, 224), (21, 5, 96), (17, 2, 192), (18, 3, 288)], ids=["k21_n1_224", "k21_n5_96", "k17_n2_192", "k18_n3_288"])
+def test_ragged_shapes_key_point_counts_and_batch_sizes(K, N, HW):
+    """Shapes off the benchmark's grid: key-point counts that are not multiples of 8 (21: the reference's hand datasets, 17, 18), batch sizes
+    1 / 3 / 5, inputs whose layer4 maps are 7x7 / 3x3 / 6x6 / 9x9 (partial tiles in every implicit-GEMM form, odd sub-pixel classes in the
+    stride-2 data gradients).  Exact-fp32 forward against the fp32 oracle (indexing faults show as O(1) errors, rounding as 1e-5), then the
+    16-bit forward + backward: every gradient's direction and size against the bf16-storage emulation."""
+    from oracle.bf16_emulation import forward_bf16_emulated
+    ref, net = _pair((1, 1, 1, 1), K, seed=K + N, gamma3=0.25)
+    g = torch.Generator().manual_seed(HW)
+    x = torch.randn(N, 3, HW, HW, generator=g)
+    ref.train(); net.train()
+    with torch.no_grad():
+        y_ref = ref(x)
+        net.precision = "fp32"
+        y32 = net(x.cuda())
+    assert y32.shape == y_ref.shape == (N, K, HW // 4, HW // 4)
+    scale = y_ref.abs().max().item()
+    err32 = (y32.cpu() - y_ref).abs().max().item()
+    assert err32 <= 2e-4 * scale + 1e-5, (err32, scale)
+    net.precision = "bf16"
+    net._handles = {}
+    y = net(x.cuda())
+    with torch.no_grad():
+        y_emu = forward_bf16_emulated(ref, x)
+    noise = (y_emu - y_ref).abs().max().item()
+    assert (y.detach().cpu() - y_ref).abs().max().item() <= 2.0 * noise + 2e-3 * scale
+    R = torch.randn(y_ref.shape, generator=g)
+    ref.zero_grad()
+    (forward_bf16_emulated(ref, x) * R).sum().backward()
+    (y * R.cuda()).sum().backward()
+    for (name, p_r), (_, p_n) in zip(ref.named_parameters(), net.named_parameters()):
+        if name.startswith("backbone.fc"):
+            assert p_n.grad is None
+            continue
+        cos = torch.nn.functional.cosine_similarity(p_n.grad.cpu().flatten(), p_r.grad.flatten(), dim=0).item()
+        assert cos > 0.95 and _rel(p_n.grad.cpu(), p_r.grad) < 0.35, (name, cos)
+
+
 @pytest.mark.parametrize("arch", ["pose_resnet50", "pose_resnet101"])
 def test_fp32_mode_meets_the_1e3_heatmap_bar_and_identical_argmax(arch):
     """north_star's bar, on the precision the reference itself uses for the teacher / validate(): exact fp32 MFMA forward
