@@ -87,6 +87,23 @@ __global__ void sqdiff_bwd_k(const float* __restrict__ a, const float* __restric
     }
 }
 
+// the same element by element, for maps whose pixel count is not a multiple of 4 (rows are then not 16-byte aligned)
+__global__ void sqdiff_bwd_scalar_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w,
+                                    const unsigned char* __restrict__ mask, const float* __restrict__ gscale, float coef, int HW,
+                                    size_t total, float* __restrict__ da, const unsigned char* __restrict__ valid, const float* __restrict__ count, int Kc) {
+    float gs = gscale ? gscale[0] : 1.f;
+    if (count) gs *= (float)(((double)(total / HW) / Kc) * HW / (double)count[0]);
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const size_t r = i / HW;
+        float f = gs * coef;
+        if (w) f *= w[r];
+        if (mask) f *= mask[r] ? 1.f : 0.f;
+        float o = f * (a[i] - b[i]);
+        if (valid && !valid[(r / Kc) * HW + (i - r * HW)]) o = 0.f;
+        da[i] = o;
+    }
+}
+
 // torch's total order on floats for max / kthvalue: NaN is the LARGEST value (and all NaNs are equal)
 __device__ __forceinline__ bool hm_better(float v, int i, float bv, int bi) {
     const bool vn = v != v, bn = bv != bv;
@@ -247,9 +264,16 @@ int hm_sqdiff_rows(hipStream_t s, const float* a, const float* b, const float* w
 }
 int hm_sqdiff_bwd(hipStream_t s, const float* a, const float* b, const float* w, const unsigned char* mask, const float* gscale, float coef,
                   int R, int HW, float* da, const unsigned char* valid, const float* count, int Kc) {
-    if (HW % 4) return UDAPOSE_ERR_ARG;
     if (valid && (!count || Kc < 1 || R % Kc)) return UDAPOSE_ERR_ARG;
     const size_t total = (size_t)R * HW;
+    if (HW % 4) {
+        size_t blocks = (total + TPB - 1) / TPB;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(sqdiff_bwd_scalar_k, dim3((int)blocks), dim3(TPB), 0, s, a, b, w, mask, gscale, coef, HW, total, da, valid,
+                           valid ? count : nullptr, Kc);
+        return udapose_check_launch();
+    }
     size_t blocks = (total / 4 + TPB - 1) / TPB;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sqdiff_bwd_k, dim3((int)blocks), dim3(TPB), 0, s, a, b, w, mask, gscale, coef, HW, total, da, valid, valid ? count : nullptr,
