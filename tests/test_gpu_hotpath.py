@@ -245,6 +245,31 @@ def test_warp_chain_matches_torchvision_restatement():
     assert rel < 5e-2, rel
 
 
+@pytest.mark.parametrize("cs,ss", [((150, 106), (90, 122)), ((64, 200), (64, 200)), ((33, 47), (256, 256))], ids=["150x106_90x122", "64x200", "33x47_256"])
+def test_style_net_on_odd_sizes_matches_the_oracle(cs, ss):
+    """The style pass on sizes off the loop's 256x256: odd maps through the encoder's ceil-mode pools (150 -> 75 -> 38 -> 19), content and style of
+    different sizes, a non-square strip, a map smaller than the patch kernels' tiles - the default fp32-grade mode against the fp32 CPU oracle
+    (same seeded weights) within north_star's 1e-3 of max, the output size following the reference's (x8 of the relu4_1 map)."""
+    from seeded import fill_style_weights
+    from oracle import style_ref
+    from uda_poseestimation_amd.lib.models import Style_net
+    vgg_r, dec_r = style_ref.make_vgg_ref(), style_ref.make_decoder_ref()
+    for m_, seed in ((vgg_r, 11), (dec_r, 12), (Style_net.vgg, 11), (Style_net.decoder, 12)):
+        fill_style_weights(m_, seed)
+    Style_net.vgg.cuda(); Style_net.decoder.cuda()
+    vgg31 = torch.nn.Sequential(*list(Style_net.vgg.children())[:31])
+    vgg31_r = torch.nn.Sequential(*list(vgg_r.children())[:31])
+    net = Style_net.Net(vgg31, Style_net.decoder).cuda().eval()
+    g = torch.Generator().manual_seed(cs[0] + ss[1])
+    content, style = torch.rand(2, 3, *cs, generator=g), torch.rand(2, 3, *ss, generator=g)
+    with torch.no_grad():
+        want = style_ref.style_forward_ref(vgg31_r, dec_r, content, style, 0.7)
+        got = net(content.cuda(), style.cuda(), 0.7)[2]
+    assert got.shape == want.shape
+    err = (got.cpu() - want).abs().max().item() / want.abs().max().item()
+    assert err <= 1e-3, err
+
+
 def test_captured_loss_section_backward_is_right_on_every_replay():
     """The consistency branch of the loss section - re-warp (autograd), ConsLoss, backward to dL/dy_t - captured alone into a small
     hipGraph and replayed with eager device work between the replays: every replay equals the eager result.  (With the re-warp's
