@@ -452,6 +452,50 @@ def test_mean_teacher_step_matches_cpu_oracle():
     # tests/test_gpu_steps.py::test_captured_steps_equal_eager_steps_from_identical_state_with_varying_batches: a looser check of it here could not fail)
 
 
+@pytest.mark.parametrize("N,K,S", [(1, 21, 96), (3, 17, 160), (5, 18, 64)], ids=["n1_k21_96", "n3_k17_160", "n5_k18_64"])
+def test_mean_teacher_step_on_ragged_shapes_matches_cpu_oracle(N, K, S):
+    """The whole step off the benchmark's grid - one image (BatchNorm over 3x3 = 9 values at layer4), key-point counts 17 / 18 / 21, 5x5 and 2x2
+    layer4 maps, N*K not a multiple of anything: losses and the confidence mask against oracle/step_ref, the EMA bit for bit, and the
+    captured step against the eager one from identical state."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_ref
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    layers = [1, 1, 1, 1]
+    torch.manual_seed(N + K)
+    ref_s, ref_t = PoseResNetRef(layers, K), PoseResNetRef(layers, K)
+    mk = lambda: pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
+    stu, tea = mk(), mk()
+    stu.load_state_dict(ref_s.state_dict())
+    stu, tea = stu.cuda(), tea.cuda()
+    trainer = MeanTeacherTrainer(stu, tea, image_size=S, heatmap_size=S // 4)
+    ref_t.load_state_dict(ref_s.state_dict())
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=N * 10 + K)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    w0 = [p.detach().clone() for p in ref_s.parameters()]
+    out = trainer.train_step(*args)
+    opt = torch.optim.Adam(ref_s.parameters(), lr=1e-4)
+    ref = train_step_ref(ref_s, ref_t, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"],
+                         b["aug_param_tea"], ratio=4.0)
+    assert out["y_s"].shape == (N, K, S // 4, S // 4)
+    assert abs(float(out["loss_s"]) - float(ref["loss_s"])) <= 3e-2 * float(ref["loss_s"])
+    assert abs(float(out["loss_c"]) - float(ref["loss_c"])) <= 1e-1 * float(ref["loss_c"]) + 1e-6
+    assert out["tea_mask"].shape == (N, K) and int(out["tea_mask"].sum()) == N * K - int(0.5 * N * K)
+    for p_t, p_s, p0 in zip(tea.parameters(), stu.parameters(), w0):
+        assert torch.equal(p_t.detach(), p0.cuda().mul(0.999).add(p_s.detach() * (1.0 - 0.999)))
+    s2, t2, s3, t3 = mk(), mk(), mk(), mk()
+    s3.load_state_dict(s2.state_dict())
+    tr2 = MeanTeacherTrainer(s2.cuda(), t2.cuda(), image_size=S, heatmap_size=S // 4)
+    tr3 = MeanTeacherTrainer(s3.cuda(), t3.cuda(), image_size=S, heatmap_size=S // 4)
+    gs = GraphedTrainStep(tr2, *args, warmup=1)
+    tr3.train_step(*args)
+    for _ in range(3):
+        o2, o3 = gs.step(*args), tr3.train_step(*args)
+        assert torch.isfinite(o2["loss_all"]) and abs(float(o2["loss_all"]) - float(o3["loss_all"])) <= 5e-3 * abs(float(o3["loss_all"]))
+
+
 def test_occlusion_matches_oracle():
     """A16 (train_human.py:374-412): same host draws, same boxes, images identical up to isolated nearest-neighbour ties."""
     from oracle.occlusion_ref import occlude_ref
