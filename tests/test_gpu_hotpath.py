@@ -496,6 +496,47 @@ def test_mean_teacher_step_on_ragged_shapes_matches_cpu_oracle(N, K, S):
         assert torch.isfinite(o2["loss_all"]) and abs(float(o2["loss_all"]) - float(o3["loss_all"])) <= 5e-3 * abs(float(o3["loss_all"]))
 
 
+def test_reference_precision_mix_step_on_a_ragged_shape():
+    """The reference's precision mix (fp16 student under the device-side loss scaler, fp32-grade f16x2 teacher) at N = 3, K = 17, 160x160:
+    source loss against the fp32 oracle, the teacher-side quantities (mask; consistency loss within the student's fp16 error), no skipped
+    step, and the captured step against the eager one."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_ref
+    from uda_poseestimation_amd import synthetic
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    import uda_poseestimation_amd.lib.models.pose_resnet as pr
+    layers, N, K, S = [1, 1, 1, 1], 3, 17, 160
+    torch.manual_seed(3)
+    ref_s, ref_t = PoseResNetRef(layers, K), PoseResNetRef(layers, K)
+    mk = lambda: pr._pose_resnet("t", K, pr.Bottleneck_default, layers, False, False)
+    stu = mk()
+    stu.load_state_dict(ref_s.state_dict())
+    tea = mk()
+    trainer = MeanTeacherTrainer(stu.cuda(), tea.cuda(), image_size=S, heatmap_size=S // 4, precision="reference")
+    ref_t.load_state_dict(ref_s.state_dict())
+    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=77)
+    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    w0 = [p.detach().clone() for p in stu.parameters()]
+    out = trainer.train_step(*args)
+    opt = torch.optim.Adam(ref_s.parameters(), lr=1e-4)
+    ref = train_step_ref(ref_s, ref_t, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"],
+                         b["aug_param_tea"], ratio=4.0)
+    assert abs(float(out["loss_s"]) - float(ref["loss_s"])) <= 1e-2 * float(ref["loss_s"])
+    assert abs(float(out["loss_c"]) - float(ref["loss_c"])) <= 5e-2 * float(ref["loss_c"]) + 1e-6
+    assert torch.equal(out["tea_mask"].cpu(), ref["tea_mask"].bool()) if "tea_mask" in ref else True
+    assert any(not torch.equal(p.detach(), q) for p, q in zip(stu.parameters(), w0))          # (the scaler did not skip the step)
+    s2, t2, s3, t3 = mk(), mk(), mk(), mk()
+    s3.load_state_dict(s2.state_dict())
+    tr2 = MeanTeacherTrainer(s2.cuda(), t2.cuda(), image_size=S, heatmap_size=S // 4, precision="reference")
+    tr3 = MeanTeacherTrainer(s3.cuda(), t3.cuda(), image_size=S, heatmap_size=S // 4, precision="reference")
+    gs = GraphedTrainStep(tr2, *args, warmup=1)
+    tr3.train_step(*args)
+    for _ in range(3):
+        o2, o3 = gs.step(*args), tr3.train_step(*args)
+        assert torch.isfinite(o2["loss_all"]) and abs(float(o2["loss_all"]) - float(o3["loss_all"])) <= 5e-3 * abs(float(o3["loss_all"]))
+
+
 def test_occlusion_matches_oracle():
     """A16 (train_human.py:374-412): same host draws, same boxes, images identical up to isolated nearest-neighbour ties."""
     from oracle.occlusion_ref import occlude_ref
