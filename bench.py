@@ -714,6 +714,15 @@ def main():
                                            "peak_TBps": 8.0, "note": "whole-step HBM traffic of the conv / BN / weight-gradient kernels (PMC passes under "
                                            "profiles/) over this run's step time"}
             res["roofline"]["hbm_frac"] = round(tot / (ms * 1e-3) / 8e12, 4)       # whole-step HBM bytes / step time / 8 TB/s
+            # the step against the floor of its own traffic: the PMC bytes above + the optimizer sweep's 46 B / parameter + ~0.6 GB of
+            # conversions / packs at the 6.0 TB/s this chip streams through the paths these kernels use, + the L2-hit part of the operand fills
+            # (~66 GB of the implicit GEMMs' ~90 GB, ~0.5 ms for the weight gradients) at the 35 TB/s that path gives - all constants cited from profiles/
+            floor_ms = (tot + 2.5e9 + 0.6e9) / 6.0e12 * 1e3 + 66e9 / 35e12 * 1e3 + 0.5
+            res["roofline"]["step_hbm"]["traffic_floor"] = {
+                "floor_ms": round(floor_ms, 2), "frac_of_floor": round(floor_ms / ms, 4), "cited": True,
+                "note": "what this step's own memory traffic costs with every latency hidden (57 GB at 6.0 TB/s + L2-hit operand fills at 35 TB/s; "
+                        "profiles/r4_probes.txt, r5_probe_lds_fill_tiles.txt, r5_pmc_hbm_traffic.txt) over this run's step time: the statement that goes "
+                        "with 'frac' (the convolutions priced against the MFMA peak)"}
         # the parity-compliant configurations of the same step, driver-visible (untimed extras after the headline's timed region)
         headline_cfg = (args.arch, S, K, N, args.dtype, args.precision) == ("pose_resnet101", 256, 16, 32, "bf16", None)
         if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune or args.early_source_bwd or args.arena_teacher or args.split_tail or args.wgrad_classes_concurrent):
