@@ -127,19 +127,62 @@ def cpu_baseline(n, arch_layers, seconds_budget=30.0):
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
     times = []
+    # (the start state and the FIRST step's outputs are kept: measured_parity() runs the device step from the same weights and inputs)
+    ctx = {"sd": {k: v.detach().clone() for k, v in stu.state_dict().items()}, "batch": b, "layers": list(arch_layers), "ref": None}
     for it in range(5):
         t0 = time.time()
-        train_step_ref(stu, tea, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"], b["aug_param_tea"])
+        r_ = train_step_ref(stu, tea, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"], b["aug_param_tea"])
         times.append(time.time() - t0)
+        if it == 0:
+            ctx["ref"] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in r_.items()}
         print(f"cpu_baseline step {it}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
         if time.time() - t_start + times[-1] > seconds_budget:      # (no room for another iteration)
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
+    cpu_baseline.parity_ctx = ctx
     return {"value": round(n / best, 3), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"PoseResNet-101 mean-teacher step (student fwd+bwd on 2x{n}, teacher fwd on {n}, losses, Adam, EMA) fp32 "
                       f"oracle/step_ref.py, batch {n}, {threads} threads (CPU share {share}, {logical} logical CPUs; probe s per 2-image fwd+bwd by threads: "
                       + ", ".join(f"{c}: {t:.2f}" for c, t in probe.items()) + f"), {len(times)} iteration(s), best"
                       + (" of the non-first (times fall over the first iterations: " + ", ".join(f"{t:.1f}" for t in times) + " s)" if len(times) > 1 else "") + f": {best:.2f} s/step"}
+
+
+def measured_parity(arch, dev, precision):
+    """MEASURED parity of this run (VERDICT r5 #1b): the device step in `precision` ('bf16' | 'fp16' | 'reference') from the weights and the
+    batch of the cpu_baseline leg's FIRST oracle step (oracle/step_ref.py, fp32; PoseResNet-101 at the reference initialisation, seed 0,
+    batch 8) - heat-map max-abs error and scale, arg-max key points, both losses, the k-th-value mask.  The network is the bench's own:
+    randomly initialised, train-mode BatchNorm - the worst case for 16-bit storage; the trained-network figures are
+    tests/test_gpu_fullsize.py's and tests/test_gpu_trained.py's."""
+    from oracle.keypoints_ref import get_max_preds_ref
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    import uda_poseestimation_amd.lib.models as models
+    ctx = getattr(cpu_baseline, "parity_ctx", None)
+    if ctx is None or ctx["ref"] is None or ctx["layers"] != {"pose_resnet101": [3, 4, 23, 3], "pose_resnet50": [3, 4, 6, 3]}[arch]:
+        return None
+    stu = models.__dict__[arch](num_keypoints=16, pretrained_backbone=False)
+    tea = models.__dict__[arch](num_keypoints=16, pretrained_backbone=False)
+    stu.load_state_dict(ctx["sd"]); tea.load_state_dict(ctx["sd"])
+    trainer = MeanTeacherTrainer(stu.to(dev), tea.to(dev), lr=1e-4, teacher_alpha=0.999, lambda_c=1.0, mask_ratio=0.5, sigma=2, precision=precision)
+    b, ref = ctx["batch"], ctx["ref"]
+    g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    out = trainer.train_step(g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+    torch.cuda.synchronize()
+    y_dev, y_ref = out["y_s"].detach().float().cpu(), ref["y_s"]
+    p_ref, _ = get_max_preds_ref(y_ref.numpy())
+    p_dev = kd.get_max_preds(out["y_s"].detach().float())[0].cpu().numpy()
+    same = (p_dev == p_ref).all(-1)
+    m_dev, m_ref = out["tea_mask"].cpu().bool(), ref["tea_mask"].bool()
+    ls, lsr, lc, lcr = float(out["loss_s"]), float(ref["loss_s"]), float(out["loss_c"]), float(ref["loss_c"])
+    res = {"measured": True, "student": stu._last_hd.precision, "teacher": tea._last_hd.precision,
+           "network": f"{arch} K=16 at the reference initialisation (seed 0), train-mode BN, 256x256, batch {y_ref.shape[0]} per domain: the cpu_baseline leg's first oracle step",
+           "heatmap_max_abs": (y_dev - y_ref).abs().max().item(), "heatmap_scale": y_ref.abs().max().item(),
+           "argmax_identical": f"{int(same.sum())}/{same.size}", "mask_identical": f"{int((m_dev == m_ref).sum())}/{m_ref.numel()}",
+           "loss_s_rel": abs(ls - lsr) / abs(lsr), "loss_c_rel": abs(lc - lcr) / max(abs(lcr), 1e-30), "loss_s": ls, "loss_s_oracle": lsr}
+    res["heatmap_rel"] = res["heatmap_max_abs"] / max(res["heatmap_scale"], 1e-30)
+    del trainer, stu, tea, g
+    torch.cuda.empty_cache()
+    return {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in res.items()}
 
 
 def style_extras(dev, precision):
@@ -723,9 +766,23 @@ def main():
                 "note": "what this step's own memory traffic costs with every latency hidden (57 GB at 6.0 TB/s + L2-hit operand fills at 35 TB/s; "
                         "profiles/r4_probes.txt, r5_probe_lds_fill_tiles.txt, r5_pmc_hbm_traffic.txt) over this run's step time: the statement that goes "
                         "with 'frac' (the convolutions priced against the MFMA peak)"}
+        # the CPU oracle leg (bounded sample) and, from its first step, the MEASURED parity of this run's precision(s)
+        par_ok = (S, K) == (256, 16) and not args.config2
+        if not args.no_cpu_baseline and world == 1:     # (the CPU leg runs on rank 0 of the ONE-rank run only; N > 1 lines carry null)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_images, layers)
+            if par_ok:
+                try:
+                    del graphed
+                except NameError:
+                    pass
+                torch.cuda.empty_cache()
+                print("parity: device step from the oracle's start state ...", file=sys.stderr, flush=True)
+                res["parity"] = measured_parity(args.arch, dev, args.precision or args.dtype)
+        elif world > 1:
+            res["cpu_baseline"] = None
         # the parity-compliant configurations of the same step, driver-visible (untimed extras after the headline's timed region)
         headline_cfg = (args.arch, S, K, N, args.dtype, args.precision) == ("pose_resnet101", 256, 16, 32, "bf16", None)
-        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune or args.early_source_bwd or args.arena_teacher or args.split_tail or args.wgrad_classes_concurrent):
+        if world == 1 and headline_cfg and not (args.config2 or args.eager or args.no_other_configs or args.host_inputs or tune):
             try:
                 del graphed
             except NameError:
@@ -735,13 +792,11 @@ def main():
             for tag, dt_, pr_ in (("fp16", "fp16", None), ("reference_mix", "fp16", "reference")):
                 print(f"other_configs: {tag} ...", file=sys.stderr, flush=True)
                 oc[tag] = other_config_rate(args.arch, dev, N, K, S, sigma, dt_, pr_)
-            # (`cited`: the parity figures are quoted from the named tests' measurements, not computed by this run)
-            oc["fp16"]["heatmap_error_vs_fp32_oracle"] = {"cited": True, "text": "trained PoseResNet-101, train-mode BN, 256x256: max|dy| 8.6e-4 .. 1.13e-3 over device-trained instances (AT the 1e-3 bar, not under it with margin), arg-max identical 32/32 "
-                                                          "(tests/test_gpu_trained.py::test_trained_like_forward_parity_all_precisions)"}
-            oc["reference_mix"]["heatmap_error_vs_fp32_oracle"] = {"cited": True, "text": "teacher (f16x2) 5.5e-7 on the trained network, 3.6e-5 at the reference initialisation; "
-                                                                   "student (fp16) 8.6e-4 .. 1.13e-3; arg-max identical 32/32 (same test; tests/test_gpu_f16x2.py)"}
-            oc["note"] = ("the headline (bf16, BASELINE.json configs[1]) is at 5.6e-3 = 0.6 % of max|y| from the fp32 oracle on the same trained network "
-                          "(arg-max identical 32/32; cited from tests/test_gpu_trained.py): fp16 sits AT the absolute 1e-3 bar (0.86-1.13e-3), the reference mix's fp32-grade teacher is under it by three orders of magnitude")
+                # (measured by THIS run, like res["parity"]: the device step in that precision against the cpu_baseline leg's first oracle step)
+                oc[tag]["parity"] = measured_parity(args.arch, dev, pr_ or dt_) if "parity" in res else None
+            oc["note"] = ("parity figures are this run's measurements on the bench's own randomly initialised network (train-mode BN: every bottleneck amplifies "
+                          "storage rounding); on a TRAINED network the same comparisons at the benchmarked size are tests/test_gpu_fullsize.py's "
+                          "(bf16 ~5e-3, fp16 ~1e-3, the reference mix's fp32-grade teacher ~5e-7 absolute)")
             # BASELINE.json's other single-GPU configurations (the ones the reference actually trains: train_human.py:345-358,
             # train_animal.py:330-483), same harness: 20 graph replays each
             for tag, kw in (("configs[2]_bf16_style", dict(dtype="bf16", precision=None, config2=True)),
@@ -754,10 +809,6 @@ def main():
             oc["configs[2]_reference_mix"]["workload"] = "the same in the reference's precision mix (fp16 student, f16x2 teacher and style network)"
             oc["configs[4]_workload_1gpu_fp16"]["workload"] = f"{args.arch} K=18, 384x384 (heat-maps 96x96), sigma 1.0, fp16, b={N} on ONE GPU (configs[4] is this workload on 8)"
             res["other_configs"] = oc
-        if not args.no_cpu_baseline and world == 1:     # (the CPU leg runs on rank 0 of the ONE-rank run only; N > 1 lines carry null)
-            res["cpu_baseline"] = cpu_baseline(args.cpu_images, layers)
-        elif world > 1:
-            res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
     if os.environ.get("UDAPOSE_BENCH_DEBUG_EXIT"):
         import faulthandler

@@ -1,0 +1,336 @@
+"""The BENCHMARKED step at its BENCHMARKED size against the CPU oracle.
+
+Every other whole-step parity test runs small networks (one bottleneck per stage, N = 4, 128x128) or N = 2; the graph the driver
+times - PoseResNet-101, N = 32, 256x256, three streams, ~1280 nodes - was compared with the oracle only through layer-level
+identities.  Here BASELINE.json configs[1] runs exactly as bench.py runs it (captured one-graph step; bf16, fp16 and the reference's
+precision mix) from the weights of a TRAINED-LIKE network (tests/conftest.py) on images of the kind it was trained on, and every
+quantity SURVEY.md 8(d) names as a parity gate is compared with oracle/step_ref.train_step_ref (train_human.py:326-444) on identical
+weights and inputs: the k-th-value mask element for element, arg-max key points and PCK@0.05 (with the near-tie rate), both losses,
+heat-map max-abs error, the EMA to the bit, and captured == eager at THIS size.  configs[2] (N = 32, both style directions, host
+occlusion draws in the reference's order) and configs[4] (K = 18, 384x384, sigma 1.0, fp16 student, N = 8) follow.
+
+The CPU leg is one fp32 oracle step at N = 32 (a few seconds on the GPU box's host cores, ~25 GB of autograd state): computed once
+per configuration in a module fixture and shared by the precisions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RECOVER_LO, RECOVER_HI = [-2.1179, -2.0357, -1.8044], [2.2489, 2.4285, 2.64]        # (0 - mean) / std, (1 - mean) / std (train_human.py:32-33)
+
+
+def _host_mem_gb():
+    """Memory this process may still take: MemAvailable, cut by the cgroup limit when one is set."""
+    avail = None
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            avail = int(line.split()[1]) / 2 ** 20
+    for path, used in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                       ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            lim = open(path).read().strip()
+            if lim != "max" and int(lim) < 2 ** 60:
+                avail = min(avail, (int(lim) - int(open(used).read())) / 2 ** 30)
+        except Exception:
+            pass
+    return avail
+
+
+def _need_host_mem(gb):
+    have = _host_mem_gb()
+    if have is not None and have < gb:
+        pytest.skip(f"the fp32 CPU oracle step of this size needs ~{gb} GB of host memory, {have:.0f} GB available")
+
+
+def keypoint_mean_teacher_batch(n, K=16, S=256, sigma=2, seed=0):
+    """A mean-teacher batch (the fields of train_human.py:329-340) whose images carry key points the trained network recognises:
+    source images + labels, two further image sets as the student's and the teacher's target views, random inverse-augmentation tuples."""
+    from uda_poseestimation_amd import synthetic
+    x_s, lab, wt = synthetic.keypoint_batch(n, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=seed)
+    x_t_stu = synthetic.keypoint_batch(n, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=seed + 1)[0]
+    x_t_tea = synthetic.keypoint_batch(n, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=seed + 2)[0]
+    rs = np.random.RandomState(seed + 3)
+    return {"x_s": x_s, "label_s": lab, "weight_s": wt, "x_t_stu": x_t_stu, "x_t_tea": x_t_tea,
+            "aug_param_stu": synthetic.aug_params(n, rs), "aug_param_tea": synthetic.aug_params(n, rs)}
+
+
+def _args(g):
+    return (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
+
+
+def _to_dev(b):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def _device_pair(sd, K):
+    import uda_poseestimation_amd.lib.models as models
+    stu = models.pose_resnet101(num_keypoints=K, pretrained_backbone=False)
+    tea = models.pose_resnet101(num_keypoints=K, pretrained_backbone=False)
+    stu.load_state_dict(sd)
+    tea.load_state_dict(sd)
+    return stu.cuda(), tea.cuda()
+
+
+def _rewind(trainer, stu, tea, sd):
+    """Put networks and optimizer back to the start state IN PLACE (the captured launches hold raw pointers): weights and BatchNorm
+    buffers from `sd`, zero moments, step counter 0, the loss scaler's initial scale."""
+    import copy
+    stu.load_state_dict(sd)
+    tea.load_state_dict(sd)
+    opt = trainer.stu_optimizer
+    osd = copy.deepcopy(opt.state_dict())
+    for st in osd["state"].values():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                v.zero_()
+    for gp in osd["param_groups"]:
+        gp["step"] = 0
+        if opt._scaler is not None:
+            gp["loss_scale"], gp["growth_tracker"] = float(opt._scaler["init_scale"]), 0
+    opt.load_state_dict(osd)
+    torch.cuda.synchronize()
+
+
+def _oracle_step(sd, b, K, sigma=2, S=256, **kw):
+    """One fp32 oracle step from `sd` on the CPU: outputs, the student's heat-maps of both passes' inputs, the post-step weights."""
+    from oracle.pose_resnet_ref import pose_resnet101_ref
+    from oracle.step_ref import train_step_full_ref
+    ref_s, ref_t = pose_resnet101_ref(K), pose_resnet101_ref(K)
+    ref_s.load_state_dict(sd)
+    ref_t.load_state_dict(sd)
+    opt = torch.optim.Adam(ref_s.parameters(), lr=1e-4)
+    out = train_step_full_ref(ref_s, ref_t, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"],
+                              b["aug_param_tea"], sigma=sigma, ratio=4.0, image_size=S, **kw)
+    out = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+    out["student_after"] = [p.detach().clone() for p in ref_s.parameters()]
+    out["teacher_after"] = [p.detach().clone() for p in ref_t.parameters()]
+    out["activates"] = out["y_t_tea_recon"].amax(dim=(2, 3))
+    del ref_s, ref_t, opt
+    return out
+
+
+def _compare_with_oracle(tag, out, ref, label_s, stu, tea, sd, err_teacher_bar, hm_bar, loss_s_bar, loss_c_bar, exact_mask):
+    """The parity gates of SURVEY.md 8(d) for one device step against the oracle step; returns the measured figures."""
+    from oracle.keypoints_ref import accuracy_ref, get_max_preds_ref
+    from uda_poseestimation_amd.lib import keypoint_detection as kd
+    y_dev, y_ref = out["y_s"].detach().float().cpu(), ref["y_s"]
+    scale = y_ref.abs().max().item()
+    hm = (y_dev - y_ref).abs().max().item()
+    # arg-max key points: identical wherever the oracle's peak margin exceeds twice the measured error; near-tie rate reported
+    p_ref, _ = get_max_preds_ref(y_ref.numpy())
+    p_dev, _ = kd.get_max_preds(out["y_s"].detach().float())
+    p_dev = p_dev.cpu().numpy() if torch.is_tensor(p_dev) else np.asarray(p_dev)
+    same = (p_dev == p_ref).all(-1)
+    top2 = y_ref.reshape(y_ref.shape[0] * y_ref.shape[1], -1).topk(2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 2 * hm).reshape(same.shape).numpy()
+    assert same[clear].all(), f"{tag}: arg-max differs on key points whose peak margin exceeds twice the heat-map error"
+    # PCK@0.05 (lib/keypoint_detection.py:60-94) of the source batch
+    acc_ref = accuracy_ref(y_ref.numpy(), label_s.numpy())
+    acc_dev = kd.accuracy(y_dev.numpy(), label_s.numpy())
+    n_diff = int((~same).sum())
+    if n_diff == 0:
+        assert abs(float(acc_dev[1]) - float(acc_ref[1])) < 1e-6 and int(acc_dev[2]) == int(acc_ref[2])      # (float32 / float64 of the same ratio)
+    else:
+        assert abs(float(acc_dev[1]) - float(acc_ref[1])) <= n_diff / max(same.size, 1) + 1e-9
+    # the k-th-value mask (train_human.py:427-430): element for element outside the teacher-error band around the threshold
+    m_dev, m_ref = out["tea_mask"].cpu().bool(), ref["tea_mask"].bool()
+    e_tea = float(out.get("_err_teacher", float("nan")))
+    act, thr = ref["activates"], ref["thr"]
+    band = (act - thr).abs() <= 2 * e_tea if e_tea == e_tea else torch.zeros_like(m_ref)
+    mism = m_dev != m_ref
+    assert not bool((mism & ~band).any()), f"{tag}: the confidence mask differs outside the near-tie band"
+    if exact_mask:
+        assert torch.equal(m_dev, m_ref), f"{tag}: {int(mism.sum())} mask elements differ"
+    ls, lsr = float(out["loss_s"]), float(ref["loss_s"])
+    lc, lcr = float(out["loss_c"]), float(ref["loss_c"])
+    rel_s, rel_c = abs(ls - lsr) / abs(lsr), abs(lc - lcr) / max(abs(lcr), 1e-30)
+    print(f"{tag}: max|y| {scale:.3f}; heat-map max|device - oracle| {hm:.3e} ({hm / scale:.2e} of max|y|); teacher re-warped maps {e_tea:.3e}; "
+          f"arg-max identical {int(same.sum())}/{same.size} (near-tie rate {1.0 - clear.mean():.4f}); PCK@0.05 {float(acc_dev[1]):.4f} / {float(acc_ref[1]):.4f}; "
+          f"mask mismatches {int(mism.sum())}/{mism.numel()} ({int(band.sum())} inside the near-tie band); loss_s {ls:.6e} / {lsr:.6e} (rel {rel_s:.2e}); "
+          f"loss_c {lc:.6e} / {lcr:.6e} (rel {rel_c:.2e})")
+    assert hm <= hm_bar, (tag, hm, hm_bar)
+    assert e_tea != e_tea or e_tea <= err_teacher_bar, (tag, e_tea)
+    assert rel_s <= loss_s_bar and rel_c <= loss_c_bar, (tag, rel_s, rel_c)
+    return {"heatmap_max_abs": hm, "scale": scale, "argmax_identical": int(same.sum()), "near_tie_rate": float(1.0 - clear.mean()),
+            "loss_s_rel": rel_s, "loss_c_rel": rel_c, "mask_mismatch": int(mism.sum())}
+
+
+def _ema_bit_exact(tea, sd, stu, alpha=0.999):
+    """OldWeightEMA.step (utils.py:21-25) on the device == the two-rounding reference form applied to (teacher before, the DEVICE's
+    student after Adam), bit for bit, over all parameters."""
+    from oracle.mean_teacher_ref import ema_step_ref
+    names = [n for n, _ in tea.named_parameters()]
+    before = [sd[n].clone() for n in names]
+    src = [p.detach().cpu().clone() for p in stu.parameters()]
+    tp = [torch.nn.Parameter(t.clone()) for t in before]
+    sp = [torch.nn.Parameter(t) for t in src]
+    ema_step_ref(tp, sp, alpha)
+    bad = sum(int(not torch.equal(a.detach().cpu(), b.detach())) for a, b in zip(tea.parameters(), tp))
+    assert bad == 0, f"{bad} teacher tensors differ from the reference EMA form"
+
+
+@pytest.fixture(scope="module")
+def config1(trained_r101_k16):
+    _need_host_mem(48)
+    sd = trained_r101_k16[0]
+    b = keypoint_mean_teacher_batch(32, seed=40)
+    import time
+    t0 = time.time()
+    ref = _oracle_step(sd, b, 16)
+    print(f"configs[1] oracle step (fp32, N=32, {torch.get_num_threads()} threads): {time.time() - t0:.1f} s")
+    return sd, b, ref
+
+
+# bars: (teacher re-warped maps, student heat-maps, loss_s rel, loss_c rel, mask asserted identical outright)
+BARS = {"bf16": (2e-2, 2e-2, 2e-2, 6e-2, False), "fp16": (3e-3, 3e-3, 3e-3, 1e-2, False), "reference": (1e-3, 3e-3, 3e-3, 1e-2, True)}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "reference"])
+def test_config1_full_size_captured_step_vs_oracle(config1, precision):
+    """BASELINE.json configs[1] as bench.py times it - PoseResNet-101, K = 16, N = 32, 256x256, ONE captured hipGraph - against the fp32
+    oracle step from identical weights and inputs, and against its own eager twin."""
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    sd, b, ref = config1
+    g = _to_dev(b)
+    burn = _to_dev(keypoint_mean_teacher_batch(32, seed=50))         # the capture's warm-up step runs on another batch
+    stu, tea = _device_pair(sd, 16)
+    tr = MeanTeacherTrainer(stu, tea, lr=1e-4, precision=precision)
+    gs = GraphedTrainStep(tr, *_args(burn), warmup=1)
+    assert gs.one_graph and not gs.split
+    _rewind(tr, stu, tea, sd)
+    out = dict(gs.step(*_args(g)))
+    torch.cuda.synchronize()
+    out["y_s"], out["tea_mask"] = out["y_s"].clone(), out["tea_mask"].clone()
+    # the teacher's re-warped heat-maps (what the mask and the consistency target are made from) against the oracle's
+    with torch.no_grad():
+        from uda_poseestimation_amd import warp
+        tea2 = _device_pair(sd, 16)[1]
+        tea2.precision = tea.precision
+        tea2.train()
+        y_t = tea2(g["x_t_tea"])
+        rec = warp.warp_chain(y_t, warp.recon_thetas(g["aug_param_tea"], 32, 4.0, y_t.device))
+        out["_err_teacher"] = (rec.cpu() - ref["y_t_tea_recon"]).abs().max().item()
+        del tea2
+    bar_t, bar_h, bar_s, bar_c, exact = BARS[precision]
+    _compare_with_oracle(f"configs[1] N=32 captured {precision}", out, ref, b["label_s"], stu, tea, sd, bar_t, bar_h, bar_s, bar_c, exact)
+    _ema_bit_exact(tea, sd, stu)
+    # Adam: the device's first update against the oracle's (sign agreement over the entries the oracle moves by more than lr / 2)
+    names = [n for n, _ in stu.named_parameters()]
+    agree = total = 0
+    for n_, p_dev, p_ref in zip(names, stu.parameters(), ref["student_after"]):
+        d_dev, d_ref = p_dev.detach().cpu() - sd[n_], p_ref - sd[n_]
+        sel = d_ref.abs() > 5e-5
+        agree += int((torch.sign(d_dev[sel]) == torch.sign(d_ref[sel])).sum())
+        total += int(sel.sum())
+    print(f"  Adam update sign agreement with the fp32 oracle: {agree / max(total, 1):.4f} over {total} entries")
+    assert total > 1e7 and agree / total > (0.9 if precision != "bf16" else 0.8)
+    # captured == eager at this size: an eager twin from the same start state
+    stu_e, tea_e = _device_pair(sd, 16)
+    tr_e = MeanTeacherTrainer(stu_e, tea_e, lr=1e-4, precision=precision)
+    out_e = tr_e.train_step(*_args(g))
+    torch.cuda.synchronize()
+    assert torch.equal(out_e["tea_mask"].cpu(), out["tea_mask"].cpu())
+    num = den = 0.0
+    nbit = 0
+    for n_, pg, pe in zip(names, stu.parameters(), stu_e.parameters()):
+        num += float(((pg.detach() - pe.detach()).double() ** 2).sum())
+        den += float(((pe.detach().cpu() - sd[n_]).double() ** 2).sum())
+        nbit += int(torch.equal(pg.detach(), pe.detach()))
+    rel = (num / max(den, 1e-300)) ** 0.5
+    print(f"  captured vs eager twin: ||dp|| / ||update|| = {rel:.3e}; {nbit}/{len(names)} parameter tensors identical to the bit; "
+          f"loss_all {float(out['loss_all']):.6e} / {float(out_e['loss_all']):.6e}")
+    assert rel < 5e-2 and abs(float(out["loss_all"]) - float(out_e["loss_all"])) <= 1e-5 * abs(float(out_e["loss_all"]))
+    gs.release()
+
+
+@pytest.fixture(scope="module")
+def config2(trained_r101_k16):
+    _need_host_mem(48)
+    from seeded import fill_style_weights
+    from oracle.style_ref import make_decoder_ref, make_vgg_ref
+    from uda_poseestimation_amd.lib.models import Style_net
+    sd = trained_r101_k16[0]
+    b = keypoint_mean_teacher_batch(32, seed=60)
+    fill_style_weights(Style_net.vgg, 11)
+    fill_style_weights(Style_net.decoder, 12)
+    vgg_ref, dec_ref = make_vgg_ref(), make_decoder_ref()
+    vgg_ref.load_state_dict({k: v.cpu() for k, v in Style_net.vgg.state_dict().items()})
+    dec_ref.load_state_dict({k: v.cpu() for k, v in Style_net.decoder.state_dict().items()})
+    vgg31_ref = torch.nn.Sequential(*list(vgg_ref.children())[:31]).eval()
+    kw = dict(s2t_freq=1.0, t2s_freq=1.0, s2t_alpha=(0.2, 1.0), t2s_alpha=(0.2, 1.0), occlude_rate=0.5, occlude_thresh=0.9, occlude_size=10)
+    rng = np.random.RandomState(7)
+    import time
+    t0 = time.time()
+    ref = _oracle_step(sd, b, 16, style=(vgg31_ref, dec_ref), rng=rng, recover=(torch.tensor(RECOVER_LO), torch.tensor(RECOVER_HI)), **kw)
+    print(f"configs[2] oracle step (fp32, N=32, both style directions, occlusion): {time.time() - t0:.1f} s; occluded {ref['occluded']}")
+    return sd, b, ref, kw, rng.get_state()
+
+
+def test_config2_full_size_step_vs_oracle(config2):
+    """BASELINE.json configs[2] at N = 32: AdaIN s2t + t2s (both drawn, random alpha), recover clamp, adaptive occlusion with the
+    reference's host draws, in the reference's precision mix, against oracle.step_ref.train_step_full_ref (train_human.py:345-438)."""
+    from uda_poseestimation_amd.engine import MeanTeacherTrainer
+    from uda_poseestimation_amd.lib.models import Style_net
+    sd, b, ref, kw, rng_state = config2
+    g = _to_dev(b)
+    Style_net.vgg.cuda(); Style_net.decoder.cuda()
+    net = Style_net.Net(torch.nn.Sequential(*list(Style_net.vgg.children())[:31]), Style_net.decoder).cuda()
+    stu, tea = _device_pair(sd, 16)
+    rng_dev = np.random.RandomState(7)
+    tr = MeanTeacherTrainer(stu, tea, lr=1e-4, style_net=net, recover=(torch.tensor(RECOVER_LO).cuda(), torch.tensor(RECOVER_HI).cuda()),
+                            rng=rng_dev, precision="reference", **kw)
+    tr.device_occlusion = False
+    seen = {}
+    orig = tr._forward_backward
+
+    def spy(x_s_in, label_s, weight_s, x_t_stu, x_t_teas_in, theta_stu, thetas_tea):
+        seen["x_s_in"], seen["x_t_tea_in"] = x_s_in.detach().clone(), x_t_teas_in[0].detach().clone()
+        return orig(x_s_in, label_s, weight_s, x_t_stu, x_t_teas_in, theta_stu, thetas_tea)
+    tr._forward_backward = spy
+    out = dict(tr.train_step(*_args(g)))
+    torch.cuda.synchronize()
+    st_d = rng_dev.get_state()
+    assert st_d[2] == rng_state[2] and np.array_equal(st_d[1], rng_state[1]), "the device step consumed other host draws than the oracle"
+    for key, which in (("x_s_in", "alpha_s2t"), ("x_t_tea_in", "alpha_t2s")):
+        e = (seen[key].cpu() - ref[key]).abs().max().item()
+        print(f"configs[2] N=32: {which} = {ref[which]:.4f}, effective input max|device - oracle| {e:.2e}")
+        assert e < 5e-4
+    assert list(tr.occluded) == list(ref["occluded"]), (tr.occluded, ref["occluded"])
+    out["_err_teacher"] = float("nan")
+    _compare_with_oracle("configs[2] N=32 eager reference mix", out, ref, b["label_s"], stu, tea, sd, 1e-3, 3e-3, 3e-3, 1e-2, True)
+    _ema_bit_exact(tea, sd, stu)
+
+
+@pytest.fixture(scope="module")
+def trained_k18():
+    from conftest import train_keypoint_net
+    sd, hist, pck = train_keypoint_net(18, steps=300, seed=1)
+    print("trained-like PoseResNet-101 (K=18): JointsMSE " + " ".join(f"{h:.3e}" for h in hist) + f"; held-out PCK@0.05 {pck:.3f}")
+    assert hist[-1] < 0.5 * hist[0]
+    return sd
+
+
+def test_config4_full_size_captured_step_vs_oracle(trained_k18):
+    """BASELINE.json configs[4]'s per-GPU workload - K = 18, 384x384 (heat-maps 96x96), sigma 1.0 (7x7 stamps), fp16 student under the loss
+    scaler with the fp32-grade teacher (train_animal.py:330-483) - N = 8, captured, against the oracle step."""
+    _need_host_mem(32)
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    sd = trained_k18
+    K, S, N, sigma = 18, 384, 8, 1.0
+    b = keypoint_mean_teacher_batch(N, K=K, S=S, sigma=sigma, seed=70)
+    ref = _oracle_step(sd, b, K, sigma=sigma, S=S)
+    g = _to_dev(b)
+    burn = _to_dev(keypoint_mean_teacher_batch(N, K=K, S=S, sigma=sigma, seed=80))
+    stu, tea = _device_pair(sd, K)
+    tr = MeanTeacherTrainer(stu, tea, lr=1e-4, sigma=sigma, image_size=S, heatmap_size=S // 4, precision="reference")
+    gs = GraphedTrainStep(tr, *_args(burn), warmup=1)
+    _rewind(tr, stu, tea, sd)
+    out = dict(gs.step(*_args(g)))
+    torch.cuda.synchronize()
+    out["_err_teacher"] = float("nan")
+    _compare_with_oracle("configs[4] N=8 384x384 captured reference mix", out, ref, b["label_s"], stu, tea, sd, 1e-3, 5e-3, 5e-3, 2e-2, True)
+    _ema_bit_exact(tea, sd, stu)
+    gs.release()

@@ -24,42 +24,23 @@ def _stage(name):
 
 
 @pytest.fixture(scope="module")
-def trained():
-    """(device network with trained weights, CPU oracle with the same weights, batch dict, loss history)"""
+def trained(trained_r101_k16):
+    """(device network with trained weights, CPU oracle with the same weights, held-out batches, loss history); the training run is the
+    session's (tests/conftest.py::trained_r101_k16)."""
     import uda_poseestimation_amd.lib.models as models
     from oracle.pose_resnet_ref import pose_resnet101_ref
     from uda_poseestimation_amd import synthetic
-    from uda_poseestimation_amd.lib.models.loss import JointsMSELoss
-    from uda_poseestimation_amd.optim import FusedAdam
-    torch.manual_seed(0)
-    net = models.pose_resnet101(num_keypoints=16, pretrained_backbone=False).cuda().train()
+    sd, hist, _ = trained_r101_k16
+    net = models.pose_resnet101(num_keypoints=16, pretrained_backbone=False)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
     net.precision = "fp16"
-    from uda_poseestimation_amd.lib import keypoint_detection as kd
-    opt = FusedAdam(net.parameters(), lr=2e-4, dynamic_loss_scale=True, init_scale=1024.0)
-    crit = JointsMSELoss()
-    hist = []
-    for it in range(400):
-        x, lab, wt = (t.cuda() for t in synthetic.keypoint_batch(8, seed=1000 + it))
-        opt.zero_grad()
-        y = net(x)
-        loss = crit(y, lab, wt)
-        opt.scale_loss(loss).backward()
-        opt.step()
-        if it % 80 == 0 or it == 399:
-            hist.append(float(loss.detach()))
     batches = []
     for seed in (5, 6):             # held-out batches (never trained on)
         x, lab, wt = (t.cuda() for t in synthetic.keypoint_batch(8, seed=seed))
         batches.append({"x_s": x, "label_s": lab, "weight_s": wt})
-    net.eval()
-    with torch.no_grad():
-        pck = kd.accuracy(net(batches[0]["x_s"]), batches[0]["label_s"])[1]
-    net.train()
-    torch.cuda.synchronize()
     ref = pose_resnet101_ref(16)
-    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
-    print("trained-like PoseResNet-101: JointsMSE over the 400 steps " + " ".join(f"{h:.3e}" for h in hist) + f"; held-out PCK@0.05 (eval mode) {pck:.3f}")
-    assert hist[-1] < 0.5 * hist[0] and pck > 0.5, (hist, pck)           # it learned the task, and generalises
+    ref.load_state_dict(sd)
     return net, ref, batches, hist
 
 
