@@ -147,17 +147,41 @@ def cpu_baseline(n, arch_layers, seconds_budget=30.0):
                       + (" of the non-first (times fall over the first iterations: " + ", ".join(f"{t:.1f}" for t in times) + " s)" if len(times) > 1 else "") + f": {best:.2f} s/step"}
 
 
-def measured_parity(arch, dev, precision):
-    """MEASURED parity of this run (VERDICT r5 #1b): the device step in `precision` ('bf16' | 'fp16' | 'reference') from the weights and the
-    batch of the cpu_baseline leg's FIRST oracle step (oracle/step_ref.py, fp32; PoseResNet-101 at the reference initialisation, seed 0,
-    batch 8) - heat-map max-abs error and scale, arg-max key points, both losses, the k-th-value mask.  The network is the bench's own:
-    randomly initialised, train-mode BatchNorm - the worst case for 16-bit storage; the trained-network figures are
-    tests/test_gpu_fullsize.py's and tests/test_gpu_trained.py's."""
+def trained_parity_context(arch, threads, n=8):
+    """The start state of `measured_parity` on a TRAINED-LIKE network: `arch` trained on the device (synthetic.trained_like_state_dict,
+    300 steps of 8 images whose content determines the labels: ~15 s), one fp32 oracle step (oracle/step_ref.py) from those weights on
+    a held-out batch of `n` images per domain on the host."""
+    from oracle.pose_resnet_ref import PoseResNetRef
+    from oracle.step_ref import train_step_ref
+    from uda_poseestimation_amd import synthetic
+    layers = {"pose_resnet101": [3, 4, 23, 3], "pose_resnet50": [3, 4, 6, 3]}[arch]
+    sd, hist, pck = synthetic.trained_like_state_dict(16, steps=300, arch=arch)
+    b = synthetic.keypoint_mean_teacher_batch(n, seed=40)
+    torch.set_num_threads(threads)
+    stu, tea = PoseResNetRef(layers, 16), PoseResNetRef(layers, 16)
+    stu.load_state_dict(sd); tea.load_state_dict(sd)
+    opt = torch.optim.Adam(stu.parameters(), lr=1e-4)
+    r_ = train_step_ref(stu, tea, opt, b["x_s"], b["label_s"], b["weight_s"], b["x_t_stu"], b["x_t_tea"], b["aug_param_stu"], b["aug_param_tea"])
+    return {"sd": sd, "batch": b, "layers": layers, "ref": {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in r_.items()},
+            "what": f"{arch} K=16 TRAINED on the device (300 steps x 8 synthetic key-point images, JointsMSE {hist[0]:.2e} -> {hist[-1]:.2e}, held-out PCK@0.05 "
+                    f"{pck:.2f}), train-mode BN, 256x256, held-out batch of {n} per domain"}
+
+
+def measured_parity(arch, dev, precision, ctx=None):
+    """MEASURED parity of this run (VERDICT r5 #1b): the device step in `precision` ('bf16' | 'fp16' | 'reference') against ONE fp32 oracle
+    step (oracle/step_ref.py, train_human.py:326-444) from identical weights and inputs - heat-map max-abs error of the student's
+    source pass and of the teacher's re-warped maps, arg-max key points, both losses, the k-th-value mask.  ctx None: the cpu_baseline
+    leg's first step = the bench's OWN network (reference initialisation, seed 0, batch 8: randomly initialised train-mode BatchNorm, the
+    worst case for 16-bit storage); ctx from trained_parity_context: the same on a trained-like network.  The
+    benchmarked size (N = 32, captured) is tests/test_gpu_fullsize.py's."""
     from oracle.keypoints_ref import get_max_preds_ref
     from uda_poseestimation_amd.engine import MeanTeacherTrainer
     from uda_poseestimation_amd.lib import keypoint_detection as kd
     import uda_poseestimation_amd.lib.models as models
-    ctx = getattr(cpu_baseline, "parity_ctx", None)
+    what = None
+    if ctx is None:
+        ctx = getattr(cpu_baseline, "parity_ctx", None)
+        what = f"{arch} K=16 at the reference initialisation (seed 0), train-mode BN, 256x256: the cpu_baseline leg's first oracle step"
     if ctx is None or ctx["ref"] is None or ctx["layers"] != {"pose_resnet101": [3, 4, 23, 3], "pose_resnet50": [3, 4, 6, 3]}[arch]:
         return None
     stu = models.__dict__[arch](num_keypoints=16, pretrained_backbone=False)
@@ -174,9 +198,9 @@ def measured_parity(arch, dev, precision):
     same = (p_dev == p_ref).all(-1)
     m_dev, m_ref = out["tea_mask"].cpu().bool(), ref["tea_mask"].bool()
     ls, lsr, lc, lcr = float(out["loss_s"]), float(ref["loss_s"]), float(out["loss_c"]), float(ref["loss_c"])
-    res = {"measured": True, "student": stu._last_hd.precision, "teacher": tea._last_hd.precision,
-           "network": f"{arch} K=16 at the reference initialisation (seed 0), train-mode BN, 256x256, batch {y_ref.shape[0]} per domain: the cpu_baseline leg's first oracle step",
-           "heatmap_max_abs": (y_dev - y_ref).abs().max().item(), "heatmap_scale": y_ref.abs().max().item(),
+    res = {"measured": True, "student": stu._last_hd.precision, "teacher": tea._last_hd.precision, "network": ctx.get("what") or what,
+           "batch": int(y_ref.shape[0]), "heatmap_max_abs": (y_dev - y_ref).abs().max().item(), "heatmap_scale": y_ref.abs().max().item(),
+           "teacher_heatmap_max_abs": (out["y_t_tea_recon"].detach().float().cpu() - ref["y_t_tea_recon"]).abs().max().item(),
            "argmax_identical": f"{int(same.sum())}/{same.size}", "mask_identical": f"{int((m_dev == m_ref).sum())}/{m_ref.numel()}",
            "loss_s_rel": abs(ls - lsr) / abs(lsr), "loss_c_rel": abs(lc - lcr) / max(abs(lcr), 1e-30), "loss_s": ls, "loss_s_oracle": lsr}
     res["heatmap_rel"] = res["heatmap_max_abs"] / max(res["heatmap_scale"], 1e-30)
@@ -336,21 +360,13 @@ def main():
     ap.add_argument("--wgrad-stages", type=int, default=0, help="tuning: 64-pixel stages per work-group of the grouped wgrad")
     ap.add_argument("--policy", action="append", default=[], metavar="FIELD=INT", help="tuning: override one field of the dispatch policy "
                     "(include/udapose.h udapose_policy), e.g. --policy igemm_h3=0; repeatable")
-    ap.add_argument("--wgrad-side", action="store_true", help="tuning: the upper part's weight gradients on a side stream under the lower "
-                    "part's gradient chain instead of after the whole chain (measured slower: profiles/r2_ab_runs.txt)")
-    ap.add_argument("--early-source-bwd", action="store_true", help="tuning: the source pass's gradient chain starts right after its own forward")
-    ap.add_argument("--wgrad-streams", type=int, default=1, help="tuning: side streams of the staged weight gradients (--policy wgrad_overlap=N)")
     ap.add_argument("--no-merge-wgrad", action="store_true", help="tuning: each pass launches its own grouped weight gradients")
     ap.add_argument("--two-graphs", action="store_true", help="tuning: the optimizer tail as its own graph on one rank too")
     ap.add_argument("--force-overlap", action="store_true", help="tuning: the data-parallel backward (two parts, gradient sums per part) without a "
                     "process group: isolates what the cut costs on one rank")
     ap.add_argument("--stream-priority", type=int, default=0, help="tuning: priority of the three branch streams (-1 = high; side streams stay 0)")
     ap.add_argument("--no-sum-in-tail", action="store_true", help="tuning: a separate launch adds the two passes' gradient buffers")
-    ap.add_argument("--split-tail", action="store_true", help="tuning: the optimizer sweep's first part (the parameters the first weight-gradient phase "
-                    "completed) on a side stream beside the second weight-gradient phase (measured slower: profiles/r5_ab_runs.txt)")
     ap.add_argument("--no-fuse-rectify", action="store_true", help="tuning: activations and rectify as two arg-max sweeps")
-    ap.add_argument("--wgrad-classes-concurrent", action="store_true", help="tuning: the pair weight-gradient launch's two tile classes on two streams "
-                    "(profiles/r5_ab_runs.txt 11)")
     ap.add_argument("--no-fuse-tail", action="store_true", help="tuning: separate Adam / EMA / weight-pack launches instead of the fused tail")
     ap.add_argument("--dp-form", default="auto", choices=["auto", "fixed"], help="data parallel (world > 1): 'auto' times 5 steps of each form - {two gradient "
                     "buckets, the first under backward part 2 | one bucket after the whole backward} x {fp32, bf16 on the wire} - during spin-up, "
@@ -359,8 +375,7 @@ def main():
     ap.add_argument("--grad-comm", default=None, choices=["fp32", "bf16"], help="data parallel: wire format of the gradient buckets (bf16: one "
                     "rounding per contribution, all-to-all + fp32 accumulation on the shard's owner + all-gather: half the bytes per xGMI link)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--branch-graphs", action="store_true", help="tuning: the one-rank step as nine linear hipGraphs on three streams joined by events instead "
-                    "of ONE hipGraph with three branches (measured: no faster, and dependent on the stream -> hardware-queue lottery: profiles/r5_ab_runs.txt)")
+    ap.add_argument("--no-trained-parity", action="store_true", help="skip the parity leg on a network trained in this run (~20 s)")
     ap.add_argument("--no-capture-comm", action="store_true", help="data parallel: keep the collectives eager between four graphs instead of capturing "
                     "them into the step's one graph (round 5's default with RCCL)")
     ap.add_argument("--one-bucket", action="store_true", help="data parallel: the whole backward with one merged weight-gradient tail, then ONE "
@@ -403,6 +418,7 @@ def main():
     guard = _HangGuard()
     guard.enabled = world > 1 or force_dist
     guard.arm(300, "process group / communicator creation")
+    t_comm0 = time.perf_counter()
     sys.stdout.flush()
     saved_out = os.dup(1)
     os.dup2(2, 1)
@@ -425,6 +441,7 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_out, 1)
         os.close(saved_out)
+    setup_s = {"communicator_s": round(time.perf_counter() - t_comm0, 2)} if dist.is_initialized() else {}
 
     from uda_poseestimation_amd import _hip, synthetic
     from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
@@ -461,7 +478,6 @@ def main():
     teacher = models.__dict__[args.arch](num_keypoints=K, pretrained_backbone=False).to(dev)
     student.policy.update(tune)
     teacher.policy.update(tune)
-    student.wgrad_side_stream = bool(args.wgrad_side)
     extra = {}
     if args.config2:
         extra = style_extras(dev, args.precision)
@@ -469,17 +485,11 @@ def main():
                                  heatmap_size=S // 4, precision=(args.precision or args.dtype), grad_comm=args.grad_comm, **extra)
     if args.no_fuse_tail:
         trainer.fuse_tail = False
-    if args.split_tail:
-        trainer.split_tail = True
-    if args.wgrad_classes_concurrent:
-        student.wgrad_classes_concurrent = True
     if args.no_fuse_rectify:
         trainer.fuse_rectify = False
     trainer.stream_priority = args.stream_priority
     if args.no_merge_wgrad:
         trainer.merge_wgrad = False
-    trainer.early_source_backward = bool(args.early_source_bwd)
-    trainer.wgrad_streams = args.wgrad_streams
     if args.two_graphs:
         trainer.single_graph = False
     if args.force_overlap:
@@ -506,7 +516,7 @@ def main():
         def build_graphed():
             return GraphedTrainStep(trainer, g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"],
                                     g["aug_param_tea"], split=(True if args.split_graphs else None),
-                                    capture_comm=(False if args.no_capture_comm else None), branch_graphs=bool(args.branch_graphs))
+                                    capture_comm=(not args.no_capture_comm and dist.is_initialized() and dist.get_backend() == "nccl" and not args.split_graphs))
 
         guard.arm(420, "capture / selection of the data-parallel form")
         if dp_auto and dist.is_initialized() and (world > 1 or force_dist):
@@ -515,14 +525,19 @@ def main():
             forms = [("two_buckets_fp32", True, "fp32"), ("one_bucket_fp32", False, "fp32"), ("two_buckets_bf16", True, "bf16"), ("one_bucket_bf16", False, "bf16")]
             if dist.get_backend() != "nccl":
                 forms = forms[:2]                       # (bf16 on the wire needs RCCL)
-            timings, built = {}, {}
+            timings, built, capture_s, fallbacks = {}, {}, {}, {}
+            t_sel0 = time.perf_counter()
             for name, overlap, wire in forms:
                 trainer.overlap_allreduce, trainer.sync.comm_dtype = overlap, wire
                 gr, err = None, None
+                t_c0 = time.perf_counter()
                 try:
                     gr = build_graphed()
                 except Exception as e:          # (a form this stack cannot build on some rank is dropped on all of them)
                     err = e
+                capture_s[name] = round(time.perf_counter() - t_c0, 2)
+                if gr is not None and getattr(gr, "capture_fallback", None):
+                    fallbacks[name] = gr.capture_fallback        # (the engine's collective fallback: every rank built the four-graph form instead)
                 okt = torch.tensor([0.0 if gr is None else 1.0], device=dev)
                 dist.all_reduce(okt, op=dist.ReduceOp.MIN)
                 if float(okt.item()) < 1.0:
@@ -554,11 +569,18 @@ def main():
             built.clear()
             gr = None            # (every graph that captured RCCL launches must be gone before the process group is destroyed: see the end of main)
             torch.cuda.empty_cache()
-            dp_choice = {"chosen": name, "ms_per_step_5_steps": timings}
+            setup_s.update({"capture_s": capture_s, "selection_s": round(time.perf_counter() - t_sel0, 2)})
+            dp_choice = {"chosen": name, "ms_per_step_5_steps": timings, "collectives_captured": bool(getattr(graphed, "capture_comm", False)),
+                         "capture_fallback": (fallbacks or None)}
             if rank == 0:
                 print(f"dp form: {dp_choice}", file=sys.stderr, flush=True)
         else:
+            t_c0 = time.perf_counter()
             graphed = build_graphed()
+            if dist.is_initialized():
+                setup_s["capture_s"] = {"fixed": round(time.perf_counter() - t_c0, 2)}
+                if getattr(graphed, "capture_fallback", None):
+                    dp_choice = {"chosen": "fixed", "ms_per_step_5_steps": None, "collectives_captured": False, "capture_fallback": {"fixed": graphed.capture_fallback}}
 
         host = {k: v.cpu().pin_memory() for k, v in g.items() if torch.is_tensor(v)} if args.host_inputs else None
 
@@ -672,8 +694,7 @@ def main():
         dist.all_gather(every_t, mine)
         rank_ms = [[round(float(e[0]), 3), round(float(e[1]), 3)] for e in every_t]
     loss = float(out["loss_all"])
-    invalid = bool(tune.get("exp0"))      # (exp0: timing experiments that skip work on purpose; only in builds made with -DUDAPOSE_TIMING_EXPERIMENTS)
-    assert loss == loss or invalid, "loss is NaN"
+    assert loss == loss, "loss is NaN"
     in_sync = None
     if world > 1:
         # data-parallel invariant (outside the timed region): every rank holds the same student and teacher after the run
@@ -703,9 +724,7 @@ def main():
                 else:
                     what = "3 hipGraphs around the two RCCL collectives"
             else:
-                what = ("linear hipGraphs on three streams (head | teacher forward | source forward | target forward | losses | two gradient chains | "
-                        "weight gradients + Adam + EMA + packs), joined by events" if getattr(graphed, "branch", False) else
-                        ("1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs"))
+                what = "1 hipGraph (forwards, losses, backward, Adam + EMA + packs)" if graphed.one_graph else "2 hipGraphs"
             launch_desc = (("2 style-transfer hipGraphs (alpha on the device) + " if args.config2 else "") + what
                            + "; timed region = graph replays only (the instrumented eager roofline sample runs after it, untimed)")
         res = {
@@ -729,13 +748,13 @@ def main():
             "loss": loss, "launch": launch_desc,
             "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0),
             "grad_comm": args.grad_comm if dist.is_initialized() else None,
-            "dp_form": dp_choice,
+            "dp_form": dp_choice, "dp_setup_s": (setup_s or None),
             "comm_exposed_ms_per_step": round(comm_exposed_ms, 3) if comm_exposed_ms is not None else None,
             "rank_ms_per_step_min_max": ([min(r[0] for r in rank_ms), max(r[0] for r in rank_ms)] if rank_ms else None),
             "rank_comm_exposed_ms": ([r[1] for r in rank_ms] if rank_ms else None),
             "replicas_in_sync": in_sync, "inputs": "pinned host memory: every step's batch is copied H2D on a copy stream under the previous step" if args.host_inputs else "resident in HBM",
             "step_tflops_per_gpu": round(7 * N * FWD_GFLOP_PER_IMAGE / 1e3 / (ms * 1e-3), 2) if (args.arch, S, K) == ("pose_resnet101", 256, 16) else None,
-            "policy_overrides": (tune or None), "valid": not invalid,
+            "policy_overrides": (tune or None), "valid": True,
             "roofline": {"bound": "mfma", "kernel": f"igemm_kernel (implicit-GEMM conv fprop+dgrad, {args.dtype} MFMA 16x16x32)",
                          "bound_note": "priced against the dense MFMA peak as SURVEY.md 8(d) prescribes for the convolutions (>99 % of the FLOPs); the MEASURED "
                                        "limiter of these launches is neither roof: per-CU L2->LDS operand fill (137-146 GB/s per CU, shared by the step's three "
@@ -778,6 +797,10 @@ def main():
                 torch.cuda.empty_cache()
                 print("parity: device step from the oracle's start state ...", file=sys.stderr, flush=True)
                 res["parity"] = measured_parity(args.arch, dev, args.precision or args.dtype)
+                if not args.no_trained_parity:
+                    print("parity: training the trained-like network, one oracle step from it ...", file=sys.stderr, flush=True)
+                    ctx_tr = trained_parity_context(args.arch, res["cpu_baseline"]["cores"])
+                    res["parity_trained"] = measured_parity(args.arch, dev, args.precision or args.dtype, ctx_tr)
         elif world > 1:
             res["cpu_baseline"] = None
         # the parity-compliant configurations of the same step, driver-visible (untimed extras after the headline's timed region)
@@ -794,9 +817,10 @@ def main():
                 oc[tag] = other_config_rate(args.arch, dev, N, K, S, sigma, dt_, pr_)
                 # (measured by THIS run, like res["parity"]: the device step in that precision against the cpu_baseline leg's first oracle step)
                 oc[tag]["parity"] = measured_parity(args.arch, dev, pr_ or dt_) if "parity" in res else None
-            oc["note"] = ("parity figures are this run's measurements on the bench's own randomly initialised network (train-mode BN: every bottleneck amplifies "
-                          "storage rounding); on a TRAINED network the same comparisons at the benchmarked size are tests/test_gpu_fullsize.py's "
-                          "(bf16 ~5e-3, fp16 ~1e-3, the reference mix's fp32-grade teacher ~5e-7 absolute)")
+                oc[tag]["parity_trained"] = measured_parity(args.arch, dev, pr_ or dt_, ctx_tr) if "parity_trained" in res else None
+            oc["note"] = ("`parity` = this run's measurement on the bench's own randomly initialised network (train-mode BN: every bottleneck amplifies storage "
+                          "rounding; no 16-bit format is close to the fp32 oracle there), `parity_trained` = the same on a network trained in this run; "
+                          "the benchmarked size (N = 32, captured) against the oracle is tests/test_gpu_fullsize.py")
             # BASELINE.json's other single-GPU configurations (the ones the reference actually trains: train_human.py:345-358,
             # train_animal.py:330-483), same harness: 20 graph replays each
             for tag, kw in (("configs[2]_bf16_style", dict(dtype="bf16", precision=None, config2=True)),

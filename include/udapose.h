@@ -48,8 +48,7 @@ int udapose_elem_kind(void);
  * (lib/models/Style_net.py:32-118). */
 /* Explicit dispatch policy (tests force a code path with it, bench.py's tuning flags run A/B comparisons through it).
  * udapose_policy_default fills in the production policy; fields: igemm_tile / wgrad_tile / wgrad_ksplit -1 = heuristics;
- * igemm_h3: run-staged 3x3 form 0 off, 1 measured per-shape policy, 2 / 3 force the 64- / 128-row form, 4 three taps per
- * barrier; wgrad_group: one grouped weight-gradient launch per tile class in udapose_net_backward (0: layer by layer),
+ * igemm_h3: run-staged 3x3 form 0 off, 1 measured per-shape policy, 2 / 3 force the 64- / 128-row form; wgrad_group: one grouped weight-gradient launch per tile class in udapose_net_backward (0: layer by layer),
  * wgrad_stages: 64-pixel stages a work-group reduces before a layer's pixel range is split; bn_bwd_fused: dgrad epilogues
  * mask for the consumer BatchNorm and reduce its backward sums; bn_fwd_chunked / bn_bwd_chunked: finalize + apply of the wide,
  * small-spatial BatchNorm layers in one launch (0 off, 1 on, > 1: on with that target work-group count instead of 1024);
@@ -70,33 +69,18 @@ typedef struct {
     int bn3_mask;
     int stem_fused;
     int debug_sync;
-    int igemm_q_tile;     /* tile id for launches whose 128x64 grid has 769..1024 work-groups (a second, mostly empty round on the 768
-                           * resident slots); -1: the general heuristic */
-    int exp0;             /* tuning scratch value read by whichever experiment is being A/B-ed (0 in production) */
-    int wgrad_big;        /* grouped weight gradients: 256x128 tiles (128x64 per wave: 25 % fewer LDS bytes per FLOP than 64x64 per wave) for
-                           * stride-1 layers on power-of-two maps with Co % 256 == 0 and Ci % 128 == 0 (layer3 / layer4, layer2's c3) */
     int igemm_big_min;    /* > 0: 128x128 tiles (2-stage ring) for single-class launches with Co % 128 == 0 whose 128x64 grid has at least this
                            * many work-groups - the style network's large maps, run on one stream (+13-18 % there); 0 (default): never */
     int patch_conv;       /* reflection-padded 3x3 stride-1 convolutions (the style network) through the patch-staged kernels (input patch staged once,
                            * not once per tap): 0 never (the implicit GEMM for every layer), 1 the 64 -> 3 and 3 -> 64 end layers, 2 (default)
                            * the trunk layers too, 3 = 2 with 128 output channels per work-group in the 16-bit form */
-    int wgrad_overlap;    /* > 0: the weight gradients of a backward pass go out STAGE BY STAGE on a side stream, each stage as soon as the
-                           * gradient chain has left its layers (udapose_net_backward_staged + udapose_net_wgrad_staged): stage 0 = head +
-                           * deconvolutions, then groups of this many bottleneck blocks counted from the top (or the cuts below) */
-    int wgrad_cap;        /* > 0: grouped weight-gradient launches are PERSISTENT grids of this many work-groups (256 = one per CU) pulling
-                           * table entries from per-XCD heads: bounded residency, so a launch can run under the gradient chain */
-    int wgrad_cut_lo, wgrad_cut_hi;   /* staged launches: bit b set = bottleneck block b (0 = layer1's first) is the LOWEST block of its stage;
-                           * 0 / 0 = every wgrad_overlap-th block counted from the top */
     int eval_fold;        /* 1 (default): eval-mode network forwards (validate(), train_human.py:461-500) apply BatchNorm's running-statistics scale /
                            * shift, the residual and the ReLU in the convolution's epilogue: no BN-apply launch, no pre-BN tensor; 0: conv + apply */
     int bn_xcd_rows;      /* 1 (default): the BatchNorm apply kernels give XCD k the k-th eighth of the pixel rows - what the implicit GEMMs' work-groups on
                            * XCD k wrote and will read - so activations cross the conv <-> BatchNorm kernel boundaries through one L2; 0: interleaved */
-    int wgrad_merge;      /* 1: the pair launch (udapose_net_wgrad_pair) reduces BOTH passes' pixels inside one work-group per (layer, tile, split) - pass A's
-                           * stages, then pass B's, one accumulator tile, one epilogue - into pass A's gradient tensors; pass B's buffer keeps only what its
-                           * gradient chain wrote (BatchNorm / bias gradients).  Half the output tiles, epilogues and split atomics (round 5; 0 = default) */
-    int bn_fin_apply;     /* 1: the BatchNorm layers that run a finalize launch and a streaming apply launch (layer1, layer2, the last deconvolutions) run
-                           * ONE launch instead: the first C/8 blocks finalize and raise a counter, the others - the apply - wait for it with their first loads
-                           * already in flight (in-grid hand-off, self-resetting counters); bit-identical results (round 5) */
+    int wgrad_det;        /* 1 (default, round 6): split weight-gradient reductions of the grouped launches store per-split partial tiles into the pass's
+                           * workspace and ONE launch adds them in split order (bit-reproducible gradients; the `loss.backward()` of
+                           * train_human.py:436 run twice gives the same bits); 0: fp32 atomics into cleared tensors, arrival order */
     int igemm_ns3_k;      /* 64x64 implicit-GEMM tiles take the 3-stage LDS ring from this reduction length on (K = taps x Ci), the 2-stage ring
                            * below it; 0 = the default, 2048 */
     void* timeline;
@@ -258,38 +242,13 @@ int udapose_net_backward_phase(udapose_net_t net, void* stream, const float* dou
                                void* act, void* ws, void* const* h_grads, float beta, int part, int phase);
 /* The grouped weight-gradient launches (phase 2) of TWO passes of one plan whose gradient chains (phase 1) have run - each with its
  * own act / ws arenas, gradient tensors and beta - as ONE launch per tile class: the two student passes of a mean-teacher step end
- * together and their weight gradients are exposed there; one grid of twice the size has half the tail. */
+ * together and their weight gradients are exposed there; one grid of twice the size has half the tail.
+ * Determinism (round 6, udapose_policy.wgrad_det = 1, the default): a layer whose pixel range is split over several work-groups (layer1 / layer2,
+ * the last deconvolution, the head, the stem) has every split store its partial tile into `ws`; one launch then adds the splits in split order
+ * into the gradient tensor.  Two runs of a backward on the same inputs give the same bits (rounds 1-5 accumulated the splits with fp32
+ * atomics in arrival order).  `ws` must have the size udapose_net_ws_bytes returns AFTER udapose_net_set_policy. */
 int udapose_net_wgrad_pair(udapose_net_t net, void* stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a,
                            const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int part);
-/* The same in two phases (round 5): phase 1 = the clearing launches and the tile classes that hold the 1x1 convolutions of layer2-4, the
- * deconvolutions and the strided convolutions (60 % of the parameters); phase 2 = the remaining class (3x3 convolutions, layer1, head, stem).
- * Between the two a caller starts udapose_net_fused_update_part(part 1) - the optimizer sweep of the parameters phase 1 completed - on another
- * stream: the HBM-bound sweep runs beside phase 2's LDS-fill-bound launch instead of behind it.  phase 0 = udapose_net_wgrad_pair.
- * phase 3 = the clearing launches only, phase 4 = phase 1 without them: 3, then 2 on a second stream behind it and 4 on the first, runs the
- * tile classes' grids side by side. */
-int udapose_net_wgrad_pair_phase(udapose_net_t net, void* stream, const void* act_a, void* ws_a, void* const* h_grads_a, float beta_a,
-                                 const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int part, int phase);
-/* Staged weight gradients (udapose_policy.wgrad_overlap > 0; round 4): the ONE `loss.backward()` of the reference's step
- * (train_human.py:436) computes every layer's weight gradient as soon as that layer's output gradient exists; here the plan's
- * layers are cut into stages in chain order (stage 0 = head + deconvolutions, then groups of bottleneck blocks from the top, the
- * stem with the last), and
- *   udapose_net_backward_staged  runs the gradient chain of the whole backward on `stream` (= udapose_net_backward_phase(part 0,
- *                                phase 1)) and records the plan's stage events of `slot` (0..3: one per concurrent pass of a step)
- *                                as the chain leaves each stage;
- *   udapose_net_wgrad_staged     enqueues on the side streams (host array of n_streams handles; stage k goes to stream k mod n_streams:
- *                                one stream = stages strictly in order, several = lagging stages run beside each other), stage by
- *                                stage: wait for the stage's event of pass A (and
- *                                of pass B when act_b != NULL: the two passes of one plan share every launch), then that stage's
- *                                grouped weight gradients.  Every stage but the last is a PERSISTENT grid of udapose_policy.wgrad_cap
- *                                work-groups (bounded residency: the chain kernels of the layers below keep their CU slots).
- * The caller joins every side stream into the stream of the optimizer step.  Gradients are bit-identical to the unstaged backward for layers
- * that reduce inside one work-group; layers split over pixels accumulate with fp32 atomics in either form (order not fixed).
- * Both need udapose_net_bind_grads for the gradient placement (it builds the stage tables, events and head counters). */
-int udapose_net_num_stages(udapose_net_t net);
-int udapose_net_backward_staged(udapose_net_t net, void* stream, const float* dout_nchw, const void* const* h_params, const void* wpack,
-                                void* act, void* ws, void* const* h_grads, float beta, int slot);
-int udapose_net_wgrad_staged(udapose_net_t net, void* const* h_wg_streams, int n_streams, const void* act_a, void* ws_a, void* const* h_grads_a,
-                             float beta_a, int slot_a, const void* act_b, void* ws_b, void* const* h_grads_b, float beta_b, int slot_b);
 long long udapose_net_grad_split_param(udapose_net_t net);
 
 /* ---------------------------------------------------------------- heat-map losses and decode (fp32 NCHW rows [R=B*K][HW]) */
@@ -354,14 +313,6 @@ int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void*
                              void* const* h_exp_avg, void* const* h_params_t, void* wpack_s, void* wpack_t, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha,
                              float one_minus_alpha, int do_adam, long long grad2_delta_bytes);
-/* The sweep in two parts (round 5; `stu_optimizer.step(); tea_optimizer.step()` of train_human.py:437-438 still once per step): part 1 = the
- * convolution weights whose gradients udapose_net_wgrad_pair_phase(phase 1) completed (and the step counter's tick), part 2 = every other
- * parameter and the two odd packs; parts 1 + 2 run the blocks of part 0 = udapose_net_fused_update, each exactly once.  The split follows the
- * weight-gradient tables of udapose_net_bind_grads: call udapose_net_bind_update after it. */
-int udapose_net_fused_update_part(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* h_params_s, void* const* h_grads,
-                                  void* const* h_exp_avg, void* const* h_params_t, void* wpack_s, void* wpack_t, float lr, float beta1,
-                                  float beta2, float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha,
-                                  float one_minus_alpha, int do_adam, long long grad2_delta_bytes, int part);
 /* grad2_delta_bytes != 0: the gradient is h_grads[i] + the tensor grad2_delta_bytes behind it (the second per-pass gradient buffer
  * of a step whose two backward passes ran on different streams; a multiple of 16): the sum udapose_axpy_f32 would have written
  * first, taken in the same sweep.  h_grads itself is left holding the first pass's share. */

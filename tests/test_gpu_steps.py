@@ -436,30 +436,6 @@ def rng_state_equal(a, b):
     return sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
 
 
-def test_weight_gradients_on_a_side_stream_are_bit_identical_eager_and_captured():
-    """udapose_net_backward_phase: the upper part's grouped weight gradients on a side stream under the lower part's gradient
-    chain (student.wgrad_side_stream, off by default: measured slower) give exactly the in-stream result, eagerly and captured
-    (the side streams join the capture's origin stream: tools/capture_fork_patterns.py)."""
-    from uda_poseestimation_amd import synthetic
-    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
-    N, K, S = 4, 16, 128
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=2)
-    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
-    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
-    res = {}
-    for side in (False, True):
-        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=0).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=0).cuda()
-        stu.wgrad_side_stream = side
-        tr = MeanTeacherTrainer(stu, tea, image_size=S, heatmap_size=S // 4)
-        tr.train_step(*args)
-        gs = GraphedTrainStep(tr, *args, warmup=1)
-        for _ in range(3):
-            out = gs.step(*args)
-        assert torch.isfinite(out["loss_all"])
-        res[side] = [p.detach().clone() for p in stu.parameters()]
-    assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
-
-
 def test_gradient_buffers_summed_inside_the_fused_tail_are_bit_identical_to_the_separate_sum():
     """udapose_net_fused_update(grad2_delta_bytes): the two passes' gradient buffers added inside the Adam / EMA / pack sweep give
     exactly the parameters of axpy-then-sweep, eagerly and captured; p.grad is completed on demand by finish_grads()."""
@@ -492,252 +468,6 @@ def test_gradient_buffers_summed_inside_the_fused_tail_are_bit_identical_to_the_
     part = stu.head.weight.grad.clone()
     stu.finish_grads()
     assert stu.pending_grad_sum() == 0 and not torch.equal(part, stu.head.weight.grad)
-
-
-def test_split_optimizer_tail_beside_the_second_weight_gradient_phase_is_bit_identical():
-    """Round 5: the step's serial end - `loss.backward()`'s weight gradients, `stu_optimizer.step()`,
-    `tea_optimizer.step()` (train_human.py:436-438) - with the optimizer sweep of the parameters the FIRST weight-gradient phase completed
-    running on a side stream beside the second phase (udapose_net_wgrad_pair_phase, udapose_net_fused_update_part).
-    (a) The sweep itself: from ONE saved state and ONE set of gradients, parts 1 + 2 leave every parameter, moment, teacher tensor, the step
-    counter's device state and both networks' weight packs bit-identical to the one-launch sweep (same kernel, disjoint block lists that
-    together are the whole list; both lists non-empty on this network).  (Two whole steps are not bit-comparable: the re-warp's backward and
-    the stem's weight gradient accumulate with fp32 atomics in arrival order.)
-    (b) The step: eagerly and captured, the trainer issues phase 1 | part 1 beside phase 2 | part 2, and trains (finite losses)."""
-    from uda_poseestimation_amd import synthetic, warp
-    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
-    N, K, S = 4, 16, 128
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=12)
-    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
-    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
-    th = lambda ap: warp.recon_thetas(ap, N, 4.0, "cuda")
-    # ---- (a)
-    stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=7).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=7).cuda()
-    tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
-    tr.train_step(*args)                                   # optimizer state, update table, packs
-    tr._forward_backward(args[0], args[1], args[2], args[3], [args[4]], th(args[5]), [th(args[6])])
-    stu.finish_grads()                                     # p.grad complete: both sweeps below read the same gradients
-    torch.cuda.synchronize()
-    opt, ema = tr.stu_optimizer, tr.tea_optimizer
-    group = opt.param_groups[0]
-    ent = opt._dev_state(0, group, next(stu.parameters()).device)
-    hd_s, hd_t = stu._last_hd, tea._last_hd
-    live = ([p.data for p in stu.parameters()] + [p.data for p in tea.parameters()]
-            + [opt.state[p][k_] for p in stu.parameters() if p in opt.state for k_ in ("exp_avg", "exp_avg_sq")] + [ent[0], hd_s.wpack, hd_t.wpack])
-    saved = [t.clone() for t in live]
-    step0 = group["step"]
-    results = []
-    for parts in ((0,), (1, 2)):
-        for t, sv in zip(live, saved):
-            t.copy_(sv)
-        group["step"] = step0
-        for part in parts:
-            assert opt.fused_tail_step(stu, tea, ema, part=part)
-        torch.cuda.synchronize()
-        results.append([t.clone() for t in live])
-    assert all(torch.equal(a, c) for a, c in zip(*results))
-    assert any(not torch.equal(a, sv) for a, sv in zip(results[0], saved))           # (the sweep did move the state)
-    import ctypes as C
-    # (both block lists non-empty: part 1 alone changes some but not all parameters)
-    for t, sv in zip(live, saved):
-        t.copy_(sv)
-    group["step"] = step0
-    assert opt.fused_tail_step(stu, tea, ema, part=1)
-    torch.cuda.synchronize()
-    n_par = len(list(stu.parameters()))
-    moved = [not torch.equal(t, sv) for t, sv in zip(live[:n_par], saved[:n_par])]
-    assert any(moved) and not all(moved)
-    assert opt.fused_tail_step(stu, tea, ema, part=2)
-    # ---- (b)
-    stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=7).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=7).cuda()
-    tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
-    tr.split_tail = True
-    seen = []
-    orig = tr.stu_optimizer.fused_tail_step
-    tr.stu_optimizer.fused_tail_step = lambda *a, part=0, _o=orig, _s=seen: (_s.append(part), _o(*a, part=part))[1]
-    for _ in range(2):
-        out = tr.train_step(*args)
-    assert tr.fused_last and not stu._pending_wg and seen == [1, 2, 1, 2], seen
-    gs = GraphedTrainStep(tr, *args, warmup=1)
-    seen.clear()
-    for _ in range(3):
-        out = gs.step(*args)
-    assert torch.isfinite(out["loss_all"]) and not seen                # (replays launch nothing from Python)
-
-
-def test_one_reduction_over_both_passes_pixels_equals_the_sum_of_the_two_passes():
-    """Round 5 (VERDICT r4 next #1a; policy wgrad_merge, OFF - measured 2.67 against 2.49 ms for the pair launch): the pair launch with ONE unit
-    per (layer, tile, split) that walks pass A's stages and then pass B's into one accumulator tile and writes pass A's gradient tensors.
-    After `loss.backward()` of a whole mean-teacher step (train_human.py:436) every parameter gradient equals the unmerged launch's gA + gB
-    to fp32 summation order (the reduction is re-associated, the stem and the split layers accumulate atomically in both forms)."""
-    from uda_poseestimation_amd import synthetic, warp
-    from uda_poseestimation_amd.engine import MeanTeacherTrainer
-    N, K, S = 4, 16, 128
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=14)
-    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
-    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
-    th = lambda ap: warp.recon_thetas(ap, N, 4.0, "cuda")
-    grads = {}
-    for merge in (0, 1):
-        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=11).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=11).cuda()
-        stu.policy.update(dict(wgrad_merge=merge))
-        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
-        tr._forward_backward(args[0], args[1], args[2], args[3], [args[4]], th(args[5]), [th(args[6])])
-        if merge:       # pass B's buffer holds what its gradient chain wrote and nothing of the weight-gradient launch
-            off = 0
-            for n_, p in stu.named_parameters():
-                if n_ in ("backbone.layer1.0.conv1.weight", "backbone.layer3.0.conv2.weight", "upsampling.0.weight"):
-                    assert float(stu._flat_grad2[off:off + p.numel()].abs().max()) == 0.0, n_
-                if n_ == "backbone.layer1.0.bn1.weight":
-                    assert float(stu._flat_grad2[off:off + p.numel()].abs().max()) > 0.0
-                off += p.numel()
-        stu.finish_grads()
-        torch.cuda.synchronize()
-        grads[merge] = {n_: p.grad.detach().clone() for n_, p in stu.named_parameters() if p.grad is not None}
-    assert grads[0].keys() == grads[1].keys()
-    for n_, g0 in grads[0].items():
-        g1 = grads[1][n_]
-        assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item() + 1e-10, n_
-
-
-def test_merged_weight_gradient_launch_is_bit_identical():
-    """udapose_net_wgrad_pair: both passes' grouped weight gradients as one launch per tile class (engine.merge_wgrad) against each
-    pass launching its own - same tables, same kernels, bit-identical parameters; eager and captured, and with gradient accumulation
-    in front (an accumulate-mode pass paired with an overwrite-mode one)."""
-    from uda_poseestimation_amd import synthetic
-    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
-    N, K, S = 4, 16, 128
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=8)
-    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
-    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
-    res = {}
-    for merge in (False, True):
-        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda()
-        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
-        tr.merge_wgrad = merge
-        tr.train_step(*args)
-        assert not stu._pending_wg
-        gs = GraphedTrainStep(tr, *args, warmup=1)
-        for _ in range(2):
-            out = gs.step(*args)
-        assert torch.isfinite(out["loss_all"])
-        res[merge] = [p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
-    assert all(torch.equal(a, c) for a, c in zip(res[False], res[True]))
-
-
-def test_pair_launch_tile_classes_on_two_streams_give_the_same_step():
-    """PoseResNet.wgrad_classes_concurrent (off: measured +0.12 ms, profiles/r5_ab_runs.txt 11): the pair launch as clears | class 1 on a side
-    stream | classes 0 / 2 (udapose_net_wgrad_pair_phase 3 / 2 / 4).  Same kernels on the same tables: the parameters after captured steps agree
-    with the default form's (to the rounding of the fp32 atomics' arrival order)."""
-    from uda_poseestimation_amd import synthetic
-    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
-    N, K, S = 4, 16, 128
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=8)
-    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
-    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
-    res = {}
-    for conc in (False, True):
-        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=5).cuda()
-        stu.wgrad_classes_concurrent = conc
-        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
-        gs = GraphedTrainStep(tr, *args, warmup=1)
-        for _ in range(3):
-            out = gs.step(*args)
-        assert torch.isfinite(out["loss_all"]) and not stu._pending_wg
-        res[conc] = [p.detach().clone() for p in list(stu.parameters()) + list(tea.parameters())]
-    for a, c in zip(res[False], res[True]):
-        assert torch.allclose(a, c, rtol=1e-3, atol=2e-5), (a - c).abs().max()
-
-
-@pytest.mark.parametrize("pol", [dict(wgrad_overlap=1, wgrad_cap=8), dict(wgrad_overlap=2, wgrad_cap=256), dict(wgrad_overlap=3, wgrad_cap=0),
-                                 dict(wgrad_overlap=1, wgrad_cap=64, wgrad_cut_lo=0b010101)])
-def test_staged_persistent_weight_gradients_are_bit_identical(pol):
-    """udapose_net_backward_staged + udapose_net_wgrad_staged (policy wgrad_overlap / wgrad_cap): the weight gradients launched stage by
-    stage on a side stream behind the events the gradient chain records, as persistent residency-capped grids that pull their table
-    entries (per-XCD heads, stealing, self-resetting counters), against the one grouped launch after the chain: same table entries,
-    same tile kernels - every gradient bit for bit after one backward (both passes' buffers summed), for caps far below and above the
-    entry count and for an explicit cut mask; the stem's weight gradient, which is ALWAYS accumulated by fp32 atomics in arrival
-    order (row-tap form, 8192-stage split), to rounding.  Then several replays of the captured step (the head counters must have reset
-    themselves): finite losses and parameters that track the unstaged run."""
-    from uda_poseestimation_amd import synthetic, warp
-    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
-    N, K, S = 4, 16, 128
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=8)
-    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
-    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
-    th = lambda ap: warp.recon_thetas(ap, N, 4.0, "cuda")
-    grads, res, losses = {}, {}, {}
-    for staged in (False, True):
-        stu, tea = _tiny(K, layers=(1, 2, 3, 1), seed=5).cuda(), _tiny(K, layers=(1, 2, 3, 1), seed=5).cuda()
-        if staged:
-            stu.policy.update(pol)
-        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4)
-        tr._forward_backward(args[0], args[1], args[2], args[3], [args[4]], th(args[5]), [th(args[6])])
-        stu.finish_grads()
-        torch.cuda.synchronize()
-        assert not stu._pending_wg
-        grads[staged] = {n_: p.grad.detach().clone() for n_, p in stu.named_parameters() if p.grad is not None}
-        if staged:
-            hd = stu._last_hd
-            assert hd.staged and hd.L.udapose_net_num_stages(hd.h) >= 3
-        tr._update()
-        gs = GraphedTrainStep(tr, *args, warmup=1)
-        for _ in range(4):
-            out = gs.step(*args)
-        assert torch.isfinite(out["loss_all"])
-        losses[staged] = float(out["loss_all"])
-        res[staged] = [p.detach().clone() for p in stu.parameters()]
-    for n_, g0 in grads[False].items():
-        g1 = grads[True][n_]
-        if n_ == "backbone.conv1.weight":
-            assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item() + 1e-12, n_
-        else:
-            assert torch.equal(g0, g1), n_
-    # after five Adam steps (lr 1e-3) the two runs differ by what the stem's atomic summation order lets through Adam's sign-like update of
-    # near-zero gradients: bounded by 2 * lr * steps per weight (measured 0.4e-3 .. 3.3e-3), and the replays' losses agree
-    for a, c in zip(res[False], res[True]):
-        assert torch.isfinite(c).all() and (a - c).abs().max().item() <= 2 * 1e-3 * 5
-    assert abs(losses[True] - losses[False]) <= 1e-1 * abs(losses[False])          # (measured 0.1 .. 5.6 % over this round's runs)
-
-
-@pytest.mark.parametrize("occlusion", [False, True], ids=["plain", "device_occlusion"])
-def test_branch_graph_step_tracks_the_one_graph_step(occlusion):
-    """Round 5: GraphedTrainStep(branch_graphs=True) - the mean-teacher step (train_human.py:326-444) as nine linear hipGraphs on three streams joined
-    by events (autograd cut at the student's outputs; the loss section's own backward yields dL/dy_s and dL/dy_t_stu; each gradient chain is
-    PoseResNet._run_backward) - against the one-graph step from identical state: the same kernels on the same data in another launch structure.
-    After one replay every parameter agrees to what the atomically accumulated gradients (stem, re-warp backward) allow - Adam's first update is
-    lr * sign-like, so a last-bit gradient difference moves a weight by at most ~2 lr per step - and the losses of that replay agree to 1e-3;
-    several more replays stay finite and close.  With the device-side occlusion the target chain waits for the teacher's."""
-    from uda_poseestimation_amd import synthetic
-    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
-    N, K, S = 4, 16, 128
-    b = synthetic.mean_teacher_batch(N, num_keypoints=K, image_size=S, heatmap_size=S // 4, seed=15)
-    g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
-    args = (g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"], g["aug_param_tea"])
-    res = {}
-    for branch in (False, True):
-        stu, tea = _tiny(K, layers=(1, 2, 2, 1), seed=13).cuda(), _tiny(K, layers=(1, 2, 2, 1), seed=13).cuda()
-        extra = dict(occlude_rate=0.5, occlude_thresh=0.0, occlude_size=6, rng=np.random.RandomState(3)) if occlusion else {}
-        tr = MeanTeacherTrainer(stu, tea, lr=1e-3, image_size=S, heatmap_size=S // 4, **extra)
-        tr.device_occlusion = occlusion
-        gs = GraphedTrainStep(tr, *args, warmup=1, branch_graphs=branch)
-        assert gs.branch == branch
-        out = gs.step(*args)
-        torch.cuda.synchronize()
-        first = (float(out["loss_all"]), float(out["loss_s"]), float(out["loss_c"]))
-        p1 = [p.detach().clone() for p in stu.parameters()]
-        for _ in range(3):
-            out = gs.step(*args)
-        m = gs.step_async(*args)
-        m = gs.flush_metrics()
-        assert m is not None and np.isfinite(m["loss_all"]) and len(m["acc_per_keypoint"]) == K
-        res[branch] = (first, p1, float(out["loss_all"]), [p.detach().clone() for p in tea.parameters()])
-    for a, c in zip(res[False][0], res[True][0]):
-        assert abs(a - c) <= 1e-3 * abs(a) + 1e-9, (res[False][0], res[True][0])
-    for a, c in zip(res[False][1], res[True][1]):
-        assert (a - c).abs().max().item() <= 5e-3
-    assert np.isfinite(res[True][2]) and abs(res[True][2] - res[False][2]) <= 0.1 * abs(res[False][2])
-    for a, c in zip(res[False][3], res[True][3]):
-        assert torch.isfinite(c).all() and (a - c).abs().max().item() <= 5e-3
 
 
 def test_deferred_metric_readback_returns_the_synchronous_loops_values():

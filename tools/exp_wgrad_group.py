@@ -49,21 +49,3 @@ for rep in range(3):
     for _ in range(20): run()
     b.record(); torch.cuda.synchronize()
     print(f"grouped weight gradients of TWO passes in one pair launch, N={N} each: {a.elapsed_time(b) / 20 * 1e3:.1f} us", flush=True)
-
-if "wgrad_merge" in POL:
-    # correctness of the merged pair launch: pass A's buffer must hold gA + gB of the unmerged launch (to fp32 summation order)
-    from uda_poseestimation_amd import _hip
-    def with_merge(v):
-        pol = _hip.policy(**{**{k: int(x) for k, x in POL.items()}, "wgrad_merge": v})
-        check(hd.L.udapose_net_set_policy(hd.h, C.byref(pol)), "set_policy")
-    with_merge(0)
-    net._flat_grad.zero_(); flat2.zero_()
-    run(); torch.cuda.synchronize()
-    ref = (net._flat_grad + flat2).clone()
-    with_merge(1)
-    net._flat_grad.zero_(); flat2.zero_()
-    run(); torch.cuda.synchronize()
-    got, gb = net._flat_grad.clone(), flat2.clone()
-    # (BatchNorm / bias / fc entries are not written by the weight-gradient launches: both runs leave them zero)
-    err = (got - ref).abs().max().item()
-    print(f"merged pair launch: max|gA_merged - (gA + gB)| = {err:.3e} (max|ref| {ref.abs().max().item():.3e}), pass B's buffer max after the merged launch {gb.abs().max().item():.3e}", flush=True)

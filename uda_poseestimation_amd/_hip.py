@@ -21,7 +21,8 @@ class Policy(C.Structure):
     given fields overridden; tests force code paths with it, bench.py's tuning flags run A/B comparisons through it."""
     _fields_ = [(k, C.c_int) for k in ("igemm_tile", "igemm_h3", "igemm_lean", "igemm_short_lds", "igemm_tap0", "wgrad_tile", "wgrad_ksplit",
                                        "wgrad_fastgeo", "wgrad_group", "wgrad_stages", "wgrad_group_stem", "bn_bwd_fused", "bn_fwd_chunked",
-                                       "bn_bwd_chunked", "bn_bwd_pre_legacy", "igemm_wg_min", "wgrad_row3", "bn3_mask", "stem_fused", "debug_sync", "igemm_q_tile", "exp0", "wgrad_big", "igemm_big_min", "patch_conv", "wgrad_overlap", "wgrad_cap", "wgrad_cut_lo", "wgrad_cut_hi", "eval_fold", "bn_xcd_rows", "wgrad_merge", "bn_fin_apply", "igemm_ns3_k")] + [("timeline", C.c_void_p)]
+                                       "bn_bwd_chunked", "bn_bwd_pre_legacy", "igemm_wg_min", "wgrad_row3", "bn3_mask", "stem_fused", "debug_sync", "igemm_big_min", "patch_conv",
+                                       "eval_fold", "bn_xcd_rows", "wgrad_det", "igemm_ns3_k")] + [("timeline", C.c_void_p)]
 
 
 def policy(**overrides):
@@ -95,15 +96,10 @@ _SIGS = {
     "udapose_net_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf]),
     "udapose_net_backward_part": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci]),
     "udapose_net_backward_phase": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]),
-    "udapose_net_num_stages": (ci, [vp]),
-    "udapose_net_backward_staged": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci]),
-    "udapose_net_wgrad_staged": (ci, [vp, vp, ci, vp, vp, vp, cf, ci, vp, vp, vp, cf, ci]),
     "udapose_net_wgrad_pair": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, cf, ci]),
-    "udapose_net_wgrad_pair_phase": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, vp, cf, ci, ci]),
     "udapose_net_grad_split_param": (ll, [vp]),
     "udapose_net_bind_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "udapose_net_fused_update": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, cf, cf, ci, ll]),
-    "udapose_net_fused_update_part": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, cf, vp, cf, cf, ci, ll, ci]),
     "udapose_joints_mse_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),
     "udapose_joints_mse_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
     "udapose_cons_loss_fwd": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),

@@ -4,7 +4,7 @@
 // as a chain of index maps p3 -> p2 -> p1 -> p0 (NOT as one composed matrix: that would change results).
 // Arithmetic follows torchvision/_gen_affine_grid + ATen grid_sampler(nearest, zeros, align_corners=False) in fp32:
 // theta / (0.5*[W,H]); base grid at half-integers; ix = ((x+1)*W-1)/2; nearbyint.
-#include "common.h"
+#include "conv_plan.h"
 
 namespace {
 constexpr int TPB = 256;
@@ -42,6 +42,54 @@ __global__ void warp_chain_k(const float* __restrict__ src, float* __restrict__ 
             for (int c = blockIdx.y; c < C; c += gridDim.y) atomicAdd(dst + o + (size_t)c * H * W + py * W + px, src[o + (size_t)c * H * W + rem]);
         }
     }
+}
+// Backward of the chain, DETERMINISTIC form (round 6).  d(in)[p] = sum of d(out)[i] over the output pixels i whose chain ends at p; an up-scaling
+// chain sends several outputs to one input pixel, and fp32 atomics add them in arrival order (rounds 1-5: the one place outside the weight
+// gradients where two runs of a step could differ in the last bit).  Here one work-group owns one (sample, channel) plane: it computes the
+// plane's index map into LDS, RANKS the outputs that share a target by ascending output index (round r: every unranked output proposes itself
+// with an LDS atomicMin on its target's slot - an integer minimum is order-independent - and the winner takes rank r), and then adds
+// rank 0, rank 1, ... into an LDS accumulator with one barrier per rank: every input pixel receives its contributions in ascending output
+// index, whatever the scheduling.  The plane is stored with plain coalesced stores (no clear of dst beforehand).
+// LDS: (int target + int slot + float acc) per pixel + 1 byte rank = 13 bytes per pixel (53 KB for 64x64, 120 KB for 96x96).
+__global__ __launch_bounds__(TPB) void warp_chain_bwd_det_k(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ theta,
+                                                            int C, int H, int W, int nstage) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int HW = H * W;
+    int* tgt = (int*)smem;
+    int* slot = tgt + HW;
+    float* acc = (float*)(slot + HW);
+    unsigned char* rank = (unsigned char*)(acc + HW);
+    const int n = blockIdx.x / C, c = blockIdx.x % C;
+    for (int i = threadIdx.x; i < HW; i += TPB) {
+        int py = i / W, px = i % W;
+        bool ok = true;
+        for (int s = nstage - 1; s >= 0 && ok; --s) ok = step(theta + ((size_t)n * nstage + s) * 6, W, H, px, py);
+        tgt[i] = ok ? py * W + px : -1;
+        rank[i] = ok ? 255 : 254;          // 255: not ranked yet; 254: contributes nothing
+        acc[i] = 0.f;
+    }
+    __syncthreads();
+    int nrounds = 0;
+    for (int r = 0; r < 254; ++r) {
+        for (int i = threadIdx.x; i < HW; i += TPB) slot[i] = 0x7fffffff;
+        __syncthreads();
+        int pending = 0;
+        for (int i = threadIdx.x; i < HW; i += TPB)
+            if (rank[i] == 255) { atomicMin(&slot[tgt[i]], i); pending = 1; }
+        if (!__syncthreads_or(pending)) break;
+        for (int i = threadIdx.x; i < HW; i += TPB)
+            if (rank[i] == 255 && slot[tgt[i]] == i) rank[i] = (unsigned char)r;
+        nrounds = r + 1;
+        __syncthreads();
+    }
+    const float* sp = src + ((size_t)n * C + c) * HW;
+    for (int r = 0; r < nrounds; ++r) {
+        for (int i = threadIdx.x; i < HW; i += TPB)
+            if (rank[i] == r) acc[tgt[i]] += sp[i];        // (one writer per target and round)
+        __syncthreads();
+    }
+    float* dp = dst + ((size_t)n * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += TPB) dp[i] = acc[i];
 }
 // Occlusion paste (train_human.py:409): img[:, r0:r1, c0:c1] = img[:, rs:rs+(r1-r0), cs:cs+(c1-c0)] for each listed image,
 // reading the whole source patch before writing (one block per image; patches are at most 20x20x3 = 1200 values).
@@ -173,6 +221,18 @@ int affine_warp_chain(hipStream_t s, const float* src, float* dst, const float* 
     if (blocks > 4096) blocks = 4096;
     const int cgroups = C >= 16 ? 16 : (C >= 4 ? 4 : 1);
     if (backward) {
+        // deterministic form (one work-group per (sample, channel) plane, ranks in LDS) wherever the plane fits; more than 253 outputs on one
+        // input pixel cannot happen with the loop's scales (<= 1 / 0.6 per axis), and a plane beyond the LDS budget takes the atomic form
+        const size_t lds = (size_t)H * W * 13 + 16;
+        if (lds <= 150 * 1024 && (long long)N * C < (1ll << 31)) {
+            static std::atomic<unsigned long long> attr_done{0};
+            static std::mutex attr_mu;
+            once_per_device(attr_done, attr_mu, [] {
+                (void)hipFuncSetAttribute((const void*)warp_chain_bwd_det_k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            });
+            hipLaunchKernelGGL(warp_chain_bwd_det_k, dim3(N * C), dim3(TPB), (unsigned)((lds + 15) & ~(size_t)15), s, src, dst, theta, C, H, W, nstage);
+            return udapose_check_launch();
+        }
         if (pw_zero(s, dst, (size_t)N * C * H * W * sizeof(float)) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
         hipLaunchKernelGGL(warp_chain_k<true>, dim3(blocks, cgroups), dim3(TPB), 0, s, src, dst, theta, N, C, H, W, nstage);
     } else {

@@ -78,7 +78,7 @@ int net_bind_grads(void*, void* const*);
 long long net_grad_split_param(void*);
 int net_bind_update(void*, void*, void* const*, void* const*, void* const*, void* const*, void* const*, void*, void*);
 int net_fused_update(void*, void*, hipStream_t, void* const*, void* const*, void* const*, void* const*, void*, void*, float, float, float, float, float,
-                     int, float, float*, float, float, int, long long, int);
+                     int, float, float*, float, float, int, long long);
 int net_num_params(void*);
 int net_num_buffers(void*);
 long long net_param_numel(void*, int);
@@ -89,10 +89,7 @@ void net_out_shape(void*, int*);
 int net_pack_weights(void*, hipStream_t, const void* const*, void*, int);
 int net_forward(void*, hipStream_t, const float*, const void* const*, void* const*, const void*, void*, void*, float*, int, float);
 int net_backward(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int, int);
-int net_wgrad_pair(void*, hipStream_t, const void*, void*, void* const*, float, const void*, void*, void* const*, float, int, int);
-int net_num_stages(void*);
-int net_wgrad_staged(void*, void* const*, int, const void*, void*, void* const*, float, int, const void*, void*, void* const*, float, int);
-int net_backward_staged(void*, hipStream_t, const float*, const void* const*, const void*, void*, void*, void* const*, float, int);
+int net_wgrad_pair(void*, hipStream_t, const void*, void*, void* const*, float, const void*, void*, void* const*, float, int);
 
 static Policy from_c(const udapose_policy& c) {
     Policy p;
@@ -100,15 +97,7 @@ static Policy from_c(const udapose_policy& c) {
     p.igemm_tap0 = c.igemm_tap0; p.wgrad_tile = c.wgrad_tile; p.wgrad_ksplit = c.wgrad_ksplit; p.wgrad_fastgeo = c.wgrad_fastgeo;
     p.wgrad_group = c.wgrad_group; p.wgrad_stages = c.wgrad_stages > 0 ? c.wgrad_stages : 128; p.wgrad_group_stem = c.wgrad_group_stem;
     p.bn_bwd_fused = c.bn_bwd_fused; p.bn_fwd_chunked = c.bn_fwd_chunked; p.bn_bwd_chunked = c.bn_bwd_chunked;
-    p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.igemm_wg_min = c.igemm_wg_min; p.wgrad_row3 = c.wgrad_row3; p.bn3_mask = c.bn3_mask; p.stem_fused = c.stem_fused; p.debug_sync = c.debug_sync; p.igemm_q_tile = c.igemm_q_tile; p.exp0 = c.exp0; p.wgrad_big = c.wgrad_big; p.igemm_big_min = c.igemm_big_min; p.patch_conv = c.patch_conv; p.wgrad_overlap = c.wgrad_overlap; p.wgrad_cap = c.wgrad_cap; p.wgrad_cut_lo = c.wgrad_cut_lo; p.wgrad_cut_hi = c.wgrad_cut_hi; p.eval_fold = c.eval_fold; p.bn_xcd_rows = c.bn_xcd_rows; p.igemm_ns3_k = c.igemm_ns3_k; p.wgrad_merge = c.wgrad_merge; p.bn_fin_apply = c.bn_fin_apply; p.timeline = (unsigned long long*)c.timeline;
-#ifdef UDAPOSE_TIMING_EXPERIMENTS
-    if (p.exp0) {       // exp0 switches on timing experiments that SKIP work (wrong gradients / activations): never silent
-        static bool warned = false;
-        if (!warned) { warned = true; fprintf(stderr, "udapose: policy.exp0 = %d - a timing experiment is active, results are NOT valid\n", p.exp0); }
-    }
-#else
-    p.exp0 = 0;         // the work-skipping branches are not in this build (make EXTRA=-DUDAPOSE_TIMING_EXPERIMENTS); udapose_net_set_policy refuses the value
-#endif
+    p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.igemm_wg_min = c.igemm_wg_min; p.wgrad_row3 = c.wgrad_row3; p.bn3_mask = c.bn3_mask; p.stem_fused = c.stem_fused; p.debug_sync = c.debug_sync; p.igemm_big_min = c.igemm_big_min; p.patch_conv = c.patch_conv; p.eval_fold = c.eval_fold; p.bn_xcd_rows = c.bn_xcd_rows; p.igemm_ns3_k = c.igemm_ns3_k; p.wgrad_det = c.wgrad_det; p.timeline = (unsigned long long*)c.timeline;
     return p;
 }
 static void to_c(const Policy& p, udapose_policy* c) {
@@ -116,7 +105,7 @@ static void to_c(const Policy& p, udapose_policy* c) {
     c->igemm_tap0 = p.igemm_tap0; c->wgrad_tile = p.wgrad_tile; c->wgrad_ksplit = p.wgrad_ksplit; c->wgrad_fastgeo = p.wgrad_fastgeo;
     c->wgrad_group = p.wgrad_group; c->wgrad_stages = p.wgrad_stages; c->wgrad_group_stem = p.wgrad_group_stem;
     c->bn_bwd_fused = p.bn_bwd_fused; c->bn_fwd_chunked = p.bn_fwd_chunked; c->bn_bwd_chunked = p.bn_bwd_chunked;
-    c->bn_bwd_pre_legacy = p.bn_bwd_pre_legacy; c->igemm_wg_min = p.igemm_wg_min; c->wgrad_row3 = p.wgrad_row3; c->bn3_mask = p.bn3_mask; c->stem_fused = p.stem_fused; c->debug_sync = p.debug_sync; c->igemm_q_tile = p.igemm_q_tile; c->exp0 = p.exp0; c->wgrad_big = p.wgrad_big; c->igemm_big_min = p.igemm_big_min; c->patch_conv = p.patch_conv; c->wgrad_overlap = p.wgrad_overlap; c->wgrad_cap = p.wgrad_cap; c->wgrad_cut_lo = p.wgrad_cut_lo; c->wgrad_cut_hi = p.wgrad_cut_hi; c->eval_fold = p.eval_fold; c->bn_xcd_rows = p.bn_xcd_rows; c->igemm_ns3_k = p.igemm_ns3_k; c->wgrad_merge = p.wgrad_merge; c->bn_fin_apply = p.bn_fin_apply; c->timeline = p.timeline;
+    c->bn_bwd_pre_legacy = p.bn_bwd_pre_legacy; c->igemm_wg_min = p.igemm_wg_min; c->wgrad_row3 = p.wgrad_row3; c->bn3_mask = p.bn3_mask; c->stem_fused = p.stem_fused; c->debug_sync = p.debug_sync; c->igemm_big_min = p.igemm_big_min; c->patch_conv = p.patch_conv; c->eval_fold = p.eval_fold; c->bn_xcd_rows = p.bn_xcd_rows; c->igemm_ns3_k = p.igemm_ns3_k; c->wgrad_det = p.wgrad_det; c->timeline = p.timeline;
 }
 // a convolution descriptor and the policy it names, as the host-side geometry (the policy lives as long as this object)
 struct Geom {
@@ -245,9 +234,6 @@ int udapose_net_create(const int layers[4], int K, int N, int H, int W, int fp32
 void udapose_net_destroy(udapose_net_t n) { net_destroy(n); }
 int udapose_net_set_policy(udapose_net_t n, const udapose_policy* p) {
     if (!n || !p) return UDAPOSE_ERR_ARG;
-#ifndef UDAPOSE_TIMING_EXPERIMENTS
-    if (p->exp0) return UDAPOSE_ERR_UNSUPPORTED;     // timing experiments that skip work exist only in builds made with -DUDAPOSE_TIMING_EXPERIMENTS
-#endif
     net_set_policy(n, from_c(*p));
     return UDAPOSE_OK;
 }
@@ -294,28 +280,12 @@ int udapose_net_backward_part(udapose_net_t n, void* stream, const float* dout, 
 int udapose_net_wgrad_pair(udapose_net_t n, void* stream, const void* act_a, void* ws_a, void* const* grads_a, float beta_a, const void* act_b,
                            void* ws_b, void* const* grads_b, float beta_b, int part) {
     if (!n || !act_a || !ws_a || !grads_a || !act_b || !ws_b || !grads_b) return UDAPOSE_ERR_ARG;
-    return net_wgrad_pair(n, S(stream), act_a, ws_a, grads_a, beta_a, act_b, ws_b, grads_b, beta_b, part, 0);
-}
-int udapose_net_wgrad_pair_phase(udapose_net_t n, void* stream, const void* act_a, void* ws_a, void* const* grads_a, float beta_a, const void* act_b,
-                                 void* ws_b, void* const* grads_b, float beta_b, int part, int phase) {
-    if (!n || !act_a || !ws_a || !grads_a || !act_b || !ws_b || !grads_b) return UDAPOSE_ERR_ARG;
-    return net_wgrad_pair(n, S(stream), act_a, ws_a, grads_a, beta_a, act_b, ws_b, grads_b, beta_b, part, phase);
+    return net_wgrad_pair(n, S(stream), act_a, ws_a, grads_a, beta_a, act_b, ws_b, grads_b, beta_b, part);
 }
 int udapose_net_backward_phase(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act,
                                void* ws, void* const* grads, float beta, int part, int phase) {
     if (!n) return UDAPOSE_ERR_ARG;
     return net_backward(n, S(stream), dout, params, wpack, act, ws, grads, beta, part, phase);
-}
-int udapose_net_num_stages(udapose_net_t n) { return n ? net_num_stages(n) : 0; }
-int udapose_net_backward_staged(udapose_net_t n, void* stream, const float* dout, const void* const* params, const void* wpack, void* act, void* ws,
-                                void* const* grads, float beta, int slot) {
-    if (!n || !dout || !params || !wpack || !act || !ws || !grads) return UDAPOSE_ERR_ARG;
-    return net_backward_staged(n, S(stream), dout, params, wpack, act, ws, grads, beta, slot);
-}
-int udapose_net_wgrad_staged(udapose_net_t n, void* const* wg_streams, int n_streams, const void* act_a, void* ws_a, void* const* grads_a, float beta_a,
-                             int slot_a, const void* act_b, void* ws_b, void* const* grads_b, float beta_b, int slot_b) {
-    if (!n || !wg_streams || n_streams < 1 || !act_a || !ws_a || !grads_a || (act_b && (!ws_b || !grads_b))) return UDAPOSE_ERR_ARG;
-    return net_wgrad_staged(n, wg_streams, n_streams, act_a, ws_a, grads_a, beta_a, slot_a, act_b, ws_b, grads_b, beta_b, slot_b);
 }
 long long udapose_net_grad_split_param(udapose_net_t n) { return net_grad_split_param(n); }
 int udapose_net_bind_update(udapose_net_t student, udapose_net_t teacher, void* const* params_s, void* const* grads, void* const* exp_avg,
@@ -329,15 +299,7 @@ int udapose_net_fused_update(udapose_net_t student, udapose_net_t teacher, void*
                              int do_adam, long long grad2_delta_bytes) {
     if (!student || !teacher) return UDAPOSE_ERR_ARG;
     return net_fused_update(student, teacher, S(stream), params_s, grads, exp_avg, params_t, wpack_s, wpack_t, lr, beta1, beta2, eps, weight_decay,
-                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam, grad2_delta_bytes, 0);
-}
-int udapose_net_fused_update_part(udapose_net_t student, udapose_net_t teacher, void* stream, void* const* params_s, void* const* grads,
-                                  void* const* exp_avg, void* const* params_t, void* wpack_s, void* wpack_t, float lr, float beta1, float beta2,
-                                  float eps, float weight_decay, int step, float grad_scale, float* dev_state, float alpha, float one_minus_alpha,
-                                  int do_adam, long long grad2_delta_bytes, int part) {
-    if (!student || !teacher) return UDAPOSE_ERR_ARG;
-    return net_fused_update(student, teacher, S(stream), params_s, grads, exp_avg, params_t, wpack_s, wpack_t, lr, beta1, beta2, eps, weight_decay,
-                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam, grad2_delta_bytes, part);
+                            step, grad_scale, dev_state, alpha, one_minus_alpha, do_adam, grad2_delta_bytes);
 }
 
 int udapose_joints_mse_fwd(void* stream, const float* pred, const float* gt, const float* w, int R, int HW, float* rows, float* mean_out) {

@@ -11,7 +11,7 @@
 // values exist for tests (force a code path) and tuning (A/B runs through bench.py flags).
 struct Policy {
     int igemm_tile = -1;        // force one igemm tile configuration id (-1: the heuristics of igemm_pick_tile)
-    int igemm_h3 = 1;           // run-staged 3x3 form: 0 off, 1 measured per-shape policy, 2 / 3: force the 64- / 128-row form, 4: three taps per barrier
+    int igemm_h3 = 1;           // run-staged 3x3 form: 0 off, 1 measured per-shape policy, 2 / 3: force the 64- / 128-row form
     int igemm_lean = 1;         // lean 1x1 form (saddr LDS-DMA loads) where eligible
     int igemm_short_lds = 1;    // one-stage LDS request for launches whose K loop is one stage
     int igemm_tap0 = 1;         // 1x1 kernels skip the tap-table read
@@ -33,32 +33,20 @@ struct Policy {
     int bn3_mask = 1;           // block outputs: the forward saves the ReLU bit mask, the data gradients read it instead of z (0: read z)
     int stem_fused = 1;         // stem: 1 = BN apply + ReLU + max-pool in one sweep; 2 = also the max-pool backward gathered inside the BN backward's
                                 // two sweeps (0.2 GB less traffic, but 99 + 87 us against 55 + 30 + 48 us for the three separate launches: neutral in the step)
-    int wgrad_big = 0;          // grouped weight gradients: 256x128 tiles (128x64 per wave) for fast-geometry layers with Co % 256 == 0, Ci % 128 == 0.
-                                // +16-19 % per layer alone (+40-55 % against the filter-row form on layer3 / layer4's 3x3), but the third class
-                                // launch and its 2 work-groups per CU cost the grouped launch +9 % (2.73 against 2.48 ms for both passes): OFF
     int igemm_big_min = 0;      // > 0: tile 4 (128x128, 2-stage ring) when Co % 128 == 0 and the 128x64 grid has >= this many work-groups
     int patch_conv = 2;         // reflection-padded 3x3 stride-1 convolutions (the style network) through the patch-staged kernels of patchconv.hip
                                 // (the input patch staged once instead of once per tap): 0 = never (the igemm for every layer), 1 = the 64 -> 3
                                 // and 3 -> 64 end layers only, 2 = the trunk layers too (128 pixels x 64 channels per work-group), 3 = 128
                                 // channels per work-group in the 16-bit form where Co % 128 == 0 (measured equal to 2)
-    int igemm_q_tile = -1;      // tile id for launches whose 128x64 grid has 769..1024 work-groups (second round mostly empty); -1: heuristic
-    int wgrad_overlap = 0;      // > 0: the weight gradients of a backward pass are launched STAGE BY STAGE on a side stream, each stage as soon as
-                                // the gradient chain has left its layers (net_backward_staged / net_wgrad_staged): stage 0 = head + deconvolutions,
-                                // then groups of this many bottleneck blocks from the top (or the cuts of wgrad_cut_lo / hi)
-    int wgrad_cap = 0;          // > 0: grouped weight-gradient launches are PERSISTENT grids of this many work-groups (256 = one per CU) that
-                                // pull table entries, so that a launch running under the gradient chain leaves the chain kernels their slots
-    int wgrad_cut_lo = 0, wgrad_cut_hi = 0;   // staged launches: bit b set = block b (0 = first block of layer1) is the LOWEST block of its stage
-                                // (0 / 0: every wgrad_overlap-th block counted from the top)
     int eval_fold = 1;          // eval-mode forwards (validate()): BatchNorm's running-statistics scale / shift, the residual and the ReLU are applied in
                                 // the convolution's epilogue - z is written by the conv, no BN-apply launch, no pre-BN tensor (0: conv + apply launches)
     int bn_xcd_rows = 1;        // BatchNorm apply kernels (forward and backward, chunked and streaming forms): XCD k processes the k-th eighth of the pixel
                                 // rows, the rows the implicit GEMMs' work-groups on XCD k produce and consume (each XCD owns a contiguous range of
                                 // m-tiles there), so activations cross the conv <-> BatchNorm kernel boundaries through that XCD's L2
                                 // (tools/probe/l2_handoff.hip: 17.9 against 6.7 TB/s); bit-identical results, -0.06..-0.15 ms per step (r4_ab_runs.txt)
-    int wgrad_merge = 0;        // pair launch: one reduction over both passes' pixels per (layer, tile, split) unit (udapose.h)
-    int bn_fin_apply = 0;       // BatchNorm finalize + streaming apply as one launch with an in-grid hand-off (pointwise.hip bn_fin_apply_k)
+    int wgrad_det = 1;          // grouped weight gradients: split pixel reductions store per-split partial tiles that ONE launch adds in split order
+                                // (bit-reproducible gradients; 0: fp32 atomics into cleared tensors, arrival order - rounds 1-5)
     int igemm_ns3_k = 0;        // 64x64 igemm tiles: 3-stage ring from this K on, 2-stage below (0 = 2048)
-    int exp0 = 0;               // tuning scratch value (A/B experiments)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null
 };
@@ -115,13 +103,12 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
 // Grouped wgrad (many layers, one launch per tile class).  wgrad_group_plan completes p for the group kernels and returns
 // the tile class (0 = 128x128, 1 = 64x64) or < 0 when the layer needs its own launch; stages_per_block bounds a work-group's
 // pixel range (longer reductions are split and accumulated with fp32 atomics into a zeroed dW).
-#define WG_CLASSES 3      // tile classes of a grouped launch: 0 = 128x128, 1 = 64x64 (+ filter-row form), 2 = 256x128
+#define WG_CLASSES 2      // tile classes of a grouped launch: 0 = 128x128, 1 = 64x64 (+ filter-row form)
 int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Policy& pol);
 // the x / dy / dw fields of the table entries are byte offsets from the three bases
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr,
-                       const void* x_base2 = nullptr, const void* dy_base2 = nullptr, void* dw_base2 = nullptr, int cap = 0,
-                       unsigned int* ctr = nullptr, int merge = 0);   // cap > 0 (with 9 zeroed counter words `ctr`): persistent grid of `cap` work-groups
+                       const void* x_base2 = nullptr, const void* dy_base2 = nullptr, void* dw_base2 = nullptr);
 
 struct ConvEpilogue {
     const elem_t* res = nullptr;

@@ -75,6 +75,8 @@ struct WgParams {
     int total_taps;
     int rows_valid;         // dW rows actually stored (<= R; head: Co is padded to 32 in dy)
     int kw;                 // grouped Ci == 8 form only: real taps per filter row (the 8th column chunk is padding)
+    unsigned part_stride;   // != 0: split bz stores its partial tile with plain stores at element offset bz * part_stride from dw (deterministic
+                            // split reductions of the grouped launches: pw_split_sum adds the splits in order); 0: direct stores / atomics
 };
 struct WgGroupBlk { int prob, local; };   // grouped wgrad: problem index (< 0: padding) and linear block index inside it
 #define WG_FLAG_SWAP 32       // rows of dW come from x (deconv weight layout [Ci][tap][Co])

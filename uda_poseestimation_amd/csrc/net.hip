@@ -23,8 +23,6 @@ int pw_unpack_strided(hipStream_t, const float*, float*, int, int, int, int, int
 int pw_bn_finalize(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
                    float*, float*, const float*);
 int pw_bn_eval_coeff(hipStream_t, int, const float*, const float*, const float*, const float*, float, float*, float*);
-int pw_bn_finalize_apply(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*, float, float, float*, float*,
-                         float*, float*, const elem_t*, const elem_t*, elem_t*, size_t, int, unsigned char*, int, unsigned int*);
 int pw_bn_apply(hipStream_t, const elem_t*, const elem_t*, elem_t*, size_t, int, const float*, const float*, int, unsigned char*, int);
 int pw_bn_bwd_rows(size_t);
 int pw_bn_bwd(hipStream_t, const void*, int, const elem_t*, const elem_t*, elem_t*, elem_t*, size_t, int, const float*, const float*, const float*, int,
@@ -126,8 +124,8 @@ struct Net {
     int fc_w_idx = -1, fc_b_idx = -1;
     size_t act_bytes = 0, wpack_bytes = 0, ws_bytes = 0;
     // workspace carve (bytes)
-    size_t ws_sync = 0;
     size_t ws_slab = 0, ws_slabf = 0, ws_coef = 0, ws_gbuf[6] = {0, 0, 0, 0, 0, 0}, ws_dyhead = 0, ws_dwtmp = 0, ws_headbwd = 0;
+    size_t ws_wgpart = 0, ws_wgpart_bytes = 0;      // partial tiles of the split weight-gradient reductions (sized by net_ws_bytes from the policy of that moment)
     size_t gbuf_bytes = 0;
     int Hout = 0, Wout = 0;
     // batched weight packing: device job tables, rebuilt when the parameter / pack pointers change
@@ -144,39 +142,21 @@ struct Net {
         double flops[WG_CLASSES] = {};
         std::vector<std::pair<ptrdiff_t, size_t>> zero;  // dW ranges (offset from grads[0], bytes) cleared first (split reductions, when overwriting)
         ZeroJob* d_zero = nullptr; int n_zero = 0;       // the same ranges as a device job table, when all are 16-byte granular
+        // Deterministic split reductions (round 6): a layer whose pixel range is split over several work-groups (layer1 / layer2, the last
+        // deconvolution, head, stem) has every split store its PARTIAL tile into the pass's workspace (ws_wgpart); one launch then adds the
+        // splits of all such layers in split order into the gradient tensors (pw_split_sum): no atomics, no clears, bit-reproducible
+        SumJob* d_sum = nullptr; int* d_sum_blk = nullptr; int n_sum_blk = 0;
         unsigned long long last_use = 0;
-        int ord = 0;                                     // position in wg_groups: names this group's head-counter sets (persistent launches)
     };
     std::deque<WgGroup> wg_groups;       // (stable addresses, never evicted: a captured hipGraph may reference any table built so far)
     // fused optimizer tail (Adam + EMA + weight packs of student and teacher in one sweep): device job table
-    // (block lists: [0, nblocks) all jobs; the same blocks reordered as EARLY part [0, n_early) - the conv weights whose gradients the first
-    //  weight-gradient phase (tile classes 0 and 2) completes - followed by the LATE part: net_fused_update's `part`)
-    struct UpdTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0; int n_early = 0;
+    struct UpdTab { void* jobs = nullptr; int* blk_job = nullptr; int* blk_sub = nullptr; int nblocks = 0;
                     const void* k_ps = nullptr; const void* k_pt = nullptr; const void* k_g = nullptr; const void* k_m = nullptr;
                     const void* k_ws = nullptr; const void* k_wt = nullptr; };
     UpdTab upd;
     // batched deferred running-statistics update: device job table, rebuilt when the buffer pointers change
     BnRunJob* d_runjobs = nullptr; int n_runjobs = 0; const void* runjobs_key = nullptr;
     unsigned long long wg_tick = 0;
-    // staged weight gradients (Policy::wgrad_overlap): the backward's layers cut into stages in chain order.  Stage k's grouped
-    // launches need only the dy buffers the chain has written by the time it leaves the stage's lowest layer: the chain records
-    // ev[slot][k] there (slot = which of the step's concurrent passes) and net_wgrad_staged makes the side stream wait for it.
-    struct WgStage { int head_up, hi, lo, stem; };       // blocks hi..lo (hi < lo: none)
-    std::vector<WgStage> stages;
-    static constexpr int EV_SLOTS = 4, EV_MAX = 40;
-    hipEvent_t ev[EV_SLOTS][EV_MAX] = {};
-    int rec_slot = -1;                                   // >= 0 while net_backward_staged runs its chain
-    // persistent grouped launches (Policy::wgrad_cap): a ring of self-resetting head-counter sets (16 words each), one per launch
-    // in flight; a captured launch keeps the set it was given at capture
-    // persistent grouped launches (Policy::wgrad_cap): self-resetting head-counter sets (16 words each), ONE PER (table group, tile class) - a
-    // launch captured in a hipGraph and a later eager launch of another group can never be handed the same set (a round-robin ring
-    // of 128 sets could, once it wrapped); launches of one group are ordered by the stream(s) that carry that pass's weight gradients
-    unsigned int* d_ctr = nullptr;
-    static constexpr int CTR_SETS = 1024;
-    // gradient placements (grads[0]) that have received convolution-weight gradients from a grouped launch: the merged pair launch
-    // (Policy::wgrad_merge) leaves pass B's buffer untouched and relies on its convolution-weight ranges being zero - it is only taken
-    // while pass B's placement has never been written by an unmerged launch
-    std::vector<const void*> wg_written;
 };
 struct PackJobH { const float* src; elem_t* dst; int A, T, B, kind; long long n; };
 
@@ -311,7 +291,6 @@ Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
     n.ws_slab = o; o = align_up(o + max_slab);
     n.ws_slabf = o; o = align_up(o + max_slab);     // partial sums written by dgrad epilogues (the downsample BN keeps ws_slab)
     n.ws_coef = o; o = align_up(o + (size_t)3 * 2048 * 4 + 2 * 2048 * 4);
-    n.ws_sync = o; o = align_up(o + 64);             // hand-off counters of the one-launch finalize + apply (zeroed at the head of every forward)
     if (n.fwd_only) {           // (no backward: statistics slabs and coefficient vectors only)
         n.ws_bytes = o;
         n.stem.g.pol = &n.policy;
@@ -330,6 +309,7 @@ Net* build(const int layers[4], int K, int N, int H, int W, int mode) {
     dyb(n.stem);
     for (auto& b : n.blocks) { dyb(b.c1); dyb(b.c2); dyb(b.c3); if (b.has_ds) dyb(b.cd); }
     for (int i = 0; i < 3; ++i) dyb(n.up[i]);
+    n.ws_wgpart = o;          // (last: its size follows the policy's split length, net_ws_bytes)
     n.ws_bytes = o;
     // every convolution of the plan dispatches with the plan's policy
     n.stem.g.pol = &n.policy;
@@ -412,10 +392,6 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         return conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + b.z_off, e);
     }
     CK(conv_fprop(s, c.g, (const elem_t*)(act + c.in_off), (const elem_t*)wptr, act + c.y_off, e));
-#ifdef UDAPOSE_TIMING_EXPERIMENTS
-    if (training && !n.f32 && !no_apply && !pre_bias && (((n.policy.exp0 & 8) && b.npix <= 8192 && b.C >= 256) || (n.policy.exp0 & 16)))
-        return UDAPOSE_OK;      // TIMING EXPERIMENT ONLY (wrong results): what the step would gain if these BN launches cost nothing (r4_ab_runs.txt)
-#endif
     if (training && !n.f32 && !no_apply && !pre_bias) {
         // wide, small-spatial layers: finalize + apply in ONE launch (channel-chunked work-groups, pointwise.hip)
         const int took = pw_bn_train_fused(s, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix, b.C, slab, conv_stat_rows(c.g), gamma,
@@ -431,17 +407,6 @@ int conv_bn_fwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
         if (took < 0) return took;
         if (took) return UDAPOSE_OK;
     }
-    if (training && !n.f32 && !no_apply && !pre_bias && n.policy.bn_fin_apply)
-        // (the layers the channel-chunked form above did not take: finalize + streaming apply as ONE launch with an in-grid hand-off)
-        return pw_bn_finalize_apply(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, upd ? (float*)buffers[b.rm_idx] : nullptr,
-                                    upd ? (float*)buffers[b.rv_idx] : nullptr, upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, scale, shift,
-                                    save, save + b.C, (const elem_t*)(act + c.y_off), res, (elem_t*)(act + b.z_off), b.npix * b.C, relu, mask,
-                                    n.policy.bn_xcd_rows >= 2, (unsigned int*)(ws + n.ws_sync));
-#ifdef UDAPOSE_TIMING_EXPERIMENTS
-    if (training && (n.policy.exp0 & 32) && !n.f32) {
-        // TIMING EXPERIMENT ONLY (wrong results): the finalize launch of the layers the one-launch form does not take, skipped (r4_ab_runs.txt)
-    } else
-#endif
     if (training)
         CK(pw_bn_finalize(s, slab, conv_stat_rows(c.g), b.C, (double)b.npix, gamma, beta, upd ? (float*)buffers[b.rm_idx] : nullptr,
                           upd ? (float*)buffers[b.rv_idx] : nullptr, upd ? (long long*)buffers[b.nbt_idx] : nullptr, momentum, 1e-5f, scale, shift,
@@ -470,9 +435,7 @@ void net_destroy(void* h) {
     if (n->upd.jobs) { (void)hipFree(n->upd.jobs); (void)hipFree(n->upd.blk_job); (void)hipFree(n->upd.blk_sub); }
     for (auto& g : n->wg_groups)
         for (int t = 0; t < WG_CLASSES; ++t) { if (g.d_tab[t]) (void)hipFree(g.d_tab[t]); if (g.d_blk[t]) (void)hipFree(g.d_blk[t]); }
-    for (auto& g : n->wg_groups) if (g.d_zero) (void)hipFree(g.d_zero);
-    if (n->d_ctr) (void)hipFree(n->d_ctr);
-    for (auto& row : n->ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+    for (auto& g : n->wg_groups) { if (g.d_zero) (void)hipFree(g.d_zero); if (g.d_sum) (void)hipFree(g.d_sum); if (g.d_sum_blk) (void)hipFree(g.d_sum_blk); }
     delete n;
 }
 void net_set_policy(void* h, const Policy& p) { ((Net*)h)->policy = p; }
@@ -482,7 +445,15 @@ int net_num_buffers(void* h) { return ((Net*)h)->n_buffers; }
 long long net_param_numel(void* h, int i) { return ((Net*)h)->param_numel[i]; }
 size_t net_wpack_bytes(void* h) { return ((Net*)h)->wpack_bytes; }
 size_t net_act_bytes(void* h) { return ((Net*)h)->act_bytes; }
-size_t net_ws_bytes(void* h) { return ((Net*)h)->ws_bytes; }
+namespace { size_t wg_partial_bytes(Net& n); }
+size_t net_ws_bytes(void* h) {
+    // the partial tiles of the split weight-gradient reductions (policy wgrad_det) close the workspace: their size follows the policy's
+    // split length, which udapose_net_set_policy may have changed since the plan was created - sized here, when the caller asks
+    Net& n = *(Net*)h;
+    if (n.f32 || n.fwd_only || !n.policy.wgrad_group || !n.policy.wgrad_det) { n.ws_wgpart_bytes = 0; return n.ws_bytes; }
+    n.ws_wgpart_bytes = wg_partial_bytes(n);
+    return n.ws_bytes + n.ws_wgpart_bytes;
+}
 void net_out_shape(void* h, int* shp) { Net& n = *(Net*)h; shp[0] = n.N; shp[1] = n.K; shp[2] = n.Hout; shp[3] = n.Wout; }
 
 namespace {
@@ -613,7 +584,6 @@ int net_forward(void* h, hipStream_t s, const float* x_nchw, const void* const* 
     const char* wpack = (const char*)wpack_;
     char* act = (char*)act_;
     char* ws = (char*)ws_;
-    if (training && !n.f32 && n.policy.bn_fin_apply && pw_zero(s, ws + n.ws_sync, 64) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     if (n.f32 == 2) CK(pw_nchw_f32_to_nhwc_split(s, x_nchw, act + n.x8_off, n.N, 3, n.H * n.W, 8));
     else if (n.f32) CK(pw_nchw_f32_to_nhwc_f32(s, x_nchw, (float*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
     else CK(pw_nchw_f32_to_nhwc_bf16(s, x_nchw, (elem_t*)(act + n.x8_off), n.N, 3, n.H * n.W, 8));
@@ -665,11 +635,7 @@ int conv_bn_bwd(hipStream_t s, const Net& n, const ConvL& c, const BnL& b, const
     elem_t* dy = (elem_t*)(ws + c.dy_off);
     if (pre)
         CK(pw_bn_bwd_pre(s, dz, dz_f32, (const elem_t*)(act + c.y_off), dy, b.npix, b.C, (const float*)params[b.g_idx], save, save + b.C, pre->slab,
-                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, n.policy.bn_bwd_chunked | (n.policy.bn_xcd_rows ? (1 << 30) : 0) | (n.policy.bn_xcd_rows >= 2 ? (1 << 29) : 0) 
-#ifdef UDAPOSE_TIMING_EXPERIMENTS
-                         | ((n.policy.exp0 & 64) ? (1 << 28) : 0)
-#endif
-                         ,
+                         pre->rows, coef, (float*)grads[b.g_idx], (float*)grads[b.b_idx], beta, n.policy.bn_bwd_chunked | (n.policy.bn_xcd_rows ? (1 << 30) : 0) | (n.policy.bn_xcd_rows >= 2 ? (1 << 29) : 0),
                          n.policy.bn_bwd_pre_legacy));
     else
         CK(pw_bn_bwd(s, dz, dz_f32, (const elem_t*)(act + b.z_off), (const elem_t*)(act + c.y_off), dy, gout, b.npix, b.C, (const float*)params[b.g_idx],
@@ -725,44 +691,17 @@ DgradBnStat bn_stat_of(const Net& n, const ConvL& c, const BnL& b, const void* c
 // the rest of the backward
 inline int split_block(const Net& n) { return n.layers[0] + n.layers[1]; }
 
-// which layers a `part` of the grouped weight gradients covers: 0 all, 1 / 2 the data-parallel cut, 16 + k = stage k of the staged form
-#define WG_PART_STAGE0 16
+// which layers a `part` of the grouped weight gradients covers: 0 all, 1 / 2 the data-parallel cut
 struct PartSel { bool head_up; int hi, lo; bool stem; };
 PartSel part_sel(const Net& n, int part) {
     const int nb = (int)n.blocks.size(), split = split_block(n);
-    if (part >= WG_PART_STAGE0) {
-        const Net::WgStage& st = n.stages[part - WG_PART_STAGE0];
-        return PartSel{st.head_up != 0, st.hi, st.lo, st.stem != 0};
-    }
     if (part == 1) return PartSel{true, nb - 1, split, false};
     if (part == 2) return PartSel{false, split - 1, 0, true};
     return PartSel{true, nb - 1, 0, true};
 }
-// stage plan of the staged form: stage 0 = head + deconvolutions; then the bottleneck blocks from the top, a new stage after
-// every block whose bit is set in the cut mask (default: every wgrad_overlap-th); the last stage takes the stem
-void plan_stages(Net& n) {
-    n.stages.clear();
-    const int nb = (int)n.blocks.size();
-    if (n.policy.wgrad_overlap <= 0 || nb < 1 || nb > 64) return;
-    unsigned long long cut = ((unsigned long long)(unsigned)n.policy.wgrad_cut_hi << 32) | (unsigned)n.policy.wgrad_cut_lo;
-    if (!cut) {
-        int cnt = 0;
-        for (int b = nb - 1; b >= 0; --b)
-            if (++cnt == n.policy.wgrad_overlap) { cut |= 1ull << b; cnt = 0; }
-    }
-    cut |= 1ull;                                        // (block 0 always ends a stage)
-    n.stages.push_back(Net::WgStage{1, -1, 0, 0});
-    int hi = nb - 1;
-    for (int b = nb - 1; b >= 0; --b)
-        if ((cut >> b) & 1ull) {
-            if ((int)n.stages.size() >= Net::EV_MAX - 1) { n.stages.back().lo = 0; hi = -1; break; }     // (more cuts than events: the rest joins the last stage)
-            n.stages.push_back(Net::WgStage{0, hi, b, 0});
-            hi = b - 1;
-        }
-    n.stages.back().stem = 1;
-}
 
-int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int part) {
+// (sizing = true: a dry walk that only adds up the bytes of partial tiles the part's split reductions need, into *need)
+int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int part, bool sizing = false, size_t* need = nullptr) {
     const PartSel sel = part_sel(n, part);
     const bool upper = sel.head_up, lower = sel.stem;
     std::vector<WgParams> tab[WG_CLASSES];
@@ -772,16 +711,38 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
     G.rel.clear();
     G.rel_cls.clear();
     for (int t = 0; t < WG_CLASSES; ++t) G.flops[t] = 0.0;
+    // Split reductions: every non-empty split z of a layer stores its partial tile at ws_wgpart + part_cur + z * span (plain stores,
+    // WG_FLAG_DW_WS addressing); SumJob (part, dst, span, splits) lets pw_split_sum add them in split order into the gradient tensor
+    // (dst = beta * dst + sum) - or, for the stem's row-tap form, into its padded scratch, from which the unpack launch goes on.
+    std::vector<SumJob> sums;
+    size_t part_cur = 0;
+    auto make_partial = [&](WgParams& p, long long dst_off, int dst_ws, int Cdim) -> int {
+        const int ms_total = (p.M + 63) / 64, per = (ms_total + p.ksplit - 1) / p.ksplit;
+        const int ks_eff = (ms_total + per - 1) / per;                      // splits that own at least one stage (the others have no unit)
+        const size_t span = (size_t)p.rows_valid * p.wtaps * Cdim;
+        if (span >= (1ull << 31) || (span & 3)) return UDAPOSE_ERR_UNSUPPORTED;
+        p.flags = (p.flags & ~WG_FLAG_ATOMIC) | WG_FLAG_DW_WS;
+        p.dw = (float*)(n.ws_wgpart + part_cur);
+        p.part_stride = (unsigned)span;
+        sums.push_back(SumJob{(long long)(n.ws_wgpart + part_cur), dst_off, (unsigned)span, (unsigned)span, ks_eff, dst_ws, dst_ws ? 0.f : beta, 0});
+        part_cur = align_up(part_cur + (size_t)ks_eff * span * sizeof(float));
+        return UDAPOSE_OK;
+    };
     auto add_geom = [&](const ConvGeom& g, int w_idx, size_t dy_off, size_t in_off, int rows_valid) -> int {
         if (g.smallc()) return UDAPOSE_OK;
         WgParams p;
         double fl = 0.0;
         // byte offsets from the workspace / activation arena / gradient bases in place of pointers (see wgrad_dma_group_kernel)
-        const ptrdiff_t drel = (const char*)grads[w_idx] - (const char*)grads[0];
+        const ptrdiff_t drel = sizing ? 0 : (const char*)grads[w_idx] - (const char*)grads[0];
         G.rel.push_back({w_idx, drel});
         CK(conv_wgrad_params(g, (const elem_t*)dy_off, (const elem_t*)in_off, (float*)drel, rows_valid, &p, &fl));
         const int t = wgrad_group_plan(p, beta != 0.f, n.policy.wgrad_stages, n.policy);
         if (t < 0) return UDAPOSE_ERR_UNSUPPORTED;
+        if (p.ksplit > 1) {
+            const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
+            if (n.policy.wgrad_det) CK(make_partial(p, (long long)drel, 0, swap ? p.Co : p.Ci));
+            else if (beta == 0.f) G.zero.push_back({drel, (size_t)p.rows_valid * p.wtaps * (swap ? p.Co : p.Ci) * sizeof(float)});
+        }
         const int prob = (int)tab[t].size();
         G.rel_cls.push_back(t);
         tab[t].push_back(p);
@@ -791,10 +752,6 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         for (int z = 0; z < p.ksplit; ++z) {
             const int st = std::min(per, ms_total - z * per);
             if (st > 0) units[t].push_back(Unit{prob, z, nblk, (long)nblk * (st + 4)});
-        }
-        if (p.ksplit > 1 && beta == 0.f) {
-            const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
-            G.zero.push_back({drel, (size_t)p.rows_valid * p.wtaps * (swap ? p.Co : p.Ci) * sizeof(float)});
         }
         return UDAPOSE_OK;
     };
@@ -814,6 +771,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         p.flags |= WG_FLAG_DW_WS;
         const int t = wgrad_group_plan(p, 1, n.policy.wgrad_stages, n.policy);      // (accumulate = 1: atomics into the zeroed scratch)
         if (t != 1) return UDAPOSE_ERR_UNSUPPORTED;
+        if (n.policy.wgrad_det) CK(make_partial(p, (long long)n.ws_dwtmp, 1, 64));     // ... or partial tiles, summed into the scratch
         const int prob = (int)tab[t].size();
         tab[t].push_back(p);
         G.flops[t] += fl;
@@ -831,6 +789,8 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         if (b.has_ds) CK(add(b.cd));
         CK(add(b.c1));
     }
+    if (sizing) { if (need) *need = part_cur; return UDAPOSE_OK; }
+    if (part_cur > n.ws_wgpart_bytes) return UDAPOSE_ERR_NOT_PREPARED;      // (the policy's split length changed after the workspace was sized: udapose_net_ws_bytes)
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (G.d_tab[t]) { (void)hipFree(G.d_tab[t]); G.d_tab[t] = nullptr; }
         if (G.d_blk[t]) { (void)hipFree(G.d_blk[t]); G.d_blk[t] = nullptr; }
@@ -867,8 +827,30 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         if (hipMemcpy(G.d_zero, zj.data(), zj.size() * sizeof(ZeroJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         G.n_zero = (int)zj.size();
     }
+    // the split-sum launch's tables: jobs, and one block per 4096-element chunk of a job
+    if (G.d_sum) { (void)hipFree(G.d_sum); G.d_sum = nullptr; }
+    if (G.d_sum_blk) { (void)hipFree(G.d_sum_blk); G.d_sum_blk = nullptr; }
+    G.n_sum_blk = 0;
+    if (!sums.empty()) {
+        std::vector<int> blk;
+        for (size_t j = 0; j < sums.size(); ++j)
+            for (unsigned c = 0; c < (sums[j].n + 4095u) / 4096u; ++c) { blk.push_back((int)j); blk.push_back((int)c); }
+        if (hipMalloc((void**)&G.d_sum, sums.size() * sizeof(SumJob)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMalloc((void**)&G.d_sum_blk, blk.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemcpy(G.d_sum, sums.data(), sums.size() * sizeof(SumJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        if (hipMemcpy(G.d_sum_blk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
+        G.n_sum_blk = (int)(blk.size() / 2);
+    }
     G.k_beta = beta; G.k_stages = n.policy.wgrad_stages; G.k_part = part;
     return UDAPOSE_OK;
+}
+
+// bytes of partial tiles a whole backward pass needs with the plan's current policy (a dry walk of the table builder; part 0 covers parts 1 / 2)
+size_t wg_partial_bytes(Net& n) {
+    Net::WgGroup G;
+    size_t need = 0;
+    if (build_wg_group(n, G, nullptr, 0.f, 0, true, &need) != UDAPOSE_OK) return 0;
+    return need;
 }
 
 // The tables hold OFFSETS (relative to the arenas and to grads[0]), so one pair of tables - overwrite and accumulate mode -
@@ -889,45 +871,19 @@ int bind_wg_groups(Net& n, void* const* grads) {
     // 3 parts x 2 accumulate modes per gradient placement (a few KB of device tables each).  Tables are never evicted or rebuilt
     // in place: launches captured in a hipGraph hold their device pointers, and a process only ever uses a handful of
     // gradient placements (two per-pass buffers per network).
-    std::vector<int> parts = {0, 1, 2};
-    if (n.policy.wgrad_overlap > 0) {
-        if (n.stages.empty()) {
-            plan_stages(n);
-            for (int sl = 0; sl < Net::EV_SLOTS; ++sl)
-                for (size_t k = 0; k < n.stages.size(); ++k)
-                    if (!n.ev[sl][k] && hipEventCreateWithFlags(&n.ev[sl][k], hipEventDisableTiming) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        }
-        for (size_t k = 0; k < n.stages.size(); ++k) parts.push_back(WG_PART_STAGE0 + (int)k);
-    }
-    if (n.policy.wgrad_cap > 0 && !n.d_ctr) {
-        if (hipMalloc((void**)&n.d_ctr, Net::CTR_SETS * 16 * sizeof(unsigned int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        if (hipMemset(n.d_ctr, 0, Net::CTR_SETS * 16 * sizeof(unsigned int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-    }
-    for (const int part : parts)
+    for (const int part : {0, 1, 2})
         for (const float beta : {0.f, 1.f}) {
             if (find_wg_group(n, grads, beta, part)) continue;
             n.wg_groups.emplace_back();
             Net::WgGroup* G = &n.wg_groups.back();
-            G->ord = (int)n.wg_groups.size() - 1;
             const int rc = build_wg_group(n, *G, grads, beta, part);
             if (rc != UDAPOSE_OK) { n.wg_groups.pop_back(); return rc; }
             G->last_use = ++n.wg_tick;
         }
     return UDAPOSE_OK;
 }
-// the head-counter set of the next persistent launch (null: the one-work-group-per-entry grid)
-unsigned int* next_ctr(Net& n, int cap, const Net::WgGroup& G, int t) {
-    if (cap <= 0 || !n.d_ctr) return nullptr;
-    const int idx = G.ord * WG_CLASSES + t;
-    if (idx >= Net::CTR_SETS) return nullptr;           // (more groups than sets: that launch falls back to the one-work-group-per-entry grid)
-    return n.d_ctr + (size_t)idx * 16;
-}
-// cap: > 0 = persistent grid of that many work-groups (staged launches running under the gradient chain); 0 = one work-group per entry
-int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta, int part, int cap = 0) {
-    Net::WgGroup* G = find_wg_group(n, grads, beta, part);
-    if (!G) return UDAPOSE_ERR_NOT_PREPARED;
-    if (std::find(n.wg_written.begin(), n.wg_written.end(), (const void*)grads[0]) == n.wg_written.end()) n.wg_written.push_back(grads[0]);
-    const bool with_stem = part_sel(n, part).stem && n.policy.wgrad_group_stem;
+// what precedes the grouped launches of one pass (the clears of the atomic form) and what follows them (the split sums, the stem's unpack)
+int wg_before(hipStream_t s, Net& n, Net::WgGroup* G, char* ws, void* const* grads, bool with_stem) {
     G->last_use = ++n.wg_tick;
     if (G->d_zero) {
         CK(pw_zero_multi(s, G->d_zero, G->n_zero, grads[0]));
@@ -936,132 +892,67 @@ int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* 
             if (pw_zero(s, (char*)grads[0] + z.first, z.second) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     }
     const ConvGeom& sg = n.stem.g;
-    const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
-    if (with_stem && pw_zero(s, ws + n.ws_dwtmp, stem_tmp_bytes) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
-    for (int t = 0; t < WG_CLASSES; ++t) {
-        if (!G->per_xcd[t]) continue;
-        const int tok = conv_prof_before(s, 2, G->flops[t]);
-        const int rc = wgrad_group_launch(s, t, G->d_tab[t], G->d_blk[t], G->per_xcd[t], act, ws, grads[0], nullptr, nullptr, nullptr, nullptr, nullptr,
-                                          cap, next_ctr(n, cap, *G, t));
-        conv_prof_after(s, tok);
-        CK(rc);
-    }
+    if (with_stem && !n.policy.wgrad_det && pw_zero(s, ws + n.ws_dwtmp, (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float)) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
+    return UDAPOSE_OK;
+}
+int wg_after(hipStream_t s, Net& n, Net::WgGroup* G, char* ws, void* const* grads, float beta, bool with_stem) {
+    if (G->n_sum_blk) CK(pw_split_sum(s, G->d_sum, G->d_sum_blk, G->n_sum_blk, ws, (char*)grads[0]));
+    const ConvGeom& sg = n.stem.g;
     if (with_stem)
         CK(pw_unpack_strided(s, (const float*)(ws + n.ws_dwtmp), (float*)grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
                              (long)sg.KH * sg.KW * 3, (long)sg.KW * 3, 3, 1, beta));
     return UDAPOSE_OK;
 }
+int run_wg_group(hipStream_t s, Net& n, const char* act, char* ws, void* const* grads, float beta, int part) {
+    Net::WgGroup* G = find_wg_group(n, grads, beta, part);
+    if (!G) return UDAPOSE_ERR_NOT_PREPARED;
+    const bool with_stem = part_sel(n, part).stem && n.policy.wgrad_group_stem;
+    CK(wg_before(s, n, G, ws, grads, with_stem));
+    for (int t = 0; t < WG_CLASSES; ++t) {
+        if (!G->per_xcd[t]) continue;
+        const int tok = conv_prof_before(s, 2, G->flops[t]);
+        const int rc = wgrad_group_launch(s, t, G->d_tab[t], G->d_blk[t], G->per_xcd[t], act, ws, grads[0]);
+        conv_prof_after(s, tok);
+        CK(rc);
+    }
+    return wg_after(s, n, G, ws, grads, beta, with_stem);
+}
 // The grouped weight gradients of TWO passes of this plan (each with its own arenas, gradient tensors and accumulate mode) as ONE
 // launch per tile class: the step's two student passes end at about the same time and their weight-gradient launches are fully
 // exposed there; one grid of twice the size has half the tail (measured on the launches alone: 2498 us for 64 images against 2 x 1353).
-// phase (round 5): 0 = everything; 1 = the clearing launches and tile classes 0 / 2 (the 1x1 convolutions of layer2-4, the deconvolutions, the
-// strided convolutions: 60 % of the parameters); 2 = tile class 1 (the 3x3 convolutions in the filter-row form, layer1, head, stem) and the stem's
-// unpack.  Between the two the caller may start the optimizer sweep of the parameters phase 1 completed (net_fused_update part 1) on another
-// stream: an HBM-bound sweep beside an LDS-fill-bound launch.
-// 3 = the clearing launches only; 4 = tile classes 0 / 2 only (no clears): with 2 on a second stream behind 3, the two classes' grids run
-// side by side (PoseResNet.wgrad_classes_concurrent).
 int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const* gradsA, float betaA, const char* actB, char* wsB,
-                void* const* gradsB, float betaB, int part, int cap = 0, int phase = 0) {
+                void* const* gradsB, float betaB, int part) {
     Net::WgGroup* GA = find_wg_group(n, gradsA, betaA, part);
     Net::WgGroup* GB = find_wg_group(n, gradsB, betaB, part);
     if (!GA || !GB) return UDAPOSE_ERR_NOT_PREPARED;
     bool same = true;
     for (int t = 0; t < WG_CLASSES; ++t) same = same && GA->per_xcd[t] == GB->per_xcd[t];
     if (!same) {        // (different table shapes: two launches)
-        if (phase == 2 || phase == 4) return UDAPOSE_OK;      // (phase 1 / 3 did everything)
-        CK(run_wg_group(s, n, actA, wsA, gradsA, betaA, part, cap));
-        return run_wg_group(s, n, actB, wsB, gradsB, betaB, part, cap);
+        CK(run_wg_group(s, n, actA, wsA, gradsA, betaA, part));
+        return run_wg_group(s, n, actB, wsB, gradsB, betaB, part);
     }
     const bool with_stem = part_sel(n, part).stem && n.policy.wgrad_group_stem;
-    const ConvGeom& sg = n.stem.g;
-    const size_t stem_tmp_bytes = (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float);
-    struct { Net::WgGroup* G; char* ws; void* const* grads; } side[2] = {{GA, wsA, gradsA}, {GB, wsB, gradsB}};
-    // merged pair launch (Policy::wgrad_merge): one unit per table entry reduces BOTH passes' pixels into pass A's gradient tensors; pass B's
-    // buffer receives no convolution-weight gradient from this call (its BatchNorm / bias gradients were written by its gradient chain)
-    auto written = [&](const void* g0) { return std::find(n.wg_written.begin(), n.wg_written.end(), g0) != n.wg_written.end(); };
-    const bool merge = n.policy.wgrad_merge && betaA == betaB && cap == 0 && phase == 0 && gradsA[0] != gradsB[0] && !written(gradsB[0]);
-    if (!written(gradsA[0])) n.wg_written.push_back(gradsA[0]);
-    if (!merge && !written(gradsB[0])) n.wg_written.push_back(gradsB[0]);
-    if (phase != 2 && phase != 4)
-    for (auto& sd : side) {
-        if (merge && &sd == &side[1]) break;
-        sd.G->last_use = ++n.wg_tick;
-        if (sd.G->d_zero) CK(pw_zero_multi(s, sd.G->d_zero, sd.G->n_zero, sd.grads[0]));
-        else
-            for (auto& z : sd.G->zero)
-                if (pw_zero(s, (char*)sd.grads[0] + z.first, z.second) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
-        if (with_stem && pw_zero(s, sd.ws + n.ws_dwtmp, stem_tmp_bytes) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
-    }
+    CK(wg_before(s, n, GA, wsA, gradsA, with_stem));
+    CK(wg_before(s, n, GB, wsB, gradsB, with_stem));
     for (int t = 0; t < WG_CLASSES; ++t) {
         if (!GA->per_xcd[t]) continue;
-        if (phase == 3 || ((phase == 1 || phase == 4) && t == 1) || (phase == 2 && t != 1)) continue;
-#ifdef UDAPOSE_TIMING_EXPERIMENTS
-        if (n.policy.exp0 & (1 << t)) continue;          // (tuning: skip this tile class - timing experiments only)
-#endif
         const int tok = conv_prof_before(s, 2, GA->flops[t] + GB->flops[t]);
         const int rc = wgrad_group_launch(s, t, GA->d_tab[t], GA->d_blk[t], GA->per_xcd[t], actA, wsA, gradsA[0], GB->d_tab[t], GB->d_blk[t], actB, wsB,
-                                          gradsB[0], cap, next_ctr(n, cap, *GA, t), merge ? 1 : 0);
+                                          gradsB[0]);
         conv_prof_after(s, tok);
         CK(rc);
     }
-    if (with_stem && (phase == 0 || phase == 2)) {
-        const float betas[2] = {betaA, betaB};
-        for (int k = 0; k < (merge ? 1 : 2); ++k)
-            CK(pw_unpack_strided(s, (const float*)(side[k].ws + n.ws_dwtmp), (float*)side[k].grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
-                                 (long)sg.KH * sg.KW * 3, (long)sg.KW * 3, 3, 1, betas[k]));
-    }
-    return UDAPOSE_OK;
+    CK(wg_after(s, n, GA, wsA, gradsA, betaA, with_stem));
+    return wg_after(s, n, GB, wsB, gradsB, betaB, with_stem);
 }
 }  // namespace
 
 int net_wgrad_pair(void* h, hipStream_t s, const void* actA, void* wsA, void* const* gradsA, float betaA, const void* actB, void* wsB,
-                   void* const* gradsB, float betaB, int part, int phase) {
+                   void* const* gradsB, float betaB, int part) {
     Net& n = *(Net*)h;
-    if (part < 0 || part > 2 || phase < 0 || phase > 4 || n.f32 || !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
+    if (part < 0 || part > 2 || n.f32 || !n.policy.wgrad_group) return UDAPOSE_ERR_ARG;
     DbgSyncScope dbg(n.policy.debug_sync);
-    // (wgrad_cap without wgrad_overlap: the end-of-chain launches themselves as persistent grids - dynamic scheduling only)
-    return run_wg_pair(s, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, part,
-                       n.policy.wgrad_overlap > 0 ? 0 : n.policy.wgrad_cap, phase);
-}
-
-// Staged weight gradients (Policy::wgrad_overlap > 0, round 4).  net_backward_staged = the gradient chain of the whole backward
-// (phase 1) on `s`, recording the plan's stage events of `slot` as the chain leaves each stage.  net_wgrad_staged then enqueues, on
-// the side stream `sw`, stage after stage: wait for that stage's event of pass A (and of pass B), launch the stage's grouped weight
-// gradients (of both passes in one grid).  Every stage but the last runs as a persistent grid of Policy::wgrad_cap work-groups
-// (the chain kernels of the layers below keep their CU slots); the last stage starts when the chains have ended and takes the
-// whole chip.  The caller joins `sw` into the stream that runs the optimizer.  Inside a stream capture the waits become graph
-// edges, so the order in which the host enqueues chains and stages does not matter; eagerly the chains must be enqueued first.
-int net_num_stages(void* h) { return (int)((Net*)h)->stages.size(); }
-int net_wgrad_staged(void* h, void* const* sws, int nsw, const void* actA, void* wsA, void* const* gradsA, float betaA, int slotA, const void* actB,
-                     void* wsB, void* const* gradsB, float betaB, int slotB) {
-    Net& n = *(Net*)h;
-    if (n.f32 || !n.policy.wgrad_group || n.stages.empty() || slotA < 0 || slotA >= Net::EV_SLOTS || slotB >= Net::EV_SLOTS || nsw < 1 || !sws)
-        return UDAPOSE_ERR_ARG;
-    DbgSyncScope dbg(n.policy.debug_sync);
-    const int ns = (int)n.stages.size();
-    for (int k = 0; k < ns; ++k) {
-        // stage k on side stream k mod nsw: with one stream the stages run in order (a capped stage that lags delays every later one);
-        // with several, lagging stages pile up beside each other and the residency of the weight gradients grows as the chain proceeds
-        hipStream_t sw = (hipStream_t)sws[k % nsw];
-        if (hipStreamWaitEvent(sw, n.ev[slotA][k], 0) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        if (actB && hipStreamWaitEvent(sw, n.ev[slotB][k], 0) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-        const int cap = k + 1 < ns ? n.policy.wgrad_cap : 0;
-        if (actB) CK(run_wg_pair(sw, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, WG_PART_STAGE0 + k, cap));
-        else CK(run_wg_group(sw, n, (const char*)actA, (char*)wsA, gradsA, betaA, WG_PART_STAGE0 + k, cap));
-    }
-    return UDAPOSE_OK;
-}
-int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack_, void* act_, void* ws_,
-                 void* const* grads, float beta, int part, int phase);
-int net_backward_staged(void* h, hipStream_t s, const float* dout_nchw, const void* const* params, const void* wpack, void* act, void* ws,
-                        void* const* grads, float beta, int slot) {
-    Net& n = *(Net*)h;
-    if (slot < 0 || slot >= Net::EV_SLOTS || n.stages.empty()) return UDAPOSE_ERR_ARG;
-    if (!find_wg_group(n, grads, beta, WG_PART_STAGE0)) return UDAPOSE_ERR_NOT_PREPARED;
-    n.rec_slot = slot;
-    const int rc = net_backward(h, s, dout_nchw, params, wpack, act, ws, grads, beta, 0, 1);
-    n.rec_slot = -1;
-    return rc;
+    return run_wg_pair(s, n, (const char*)actA, (char*)wsA, gradsA, betaA, (const char*)actB, (char*)wsB, gradsB, betaB, part);
 }
 
 // grads[i] (fp32, same physical layout as params[i]) = beta*grads[i] + d loss / d params[i]; beta in {0,1}
@@ -1136,7 +1027,6 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         pool.put(dz);
         dz = dx;
     }
-    if (n.rec_slot >= 0 && hipEventRecord(n.ev[n.rec_slot][0], s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;     // stage 0: head + deconvolutions
     } else {
         // part 2 resumes where part 1 stopped: the gradient entering block split-1 sits in the pool buffer part 1 ended on
         // (the buffer sequence is a function of the plan alone), masked for that block's bn3 with its sums in the slab
@@ -1151,7 +1041,6 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     }
     // bottlenecks, last to first
     const int bi_hi = part == 2 ? split - 1 : (int)n.blocks.size() - 1, bi_lo = part == 1 ? split : 0;
-    int next_stage = 1;
     for (int bi = bi_hi; bi >= bi_lo; --bi) {
         Block& b = n.blocks[bi];
         // bn3 (+ReLU of the block output): g = masked dz feeds the skip branch (written in place unless the producing dgrad
@@ -1180,11 +1069,6 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         if (dxd) pool.put(dxd);
         pool.put(dz);
         dz = dxin;
-        // staged weight gradients: the chain has left stage `next_stage` (every dy of its layers is enqueued): mark it
-        if (n.rec_slot >= 0 && next_stage + 1 < (int)n.stages.size() && n.stages[next_stage].lo == bi) {
-            if (hipEventRecord(n.ev[n.rec_slot][next_stage], s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
-            ++next_stage;
-        }
     }
     if (part == 1) {
         for (int i = 0; i < 6; ++i) if ((char*)dz == ws + pool.off[i]) n.split_dz_idx = i;      // (the same value on every pass)
@@ -1212,7 +1096,6 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     CK(conv_bn_bwd(s, n, n.stem, n.stem_bn, params, wpack, act, ws, grads, beta, pool, dzs, 0, nullptr, 2, nullptr, &none, false, 0, grouped));
     pool.put(dzs);
     }
-    if (n.rec_slot >= 0 && hipEventRecord(n.ev[n.rec_slot][n.stages.size() - 1], s) != hipSuccess) return UDAPOSE_ERR_LAUNCH;   // last stage (stem included)
     if (grouped && phase == 0) CK(run_wg_group(s, n, act, ws, grads, beta, part));
     // backbone.fc is not part of the forward: zero gradient when overwriting
     if (beta == 0.f && part == 0) {
@@ -1262,16 +1145,8 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
     char* wt_ = (char*)wpack_t_;
     const size_t jb = opt_tail_job_bytes();
     std::vector<char> jobs;
-    std::vector<int> bj, bs, bj_late, bs_late;
+    std::vector<int> bj, bs;
     std::vector<char> covered(n.n_params, 0);
-    // parameters whose weight gradient the FIRST phase of the pair launch completes (tile classes 0 / 2 of the whole-backward group): their blocks
-    // come first in the block lists, so that net_fused_update(part 1) can sweep them while phase 2 still runs
-    std::vector<char> early(n.n_params, 0);
-    for (auto& G : n.wg_groups)
-        if (G.k_part == 0 && G.rel.size() == G.rel_cls.size()) {
-            for (size_t i = 0; i < G.rel.size(); ++i) early[G.rel[i].first] = (G.rel_cls[i] != 1);
-            break;
-        }
     auto push = [&](int idx, void* sd, void* td, void* sx, void* tx, int A, int T, int B) -> int {
         const long long numel = n.param_numel[idx];
         const int adam = (h_m[idx] && h_v[idx] && grads[idx]) ? 1 : 0;
@@ -1284,8 +1159,7 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
                           (float*)params_t[idx], sd, td, sx, tx, A, T, B, adam, numel);
         const int j = (int)(jobs.size() / jb) - 1;
         const long nb = A ? (long)(A / 64) * (B / 64) * T : (long)((numel + opt_chunk() - 1) / opt_chunk());
-        const bool e = A && early[idx] && adam;
-        for (long k = 0; k < nb; ++k) { (e ? bj : bj_late).push_back(j); (e ? bs : bs_late).push_back((int)k); }
+        for (long k = 0; k < nb; ++k) { bj.push_back(j); bs.push_back((int)k); }
         covered[idx] = 1;
         return UDAPOSE_OK;
     };
@@ -1308,9 +1182,6 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
     for (int i = 0; i < n.n_params; ++i)
         if (!covered[i]) CK(push(i, nullptr, nullptr, nullptr, nullptr, 0, 0, 0));                   // BN vectors, head bias, backbone.fc
     Net::UpdTab& u = n.upd;
-    u.n_early = (int)bj.size();
-    bj.insert(bj.end(), bj_late.begin(), bj_late.end());
-    bs.insert(bs.end(), bs_late.begin(), bs_late.end());
     if (u.jobs) { (void)hipFree(u.jobs); (void)hipFree(u.blk_job); (void)hipFree(u.blk_sub); u.jobs = nullptr; }
     if (hipMalloc(&u.jobs, jobs.size()) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
     if (hipMalloc((void**)&u.blk_job, bj.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
@@ -1325,20 +1196,14 @@ int net_bind_update(void* hs, void* ht, void* const* params_s, void* const* grad
 
 int net_fused_update(void* hs, void* ht, hipStream_t s, void* const* params_s, void* const* grads, void* const* h_m, void* const* params_t,
                      void* wpack_s_, void* wpack_t_, float lr, float beta1, float beta2, float eps, float wd, int step, float gscale,
-                     float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta, int part) {
+                     float* dev_state, float alpha, float oma, int do_adam, long long grad2_delta) {
     Net& n = *(Net*)hs;
     const Net& nt = *(const Net*)ht;
     DbgSyncScope dbg(n.policy.debug_sync);
     const Net::UpdTab& u = n.upd;
-    if (part < 0 || part > 2) return UDAPOSE_ERR_ARG;
     if (!u.jobs || u.k_ps != params_s[0] || u.k_pt != params_t[0] || u.k_g != grads[0] || u.k_m != h_m[0] || u.k_ws != wpack_s_ || u.k_wt != wpack_t_)
         return UDAPOSE_ERR_NOT_PREPARED;
-    // part 0: the whole sweep.  part 1: the EARLY blocks (conv weights whose gradients the first weight-gradient phase completed), with the step
-    // counter's tick; part 2: the rest, no tick, then the two odd packs.  Parts 1 + 2 = part 0, block for block (the same kernel on disjoint blocks).
-    const int b0 = part == 2 ? u.n_early : 0, b1 = part == 1 ? u.n_early : u.nblocks;
-    CK(opt_tail(s, u.jobs, u.blk_job + b0, u.blk_sub + b0, b1 - b0, lr, beta1, beta2, eps, wd, step, gscale, dev_state, alpha, oma, do_adam, grad2_delta,
-                part != 2));
-    if (part == 1) return UDAPOSE_OK;
+    CK(opt_tail(s, u.jobs, u.blk_job, u.blk_sub, u.nblocks, lr, beta1, beta2, eps, wd, step, gscale, dev_state, alpha, oma, do_adam, grad2_delta, 1));
     // the two packs that are not a cast or a per-tap transpose of a whole tensor: the stem's 3 -> 8 channel gather (both
     // networks) and the head's zero-padded dgrad pack (student)
     CK(pack_conv(s, n, n.stem, (const void* const*)params_s, (char*)wpack_s_, false));

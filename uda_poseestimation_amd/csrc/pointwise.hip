@@ -350,132 +350,6 @@ __global__ void bn_apply_k(const TY* __restrict__ y, const T* __restrict__ res, 
     }
 }
 
-// ---- finalize + streaming apply in ONE launch (round 5) ---------------------------------------------------------------------
-// The layers the channel-chunked one-launch form does not take (layer1, layer2, the last deconvolutions: large maps, slabs of 256-2048 rows)
-// ran bn_finalize_k and bn_apply_k as two dependent launches: an 8 us latency-bound kernel plus a kernel boundary on the step's chains, 78
-// times per step.  Here ONE grid holds both: blocks [0, nfin) run bn_finalize_k's body (same code, same sums: bit-identical scale / shift /
-// saved statistics / running statistics), publish scale / shift with write-through stores and raise a counter; every other block is
-// bn_apply_k's body, which first waits for the counter (its kernel-launch ramp-up - dispatch, argument loads, address set-up - runs
-// under the finalize instead of behind it), then reads the coefficients with agent-scope loads and streams.  One-directional hand-off, not
-// a grid barrier: the finalize blocks have the lowest indices, so every XCD's dispatcher places them before any waiting block (no
-// deadlock whatever the residency); the spin is bounded all the same.  The two counter words reset themselves (the last block to leave
-// clears them), so a captured launch replays without a memset node.  sync: [0] finalize blocks done, [1] blocks left.
-template <typename T, typename TY = T>
-__global__ __launch_bounds__(TPB) void bn_fin_apply_k(const float* __restrict__ slab, int rows, int C, double count, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                      long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ scale,
-                                                      float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                      const TY* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, size_t n8, int relu,
-                                                      unsigned char* __restrict__ mask, int xcd, int nfin, int nfin_pad, unsigned int* __restrict__ sync) {
-    __shared__ double red[FIN_RL][FIN_C][2];
-    static_assert(FIN_T == TPB, "the finalize part runs in the apply kernel's block shape");
-    if ((int)blockIdx.x < nfin_pad) {
-        if ((int)blockIdx.x < nfin) {
-            const int c = blockIdx.x * FIN_C + (threadIdx.x % FIN_C);
-            if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-            double s1, s2;
-            slab_colsum(slab, rows, C, c, c < C, s1, s2, red);
-            if ((threadIdx.x / FIN_C) == 0 && c < C) {
-                // (bn_finalize_k's tail, expression for expression; no pre_bias here: layers with a bias in front of the BatchNorm keep two launches)
-                double mean = s1 / count;
-                double var = s2 / count - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-                const float sc = gamma[c] * invstd;
-                __hip_atomic_store(scale + c, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(shift + c, beta[c] - (float)mean * sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                save_mean[c] = (float)mean;
-                save_invstd[c] = invstd;
-                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-                save_invstd[C + c] = (float)unb;
-                if (running_mean) {
-                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have completed
-            __syncthreads();
-            // (RELAXED on purpose: the coefficients went out as write-through stores that have completed; a release fence here would write back
-            //  the whole L2 - the convolution's output is still dirty in it - once per finalize block: measured +130 us per launch)
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        const unsigned bx = blockIdx.x - (unsigned)nfin_pad, gx = gridDim.x - (unsigned)nfin_pad;
-        const int G = C >> 3;
-        const int c0 = (int)(((size_t)bx * TPB + threadIdx.x) % G) * 8;
-        size_t i = (size_t)bx * TPB + threadIdx.x, iend = n8, istep = (size_t)gx * TPB;
-        if (xcd) {      // (nfin_pad % 8 == 0: block bx still runs on XCD bx mod 8)
-            const size_t rws = n8 / G, per = (rws + 7) / 8;
-            const unsigned x = bx & 7u, local = bx >> 3, nb = gx >> 3;
-            const unsigned RB = TPB / G;
-            size_t rend = (size_t)(x + 1) * per;
-            if (rend > rws) rend = rws;
-            i = ((size_t)x * per + (size_t)local * RB + threadIdx.x / G) * G + threadIdx.x % G;
-            iend = rend * G;
-            istep = (size_t)nb * RB * G;
-        }
-        // the first element's loads are issued BEFORE the wait: their latency runs under the finalize
-        float v0[8], r0[8];
-        const bool have0 = i < iend;
-        if (have0) {
-            ld8<TY>(y + i * 8, v0);
-            if (res) ld8<T>(res + i * 8, r0);
-        }
-        if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            // (polls go past the L2 - agent scope - to ONE address: 2048 work-groups polling every few hundred cycles saturate that channel and
-            //  starve the finalize blocks' own traffic - measured: the step 16 -> 26 ms with s_sleep(2); so: long sleeps, ~3 us apart)
-            while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nfin && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(32);
-        }
-        __syncthreads();
-        float sa[8], ha[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sa[e] = __hip_atomic_load(scale + c0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ha[e] = __hip_atomic_load(shift + c0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        bool first = true;
-        for (; i < iend; i += istep) {
-            float v[8], r[8];
-            if (first) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] = v0[e]; r[e] = r0[e]; }
-            } else {
-                ld8<TY>(y + i * 8, v);
-                if (res) ld8<T>(res + i * 8, r);
-            }
-            first = false;
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = v[e] * sa[e] + ha[e];
-            if (res) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] += r[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (relu && o[e] < 0.f) ? 0.f : o[e];
-            st8<T>(z + i * 8, o);
-            if constexpr (sizeof(T) == 2) {
-                if (mask) {
-                    unsigned mb = 0u;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) mb |= ((float)(T)o[e] > 0.f ? 1u : 0u) << e;
-                    mask[i] = (unsigned char)mb;
-                }
-            }
-        }
-    }
-    // leave: the last block of the grid clears both words (every other block has read what it needed by then)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned left = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == gridDim.x - 1u) {
-            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // 8 consecutive gradient values as fp32 (the gradient entering a BN backward may be kept in fp32 near the loss, where
 // g - mean(g) - xhat*mean(g*xhat) cancels most of g and bf16 rounding of g would dominate the result)
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]);
@@ -1400,6 +1274,36 @@ int pw_zero(hipStream_t s, void* p, size_t bytes) {
     hipLaunchKernelGGL(zero_k, dim3((unsigned)g), dim3(TPB), 0, s, (unsigned int*)p, head, n16, tail);
     return udapose_check_launch();
 }
+// Deterministic split reductions of the grouped weight-gradient launches (net.hip build_wg_group): split z of a layer stored its partial tile at
+// part + z * stride; dst = beta * dst + ((p0 + p1) + p2) + ... in split order.  One block per 4096-element chunk of a job (blk: (job, chunk) pairs).
+__global__ __launch_bounds__(TPB) void split_sum_k(const SumJob* __restrict__ jobs, const int* __restrict__ blk, char* __restrict__ ws, char* __restrict__ gbase) {
+    const SumJob j = jobs[blk[2 * blockIdx.x]];
+    const unsigned c0 = (unsigned)blk[2 * blockIdx.x + 1] * 4096u;
+    const unsigned c1 = c0 + 4096u < j.n ? c0 + 4096u : j.n;
+    const float* part = (const float*)(ws + j.part_off);
+    float* dst = (float*)((j.dst_ws ? ws : gbase) + j.dst_off);
+    if (((((uintptr_t)part) | ((uintptr_t)dst)) & 15) == 0 && (j.stride & 3u) == 0 && (j.n & 3u) == 0) {
+        for (unsigned e = c0 + threadIdx.x * 4u; e < c1; e += TPB * 4u) {
+            f32x4 a = *(const f32x4*)(part + e);
+#pragma unroll 4
+            for (int z = 1; z < j.ks; ++z) a += *(const f32x4*)(part + (size_t)z * j.stride + e);
+            if (j.beta != 0.f) a = *(const f32x4*)(dst + e) + a;
+            *(f32x4*)(dst + e) = a;
+        }
+    } else {
+        for (unsigned e = c0 + threadIdx.x; e < c1; e += TPB) {
+            float a = part[e];
+            for (int z = 1; z < j.ks; ++z) a += part[(size_t)z * j.stride + e];
+            if (j.beta != 0.f) a = dst[e] + a;
+            dst[e] = a;
+        }
+    }
+}
+int pw_split_sum(hipStream_t s, const SumJob* d_jobs, const int* d_blk, int nblk, void* ws, void* grad_base) {
+    if (nblk <= 0) return UDAPOSE_OK;
+    hipLaunchKernelGGL(split_sum_k, dim3(nblk), dim3(TPB), 0, s, d_jobs, d_blk, (char*)ws, (char*)grad_base);
+    return udapose_check_launch();
+}
 int pw_axpy(hipStream_t s, float* y, const float* x, size_t n) {
     const size_t n4 = n / 4;
     if (n4) hipLaunchKernelGGL(axpy_k, dim3(grid_for(n4)), dim3(TPB), 0, s, y, x, n4);
@@ -1428,18 +1332,6 @@ int pw_bn_apply(hipStream_t s, const elem_t* y, const elem_t* res, elem_t* z, si
     // (XCD-aligned rows: needs whole rows per block pass, a grid that is a multiple of the 8 XCDs and enough rows to give every XCD work)
     const int ok = xcd && (TPB % G) == 0 && (grid % 8) == 0 && (n / 8 / G) >= (size_t)8 * (TPB / G);
     hipLaunchKernelGGL(bn_apply_k<elem_t>, dim3(grid), dim3(TPB), 0, s, y, res, z, n / 8, C, scale, shift, relu, mask, ok);
-    return udapose_check_launch();
-}
-// finalize + apply in one launch (bn_fin_apply_k): same arguments as pw_bn_finalize followed by pw_bn_apply; sync = two zeroed words of the pass's workspace
-int pw_bn_finalize_apply(hipStream_t s, const float* slab, int rows, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
-                         long long* nbt, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
-                         const elem_t* y, const elem_t* res, elem_t* z, size_t n, int relu, unsigned char* mask, int xcd, unsigned int* sync) {
-    if (C % 8 || n % 8 || !sync) return UDAPOSE_ERR_ARG;
-    const int grid = bn_apply_grid(n / 8, C), G = C / 8;
-    const int ok = xcd && (TPB % G) == 0 && (grid % 8) == 0 && (n / 8 / G) >= (size_t)8 * (TPB / G);
-    const int nfin = (C + FIN_C - 1) / FIN_C, nfin_pad = (nfin + 7) & ~7;
-    hipLaunchKernelGGL((bn_fin_apply_k<elem_t, elem_t>), dim3(nfin_pad + grid), dim3(TPB), 0, s, slab, rows, C, count, gamma, beta, rm, rv, nbt, momentum, eps,
-                       scale, shift, save_mean, save_invstd, y, res, z, n / 8, relu, mask, ok, nfin, nfin_pad, sync);
     return udapose_check_launch();
 }
 // f16x2 mode: y fp32 (the conv epilogue's fp32 output), residual and z split
@@ -1514,12 +1406,7 @@ int pw_bn_bwd_pre(hipStream_t s, const void* g, int g_is_f32, const elem_t* y, e
     if (C % 8 || G > 256 || (G & (G - 1)) || rows < 1) return UDAPOSE_ERR_UNSUPPORTED;
     const int xcd = (chunked >> 30) & 1, xcd_stream = (chunked >> 29) & 1;     // (bit 30: XCD-aligned pixel ranges in the chunked form; bit 29: in the streaming form too)
     chunked &= ~(3 << 29);
-#ifdef UDAPOSE_TIMING_EXPERIMENTS
-    const int skip_finalize = (chunked >> 28) & 1;      // TIMING EXPERIMENT ONLY (policy exp0 & 64, wrong results): the ceiling of removing the finalize launch
-#else
     const int skip_finalize = 0;
-#endif
-    chunked &= ~(1 << 28);
     if (chunked && C >= 256 && npix <= 32768 && npix >= 1024 && rows <= 128) {
         const int chunks = C / 64;
         int S = (chunked > 1 ? chunked : 1024) / chunks;

@@ -232,12 +232,12 @@ struct WdCfg {
 };
 
 // One work-group: tile bx of dW tap `by`, pixel split bz of problem p.
-// (x_base2 / dy_base2 != 0, round 5: MERGED pair launch - the unit reduces pass A's stages and then pass B's into one accumulator tile and
-//  writes pass A's gradient: stage index st >= nsteps addresses the second pass's arenas)
+// Split reductions (ksplit > 1) come in two forms: fp32 atomics into a zeroed dW (WG_FLAG_ATOMIC; the per-layer launches), or - the grouped
+// launches' form, round 6 - PARTIAL TILES: gp.part_stride != 0, dw points into the pass's workspace and split bz stores its tile with plain
+// stores at element offset bz * part_stride; pw_split_sum adds the splits in split order afterwards (bit-reproducible).
 template <int RT, int CT, int WR, int WC, int NS, int PX = 64, bool FAST = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
-                                               const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0,
-                                               const uintptr_t x_base2 = 0, const uintptr_t dy_base2 = 0) {
+                                               const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
     // scalar copies of the fields used below (gp may live in global memory: read it once, up front, into SGPRs)
     struct {
         const elem_t* dy; const elem_t* x; float* dw; const IgTap* taps;
@@ -270,11 +270,8 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     const int ms0 = bz * per;
     int ms1 = ms0 + per;
     if (ms1 > ms_total) ms1 = ms_total;
-    const int nsteps1 = ms1 > ms0 ? ms1 - ms0 : 0;
-    const bool merged = dy_base2 != 0;
-    const int nsteps = merged ? 2 * nsteps1 : nsteps1;
-    const elem_t* const dyA = p.dy; const elem_t* const xA = p.x;
-    const elem_t* const dyB = (const elem_t*)((uintptr_t)gp.dy + dy_base2); const elem_t* const xB = (const elem_t*)((uintptr_t)gp.x + x_base2);
+    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const size_t part_off = (size_t)bz * gp.part_stride;
     const char* zsrc = (const char*)g_wzero16;
 
     // Address generation is the issue-slot hog of this loop (measured 24 VALU instructions per MFMA when every row was
@@ -297,9 +294,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
     const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
     const int lgw = 31 - __builtin_clz((unsigned)(p.Wi > 0 ? p.Wi : 1));
     auto issue_stage = [&](int st, int buf) {
-        const bool second = st >= nsteps1;
-        const int mb = (ms0 + (second ? st - nsteps1 : st)) * PX;
-        p.dy = second ? dyB : dyA; p.x = second ? xB : xA;
+        const int mb = (ms0 + st) * PX;
         char* P = smem + buf * C::STAGE1;
         char* Q = P + C::P_BYTES;
         if constexpr (FAST) {
@@ -435,14 +430,12 @@ __device__ __forceinline__ void wgrad_dma_body(const WgParams& gp, const uint32_
                 const int rr = r0 + wr * TR + i * 16 + (lane >> 4) * 4 + r;
                 const int cc = c0 + wc * TC + j * 16 + (lane & 15);
                 if (rr >= Rdim || rr >= p.rows_valid || cc >= Cdim) continue;
-                const size_t off = ((size_t)rr * p.wtaps + tp.widx) * Cdim + cc;
+                const size_t off = ((size_t)rr * p.wtaps + tp.widx) * Cdim + cc + part_off;
                 const float v = acc[i][j][r];
                 if (atomic) atomicAdd(p.dw + off, v);
                 else p.dw[off] = v;
             }
 }
-
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fast-geometry body, second form (WG_FLAG_FAST2): the same tiles, ring and MFMA loop as wgrad_dma_body<.., FAST = true>, with the
@@ -457,12 +450,9 @@ template <int U> struct WIC { static constexpr int value = U; };
 template <int N, typename F> __device__ __forceinline__ void w_static_for(F&& f) {
     if constexpr (N > 0) { w_static_for<N - 1>(f); f(WIC<N - 1>{}); }
 }
-// (TAG: a second call site of one specialization fails to compile in hipcc 7.2's host pass - "substitution failure" - so each
-// calling kernel instantiates its own copy)
-template <int RT, int CT, int WR, int WC, int NS, int PX, int TAG = 0>
+template <int RT, int CT, int WR, int WC, int NS, int PX>
 __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
-                                                 const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0,
-                                                 const uintptr_t x_base2 = 0, const uintptr_t dy_base2 = 0) {
+                                                 const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
     struct {
         const elem_t* dy; const elem_t* x; float* dw; const IgTap* taps;
         int Hi, Wi, Ci, Co, M, wtaps, flags, ksplit, c_tiles, rows_valid;
@@ -491,15 +481,12 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
     const int ms0 = bz * per;
     int ms1 = ms0 + per;
     if (ms1 > ms_total) ms1 = ms_total;
-    const int nsteps1 = ms1 > ms0 ? ms1 - ms0 : 0;
-    const bool merged = dy_base2 != 0;
-    const int nsteps = merged ? 2 * nsteps1 : nsteps1;
+    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const size_t part_off = (size_t)bz * gp.part_stride;
     const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
     const int lgw = 31 - __builtin_clz((unsigned)p.Wi);
     // raw buffers over the two tensors; the x buffer starts at the tap's pixel offset (possibly in front of the tensor: every pixel
     // that would be read from outside the tensor is a tap outside the image and gets the out-of-range offset instead)
-    // (merged pair launch: ONE descriptor pair, re-pointed at the second pass's tensors when the stage index crosses nsteps1 - a second pair
-    //  held alive through the loop pushed the kernel's scalar registers into scratch: 2.43 -> 3.54 ms for the pair launch)
     __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.M * p.Co * 2, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (long long)toff * p.Ci * 2), 0, p.M * p.Ci * 2, 0x00020000);
     int vd[P_PW], vx[Q_PW], rowl[Q_PW];
@@ -520,14 +507,8 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
 
     auto issue_stage = [&](int st, auto ub) __attribute__((always_inline)) {
         constexpr int UB = decltype(ub)::value;
-        const bool second = st >= nsteps1;                                   // (wave-uniform)
-        const int ls = second ? st - nsteps1 : st;
-        if (merged && st == nsteps1) {
-            rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)((uintptr_t)gp.dy + dy_base2), 0, p.M * p.Co * 2, 0x00020000);
-            rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)((uintptr_t)gp.x + x_base2) + (long long)toff * p.Ci * 2), 0, p.M * p.Ci * 2, 0x00020000);
-        }
-        const int mb = (ms0 + ls) * PX;
-        const int sd = (ms0 + ls) * sd_step, sx = (ms0 + ls) * sx_step;      // scalar byte offsets of the stage
+        const int mb = (ms0 + st) * PX;
+        const int sd = (ms0 + st) * sd_step, sx = (ms0 + st) * sx_step;      // scalar byte offsets of the stage
         char* P = smem + UB * C::STAGE1;
         char* Q = P + C::P_BYTES;
 #pragma unroll
@@ -629,7 +610,7 @@ __device__ __forceinline__ void wgrad_fast2_body(const WgParams& gp, const uint3
                 const int rr = r0 + wr * TR + i * 16 + (lane >> 4) * 4 + r;
                 const int cc = c0 + wc * TC + j * 16 + (lane & 15);
                 if (rr >= p.Co || rr >= p.rows_valid || cc >= p.Ci) continue;
-                const size_t off = ((size_t)rr * p.wtaps + tp.widx) * p.Ci + cc;
+                const size_t off = ((size_t)rr * p.wtaps + tp.widx) * p.Ci + cc + part_off;
                 const float v = acc[i][j][r];
                 if (atomic) atomicAdd(p.dw + off, v);
                 else p.dw[off] = v;
@@ -654,8 +635,7 @@ struct Row3Cfg {
 };
 template <int NS>
 __device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32_t bx, const uint32_t by, const uint32_t bz, char* smem,
-                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0,
-                                                const uintptr_t x_base2 = 0, const uintptr_t dy_base2 = 0) {
+                                                const uintptr_t x_base = 0, const uintptr_t dy_base = 0, const uintptr_t dw_base = 0) {
     using R = Row3Cfg;
     constexpr int PX = R::PX, LPS = 5;                                 // 2 dy pieces + 3 x-window pieces per wave and stage
     struct {
@@ -674,11 +654,8 @@ __device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32
     const int ms0 = bz * per;
     int ms1 = ms0 + per;
     if (ms1 > ms_total) ms1 = ms_total;
-    const int nsteps1 = ms1 > ms0 ? ms1 - ms0 : 0;
-    const bool merged = dy_base2 != 0;
-    const int nsteps = merged ? 2 * nsteps1 : nsteps1;
-    const elem_t* const dyA = p.dy; const elem_t* const xA = p.x;
-    const elem_t* const dyB = (const elem_t*)((uintptr_t)gp.dy + dy_base2); const elem_t* const xB = (const elem_t*)((uintptr_t)gp.x + x_base2);
+    const int nsteps = ms1 > ms0 ? ms1 - ms0 : 0;
+    const size_t part_off = (size_t)bz * gp.part_stride;
     const char* zsrc = (const char*)g_wzero16;
     char* const dump = smem + NS * R::STAGE1;
     const unsigned w_mask = (unsigned)p.Wi - 1u, hw_mask = (unsigned)(p.Hi * p.Wi) - 1u;
@@ -687,9 +664,7 @@ __device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32
     const int xoff0 = dyk * p.Wi - 1;                                  // x pixel of window row 0 relative to the stage's first pixel
 
     auto issue_stage = [&](int st, int buf) {
-        const bool second = st >= nsteps1;
-        const int mb = (ms0 + (second ? st - nsteps1 : st)) * PX;
-        p.dy = second ? dyB : dyA; p.x = second ? xB : xA;
+        const int mb = (ms0 + st) * PX;
         char* P = smem + buf * R::STAGE1;
         char* Q = P + R::P_BYTES;
 #pragma unroll
@@ -810,7 +785,7 @@ __device__ __forceinline__ void wgrad_row3_body(const WgParams& gp, const uint32
                     const int rr = r0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
                     const int cc = c0 + wc * 32 + j * 16 + (lane & 15);
                     if (rr >= p.Co || rr >= p.rows_valid || cc >= p.Ci) continue;
-                    const size_t off = ((size_t)rr * p.wtaps + (3 * by + t)) * p.Ci + cc;      // tap (dy, dx) -> weight slab 3*(dy+1) + (dx+1)
+                    const size_t off = ((size_t)rr * p.wtaps + (3 * by + t)) * p.Ci + cc + part_off;      // tap (dy, dx) -> weight slab 3*(dy+1) + (dx+1)
                     const float v = acc[t][i][j][r];
                     if (atomic) atomicAdd(p.dw + off, v);
                     else p.dw[off] = v;
@@ -833,51 +808,21 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgParams p) {
     else wgrad_dma_body<RT, CT, WR, WC, NS>(p, bx, by, bz, smem);
 }
 
-// 128x256 / 256x128 tiles (64x128 / 128x64 per wave: 25 % fewer LDS bytes, filled and read, per FLOP than 64x64 per wave), fast
-// geometry only, 32-pixel stages (24 KB per stage); 2 work-groups per CU (192 accumulator + operand registers).
-template <int RT, int CT, int WR, int WC, int NS, int PX>
-__global__ __launch_bounds__(64 * WR * WC) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_big_kernel(const WgParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t gxy = gridDim.x * gridDim.y;
-    const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
-    const uint32_t bz = lin / gxy, bxy = lin - bz * gxy;
-    const uint32_t by = bxy / gridDim.x, bx = bxy - by * gridDim.x;
-    wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem);
-}
-template <int RT, int CT, int WR, int WC, int NS, int PX>
-int launch_wbig(WgParams& p, hipStream_t stream) {
-    using C = WdCfg<RT, CT, WR, WC, NS, PX>;
-    if (!(p.flags & WG_FLAG_FAST2) || p.M % PX) return UDAPOSE_ERR_UNSUPPORTED;
-    p.r_tiles = (p.Co + RT - 1) / RT;
-    p.c_tiles = (p.Ci + CT - 1) / CT;
-    static std::atomic<unsigned long long> attr_done{0};
-    static std::mutex attr_mu;
-    once_per_device(attr_done, attr_mu, [] {
-        (void)hipFuncSetAttribute((const void*)wgrad_big_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    });
-    dim3 grid(p.r_tiles * p.c_tiles, p.total_taps, p.ksplit);
-    hipLaunchKernelGGL((wgrad_big_kernel<RT, CT, WR, WC, NS, PX>), grid, dim3(64 * WR * WC), C::LDS_BYTES, stream, p);
-    return udapose_check_launch();
-}
-
 // Grouped form: ONE launch computes the weight gradients of many layers.  blk is an [8][per_xcd] table (work-group b runs
 // on XCD b & 7, the hardware's round-robin, and takes entry [b & 7][b >> 3]); an entry names a problem of `tab` and the
 // work-group's linear index inside that problem's (tile, tap, split) grid, or prob < 0 = padding.  The host deals whole
 // (problem, split) units to XCDs by load, so the tiles that re-read one pixel range share an L2.  The table holds byte
 // OFFSETS in its x / dy / dw fields, relative to the three bases passed per launch, so one table serves every pass.
 template <int RT, int CT, int WR, int WC, int NS, int PX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 128 * 128 ? 2 : 4))) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void wgrad_dma_group_kernel(const WgParams* __restrict__ tab, const WgGroupBlk* __restrict__ blk,
                                                               const uint32_t per_xcd, const char* x_base, const char* dy_base, char* dw_base,
                                                               const WgParams* __restrict__ tab2, const WgGroupBlk* __restrict__ blk2,
-                                                              const char* x_base2, const char* dy_base2, char* dw_base2, const int merge) {
+                                                              const char* x_base2, const char* dy_base2, char* dw_base2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // PAIR launch (tab2 != null): the groups of TWO passes of one plan (same table shape, their own arenas and gradient buffers) in one
     // grid, interleaved slot by slot - the second pass's heavy work-groups start beside the first's instead of behind its tail.
-    // merge (round 5): ONE unit per table entry reduces both passes' pixels (the bodies' x_base2 / dy_base2) into pass A's gradient
     uint32_t slot = blockIdx.x >> 3;
-    uintptr_t mx = 0, md = 0;
-    if (tab2 && merge) { mx = (uintptr_t)x_base2; md = (uintptr_t)dy_base2; }
-    else if (tab2) {
+    if (tab2) {
         if (slot & 1u) { tab = tab2; blk = blk2; x_base = x_base2; dy_base = dy_base2; dw_base = dw_base2; }
         slot >>= 1;
     }
@@ -888,107 +833,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 1
     const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
     const uint32_t by = bxy / gx, bx = bxy - by * gx;
     if constexpr (RT == 64 && CT == 64 && PX == 64) {
-        if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md); return; }
+        if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base); return; }
     }
-    if constexpr (RT != CT) {
-        // (the 256x128 class holds fast-geometry layers only: wgrad_group_plan)
-        wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
-    } else {
-    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
-    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
-    else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base, mx, md);
-    }
-}
-
-// Persistent, residency-capped form of the grouped launch (round 4): the grid is `cap` work-groups (1-2 per CU) instead of one per
-// table entry, and every work-group PULLS entries until the table is drained.  A launch of this form can run on a side stream
-// UNDER the latency-bound gradient chain of the layers below it without flooding the CUs: it holds at most cap / 256 work-groups'
-// worth of LDS and wave slots per CU, whatever the table's size (the one-work-group-per-entry grid put four 32 KB work-groups
-// on every CU for ~130 us each and starved the chain kernels: profiles/r2_ab_runs.txt, r3_ab_runs.txt).
-// Scheduling: one head counter per XCD list (ctr[0..7]; the guide's `dequeue` row: 0.3-1.3 us per pull with sharded heads
-// against units of 20-130 us).  A work-group starts on the list of the XCD it actually runs on (HW_REG_XCC_ID: the tiles that
-// re-read one pixel range share that L2) and, once that list is empty, steals from the next ones, so every list is drained
-// wherever the dispatcher placed the grid - placement is a speed matter only.  Exit: every work-group leaves after ONE failed
-// pull on each of the 8 lists (bounded: the heads only grow).  The counters reset themselves: the last work-group to leave
-// (ctr[8] counts leavers) zeroes all nine words, so a captured launch replays without a memset node.
-template <int RT, int CT, int WR, int WC, int NS, int PX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT * CT > 128 * 128 ? 2 : 4))) void wgrad_persist_kernel(
-    const WgParams* __restrict__ tabA, const WgGroupBlk* __restrict__ blkA, const uint32_t per_xcd, const char* x_baseA, const char* dy_baseA,
-    char* dw_baseA, const WgParams* __restrict__ tabB, const WgGroupBlk* __restrict__ blkB, const char* x_baseB, const char* dy_baseB,
-    char* dw_baseB, unsigned int* __restrict__ ctr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ unsigned int s_slot;
-    const uint32_t nslots = tabB ? 2u * per_xcd : per_xcd;           // entries per XCD list (pair launch: the two passes interleaved)
-    // (s_getreg HW_REG_XCC_ID: id 20, offset 0, 4 bits)
-    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-    for (uint32_t hop = 0; hop < 8u; ++hop) {
-        const uint32_t lst = (xcc + hop) & 7u;
-        while (true) {
-            __syncthreads();                                          // (the previous unit's last LDS reads, and s_slot's readers)
-            if (threadIdx.x == 0) s_slot = atomicAdd(&ctr[lst], 1u);
-            __syncthreads();
-            uint32_t slot = s_slot;
-            if (slot >= nslots) break;
-            const WgParams* tab = tabA; const WgGroupBlk* blk = blkA;
-            const char* x_base = x_baseA; const char* dy_base = dy_baseA; char* dw_base = dw_baseA;
-            if (tabB) {
-                if (slot & 1u) { tab = tabB; blk = blkB; x_base = x_baseB; dy_base = dy_baseB; dw_base = dw_baseB; }
-                slot >>= 1;
-            }
-            const WgGroupBlk b = blk[lst * per_xcd + slot];
-            if (b.prob < 0) continue;
-            const WgParams& p = tab[b.prob];
-            const uint32_t gx = (uint32_t)(p.r_tiles * p.c_tiles), gxy = gx * (uint32_t)p.total_taps;
-            const uint32_t bz = (uint32_t)b.local / gxy, bxy = (uint32_t)b.local - bz * gxy;
-            const uint32_t by = bxy / gx, bx = bxy - by * gx;
-            bool done = false;
-            if constexpr (RT == 64 && CT == 64 && PX == 64) {
-                if (p.flags & WG_FLAG_ROW3) { wgrad_row3_body<NS>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base); done = true; }
-            }
-            if (!done) {
-                if constexpr (RT != CT) {
-                    wgrad_fast2_body<RT, CT, WR, WC, NS, PX, 1>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
-                } else {
-                    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX, 1>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
-                    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
-                    else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
-                }
-            }
-        }
-    }
-    // leave: the last of the grid's work-groups resets the heads (every other work-group has made its last pull by then)
-    if (threadIdx.x == 0) {
-        const unsigned int left = atomicAdd(&ctr[8], 1u);
-        if (left == gridDim.x - 1u) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) atomicExch(&ctr[k], 0u);
-        }
-    }
-}
-
-template <int RT, int CT, int WR, int WC, int NS, int PX>
-int launch_wd_persist(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
-                      hipStream_t stream, const WgParams* d_tab2, const WgGroupBlk* d_blk2, const void* x_base2, const void* dy_base2,
-                      void* dw_base2, int cap, unsigned int* ctr) {
-    using C = WdCfg<RT, CT, WR, WC, NS, PX>;
-    constexpr int LDS = (RT == 64 && CT == 64 && PX == 64 && Row3Cfg::lds_bytes(NS) > C::LDS_BYTES) ? Row3Cfg::lds_bytes(NS) : C::LDS_BYTES;
-    static std::atomic<unsigned long long> attr_done{0};
-    static std::mutex attr_mu;
-    once_per_device(attr_done, attr_mu, [] {
-        (void)hipFuncSetAttribute((const void*)wgrad_persist_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    });
-    const long total = 8L * per_xcd * (d_tab2 ? 2 : 1);
-    const int grid = (int)(total < cap ? total : cap);
-    hipLaunchKernelGGL((wgrad_persist_kernel<RT, CT, WR, WC, NS, PX>), dim3(grid), dim3(256), LDS, stream, d_tab, d_blk, (uint32_t)per_xcd,
-                       (const char*)x_base, (const char*)dy_base, (char*)dw_base, d_tab2, d_blk2, (const char*)x_base2, (const char*)dy_base2,
-                       (char*)dw_base2, ctr);
-    return udapose_check_launch();
+    if (p.flags & WG_FLAG_FAST2) wgrad_fast2_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    else if (p.flags & WG_FLAG_FASTGEO) wgrad_dma_body<RT, CT, WR, WC, NS, PX, true>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
+    else wgrad_dma_body<RT, CT, WR, WC, NS, PX>(p, bx, by, bz, smem, (uintptr_t)x_base, (uintptr_t)dy_base, (uintptr_t)dw_base);
 }
 
 template <int RT, int CT, int WR, int WC, int NS, int PX>
 int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base, const void* dy_base, void* dw_base,
                     hipStream_t stream, const WgParams* d_tab2 = nullptr, const WgGroupBlk* d_blk2 = nullptr, const void* x_base2 = nullptr,
-                    const void* dy_base2 = nullptr, void* dw_base2 = nullptr, int merge = 0) {
+                    const void* dy_base2 = nullptr, void* dw_base2 = nullptr) {
     using C = WdCfg<RT, CT, WR, WC, NS, PX>;
     constexpr int LDS = (RT == 64 && CT == 64 && PX == 64 && Row3Cfg::lds_bytes(NS) > C::LDS_BYTES) ? Row3Cfg::lds_bytes(NS) : C::LDS_BYTES;
     static std::atomic<unsigned long long> attr_done{0};
@@ -996,9 +851,9 @@ int launch_wd_group(const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd,
     once_per_device(attr_done, attr_mu, [] {
         (void)hipFuncSetAttribute((const void*)wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd * ((d_tab2 && !merge) ? 2 : 1)), dim3(256), LDS, stream, d_tab, d_blk,
+    hipLaunchKernelGGL((wgrad_dma_group_kernel<RT, CT, WR, WC, NS, PX>), dim3(8 * per_xcd * (d_tab2 ? 2 : 1)), dim3(256), LDS, stream, d_tab, d_blk,
                        (uint32_t)per_xcd, (const char*)x_base, (const char*)dy_base, (char*)dw_base, d_tab2, d_blk2, (const char*)x_base2,
-                       (const char*)dy_base2, (char*)dw_base2, merge);
+                       (const char*)dy_base2, (char*)dw_base2);
     return udapose_check_launch();
 }
 
@@ -1067,8 +922,8 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     p.div_hw = make_fastdiv((uint32_t)(p.Hg * p.Wg));
     p.div_w = make_fastdiv((uint32_t)p.Wg);
     const int Rdim = swap ? p.Ci : p.Co, Cdim = swap ? p.Co : p.Ci;
-    static const int RT[7] = {128, 64, 64, 32, 128, 256, 256}, CT[7] = {128, 64, 32, 128, 256, 128, 256};
-    if (tile < 0 || tile > 6) return UDAPOSE_ERR_ARG;
+    static const int RT[4] = {128, 64, 64, 32}, CT[4] = {128, 64, 32, 128};
+    if (tile < 0 || tile > 3) return UDAPOSE_ERR_ARG;
     // measured (tools/tune_conv.py, LDS-DMA kernels): 128x128 tiles for multi-tap convs with >= 128 channels on both sides
     // (3x3 trunk convs, 4x4 deconvs), 64x64 otherwise
     if (tile == 1 && pol.wgrad_tile < 0 && Rdim >= 128 && Cdim >= 128 && p.total_taps >= 9) tile = 0;
@@ -1079,7 +934,6 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     }
     const long tiles = (long)((Rdim + RT[tile] - 1) / RT[tile]) * (smallc ? 1 : (Cdim + CT[tile] - 1) / CT[tile]) *
                        (smallc ? p.total_taps / 4 : p.total_taps);
-    const bool big = tile >= 4;                               // (tuning ids: 128x256 / 256x128 / 256x256 tiles, fast geometry)
     const bool dma = !smallc && (tile == 0 || tile == 1) && (p.Ci % 64 == 0) && (p.Co % 64 == 0);
     const int ms_total = dma ? (p.M + 63) / 64 : (p.M + 31) / 32;
     // split the pixel reduction until ~512 work-groups exist (2 per CU), keeping >= 16 (128x128) / 4 (64x64) stages per
@@ -1089,6 +943,7 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     while (tiles * ks < 512 && ms_total / (ks * 2) >= min_stages) ks *= 2;
     if (pol.wgrad_ksplit > 0) { ks = pol.wgrad_ksplit; while (ks > 1 && ms_total / ks < 1) ks /= 2; }
     p.ksplit = ks;
+    p.part_stride = 0;
     p.msteps_per_split = (ms_total + ks - 1) / ks;
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
     if (ks > 1 && !accumulate) {
@@ -1097,11 +952,6 @@ int wgrad_launch(WgParams& p, int tile, int accumulate, hipStream_t stream, cons
     }
     if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
     if ((p.flags & WG_FLAG_FASTGEO) && !(p.flags & WG_FLAG_ROW3) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0) p.flags |= WG_FLAG_FAST2; else p.flags &= ~WG_FLAG_FAST2;
-    if (big) {
-        if (smallc || swap || p.Ci % 64 || p.Co % 64) return UDAPOSE_ERR_UNSUPPORTED;
-        if (tile == 6) return launch_wbig<256, 256, 2, 4, 2, 64>(p, stream);      // 8 waves, 128x64 per wave, 64-pixel stages: 128 KB of LDS
-        return tile == 4 ? launch_wbig<128, 256, 2, 2, 3, 32>(p, stream) : launch_wbig<256, 128, 2, 2, 3, 32>(p, stream);
-    }
     if (dma) return tile == 0 ? launch_wd<128, 128, 2, 2, 2>(p, stream) : launch_wd<64, 64, 2, 2, 4>(p, stream);
     switch (tile) {
         case 0: return launch_wg<128, 128, 2, 2>(p, stream);
@@ -1123,23 +973,19 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
     // inside a group the other layers fill the chip, so a layer takes the 128x128 tile (half the L2->LDS bytes per FLOP of
     // 64x64) whenever both of its dimensions allow
     int tile = (Rdim >= 128 && Cdim >= 128) ? 0 : 1;
-    // 256x128 tiles (128x64 per wave, 25 % fewer LDS bytes per FLOP: +16-19 % per layer against 128x128, +40-55 % against the filter-row
-    // form on layer3 / layer4's 3x3 convolutions, profiles/r3_ab_runs.txt) for the second fast-geometry loader's layers
-    const bool big = pol.wgrad_big && !smallc && !swap && wg_fastgeo_ok(p, pol) && pol.wgrad_fastgeo >= 2 && p.M % 64 == 0 && p.Co % 256 == 0 &&
-                     p.Ci % 128 == 0;
-    if (big) tile = 2;
-    else if (wg_row3_ok(p, pol)) {       // filter-row form: 64x64 tiles, one work-group per (tile, filter row)
+    if (wg_row3_ok(p, pol)) {       // filter-row form: 64x64 tiles, one work-group per (tile, filter row)
         tile = 1;
         p.flags |= WG_FLAG_ROW3;
         p.total_taps = 3;
     }
-    const int TRr = tile == 2 ? 256 : (tile == 0 ? 128 : 64), TCc = tile == 1 ? 64 : 128;
+    const int TRr = tile == 0 ? 128 : 64, TCc = tile == 1 ? 64 : 128;
     p.r_tiles = (Rdim + TRr - 1) / TRr;
     p.c_tiles = (Cdim + TCc - 1) / TCc;
     const int ms_total = (p.M + 63) / 64;
     int ks = (ms_total + stages_per_block / 2) / stages_per_block;
     if (ks < 1) ks = 1;
     p.ksplit = ks;
+    p.part_stride = 0;              // (the caller turns a split problem into the partial-tile form: net.hip build_wg_group)
     p.msteps_per_split = (ms_total + ks - 1) / ks;
     if (ks > 1 || accumulate) p.flags |= WG_FLAG_ATOMIC; else p.flags &= ~WG_FLAG_ATOMIC;
     if (wg_fastgeo_ok(p, pol)) p.flags |= WG_FLAG_FASTGEO; else p.flags &= ~WG_FLAG_FASTGEO;
@@ -1149,18 +995,12 @@ int wgrad_group_plan(WgParams& p, int accumulate, int stages_per_block, const Po
 
 int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, const WgGroupBlk* d_blk, int per_xcd, const void* x_base,
                        const void* dy_base, void* dw_base, const WgParams* d_tab2, const WgGroupBlk* d_blk2, const void* x_base2,
-                       const void* dy_base2, void* dw_base2, int cap, unsigned int* ctr, int merge) {
+                       const void* dy_base2, void* dw_base2) {
     if (per_xcd <= 0) return UDAPOSE_OK;
     // 32-pixel stages for the 128x128 tile (32 KB of LDS, 128 VGPRs: four resident work-groups per CU instead of two with
     // 64-pixel stages) and a 2-stage ring of 64-pixel stages for the 64x64 tile (35 KB with the filter-row form's reserve: four per
     // CU; round 1 ran three stages = three per CU, with the buffer-load loader two measure -4.5 % alone and -0.05 ms in the step):
     // occupancy beats prefetch depth here as in the igemm (a 3-stage ring for the 128x128 tile: +40 % alone)
-    if (cap > 0 && ctr) {       // persistent, residency-capped grid (wgrad_persist_kernel)
-        if (tile == 2) return launch_wd_persist<256, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
-        if (tile == 0) return launch_wd_persist<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
-        return launch_wd_persist<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, cap, ctr);
-    }
-    if (tile == 2) return launch_wd_group<256, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, merge);
-    if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, merge);
-    return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2, merge);
+    if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
+    return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
 }

@@ -42,7 +42,7 @@ class GradSync:
 
     def __init__(self, model, comm_dtype="fp32"):
         self.model = model
-        self._work = None
+        self._work, self._upper, self._cstream = None, None, None
         # 'bf16': the buckets travel in bf16 (udapose_comm_*: one rounding per contribution, all-to-all of shards, fp32 accumulation on
         # the shard's owner, the MEAN rounded to bf16 once more for the all-gather of the averaged shards): half the bytes per xGMI
         # link, two bf16 roundings per averaged gradient element.  RCCL backend only.
@@ -265,15 +265,6 @@ class MeanTeacherTrainer:
         self.single_graph = True            # one rank: the optimizer tail is captured into the step's graph (one launch per step)
         self.sum_grads_in_tail = True       # ... which also adds the two passes' gradient buffers (no separate axpy; one rank only)
         self.fused_last = False
-        # one rank, no loss scaling: the optimizer sweep's first part beside the weight gradients' second phase (_split_tail_ok).  OFF: measured
-        # +0.1 .. 0.2 ms per step (profiles/r5_ab_runs.txt section 5) - a weight-gradient launch fills every wave slot of the chip (4 work-groups x 4 waves
-        # at 128 registers per CU), so the sweep's waves only run where they displace it; bit-identical either way (tests/test_gpu_steps.py)
-        self.split_tail = False
-        self._early_tail = False
-        # one rank: start the SOURCE-domain pass's gradient chain as soon as its own forward has finished (loss_s does not depend on the
-        # teacher), beside the teacher's and the target-domain forwards; its weight gradients still go out with the other pass's at the
-        # end.  Same gradients (the two passes own separate buffers; d(loss_s + lambda * loss_c) = d loss_s + lambda * d loss_c).
-        self.early_source_backward = False
 
     def _check_scaler(self):
         """An fp16 student forward needs the loss scaler the optimizer was built with (or the caller's own GradScaler: then build the
@@ -391,9 +382,6 @@ class MeanTeacherTrainer:
         if self._side is None or self._side[0].device != x_s.device:
             pr = self.stream_priority
             self._side = (torch.cuda.Stream(device=x_s.device, priority=pr), torch.cuda.Stream(device=x_s.device, priority=pr))
-        if getattr(self, "_wg_stream", None) is None or self._wg_stream[0].device != x_s.device:
-            # staged weight gradients (policy wgrad_overlap): side streams, created outside capture (wgrad_streams = 1: stages in order)
-            self._wg_stream = [torch.cuda.Stream(device=x_s.device) for _ in range(max(1, int(getattr(self, "wgrad_streams", 1))))]
         s_tea, s_stu = self._side if self.concurrent else (main, main)
         occl = self._occl if self.occlude_rate > -1 else None
         student.prepare(x_s)                # bf16 weight packs refreshed on `main` before the branches fork
@@ -424,27 +412,7 @@ class MeanTeacherTrainer:
                                                                         self.occlude_rate, self.occlude_thresh, self.occlude_size, self.occl_rng)
             y_t_stu = student.forward_deferred_bn(x_t_stu)     # separate forwards: separate BN statistics per domain
             y_t_stu_recon = warp.warp_chain(y_t_stu, theta_stu)
-        loss_s_early, s_src = None, None
-        early = (self.early_source_backward and occl is None and self.concurrent and not self._overlap() and self.merge_wgrad
-                 and hasattr(student, "finish_wgrad") and not getattr(student, "wgrad_side_stream", False))
-        if early:
-            # the source pass on a stream of its own: forward, JointsMSE and its gradient chain run to the end without waiting for the
-            # other branches (loss_s does not depend on the teacher), while `main` goes on to the consistency loss - an in-order
-            # stream that carried both would put the whole source chain in front of the target pass's backward
-            if getattr(self, "_src_stream", None) is None or self._src_stream.device != x_s.device:
-                self._src_stream = torch.cuda.Stream(device=x_s.device, priority=self.stream_priority)
-            s_src = self._src_stream
-            s_src.wait_stream(main)
-            with torch.cuda.stream(s_src):
-                y_s = student(x_s)
-                src_fwd_done = torch.cuda.Event()
-                src_fwd_done.record(s_src)
-                student.split_backward, student.merge_wgrad = False, True
-                loss_s_early = self.criterion(y_s, label_s, weight_s)
-                self._check_scaler()
-                self.stu_optimizer.scale_loss(loss_s_early).backward()
-            main.wait_event(src_fwd_done)    # (the source forward's own running-statistics update comes before the deferred one below)
-        elif occl is None:
+        if occl is None:
             y_s = student(x_s)
         main.wait_stream(s_stu)
         student.apply_deferred_bn()         # (x_s first, then x_t_stu: the reference's call order, train_human.py:414-417)
@@ -460,7 +428,7 @@ class MeanTeacherTrainer:
             else:
                 activates, y_t_tea_rect = mt.heatmap_activations(y_t_tea_recon), None
         return {"y_s": y_s, "y_t_stu_recon": y_t_stu_recon, "y_t_tea_recon": y_t_tea_recon, "activates": activates, "y_t_tea_rect": y_t_tea_rect,
-                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu, "loss_s_early": loss_s_early, "s_src": s_src}
+                "label_s": label_s, "weight_s": weight_s, "main": main, "s_stu": s_stu}
 
     def _overlap(self):
         on = self.overlap_allreduce
@@ -497,16 +465,13 @@ class MeanTeacherTrainer:
         student = self.student
         main, s_stu = st["main"], st["s_stu"]
         overlap = self._overlap()
-        # one device: the same cut, used to run the upper part's weight gradients on side streams under the lower part's chains
-        side = (not overlap) and getattr(student, "wgrad_side_stream", False) and hasattr(student, "finish_backward")
-        student.split_backward = True if overlap else ("side" if side else False)
+        student.split_backward = bool(overlap)
         # one rank: the two passes' grouped weight gradients go out as ONE launch after both gradient chains (finish_wgrad)
-        merge = (not overlap) and (not side) and self.merge_wgrad and hasattr(student, "finish_wgrad")
+        merge = (not overlap) and self.merge_wgrad and hasattr(student, "finish_wgrad")
         student.merge_wgrad = bool(merge)
         if getattr(self, "_metrics_cb", None) is not None:
             self._metrics_cb(st)                # (GraphedTrainStep: decode + PCK of the source batch on an idle side stream, under the backward)
-        early = st.get("loss_s_early")
-        loss_s = early.detach() if early is not None else self.criterion(st["y_s"], st["label_s"], st["weight_s"])
+        loss_s = self.criterion(st["y_s"], st["label_s"], st["weight_s"])
         self._check_scaler()
         with torch.no_grad():
             # threshold = k-th value over the GLOBAL batch (all-gather of [N,K] floats when data parallel)
@@ -514,54 +479,30 @@ class MeanTeacherTrainer:
             y_t_tea_rect = st["y_t_tea_rect"] if st.get("y_t_tea_rect") is not None else mt.rectify(st["y_t_tea_recon"], sigma=self.sigma)
         loss_c = self.con_criterion(st["y_t_stu_recon"], y_t_tea_rect, tea_mask=tea_mask)
         loss_all = loss_s + self.lambda_c * loss_c
-        # (with the source pass's chain already enqueued by _forward_part only the consistency term is left to differentiate)
-        self.stu_optimizer.scale_loss(loss_all if early is None else self.lambda_c * loss_c).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
+        self.stu_optimizer.scale_loss(loss_all).backward()      # (scaler.scale(loss_all).backward(), train_human.py:436; identity in bf16)
         if s_stu is not main:
             main.wait_stream(s_stu)             # the target-domain backward ran on its own stream
-        if st.get("s_src") is not None:
-            main.wait_stream(st["s_src"])       # ... and the early source pass on its own
-            for t in (st["y_s"], early):
-                t.record_stream(main)
         student.split_backward = False
         if merge:
             student.merge_wgrad = False
-            if self._split_tail_ok():
-                # Round 5: the serial end of the step - weight gradients, then the optimizer sweep - with the sweep's first part UNDER the weight
-                # gradients' second phase.  Phase 1 computes the gradients of 60 % of the parameters; their Adam + EMA + packs (HBM-bound,
-                # 6.9 TB/s) then run on a side stream beside phase 2 (LDS-fill-bound, ~1 TB/s of HBM); _update() issues the rest.
-                student.finish_wgrad(phase=1)
-                if getattr(self, "_tail_stream", None) is None or self._tail_stream.device != main.device:
-                    self._tail_stream = torch.cuda.Stream(device=main.device)
-                ts = self._tail_stream
-                ts.wait_stream(main)
-                with torch.cuda.stream(ts):
-                    self._early_tail = bool(self.stu_optimizer.fused_tail_step(student, self.teacher, self.tea_optimizer, part=1))
-                student.finish_wgrad(phase=2)
-                main.wait_stream(ts)
-            else:
-                student.finish_wgrad(getattr(self, "_wg_stream", None))
+            student.finish_wgrad()
         if overlap:
             student.finish_grads(part=1)    # the suffix of both passes is final: sum it ...
             if not torch.cuda.is_current_stream_capturing() or getattr(self, "capture_comm", False):
                 self.sync.start_upper()     # ... and send it off (a captured step issues the collective between its graphs, or captures it: capture_comm)
         elif student._pending_lower:
-            self._backward_lower(grads_part=0)      # weight gradients of the upper part on side streams | the lower part
+            self._backward_lower(grads_part=0)      # (overlap forced off after part 1 ran: finish the backward here)
         else:
             # adds the second pass's gradient buffer (no-op when both ran on one stream) - unless the fused optimizer tail will
             # read both buffers itself (one rank: nothing else looks at the gradients in between)
             student.finish_grads(defer=self._tail_sums_grads())
+        # (the re-warped heat-maps of both networks are handed out for the parity tests and bench.py's measured parity: references only)
         return {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": st["y_s"].detach(),
-                "tea_mask": tea_mask}
+                "tea_mask": tea_mask, "y_t_tea_recon": st["y_t_tea_recon"], "y_t_stu_recon": st["y_t_stu_recon"].detach()}
 
     def _forward_backward(self, x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea):
         st = self._forward_part(x_s, label_s, weight_s, x_t_stu, x_t_teas, theta_stu, thetas_tea)
         return self._loss_backward_part(st, gather_activates(st["activates"]))
-
-    def _split_tail_ok(self):
-        """The optimizer sweep may start before the last weight gradients exist only when nothing has to look at ALL gradients first: one
-        rank (no all-reduce), no dynamic loss scaling (its found-inf check), the fused tail summing the two passes' buffers itself."""
-        return bool(self.split_tail and self._tail_sums_grads() and getattr(self.stu_optimizer, "_scaler", None) is None
-                    and hasattr(self.student, "can_phase_wgrad") and self.student.can_phase_wgrad())
 
     def _tail_sums_grads(self):
         return bool(self.fuse_tail and self.sum_grads_in_tail and not _dist_on() and hasattr(self.stu_optimizer, "fused_tail_step")
@@ -570,10 +511,6 @@ class MeanTeacherTrainer:
     def _update(self):
         # Adam, the EMA and the next forwards' weight packs of both networks in ONE sweep when the layout allows ...
         fuse = self.fuse_tail and hasattr(self.stu_optimizer, "fused_tail_step")
-        if getattr(self, "_early_tail", False):
-            self._early_tail = False
-            self.fused_last = bool(self.stu_optimizer.fused_tail_step(self.student, self.teacher, self.tea_optimizer, part=2))
-            return
         self.fused_last = bool(fuse and self.stu_optimizer.fused_tail_step(self.student, self.teacher, self.tea_optimizer))
         if not self.fused_last:
             if hasattr(self.student, "finish_grads"):
@@ -640,7 +577,7 @@ class GraphedTrainStep:
     on the device from four uniform draws per sample (trainer.device_occlusion), inside the main graph."""
 
     def __init__(self, trainer, x_s, label_s, weight_s, x_t_stu, x_t_tea, aug_param_stu, aug_param_tea, warmup=2, split=None, metrics=True,
-                 capture_comm=None, branch_graphs=None):
+                 capture_comm=None):
         # metrics: the captured step also decodes y_s and computes PCK@0.05 against label_s on the device (the reference's per-iteration
         # `accuracy(y_s, label_s)`, train_human.py:443) and gathers the losses + PCK into ONE small device vector: step_async() reads
         # it back one step late through a pinned double buffer, so a loop that logs every iteration never drains the device
@@ -703,9 +640,14 @@ class GraphedTrainStep:
             # RCCL's watchdog thread polls the end events of the EAGER collectives issued so far (the warm-up steps'); on this HIP an
             # event query fails with hipErrorCapturedEvent once the communicator's stream has joined a capture, even for an event that
             # was recorded before it - and the watchdog then takes the process down.  Everything is complete here (synchronize above):
-            # give the watchdog (100 ms poll) time to retire those works before any collective is captured.
-            import time
-            time.sleep(0.7)
+            # give the watchdog (100 ms poll) time to retire those works before any collective is captured.  torch exposes no call that
+            # waits for the watchdog's list to drain, so this IS a timed wait (ten polls) - which is why capturing the
+            # collectives is opt-in (capture_comm below) and why the capture's failure path falls back to eager collectives.
+            if capture_comm or (capture_comm is None and os.environ.get("UDAPOSE_CAPTURE_COMM", "0") == "1"):
+                import time
+                dist.barrier()
+                torch.cuda.synchronize()
+                time.sleep(1.0)
         style_mode = "thread_local" if _dist_on() else "global"
         if self.styled:
             for which in ("enc", "s2t", "t2s"):
@@ -716,13 +658,15 @@ class GraphedTrainStep:
                 self.g_style[which] = g
         # Data parallel: the confidence all-gather sits between the forwards and the losses, the gradient all-reduce between
         # backward and the optimizer; both stay eager, so the step is cut into three graphs around them.
-        # capture_comm (round 5; default: on with the RCCL backend): the step's collectives - confidence all-gather, gradient all-reduce
-        # buckets - are captured INTO the step's graph (RCCL launches are stream-ordered kernels: capturable), so the data-parallel step is
-        # ONE graph launch like the one-rank step instead of four graphs with eager collectives between them.  If the capture raises
-        # (a collective backend that cannot be captured), the four-graph form below is built instead.
+        # capture_comm (round 5): the step's collectives - confidence all-gather, gradient all-reduce buckets - are captured INTO the step's
+        # graph (RCCL launches are stream-ordered kernels: capturable), so the data-parallel step is ONE graph launch like the one-rank step
+        # instead of four graphs with eager collectives between them.  OPT-IN (round 6, ADVICE r5: the argument, or UDAPOSE_CAPTURE_COMM=1):
+        # it rests on a timed wait for RCCL's watchdog (above), replayed collectives are invisible to torch.distributed's timeout, and no
+        # multi-GPU node has run it yet; bench.py --gpus N asks for it explicitly (with its own hang guard) and lets the ranks fall back
+        # together.  If the capture raises (a collective backend that cannot be captured), the four-graph form below is built instead.
         if capture_comm is None:
             capture_comm = (_dist_on() and dist.get_backend() == "nccl" and split is None
-                            and os.environ.get("UDAPOSE_CAPTURE_COMM", "1") == "1")
+                            and os.environ.get("UDAPOSE_CAPTURE_COMM", "0") == "1")
         self.capture_comm = bool(capture_comm) and _dist_on()
         if self.capture_comm and trainer.sync.comm_dtype == "bf16" and trainer._overlap():
             # the bf16 exchange of the suffix runs on a side stream that hands over to the communicator's stream and waits for it again:
@@ -745,33 +689,44 @@ class GraphedTrainStep:
         self.g_lb2 = None
         # one rank, nothing eager between backward and the optimizer: the update is captured into the same graph (one launch per step)
         self.one_graph = (not self.split) and (self.capture_comm or not _dist_on()) and trainer.single_graph
-        # branch_graphs (round 5, OFF): the one-rank step as nine linear graphs on three streams - head | teacher forward | source forward |
-        # target forward | metrics | loss section | the two gradient chains | weight gradients + optimizer tail - joined by events, instead
-        # of one graph with three branches.  Built to test whether hipGraph's own branch scheduling loses concurrency against plain
-        # streams: it does not (15.77-15.94 against 15.75-15.98 ms with three streams on distinct hardware queues; 29 ms with
-        # GPU_MAX_HW_QUEUES=8, where the host-side launches block: profiles/r5_ab_runs.txt section 6).  Kept as a measurement tool: every
-        # phase is its own graph, so tools/exp_branch_host.py reads the step's device timeline phase by phase.
-        branch_graphs = bool(branch_graphs)
-        self.branch = bool(branch_graphs) and (not self.split) and (not _dist_on())
-        if self.branch:
-            self.one_graph = True           # (no separate update graph: the tail is the last of the branch graphs)
-            self._capture_branches(trainer, st)
-        elif not self.split and self.capture_comm:
+        self.capture_fallback = None        # why the captured-collectives form was given up (None: it was not, or was never asked for)
+        if not self.split and self.capture_comm:
+            e = None
             try:
                 self._capture_one(trainer, st, mode)
-            except Exception as e:      # (the backend refused the capture: fall back to eager collectives between four graphs)
+            except Exception as e_:      # (the backend refused the capture: fall back to eager collectives between four graphs)
+                e = e_
+            # The fallback is a COLLECTIVE decision: a rank that kept its captured graph while another replays eager collectives would pair
+            # them wrongly and hang.  Every rank reports, the minimum decides (one eager all-reduce, outside any capture).
+            ok_here = e is None
+            if dist.is_available() and dist.is_initialized() and not torch.cuda.is_current_stream_capturing():
+                flag = torch.tensor([1.0 if ok_here else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok_all = bool(flag.item() >= 1.0)
+            else:
+                ok_all = ok_here
+            if not ok_all:
                 import warnings
-                warnings.warn(f"GraphedTrainStep: capturing the collectives into the step's graph failed ({type(e).__name__}: {e}); "
-                              "using the four-graph form with eager collectives")
+                why = f"{type(e).__name__}: {e}" if e is not None else "another rank could not capture the collectives"
+                self.capture_fallback = why
+                warnings.warn(f"GraphedTrainStep: capturing the collectives into the step's graph failed ({why}); "
+                              "every rank uses the four-graph form with eager collectives")
                 trainer.capture_comm = False
                 self.capture_comm = False
                 trainer._metrics_cb = None
+                self._macc = None
                 trainer.student._pending_lower, trainer.student._pending_wg = [], []
+                # (whatever the aborted capture left half-done in the gradient exchange: the Work of the suffix's collective, its view,
+                # the bf16 exchange's side stream - the four-graph form starts from a clean GradSync)
+                trainer.sync._work, trainer.sync._upper, trainer.sync._cstream = None, None, None
+                trainer.student._grad_state = None
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("GraphedTrainStep: the failed capture of the collectives left the stream capturing; cannot fall back")
                 torch.cuda.synchronize()
                 self.g_fb = torch.cuda.CUDAGraph()
                 self.split = True
                 self.one_graph = False
-        if self.branch or (not self.split and self.capture_comm):
+        if not self.split and self.capture_comm:
             pass
         elif not self.split:
             if self.one_graph and self.metrics:
@@ -827,146 +782,29 @@ class GraphedTrainStep:
                 m.packs_refreshed(hd, bwd)
         torch.cuda.synchronize()
 
-    def _capture_branches(self, trainer, st):
-        """One linear graph per branch and phase; every graph has its private memory pool (the graphs of one phase replay concurrently),
-        and every tensor that crosses a graph boundary is kept referenced in self._keep (its address is what the consumers captured)."""
-        t = trainer
-        student, teacher = t.student, t.teacher
-        dev = st["x_s"].device
-        picked, self.streams_concurrent = pick_concurrent_streams(dev, 3)
-        S = self._bs = dict(zip(("main", "tea", "stu"), picked))
-        G = self._bg = {}
-        keep = self._keep = []
-        ev = self._bev = {k: torch.cuda.Event() for k in ("head", "tea", "tgt", "src", "met", "loss", "bwd_tgt")}
-
-        def cap(name, stream):
-            g = G[name] = torch.cuda.CUDAGraph()
-            return torch.cuda.graph(g, stream=stream, capture_error_mode="global")
-
-        student.train()
-        teacher.train()
-        occl = t._occl if t.occlude_rate > -1 else None
-        with cap("head", S["main"]):
-            self._thetas()
-            t.stu_optimizer.zero_grad()
-            student.prepare(st["x_s_in"])
-            with torch.no_grad():
-                teacher.prepare(st["x_t_tea_in"])
-        with cap("tea", S["tea"]):
-            with torch.no_grad():
-                y_t_tea = teacher(st["x_t_tea_in"])
-                recon = warp.warp_chain(y_t_tea, st["theta_tea"])
-                y_t_tea_recon = warp.mean_views([recon])
-        keep += [y_t_tea, recon, y_t_tea_recon]
-        with cap("src", S["main"]):
-            out_s, act_s, hd_s, ws_s = student._run_forward(st["x_s_in"], save=True)
-        keep += [out_s, act_s, ws_s]
-        with cap("tgt", S["stu"]):
-            x_t_stu = st["x_t_stu"]
-            if occl is not None:
-                with torch.no_grad():
-                    x_t_stu, t.occluded = warp.occlude_keypoints_device(x_t_stu, y_t_tea_recon, st["theta_stu"], occl[1], occl[2], t.ratio, t.image_px,
-                                                                        t.occlude_rate, t.occlude_thresh, t.occlude_size)
-            out_t, act_t, hd_t, ws_t = student._run_forward(x_t_stu, save=True, defer_bn=True)
-        keep += [x_t_stu, out_t, act_t, ws_t]
-        if self.metrics:
-            with cap("met", S["tea"]):
-                acc, avg_cnt, _ = kd.accuracy_device(out_s, st["label_s"])
-            keep += [acc, avg_cnt]
-        with cap("loss", S["main"]):
-            student.apply_deferred_bn()         # (x_s first, then x_t_stu: the reference's call order, train_human.py:414-417)
-            with torch.no_grad():
-                activates, y_t_tea_rect = mt.activations_and_rectify(y_t_tea_recon, t.sigma)
-            # autograd is cut at the student's outputs: the loss section's own backward ends in dL/dy_s and dL/dy_t_stu, and the two
-            # gradient chains are enqueued from those (PoseResNet._run_backward: what _PoseNetFn.backward does)
-            y_s = out_s.detach().requires_grad_(True)
-            y_t = out_t.detach().requires_grad_(True)
-            y_t_stu_recon = warp.warp_chain(y_t, st["theta_stu"])
-            loss_s = t.criterion(y_s, st["label_s"], st["weight_s"])
-            t._check_scaler()
-            with torch.no_grad():
-                tea_mask, _, _ = mt.confidence_mask(y_t_tea_recon, t.mask_ratio, None, None, activates)
-            loss_c = t.con_criterion(y_t_stu_recon, y_t_tea_rect, tea_mask=tea_mask)
-            loss_all = loss_s + t.lambda_c * loss_c
-            t.stu_optimizer.scale_loss(loss_all).backward()
-            dy_s, dy_t = y_s.grad, y_t.grad
-        keep += [activates, y_s, y_t, y_t_stu_recon, loss_s, loss_c, loss_all, tea_mask, y_t_tea_rect, dy_s, dy_t]
-        student.split_backward, student.merge_wgrad = False, True
-        with cap("bwd_src", S["main"]):
-            student._run_backward(dy_s, act_s, hd_s, ws_s)
-        with cap("bwd_tgt", S["stu"]):
-            student._run_backward(dy_t, act_t, hd_t, ws_t)
-        student.merge_wgrad = False
-        self.out = {"loss_all": loss_all.detach(), "loss_s": loss_s.detach(), "loss_c": loss_c.detach(), "y_s": out_s, "tea_mask": tea_mask}
-        with cap("tail", S["main"]):
-            student.finish_wgrad(getattr(t, "_wg_stream", None))
-            student.finish_grads(defer=t._tail_sums_grads())
-            t._update()
-            if self.metrics:
-                parts = [self.out["loss_all"].reshape(1), self.out["loss_s"].reshape(1), self.out["loss_c"].reshape(1), avg_cnt.reshape(2), acc.reshape(-1)]
-                self._mk = int(acc.numel())
-                self._mvec = torch.cat([p_.float() for p_ in parts])
-                self.out["acc_s"], self.out["acc_avg_cnt"] = acc, avg_cnt
-        self._occl_branch = occl is not None
-
-    def _replay_branches(self):
-        S, G, ev = self._bs, self._bg, self._bev
-        cur = torch.cuda.current_stream()
-        main, tea, stu = S["main"], S["tea"], S["stu"]
-        main.wait_stream(cur)
-        with torch.cuda.stream(main):
-            G["head"].replay()
-            ev["head"].record(main)
-        tea.wait_event(ev["head"])
-        with torch.cuda.stream(tea):
-            G["tea"].replay()
-            ev["tea"].record(tea)
-        stu.wait_event(ev["head"])
-        if self._occl_branch:
-            stu.wait_event(ev["tea"])               # the occlusion reads the teacher's re-warped heat-maps
-        with torch.cuda.stream(stu):
-            G["tgt"].replay()
-            ev["tgt"].record(stu)
-        with torch.cuda.stream(main):
-            G["src"].replay()
-            ev["src"].record(main)
-        if "met" in G:
-            tea.wait_event(ev["src"])
-            with torch.cuda.stream(tea):
-                G["met"].replay()
-                ev["met"].record(tea)
-        main.wait_event(ev["tea"])
-        main.wait_event(ev["tgt"])
-        with torch.cuda.stream(main):
-            G["loss"].replay()
-            ev["loss"].record(main)
-        stu.wait_event(ev["loss"])
-        with torch.cuda.stream(stu):
-            G["bwd_tgt"].replay()
-            ev["bwd_tgt"].record(stu)
-        with torch.cuda.stream(main):
-            G["bwd_src"].replay()
-        main.wait_event(ev["bwd_tgt"])
-        if "met" in G:
-            main.wait_event(ev["met"])
-        with torch.cuda.stream(main):
-            G["tail"].replay()
-        cur.wait_stream(main)
-
     def release(self):
         """Destroy the captured graphs.  With capture_comm the graphs hold RCCL launches, and RCCL's communicator teardown waits for every
         such graph to be gone: call this (or drop every reference to the object) BEFORE torch.distributed.destroy_process_group(), which
         otherwise never returns (measured on RCCL 2.26 / ROCm 7.0)."""
         self.g_fb = self.g_lb = self.g_lb2 = self.g_up = None
         self.g_style = {}
-        self._bg = {}
         import gc
         gc.collect()
         torch.cuda.synchronize()
 
+    def __del__(self):
+        # (graphs that captured RCCL launches must be gone before destroy_process_group(): dropping the last reference does what release() does)
+        try:
+            if getattr(self, "capture_comm", False):
+                self.g_fb = self.g_lb = self.g_lb2 = self.g_up = None
+        except Exception:
+            pass
+
     def _capture_one(self, trainer, st, mode):
         """The whole data-parallel step - forwards, all-gather, losses, backward part 1, the suffix's all-reduce under backward part 2, the
         prefix's all-reduce, Adam + EMA + packs - captured into self.g_fb."""
+        if os.environ.get("UDAPOSE_TEST_FAIL_CAPTURE", "0") == "1":       # test hook (tests/test_gpu_hotpath.py): exercises the collective fallback
+            raise RuntimeError("injected capture failure (UDAPOSE_TEST_FAIL_CAPTURE=1)")
         if self.one_graph and self.metrics:
             trainer._metrics_cb = self._metrics_side
         try:
@@ -1216,10 +1054,7 @@ class GraphedTrainStep:
         seg("start")
         if self.one_graph:
             self.t.stu_optimizer.sync_hyper()    # lr scheduler / loss scale -> device state read by the captured sweep
-        if self.branch:
-            self._replay_branches()
-        else:
-            self.g_fb.replay()
+        self.g_fb.replay()
         seg("forwards")
         if self.split:
             g = gather_activates(self.fwd_state["activates"])

@@ -86,8 +86,6 @@ class _NetHandle:
         self.wpack_version = None
         # (the backward can be cut at layer3's first block, and its weight gradients are grouped launches)
         self.grouped = int((policy or {}).get("wgrad_group", 1)) != 0
-        # staged weight gradients (udapose_policy.wgrad_overlap): stage by stage on a side stream under the gradient chain
-        self.staged = self.grouped and int((policy or {}).get("wgrad_overlap", 0)) > 0 and precision in ('bf16', 'fp16')
         self.can_split = L.udapose_net_grad_split_param(h) >= 0 and self.grouped
         self.act_nograd = None
         self._fin = weakref.finalize(self, L.udapose_net_destroy, h)
@@ -117,7 +115,6 @@ class PoseResNet(nn.Module):
     """Simple Baseline for key-point detection (pose_resnet.py:59-91) on the MI355X executor."""
     default_precision = 'auto'      # what a new module's `precision` starts as (see __init__)
     _warned_bf16_fallback = False
-    wgrad_classes_concurrent = False    # finish_wgrad: the pair launch's two tile classes on two streams (measured neutral, r5_ab_runs.txt 11)
     fwd_only_plans = True           # no-grad forwards (teacher, validate()) run forward-only plans: y / z in six rotating scratch buffers
 
     def __init__(self, backbone, upsampling, feature_dim, num_keypoints, finetune=False):
@@ -171,13 +168,6 @@ class PoseResNet(nn.Module):
         # 94 % of it) are final - and finish_backward() runs part 2; the caller all-reduces the suffix in between, under part 2.
         self.split_backward = False
         self._pending_lower = []
-        # split_backward = "side" (one device, set by the engine when wgrad_side_stream): backward() runs the gradient chain of
-        # part 1 only; finish_backward() then starts part 1's weight gradients (layer3 ... head: most of the backward's MFMA work,
-        # two long launches) on a side stream and runs part 2 under them.  OFF: measured slower on configs[1] (17.06 vs 16.63 ms per
-        # step, three interleaved A/B runs on one box, profiles/r2_ab_runs.txt) - with three passes already in flight the extra
-        # concurrency costs the memory-bound lower chains more than it hides.
-        self.wgrad_side_stream = False
-        self._wg_side = {}
         # merge_wgrad (set by the engine around a step's backward): backward() runs the gradient chain only and finish_wgrad() then
         # launches the grouped weight gradients - of BOTH passes in one grid when two passes of the same plan are pending
         # (udapose_net_wgrad_pair): the passes end together and their weight-gradient launches are exposed at the step's end
@@ -437,28 +427,11 @@ class PoseResNet(nn.Module):
         on the stream its part 1 ran on."""
         pending, self._pending_lower = self._pending_lower, []
         pa, ba, params = self._pointers()
-        joins = []
-        for hd, act, ws, gptrs, beta, stream, side in pending:
-            args = (pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta)
-            if side:
-                # one device: the weight gradients of part 1 (layer3 ... head: two long MFMA-bound launches) on a side stream,
-                # under the gradient chain of part 2 (layer2, layer1, stem: short memory-bound launches)
-                sd = self._side_stream_for(stream, act.device)
-                sd.wait_stream(stream)
-                check(hd.L.udapose_net_backward_phase(hd.h, sd.cuda_stream, None, *args, 1, 2), "net_backward part 1 weight gradients")
-                act.record_stream(sd)
-                ws.record_stream(sd)
-                joins.append((stream, sd))
+        for hd, act, ws, gptrs, beta, stream in pending:
             with torch.cuda.stream(stream):
-                check(hd.L.udapose_net_backward_part(hd.h, stream.cuda_stream, None, *args, 2), "net_backward part 2")
+                check(hd.L.udapose_net_backward_part(hd.h, stream.cuda_stream, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 2), "net_backward part 2")
                 act.record_stream(stream)
                 ws.record_stream(stream)
-        # The side streams join the CALLER's stream, not the stream they forked from: inside a stream capture on this ROCm a
-        # stream that waits back on its own fork (a -> b -> a) brings hipStreamEndCapture down (tools/capture_fork_patterns.py patterns Q1 / Q5),
-        # while joining the fork into the capture's origin stream is fine (Q2 / Q6).  The caller sums the gradients on this stream.
-        here = torch.cuda.current_stream()
-        for stream, sd in joins:
-            here.wait_stream(sd)
 
     def _run_backward(self, dout, act, hd, ws):
         pa, ba, params = self._pointers()
@@ -502,23 +475,13 @@ class PoseResNet(nn.Module):
             check(hd.L.udapose_net_bind_grads(hd.h, gptrs), "net_bind_grads")
             hd.bound_grads.add(gkey)
         dout = dout.contiguous().float()
-        if self.split_backward and (self.split_backward != "side" or hd.can_split):
-            # "side": the gradient chain of part 1 only - finish_backward() starts its weight gradients on a side stream
-            side = self.split_backward == "side"
-            check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 1, int(side)),
-                  "net_backward part 1")
-            self._pending_lower.append((hd, act, ws, gptrs, beta, cur, side))       # (keeps the arenas alive until part 2 has run)
+        if self.split_backward:
+            check(hd.L.udapose_net_backward_part(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 1), "net_backward part 1")
+            self._pending_lower.append((hd, act, ws, gptrs, beta, cur))       # (keeps the arenas alive until part 2 has run)
         elif self.merge_wgrad and hd.grouped:
-            if hd.staged and len(self._pending_wg) < 2:
-                # the chain records the plan's stage events of this pass's slot; finish_wgrad() launches every stage behind its event
-                slot = len(self._pending_wg)
-                check(hd.L.udapose_net_backward_staged(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, slot),
-                      "net_backward gradient chain (staged)")
-                self._pending_wg.append((hd, act, ws, gptrs, beta, cur, slot))
-            else:
-                check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 1),
-                      "net_backward gradient chain")
-                self._pending_wg.append((hd, act, ws, gptrs, beta, cur, -1))      # (keeps the arenas alive until the weight gradients have run)
+            check(hd.L.udapose_net_backward_phase(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 1),
+                  "net_backward gradient chain")
+            self._pending_wg.append((hd, act, ws, gptrs, beta, cur))      # (keeps the arenas alive until the weight gradients have run)
         else:
             check(hd.L.udapose_net_backward(hd.h, _hip.stream(), ptr(dout), pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta), "net_backward")
         # backbone.fc is not part of forward (resnet.py:21-40): like autograd in the reference, it gets NO gradient (None, not
@@ -528,95 +491,24 @@ class PoseResNet(nn.Module):
             if p.requires_grad and id(p) not in nograd:
                 p.grad = v
 
-    def can_phase_wgrad(self):
-        """True when the pending weight gradients are two unstaged passes of one plan: finish_wgrad(phase=1) / (phase=2) then issue the pair
-        launch in two phases (udapose_net_wgrad_pair_phase) with room for the early part of the optimizer sweep between them."""
-        pend = self._pending_wg
-        return len(pend) == 2 and pend[0][0] is pend[1][0] and pend[0][6] < 0 and pend[1][6] < 0
-
-    def finish_wgrad(self, wg_stream=None, phase=0):
+    def finish_wgrad(self):
         """Launch the grouped weight gradients of the backward passes that ran with merge_wgrad, on the current stream (the caller
-        has made it wait for the streams those passes ran on): two pending passes of one plan go out as ONE launch per tile class.
-        Staged plans (policy wgrad_overlap): every stage goes to `wg_stream` behind the event its gradient chain recorded, as a
-        residency-capped persistent grid that runs UNDER the rest of the chain; the current stream then waits for `wg_stream`.
-        phase 1 / 2 (only when can_phase_wgrad()): the pair launch's two phases, see udapose_net_wgrad_pair_phase."""
-        if phase:
-            if not self.can_phase_wgrad():
-                raise RuntimeError("finish_wgrad(phase=...): needs two pending unstaged passes of one plan (can_phase_wgrad())")
-            (hd, actA, wsA, gA, bA, _, _), (_, actB, wsB, gB, bB, _, _) = self._pending_wg
-            check(hd.L.udapose_net_wgrad_pair_phase(hd.h, _hip.stream(), ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0, int(phase)),
-                  "net_wgrad_pair_phase")
-            if phase == 2:
-                cur = torch.cuda.current_stream()
-                for q in self._pending_wg:
-                    q[1].record_stream(cur)
-                    q[2].record_stream(cur)
-                self._pending_wg = []
-            return
+        has made it wait for the streams those passes ran on): two pending passes of one plan go out as ONE launch per tile class."""
         pend, self._pending_wg = self._pending_wg, []
         if not pend:
             return
         s = _hip.stream()
         cur = torch.cuda.current_stream()
         pa, ba, params = self._pointers()
-        staged = all(q[6] >= 0 for q in pend) and all(q[0] is pend[0][0] for q in pend) and len(pend) <= 2
-        if staged:
-            if wg_stream is None:
-                raise RuntimeError("finish_wgrad: a staged plan (policy wgrad_overlap) needs the weight-gradient side stream")
-            hd, actA, wsA, gA, bA, _, slA = pend[0]
-            streams = list(wg_stream) if isinstance(wg_stream, (list, tuple)) else [wg_stream]
-            sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
-            if len(pend) == 2:
-                _, actB, wsB, gB, bB, _, slB = pend[1]
-                check(hd.L.udapose_net_wgrad_staged(hd.h, sarr, len(streams), ptr(actA), ptr(wsA), gA, bA, slA, ptr(actB), ptr(wsB), gB, bB, slB),
-                      "net_wgrad_staged")
-            else:
-                check(hd.L.udapose_net_wgrad_staged(hd.h, sarr, len(streams), ptr(actA), ptr(wsA), gA, bA, slA, None, None, None, 0.0, 0),
-                      "net_wgrad_staged")
-            for st in streams[:hd.L.udapose_net_num_stages(hd.h)]:
-                for q in pend:
-                    q[1].record_stream(st)
-                    q[2].record_stream(st)
-                cur.wait_stream(st)
-        elif len(pend) == 2 and pend[0][0] is pend[1][0] and pend[0][6] < 0 and pend[1][6] < 0:
-            (hd, actA, wsA, gA, bA, _, _), (_, actB, wsB, gB, bB, _, _) = pend
-            if self.wgrad_classes_concurrent and wg_stream is not None:
-                # the two tile classes' grids side by side (the second on `wg_stream` behind the clears): the tail of one launch is filled
-                # by the other's work-groups.  Measured (round 5): see profiles/r5_ab_runs.txt 11; off by default
-                sd = wg_stream[0] if isinstance(wg_stream, (list, tuple)) else wg_stream
-                pair = lambda st_, ph: check(hd.L.udapose_net_wgrad_pair_phase(hd.h, st_, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0, ph),
-                                             "net_wgrad_pair_phase")
-                pair(s, 3)
-                sd.wait_stream(cur)
-                pair(sd.cuda_stream, 2)
-                pair(s, 4)
-                cur.wait_stream(sd)
-                for q in pend:
-                    q[1].record_stream(sd)
-                    q[2].record_stream(sd)
-            else:
-                check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0), "net_wgrad_pair")
+        if len(pend) == 2 and pend[0][0] is pend[1][0]:
+            (hd, actA, wsA, gA, bA, _), (_, actB, wsB, gB, bB, _) = pend
+            check(hd.L.udapose_net_wgrad_pair(hd.h, s, ptr(actA), ptr(wsA), gA, bA, ptr(actB), ptr(wsB), gB, bB, 0), "net_wgrad_pair")
         else:
-            for hd, act, ws, gptrs, beta, _, _ in pend:
+            for hd, act, ws, gptrs, beta, _ in pend:
                 check(hd.L.udapose_net_backward_phase(hd.h, s, None, pa, ptr(hd.wpack), ptr(act), ptr(ws), gptrs, beta, 0, 2), "net_backward weight gradients")
         for q in pend:
             q[1].record_stream(cur)
             q[2].record_stream(cur)
-
-    def _side_stream_for(self, cur, device):
-        """The side stream paired with `cur` (one per stream a backward runs on).  Streams are only CREATED outside a capture
-        (a spare is kept for the capture stream a later GraphedTrainStep will run the backward on)."""
-        key = (cur.cuda_stream, device.index)
-        side = self._wg_side.get(key)
-        if side is None:
-            spare = self._wg_side.setdefault(("spare", device.index), [])
-            if not torch.cuda.is_current_stream_capturing():
-                while len(spare) < 4:
-                    spare.append(torch.cuda.Stream(device=device))
-            if not spare:
-                return None
-            side = self._wg_side[key] = spare.pop()
-        return side
 
     def _no_grad_ids(self):
         fc = getattr(self.backbone, "fc", None)

@@ -204,24 +204,11 @@ class FusedAdam(_FusedBase):
 
 
     # ------------------------------------------------------------------ fused tail: Adam + EMA + weight packs in one sweep
-    def fused_tail_step(self, student, teacher, ema, part=0):
+    def fused_tail_step(self, student, teacher, ema):
         """One launch for torch.optim.Adam.step on the student, OldWeightEMA.step into the teacher and the weight packs of the
         two executor plans their last forwards used (udapose_net_fused_update).  Returns False - nothing done - when the
-        layout is not the one the kernel serves (then step() and ema.step() apply).
-        part 1 / part 2 (round 5): the same sweep in two launches - part 1 = the convolution weights whose gradients the first phase of
-        PoseResNet.finish_wgrad completed (issued on a side stream beside the second phase), part 2 = the rest; a step calls both or
-        neither (part 2 after a refused part 1 runs the whole sweep).  Not with dynamic loss scaling: its found-inf check needs every
-        gradient before the first parameter moves."""
+        layout is not the one the kernel serves (then step() and ema.step() apply)."""
         import ctypes as C
-        if part == 2 and getattr(self, "_tail_part1", None) is None:
-            part = 0
-        if part == 2:
-            hd_s, hd_t, ps, tps, args, t_split, ent = self._tail_part1
-            self._tail_part1 = None
-            check(hd_s.L.udapose_net_fused_update_part(*(args[:2] + (_hip.stream(),) + args[3:]), 2), "net_fused_update part 2")
-            return self._tail_finish(student, teacher, hd_s, hd_t, ps, tps, t_split, ent)
-        if part == 1 and self._scaler is not None:
-            return False
         if len(self.param_groups) != 1:
             return False
         group = self.param_groups[0]
@@ -284,11 +271,6 @@ class FusedAdam(_FusedBase):
         args = (hd_s.h, hd_t.h, None, pa_s, ga, ma, pa_t, ptr(hd_s.wpack), ptr(hd_t.wpack), float(group["lr"]),
                 float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(group["step"]),
                 float(group.get("grad_scale", 1.0)), ptr(ent[0]), float(ema.alpha), float(1.0 - ema.alpha), 1, int(delta))
-        if part == 1:
-            # (the stream argument of part 2 is filled in when it is issued: it runs on the caller's stream of that moment)
-            check(hd_s.L.udapose_net_fused_update_part(*(args[:2] + (_hip.stream(),) + args[3:]), 1), "net_fused_update part 1")
-            self._tail_part1 = (hd_s, hd_t, ps, tps, args, t_split, ent)
-            return True
         check(hd_s.L.udapose_net_fused_update(*(args[:2] + (_hip.stream(),) + args[3:])), "net_fused_update")
         return self._tail_finish(student, teacher, hd_s, hd_t, ps, tps, t_split, ent)
 

@@ -1,5 +1,6 @@
 """Synthetic batches with the shapes and statistics of the reference's data contract: used by
-bench.py, smoke() and the tests because no dataset is available offline.  Host-side numpy only.
+bench.py, smoke() and the tests because no dataset is available offline.  Host-side numpy only, except
+`trained_like_state_dict`, which trains on the device.
 
 Label heat-maps follow lib/datasets/util.py:12-70 (`generate_target`): centre int(kp/stride + 0.5), un-normalised
 (6*sigma+1)^2 Gaussian clipped at the borders, weight 0 when the centre falls outside.
@@ -111,3 +112,51 @@ def keypoint_batch(n, num_keypoints=16, image_size=256, heatmap_size=64, sigma=2
     lab = [gaussian_labels(kp[i], vis, (heatmap_size, heatmap_size), sigma, (image_size, image_size)) for i in range(n)]
     return (keypoint_images(kp, image_size, seed), torch.from_numpy(np.stack([l[0] for l in lab])),
             torch.from_numpy(np.stack([l[1] for l in lab])))
+
+
+def keypoint_mean_teacher_batch(n, num_keypoints=16, image_size=256, sigma=2, seed=0):
+    """A mean-teacher batch (the fields of train_human.py:329-340) whose images carry key points a network trained on `keypoint_batch`
+    recognises: source images + labels, two further image sets as the student's and the teacher's target views, random
+    inverse-augmentation tuples."""
+    K, S = num_keypoints, image_size
+    x_s, lab, wt = keypoint_batch(n, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=seed)
+    x_t_stu = keypoint_batch(n, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=seed + 1)[0]
+    x_t_tea = keypoint_batch(n, num_keypoints=K, image_size=S, heatmap_size=S // 4, sigma=sigma, seed=seed + 2)[0]
+    rs = np.random.RandomState(seed + 3)
+    return {"x_s": x_s, "label_s": lab, "weight_s": wt, "x_t_stu": x_t_stu, "x_t_tea": x_t_tea,
+            "aug_param_stu": aug_params(n, rs), "aug_param_tea": aug_params(n, rs)}
+
+
+def trained_like_state_dict(num_keypoints=16, steps=400, seed=0, lr=2e-4, arch="pose_resnet101"):
+    """A TRAINED-LIKE pose network: the reference initialisation trained ON THE DEVICE (fp16 student precision under the device-side
+    GradScaler, Adam, `steps` steps of 8 fresh images each from keypoint_batch), so that whole-network parity is not measured on the
+    worst case for 16-bit storage only (a randomly initialised train-mode-BatchNorm ResNet amplifies any rounding ~1.25x per bottleneck;
+    no pretrained weights are available offline).  Returns (state_dict on the CPU, loss history, held-out eval-mode PCK@0.05).  With
+    the deterministic weight-gradient accumulation (round 6) every run of this function yields the SAME network, bit for bit."""
+    from . import optim as fused_optim
+    from .lib import keypoint_detection as kd
+    from .lib import models
+    from .lib.models.loss import JointsMSELoss
+    torch.manual_seed(seed)
+    net = models.__dict__[arch](num_keypoints=num_keypoints, pretrained_backbone=False).cuda().train()
+    net.precision = "fp16"
+    opt = fused_optim.FusedAdam(net.parameters(), lr=lr, dynamic_loss_scale=True, init_scale=1024.0)
+    crit = JointsMSELoss()
+    hist = []
+    for it in range(steps):
+        x, lab, wt = (t.cuda() for t in keypoint_batch(8, num_keypoints=num_keypoints, seed=1000 + it))
+        opt.zero_grad()
+        loss = crit(net(x), lab, wt)
+        opt.scale_loss(loss).backward()
+        opt.step()
+        if it % 80 == 0 or it == steps - 1:
+            hist.append(float(loss.detach()))
+    x, lab, wt = (t.cuda() for t in keypoint_batch(8, num_keypoints=num_keypoints, seed=5))
+    net.eval()
+    with torch.no_grad():
+        pck = float(kd.accuracy(net(x), lab)[1])
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    del net, opt
+    torch.cuda.empty_cache()
+    return sd, hist, pck
