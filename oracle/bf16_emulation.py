@@ -46,3 +46,43 @@ def forward_bf16_emulated(m, x):
         for i in (0, 3, 6):
             z = _bn_train(F.conv_transpose2d(z, q(up[i].weight), stride=2, padding=1), up[i + 1])
         return F.conv2d(z, q(m.head.weight), m.head.bias)
+
+
+# ---- generalisation (round 6): any 16-bit storage type, rounding switched per (stage, tensor kind) - tools/attribute_16bit_error.py
+STAGES = ("stem", "layer1", "layer2", "layer3", "layer4", "up0", "up1", "up2", "head")
+
+
+def forward_emulated(m, x, dtype, sel):
+    """m: PoseResNetRef in train mode; `dtype` torch.float16 / torch.bfloat16; sel(stage, kind) -> bool says whether the tensors of that kind
+    are stored in `dtype` in that stage: kind "x" (the input image, stage "stem"), "w" (weight packs), "y" (pre-BatchNorm convolution outputs),
+    "z" (post-BatchNorm / ReLU outputs).  sel = always True reproduces forward_bf16_emulated's storage points (BatchNorm statistics from the
+    un-rounded convolution result, as the executor's fused epilogue computes them)."""
+    def r(t, st, kind):
+        return t.to(dtype).float() if sel(st, kind) else t
+
+    def bn(y32, b, st, res=None, relu=True):
+        mean = y32.mean((0, 2, 3))
+        var = y32.var((0, 2, 3), unbiased=False)
+        scale = b.weight / torch.sqrt(var + b.eps)
+        shift = b.bias - mean * scale
+        z = r(y32, st, "y") * scale[None, :, None, None] + shift[None, :, None, None]
+        if res is not None:
+            z = z + res
+        return r(F.relu(z) if relu else z, st, "z")
+
+    b = m.backbone
+    z = bn(F.conv2d(r(x, "stem", "x"), r(b.conv1.weight, "stem", "w"), stride=2, padding=3), b.bn1, "stem")
+    z = F.max_pool2d(z, 3, 2, 1)
+    for li, layer in enumerate((b.layer1, b.layer2, b.layer3, b.layer4)):
+        st = f"layer{li + 1}"
+        for blk in layer:
+            idt = z
+            z1 = bn(F.conv2d(z, r(blk.conv1.weight, st, "w")), blk.bn1, st)
+            z2 = bn(F.conv2d(z1, r(blk.conv2.weight, st, "w"), stride=blk.conv2.stride, padding=1), blk.bn2, st)
+            if blk.downsample is not None:
+                idt = bn(F.conv2d(z, r(blk.downsample[0].weight, st, "w"), stride=blk.downsample[0].stride), blk.downsample[1], st, relu=False)
+            z = bn(F.conv2d(z2, r(blk.conv3.weight, st, "w")), blk.bn3, st, res=idt)
+    up = m.upsampling
+    for k, i in enumerate((0, 3, 6)):
+        z = bn(F.conv_transpose2d(z, r(up[i].weight, f"up{k}", "w"), stride=2, padding=1), up[i + 1], f"up{k}")
+    return F.conv2d(z, r(m.head.weight, "head", "w"), m.head.bias)

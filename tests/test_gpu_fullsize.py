@@ -331,9 +331,9 @@ def test_config2_full_size_step_vs_oracle(config2):
 @pytest.fixture(scope="module")
 def trained_k18():
     from conftest import train_keypoint_net
-    sd, hist, pck = train_keypoint_net(18, steps=300, seed=1)
+    sd, hist, pck = train_keypoint_net(18, steps=400, seed=1)
     print("trained-like PoseResNet-101 (K=18): JointsMSE " + " ".join(f"{h:.3e}" for h in hist) + f"; held-out PCK@0.05 {pck:.3f}")
-    assert hist[-1] < 0.5 * hist[0]
+    assert hist[-1] < 0.7 * hist[0] and pck > 0.3, (hist, pck)
     return sd
 
 
@@ -357,3 +357,35 @@ def test_config4_full_size_captured_step_vs_oracle(trained_k18):
     _compare_with_oracle("configs[4] N=8 384x384 captured reference mix", out, ref, b["label_s"], stu, tea, sd, 1e-3, 5e-3, 5e-3, 2e-2, True)
     _ema_bit_exact(tea, sd, stu)
     gs.release()
+
+
+def test_two_independently_built_captured_steps_agree_to_the_bit_over_50_steps(trained_r101_k16):
+    """Run-to-run bit reproducibility (tools/soak_twin.py promoted): two trainers built independently from the same weights - their own
+    networks, optimizers, plans, workspaces, captured graphs, streams - run 50 captured steps of configs[1] at N = 32 on the same batches: every
+    parameter of both students and both teachers, the Adam moments and the losses agree TO THE BIT (rounds 1-5: weight gradients of the split
+    layers, the stem and the re-warp's backward accumulated with fp32 atomics in arrival order - twins agreed to rounding only)."""
+    from uda_poseestimation_amd.engine import GraphedTrainStep, MeanTeacherTrainer
+    sd = trained_r101_k16[0]
+    batches = [_to_dev(keypoint_mean_teacher_batch(32, seed=90 + 4 * i)) for i in range(3)]
+    twins = []
+    for _ in range(2):
+        stu, tea = _device_pair(sd, 16)
+        tr = MeanTeacherTrainer(stu, tea, lr=1e-4, precision="bf16")
+        gs = GraphedTrainStep(tr, *_args(batches[0]), warmup=1)
+        twins.append((stu, tea, tr, gs))
+    losses = [[], []]
+    for it in range(50):
+        for k, (_, _, _, gs) in enumerate(twins):
+            losses[k].append(gs.step(*_args(batches[it % 3]))["loss_all"].clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(*losses)), "the twins' losses differ"
+    (s0, t0, tr0, _), (s1, t1, tr1, _) = twins
+    for a, b in zip(list(s0.parameters()) + list(t0.parameters()) + list(s0.buffers()), list(s1.parameters()) + list(t1.parameters()) + list(s1.buffers())):
+        assert torch.equal(a.detach(), b.detach())
+    for pa, pb in zip(s0.parameters(), s1.parameters()):
+        sa, sb = tr0.stu_optimizer.state.get(pa), tr1.stu_optimizer.state.get(pb)
+        if sa:
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    print(f"50 captured steps, two independent builds: identical to the bit (loss {float(losses[0][0]):.6e} -> {float(losses[0][-1]):.6e})")
+    for _, _, _, gs in twins:
+        gs.release()

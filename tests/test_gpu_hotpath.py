@@ -965,10 +965,6 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)
 
 
-def b_plain(res):
-    return res["plain"]["loss"]
-
-
 def test_one_rank_rccl_step():
     """The data-parallel code path on the REAL RCCL backend with a one-rank process group (bench.py's UDAPOSE_FORCE_DIST hook:
     the test box has one GPU, and RCCL refuses two ranks on one device): backend "nccl" initialised with a device id, the
@@ -1007,8 +1003,9 @@ def test_one_rank_rccl_step():
     ff = res["rccl_fail"]["dp_form"]
     assert ff["collectives_captured"] is False and ff["capture_fallback"] and all("injected" in v for v in ff["capture_fallback"].values())
     assert "hipGraphs" in res["rccl_fail"]["launch"] and "captured" not in res["rccl_fail"]["launch"]
-    f_ = res["rccl_fail"]["loss"]
-    assert f_ == f_ and abs(f_ - b_plain(res)) <= 2e-2 * abs(b_plain(res)) + 1e-9
+    # (same number of steps as the run whose forms were captured - the selection runs 4 x 7 steps before the timed region -, eager collectives instead)
+    f_, a_ = res["rccl_fail"]["loss"], res["rccl_auto"]["loss"]
+    assert f_ == f_ and abs(f_ - a_) <= 2e-2 * abs(a_) + 1e-9, (f_, a_)
     assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
     assert res["rccl"]["rccl_ranks"] == 1 and res["plain"]["rccl_ranks"] == 0
     a, b = res["rccl"]["loss"], res["plain"]["loss"]

@@ -1,0 +1,352 @@
+// Dev probe (round 6): the PERSISTENT m-tile loop for the lean 1x1 implicit GEMM.
+//
+// y[M][Co] = x[M][K] * w[Co][K]^T (bf16, fp32 accumulate) + per-m-tile BatchNorm partial statistics, 64x64 tiles, four waves (2 x 2), the
+// product kernel's LDS-DMA ring, swizzle and MFMA fragment layout.  What is new: a work-group walks SEVERAL tiles, and the stage stream of its
+// ring runs on across tile boundaries - the loads of tile i+1's first NS-1 stages are in flight while tile i's accumulators go through the
+// epilogue (which has its own staging region: nothing drains) - and the grid is `slots` work-groups (1-3 per CU) instead of one per tile.
+// Grid = number of tiles gives the one-tile-per-work-group form back (the baseline inside this probe, same code).
+// Schedule: XCD x (block b & 7) owns the x-th eighth of the m-tiles; its work-groups take tiles local, local + Wx, ... of that range's
+// (m-tile, n-tile) list, n-tile fastest - with Wx a multiple of n_tiles a work-group keeps its n-tile (its weight rows stay in the L2).
+//   build: hipcc --offload-arch=gfx950 -O3 -o tools/probe/p1x1 tools/probe/p1x1.hip        run: tools/probe/p1x1
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+typedef __bf16 elem_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 elem8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    else static_assert(N < 0, "add the literal");
+}
+
+constexpr int STAGE1 = (64 + 64) * 128;         // one K stage: 64 A rows + 64 B rows of 128 bytes
+constexpr int ELD = 36, EST_BYTES = 4 * 32 * ELD * 4, XCH_BYTES = 2 * 2 * 64 * 4;
+constexpr int lds_bytes(int ns, bool alias = false) { return alias ? (ns * STAGE1 > EST_BYTES + XCH_BYTES ? ns * STAGE1 : EST_BYTES + XCH_BYTES) : ns * STAGE1 + EST_BYTES + XCH_BYTES; }
+
+// ALIAS: the epilogue's staging regions lie ON the ring (the product kernel's layout: 33 KB at NS = 2, four work-groups per CU): the ring is drained
+// before every epilogue, so a persistent work-group gains nothing from it - this is the one-tile-per-work-group baseline at the product's residency.
+// NS = 1 (with ALIAS): a single stage buffer, two barriers per stage, 19.5 KB: up to eight work-groups per CU - overlap comes from residency alone.
+template <int NS, bool ALIAS = false>
+__global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, const elem_t* __restrict__ w, elem_t* __restrict__ y, float* __restrict__ stats,
+                                              int M, int K, int Co, int m_tiles, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem;
+    float* const est_all = (float*)(smem + (ALIAS ? 0 : NS * STAGE1));
+    float* const xch = (float*)(smem + (ALIAS ? 0 : NS * STAGE1) + EST_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    // ---- schedule
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, Wx = gridDim.x >> 3;
+    const int mtx = m_tiles >> 3, Tx = mtx * n_tiles;
+    const int ntile_wg = local < Tx ? (Tx - local + Wx - 1) / Wx : 0;
+    const int nsteps = K >> 6;
+    const int S = ntile_wg * nsteps;
+    // ---- loader state (lean form: per-lane 32-bit offsets relative to the tile's first row, advanced by the scalar unit)
+    const int lrow = lane >> 3, pchunk = lane & 7;
+    unsigned a_lane[2], b_lane[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * 4 + wid) * 8 + lrow;
+        a_lane[i] = ((unsigned)r * (unsigned)K + (unsigned)((pchunk ^ swz(r)) * 8)) * 2u;
+        b_lane[i] = a_lane[i];
+    }
+    int it = 0, ist = 0, iss = 0;
+    const char* a_tile = nullptr;
+    const char* b_tile = nullptr;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (ist == 0) {
+            const int q = local + it * Wx;
+            const int nt = q % n_tiles, mt = xcd * mtx + q / n_tiles;
+            a_tile = (const char*)x + (size_t)mt * 64 * K * 2;
+            b_tile = (const char*)w + (size_t)nt * 64 * K * 2;
+        }
+        char* A = ring + (iss % NS) * STAGE1;
+        char* B = A + 64 * 128;
+        const char* as = a_tile + ist * 128;
+        const char* bs = b_tile + ist * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(as + a_lane[i]),
+                                             (__attribute__((address_space(3))) void*)(A + (i * 4 + wid) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bs + b_lane[i]),
+                                             (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
+        if (++ist == nsteps) { ist = 0; ++it; }
+        ++iss;
+    };
+    // ---- fragment offsets inside a stage
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int a_fo[2][2], b_fo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 32 + i * 16 + frow, rb = wn * 32 + i * 16 + frow;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            a_fo[i][k] = ra * 128 + (((fchunk + 4 * k) ^ swz(ra)) << 4);
+            b_fo[i][k] = 64 * 128 + rb * 128 + (((fchunk + 4 * k) ^ swz(rb)) << 4);
+        }
+    }
+    // prologue: NS-1 stages in flight (NS = 1: the stage is issued inside the loop)
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (iss < S && !(ALIAS && iss >= nsteps)) issue_next();
+
+    float* const est = est_all + wid * 32 * ELD;
+    const int cg = lane & 3, rsub = lane >> 2;       // epilogue: 4 lanes per 32-channel row, 16 rows per pass
+    int g = 0;
+    for (int ct = 0; ct < ntile_wg; ++ct) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < nsteps; ++st, ++g) {
+            if constexpr (NS == 1) {
+                __builtin_amdgcn_s_barrier();          // every wave has read the previous stage
+                issue_next();
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            } else {
+            if (iss - g - 1 >= NS - 2) wait_vmcnt<4 * (NS > 1 ? NS - 2 : 0)>();      // (younger stores of the previous epilogue only make this wait longer)
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            // (ALIAS: the ring must be empty at the tile's end - no stage of the next tile is issued before this tile's epilogue)
+            if (iss < S && !(ALIAS && iss >= (ct + 1) * nsteps)) issue_next();
+            }
+            const char* Sg = ring + (g % NS) * STAGE1;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                elem8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *(const elem8*)(Sg + a_fo[i][kk]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *(const elem8*)(Sg + b_fo[j][kk]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue of tile ct (the ring keeps filling: its own LDS regions, raw barriers, no vmcnt(0))
+        if constexpr (ALIAS) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // all fragment reads of the ring are done before it becomes the staging region
+        }
+        const int q = local + ct * Wx;
+        const int n_tile = q % n_tiles, m_tile = xcd * mtx + q / n_tiles;
+        const int m0 = m_tile * 64, n0 = n_tile * 64;
+        if (stats) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; a += v; b += v * v; }
+                a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+                a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+                const int cl = wn * 32 + j * 16 + lane;
+                if (lane < 16) { xch[(wm * 2 + 0) * 64 + cl] = a; xch[(wm * 2 + 1) * 64 + cl] = b; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 128) {
+                const int st = tid >> 6, cl = tid & 63;
+                const float t = xch[(0 * 2 + st) * 64 + cl] + xch[(1 * 2 + st) * 64 + cl];
+                stats[((size_t)m_tile * 2 + st) * Co + n0 + cl] = t;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) est[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[i][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int row = ps * 16 + rsub;
+            const f32x4 v0 = *(const f32x4*)(est + row * ELD + cg * 8), v1 = *(const f32x4*)(est + row * ELD + cg * 8 + 4);
+            elem8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (elem_t)v0[e]; o[4 + e] = (elem_t)v1[e]; }
+            *(elem8*)(y + (size_t)(m0 + wm * 32 + row) * Co + n0 + wn * 32 + cg * 8) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (ALIAS) {
+            __builtin_amdgcn_s_barrier();       // the staging regions are free again before the next tile's stages land on them
+            if (NS > 1 && iss < S) issue_next();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ void ref_k(const elem_t* x, const elem_t* w, float* yr, int M, int K, int Co) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * Co) return;
+    const int m = (int)(i / Co), c = (int)(i % Co);
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += (float)x[(size_t)m * K + k] * (float)w[(size_t)c * K + k];
+    yr[i] = a;
+}
+__global__ void fill_k(elem_t* p, size_t n, unsigned seed, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (elem_t)(((float)(h & 0xffff) / 32768.f - 1.f) * scale);
+}
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
+
+struct Prob { const elem_t* x; const elem_t* w; elem_t* y; float* stats; int M, K, Co; };
+template <int NS, bool ALIAS>
+void launch_cfg(const Prob& p, int grid, hipStream_t st) {
+    const int tiles = (p.M / 64) * (p.Co / 64);
+    hipLaunchKernelGGL((p1x1_k<NS, ALIAS>), dim3(grid > 0 ? grid : tiles), dim3(256), lds_bytes(NS, ALIAS), st, p.x, p.w, p.y, p.stats, p.M, p.K, p.Co, p.M / 64, p.Co / 64);
+}
+// `reps` launches of every problem, problem k on stream k (concurrent chains, as the step's three branches run), captured once into a graph per
+// stream so that the host's launch rate is out of the picture; returns us per round (one launch of every problem)
+template <int NS, bool ALIAS>
+float time_concurrent(const std::vector<Prob>& ps, int grid, int reps, hipStream_t* streams) {
+    std::vector<hipGraphExec_t> ex(ps.size());
+    for (size_t k = 0; k < ps.size(); ++k) {
+        hipGraph_t g;
+        CK(hipStreamBeginCapture(streams[k], hipStreamCaptureModeGlobal));
+        for (int i = 0; i < reps; ++i) launch_cfg<NS, ALIAS>(ps[k], grid, streams[k]);
+        CK(hipStreamEndCapture(streams[k], &g));
+        CK(hipGraphInstantiate(&ex[k], g, nullptr, nullptr, 0));
+        CK(hipGraphDestroy(g));
+    }
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, streams[0]));
+        for (size_t k = 1; k < ps.size(); ++k) CK(hipStreamWaitEvent(streams[k], a, 0));
+        for (size_t k = 0; k < ps.size(); ++k) CK(hipGraphLaunch(ex[k], streams[k]));
+        for (size_t k = 1; k < ps.size(); ++k) { hipEvent_t e; CK(hipEventCreate(&e)); CK(hipEventRecord(e, streams[k])); CK(hipStreamWaitEvent(streams[0], e, 0)); }
+        CK(hipEventRecord(b, streams[0]));
+        CK(hipEventSynchronize(b));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (rep) best = fminf(best, ms * 1e3f / reps);
+    }
+    for (auto& e : ex) CK(hipGraphExecDestroy(e));
+    return best;
+}
+
+int main() {
+    struct Shape { const char* name; int M, K, Co; };
+    const Shape shapes[] = {{"l3 c3 256->1024 (16x16)", 8192, 256, 1024}, {"l3 c1 1024->256", 8192, 1024, 256}, {"l4 c3 512->2048 (8x8)", 2048, 512, 2048},
+                            {"l4 c1 2048->512", 2048, 2048, 512}, {"l2 c3 128->512 (32x32)", 32768, 128, 512}, {"l2 c1 512->128", 32768, 512, 128},
+                            {"l1 c1 256->64 (64x64)", 131072, 256, 64}};
+    for (const Shape& sh : shapes) {
+        const int M = sh.M, K = sh.K, Co = sh.Co;
+        elem_t *x, *w, *y, *y2;
+        float *stats, *stats2, *yr;
+        CK(hipMalloc(&x, (size_t)M * K * 2)); CK(hipMalloc(&w, (size_t)Co * K * 2)); CK(hipMalloc(&y, (size_t)M * Co * 2)); CK(hipMalloc(&y2, (size_t)M * Co * 2));
+        CK(hipMalloc(&stats, (size_t)(M / 64) * 2 * Co * 4)); CK(hipMalloc(&stats2, (size_t)(M / 64) * 2 * Co * 4)); CK(hipMalloc(&yr, (size_t)M * Co * 4));
+        hipLaunchKernelGGL(fill_k, dim3(((size_t)M * K + 255) / 256), dim3(256), 0, 0, x, (size_t)M * K, 1u, 1.0f);
+        hipLaunchKernelGGL(fill_k, dim3(((size_t)Co * K + 255) / 256), dim3(256), 0, 0, w, (size_t)Co * K, 7u, 0.06f);
+        const int tiles = (M / 64) * (Co / 64);
+        // correctness: one tile per work-group (NS = 2) against the naive kernel; persistent grids against it, bit for bit
+        CK(hipFuncSetAttribute((const void*)p1x1_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2)));
+        CK(hipFuncSetAttribute((const void*)p1x1_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(6)));
+        CK(hipFuncSetAttribute((const void*)(p1x1_k<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1, true)));
+        CK(hipFuncSetAttribute((const void*)(p1x1_k<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, true)));
+        // (the aliased forms against the reference form, bit for bit)
+        for (int v = 0; v < 3; ++v) {
+            CK(hipMemset(y2, 0xff, (size_t)M * Co * 2)); CK(hipMemset(stats2, 0xff, (size_t)(M / 64) * 2 * Co * 4));
+            hipLaunchKernelGGL(p1x1_k<2>, dim3(tiles), dim3(256), lds_bytes(2), 0, x, w, y, stats, M, K, Co, M / 64, Co / 64);
+            if (v == 0) hipLaunchKernelGGL((p1x1_k<1, true>), dim3(tiles), dim3(256), lds_bytes(1, true), 0, x, w, y2, stats2, M, K, Co, M / 64, Co / 64);
+            if (v == 1) hipLaunchKernelGGL((p1x1_k<2, true>), dim3(tiles), dim3(256), lds_bytes(2, true), 0, x, w, y2, stats2, M, K, Co, M / 64, Co / 64);
+            if (v == 2) hipLaunchKernelGGL((p1x1_k<2, true>), dim3(512), dim3(256), lds_bytes(2, true), 0, x, w, y2, stats2, M, K, Co, M / 64, Co / 64);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned short> ha((size_t)M * Co), hb((size_t)M * Co);
+            CK(hipMemcpy(ha.data(), y, ha.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), y2, ha.size() * 2, hipMemcpyDeviceToHost));
+            size_t d = 0;
+            for (size_t i = 0; i < ha.size(); ++i) d += ha[i] != hb[i];
+            if (d) printf("  ALIAS variant %d: %zu y entries differ from the reference form!\n", v, d);
+        }
+        hipLaunchKernelGGL(p1x1_k<2>, dim3(tiles), dim3(256), lds_bytes(2), 0, x, w, y, stats, M, K, Co, M / 64, Co / 64);
+        hipLaunchKernelGGL(ref_k, dim3(((size_t)M * Co + 255) / 256), dim3(256), 0, 0, x, w, yr, M, K, Co);
+        CK(hipMemset(y2, 0xff, (size_t)M * Co * 2)); CK(hipMemset(stats2, 0xff, (size_t)(M / 64) * 2 * Co * 4));
+        hipLaunchKernelGGL(p1x1_k<6>, dim3(256), dim3(256), lds_bytes(6), 0, x, w, y2, stats2, M, K, Co, M / 64, Co / 64);
+        CK(hipDeviceSynchronize());
+        {
+            std::vector<unsigned short> hy((size_t)M * Co), hy2((size_t)M * Co);
+            std::vector<float> hr((size_t)M * Co), hs((size_t)(M / 64) * 2 * Co), hs2(hs.size());
+            CK(hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hy2.data(), y2, hy.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hr.data(), yr, hr.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hs.data(), stats, hs.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs2.data(), stats2, hs.size() * 4, hipMemcpyDeviceToHost));
+            double maxe = 0, maxr = 0;
+            size_t diff = 0, sdiff = 0;
+            for (size_t i = 0; i < hy.size(); ++i) {
+                unsigned u = (unsigned)hy[i] << 16; float f; memcpy(&f, &u, 4);
+                maxe = fmax(maxe, fabs((double)f - hr[i])); maxr = fmax(maxr, fabs((double)hr[i]));
+                diff += hy[i] != hy2[i];
+            }
+            for (size_t i = 0; i < hs.size(); ++i) sdiff += memcmp(&hs[i], &hs2[i], 4) != 0;
+            printf("%-26s M=%d K=%d Co=%d tiles=%d: max|y - naive| %.3e (max|y| %.2f); persistent(256 WGs, NS=6) vs one-tile-per-WG: %zu y / %zu stats entries differ\n",
+                   sh.name, M, K, Co, tiles, maxe, maxr, diff, sdiff);
+        }
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(y2)); CK(hipFree(stats)); CK(hipFree(stats2)); CK(hipFree(yr));
+    }
+    // ---- three concurrent chains (the step's three branches): which form does the most work per unit of chip time?
+    struct Mix { const char* name; Shape s[3]; };
+    const Mix mixes[] = {{"3 x l3 c3 (K=256, Co=1024)", {shapes[0], shapes[0], shapes[0]}}, {"l3 c3 | l3 c1 | l3 c3", {shapes[0], shapes[1], shapes[0]}},
+                         {"l4 c3 | l4 c1 | l2 c3", {shapes[2], shapes[3], shapes[4]}}, {"l2 c1 | l1 c1 | l3 c1", {shapes[5], shapes[6], shapes[1]}}};
+    CK(hipFuncSetAttribute((const void*)(p1x1_k<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2)));
+    CK(hipFuncSetAttribute((const void*)(p1x1_k<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(3)));
+    CK(hipFuncSetAttribute((const void*)(p1x1_k<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, true)));
+    CK(hipFuncSetAttribute((const void*)(p1x1_k<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1, true)));
+    hipStream_t streams[3];
+    for (auto& st : streams) CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (const Mix& mx : mixes) {
+        std::vector<Prob> ps;
+        for (const Shape& sh : mx.s) {
+            Prob p{};
+            elem_t *x, *w, *y; float* st;
+            CK(hipMalloc(&x, (size_t)sh.M * sh.K * 2)); CK(hipMalloc(&w, (size_t)sh.Co * sh.K * 2)); CK(hipMalloc(&y, (size_t)sh.M * sh.Co * 2));
+            CK(hipMalloc(&st, (size_t)(sh.M / 64) * 2 * sh.Co * 4));
+            hipLaunchKernelGGL(fill_k, dim3(((size_t)sh.M * sh.K + 255) / 256), dim3(256), 0, 0, x, (size_t)sh.M * sh.K, 1u, 1.0f);
+            hipLaunchKernelGGL(fill_k, dim3(((size_t)sh.Co * sh.K + 255) / 256), dim3(256), 0, 0, w, (size_t)sh.Co * sh.K, 7u, 0.06f);
+            p.x = x; p.w = w; p.y = y; p.stats = st; p.M = sh.M; p.K = sh.K; p.Co = sh.Co;
+            ps.push_back(p);
+        }
+        CK(hipDeviceSynchronize());
+        const int R = 40;
+        printf("%-28s us per round of the three launches | ", mx.name);
+        for (int single = 1; single >= 0; --single) {
+            std::vector<Prob> q = single ? std::vector<Prob>{ps[0]} : ps;
+            printf("%s: tile/WG NS2 %.1f, NS3 %.1f, NS2 alias(33KB) %.1f, NS1 alias(19KB) %.1f; persistent 512: NS2 %.1f; 768: NS2 %.1f; 1024: NS2 %.1f, NS2 alias %.1f; 1536: NS1 alias %.1f | ",
+                   single ? "first problem ALONE" : "three CONCURRENT",
+                   time_concurrent<2, false>(q, 0, R, streams), time_concurrent<3, false>(q, 0, R, streams), time_concurrent<2, true>(q, 0, R, streams),
+                   time_concurrent<1, true>(q, 0, R, streams), time_concurrent<2, false>(q, 512, R, streams), time_concurrent<2, false>(q, 768, R, streams),
+                   time_concurrent<2, false>(q, 1024, R, streams), time_concurrent<2, true>(q, 1024, R, streams), time_concurrent<1, true>(q, 1536, R, streams));
+        }
+        printf("\n");
+        fflush(stdout);
+        for (auto& p : ps) { CK(hipFree((void*)p.x)); CK(hipFree((void*)p.w)); CK(hipFree(p.y)); CK(hipFree(p.stats)); }
+    }
+    return 0;
+}

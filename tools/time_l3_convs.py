@@ -17,7 +17,7 @@ for name, H, Ci, Co, K, p in SHAPES:
     x = torch.randn(N, H, H, Ci, device='cuda').bfloat16()
     w = (torch.randn(Co, K * K, Ci, device='cuda') * 0.05).bfloat16()
     row = []
-    for t in (-1, 4, 1, 6, 2, 9, 5, 10, 11, 12, 13, 14):
+    for t in (-1, 4, 6, 9, 5, 10, 11):
         d = ops.conv_desc(N, H, H, Ci, Co, K, 1, p)
         if t >= 0:
             d = ops.with_policy(d, _hip.policy(igemm_tile=t))

@@ -128,7 +128,7 @@ struct ZeroJob { long long off; long long n16; };
 // one layer of the split-sum launch (pw_split_sum): `ks` partial tiles of `n` floats, `stride` floats apart, at byte offset part_off of the pass's
 // workspace, are added in split order into the tensor at byte offset dst_off of the gradient base (dst_ws: of the workspace); beta 1 accumulates
 struct SumJob { long long part_off; long long dst_off; unsigned n; unsigned stride; int ks; int dst_ws; float beta; int pad; };
-int pw_split_sum(hipStream_t s, const SumJob* d_jobs, const int* d_blk, int nblk, void* ws, void* grad_base);
+int pw_split_sum(hipStream_t s, const SumJob* d_jobs, const int* d_blk, int nblk, void* ws, void* grad_base, void* ws2 = nullptr, void* grad_base2 = nullptr);
 
 // XCD-aware work-group remap (MI355X: 8 XCDs, each with a private 4 MiB L2; work-groups are dealt round-robin, so b and
 // b+8 share an L2).  Returns a bijective permutation of the linear block id that gives every XCD one CONTIGUOUS range of

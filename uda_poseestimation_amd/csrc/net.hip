@@ -716,6 +716,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
     // (dst = beta * dst + sum) - or, for the stem's row-tap form, into its padded scratch, from which the unpack launch goes on.
     std::vector<SumJob> sums;
     size_t part_cur = 0;
+    const bool det = n.policy.wgrad_det && n.policy.wgrad_group;      // (the same condition sizes the workspace: net_ws_bytes)
     auto make_partial = [&](WgParams& p, long long dst_off, int dst_ws, int Cdim) -> int {
         const int ms_total = (p.M + 63) / 64, per = (ms_total + p.ksplit - 1) / p.ksplit;
         const int ks_eff = (ms_total + per - 1) / per;                      // splits that own at least one stage (the others have no unit)
@@ -740,7 +741,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         if (t < 0) return UDAPOSE_ERR_UNSUPPORTED;
         if (p.ksplit > 1) {
             const bool swap = (p.flags & WG_FLAG_SWAP) != 0;
-            if (n.policy.wgrad_det) CK(make_partial(p, (long long)drel, 0, swap ? p.Co : p.Ci));
+            if (det) CK(make_partial(p, (long long)drel, 0, swap ? p.Co : p.Ci));
             else if (beta == 0.f) G.zero.push_back({drel, (size_t)p.rows_valid * p.wtaps * (swap ? p.Co : p.Ci) * sizeof(float)});
         }
         const int prob = (int)tab[t].size();
@@ -771,7 +772,7 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         p.flags |= WG_FLAG_DW_WS;
         const int t = wgrad_group_plan(p, 1, n.policy.wgrad_stages, n.policy);      // (accumulate = 1: atomics into the zeroed scratch)
         if (t != 1) return UDAPOSE_ERR_UNSUPPORTED;
-        if (n.policy.wgrad_det) CK(make_partial(p, (long long)n.ws_dwtmp, 1, 64));     // ... or partial tiles, summed into the scratch
+        if (det) CK(make_partial(p, (long long)n.ws_dwtmp, 1, 64));     // ... or partial tiles, summed into the scratch
         const int prob = (int)tab[t].size();
         tab[t].push_back(p);
         G.flops[t] += fl;
@@ -892,11 +893,11 @@ int wg_before(hipStream_t s, Net& n, Net::WgGroup* G, char* ws, void* const* gra
             if (pw_zero(s, (char*)grads[0] + z.first, z.second) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     }
     const ConvGeom& sg = n.stem.g;
-    if (with_stem && !n.policy.wgrad_det && pw_zero(s, ws + n.ws_dwtmp, (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float)) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
+    if (with_stem && !(n.policy.wgrad_det && n.policy.wgrad_group) && pw_zero(s, ws + n.ws_dwtmp, (size_t)sg.Co * sg.KH * 8 * 8 * sizeof(float)) != UDAPOSE_OK) return UDAPOSE_ERR_LAUNCH;
     return UDAPOSE_OK;
 }
-int wg_after(hipStream_t s, Net& n, Net::WgGroup* G, char* ws, void* const* grads, float beta, bool with_stem) {
-    if (G->n_sum_blk) CK(pw_split_sum(s, G->d_sum, G->d_sum_blk, G->n_sum_blk, ws, (char*)grads[0]));
+int wg_after(hipStream_t s, Net& n, Net::WgGroup* G, char* ws, void* const* grads, float beta, bool with_stem, bool sums_done = false) {
+    if (G->n_sum_blk && !sums_done) CK(pw_split_sum(s, G->d_sum, G->d_sum_blk, G->n_sum_blk, ws, (char*)grads[0]));
     const ConvGeom& sg = n.stem.g;
     if (with_stem)
         CK(pw_unpack_strided(s, (const float*)(ws + n.ws_dwtmp), (float*)grads[n.stem.w_idx], sg.Co, sg.KH, sg.KWp(), sg.KW, 8, 3,
@@ -942,8 +943,11 @@ int run_wg_pair(hipStream_t s, Net& n, const char* actA, char* wsA, void* const*
         conv_prof_after(s, tok);
         CK(rc);
     }
-    CK(wg_after(s, n, GA, wsA, gradsA, betaA, with_stem));
-    return wg_after(s, n, GB, wsB, gradsB, betaB, with_stem);
+    // (equal accumulate modes: the two passes' split sums share their job table - one launch over both workspaces)
+    const bool pair_sum = betaA == betaB && GA->n_sum_blk > 0 && GA->n_sum_blk == GB->n_sum_blk;
+    if (pair_sum) CK(pw_split_sum(s, GA->d_sum, GA->d_sum_blk, GA->n_sum_blk, wsA, (char*)gradsA[0], wsB, (char*)gradsB[0]));
+    CK(wg_after(s, n, GA, wsA, gradsA, betaA, with_stem, pair_sum));
+    return wg_after(s, n, GB, wsB, gradsB, betaB, with_stem, pair_sum);
 }
 }  // namespace
 

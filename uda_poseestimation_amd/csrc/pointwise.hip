@@ -1276,9 +1276,13 @@ int pw_zero(hipStream_t s, void* p, size_t bytes) {
 }
 // Deterministic split reductions of the grouped weight-gradient launches (net.hip build_wg_group): split z of a layer stored its partial tile at
 // part + z * stride; dst = beta * dst + ((p0 + p1) + p2) + ... in split order.  One block per 4096-element chunk of a job (blk: (job, chunk) pairs).
-__global__ __launch_bounds__(TPB) void split_sum_k(const SumJob* __restrict__ jobs, const int* __restrict__ blk, char* __restrict__ ws, char* __restrict__ gbase) {
-    const SumJob j = jobs[blk[2 * blockIdx.x]];
-    const unsigned c0 = (unsigned)blk[2 * blockIdx.x + 1] * 4096u;
+// (pair form: blocks [nblk, 2 nblk) run the same jobs on the second pass's workspace and gradient base - the two passes of one plan in ONE launch)
+__global__ __launch_bounds__(TPB) void split_sum_k(const SumJob* __restrict__ jobs, const int* __restrict__ blk, int nblk, char* __restrict__ ws, char* __restrict__ gbase,
+                                                   char* __restrict__ ws2, char* __restrict__ gbase2) {
+    int bi = blockIdx.x;
+    if (bi >= nblk) { bi -= nblk; ws = ws2; gbase = gbase2; }
+    const SumJob j = jobs[blk[2 * bi]];
+    const unsigned c0 = (unsigned)blk[2 * bi + 1] * 4096u;
     const unsigned c1 = c0 + 4096u < j.n ? c0 + 4096u : j.n;
     const float* part = (const float*)(ws + j.part_off);
     float* dst = (float*)((j.dst_ws ? ws : gbase) + j.dst_off);
@@ -1299,9 +1303,9 @@ __global__ __launch_bounds__(TPB) void split_sum_k(const SumJob* __restrict__ jo
         }
     }
 }
-int pw_split_sum(hipStream_t s, const SumJob* d_jobs, const int* d_blk, int nblk, void* ws, void* grad_base) {
+int pw_split_sum(hipStream_t s, const SumJob* d_jobs, const int* d_blk, int nblk, void* ws, void* grad_base, void* ws2, void* grad_base2) {
     if (nblk <= 0) return UDAPOSE_OK;
-    hipLaunchKernelGGL(split_sum_k, dim3(nblk), dim3(TPB), 0, s, d_jobs, d_blk, (char*)ws, (char*)grad_base);
+    hipLaunchKernelGGL(split_sum_k, dim3(ws2 ? 2 * nblk : nblk), dim3(TPB), 0, s, d_jobs, d_blk, nblk, (char*)ws, (char*)grad_base, (char*)ws2, (char*)grad_base2);
     return udapose_check_launch();
 }
 int pw_axpy(hipStream_t s, float* y, const float* x, size_t n) {
