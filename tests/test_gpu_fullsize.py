@@ -191,8 +191,12 @@ def config1(trained_r101_k16):
     return sd, b, ref
 
 
-# bars: (teacher re-warped maps, student heat-maps, loss_s rel, loss_c rel, mask asserted identical outright)
-BARS = {"bf16": (2e-2, 2e-2, 2e-2, 6e-2, False), "fp16": (3e-3, 3e-3, 3e-3, 1e-2, False), "reference": (1e-3, 3e-3, 3e-3, 1e-2, True)}
+# bars: (teacher re-warped maps, student heat-maps, loss_s rel, loss_c rel, mask asserted identical outright).  The trained network is the same bits in
+# every run (deterministic training, round 6), so these are ~1.5-2x the MEASURED figures (max|y| 1.05): bf16 teacher 1.00e-2, student 1.09e-2, loss_s
+# 1.7e-4, loss_c 1.4e-3; fp16 teacher 1.26e-3, student 1.92e-3, loss_s 1.4e-5, loss_c 5.7e-6; reference mix teacher 9.5e-7, student as fp16.
+# SURVEY.md 8(d)'s gates: heat-maps 1e-3 absolute - met by the fp32-grade teacher only (the 16-bit error is spread evenly over the
+# network's stages, profiles/r6_attr_fp16.txt) -, loss scalars rel 1e-3: met by fp16 and the reference mix on both losses and by bf16 on loss_s.
+BARS = {"bf16": (2e-2, 2e-2, 1e-3, 4e-3, False), "fp16": (2.5e-3, 3e-3, 1e-4, 2e-4, False), "reference": (1e-5, 3e-3, 1e-4, 2e-4, True)}
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16", "reference"])
@@ -324,7 +328,7 @@ def test_config2_full_size_step_vs_oracle(config2):
     assert list(tr.occluded) == list(ref["occluded"]), (tr.occluded, ref["occluded"])
     # (the stylised inputs - a randomly initialised decoder's output - are far from anything the network was trained on: the fp16 student's
     #  heat-map error is that of an out-of-distribution input, measured 1 % of max|y|; the fp32-grade teacher and both losses hold their bars)
-    _compare_with_oracle("configs[2] N=32 eager reference mix", out, ref, b["label_s"], stu, tea, sd, 1e-3, 2e-2, 3e-3, 1e-2, True)
+    _compare_with_oracle("configs[2] N=32 eager reference mix", out, ref, b["label_s"], stu, tea, sd, 2e-4, 2e-2, 2e-4, 3e-4, True)
     _ema_bit_exact(tea, sd, stu)
 
 
@@ -354,7 +358,7 @@ def test_config4_full_size_captured_step_vs_oracle(trained_k18):
     _rewind(tr, stu, tea, sd)
     out = dict(gs.step(*_args(g)))
     torch.cuda.synchronize()
-    _compare_with_oracle("configs[4] N=8 384x384 captured reference mix", out, ref, b["label_s"], stu, tea, sd, 1e-3, 5e-3, 5e-3, 2e-2, True)
+    _compare_with_oracle("configs[4] N=8 384x384 captured reference mix", out, ref, b["label_s"], stu, tea, sd, 1e-5, 3e-3, 1e-4, 1e-4, True)
     _ema_bit_exact(tea, sd, stu)
     gs.release()
 

@@ -41,7 +41,7 @@ constexpr int lds_bytes(int ns, bool alias = false) { return alias ? (ns * STAGE
 // NS = 1 (with ALIAS): a single stage buffer, two barriers per stage, 19.5 KB: up to eight work-groups per CU - overlap comes from residency alone.
 template <int NS, bool ALIAS = false>
 __global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, const elem_t* __restrict__ w, elem_t* __restrict__ y, float* __restrict__ stats,
-                                              int M, int K, int Co, int m_tiles, int n_tiles) {
+                                              int M, int K, int Co, int m_tiles, int n_tiles, int mode = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring = smem;
     float* const est_all = (float*)(smem + (ALIAS ? 0 : NS * STAGE1));
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, cons
         char* B = A + 64 * 128;
         const char* as = a_tile + ist * 128;
         const char* bs = b_tile + ist * 128;
+        if (!((mode & 1) && iss >= NS)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(as + a_lane[i]),
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, cons
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bs + b_lane[i]),
                                              (__attribute__((address_space(3))) void*)(B + (i * 4 + wid) * 1024), 16, 0, 0);
+        }
         if (++ist == nsteps) { ist = 0; ++it; }
         ++iss;
     };
@@ -124,11 +126,12 @@ __global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, cons
             } else {
             if (iss - g - 1 >= NS - 2) wait_vmcnt<4 * (NS > 1 ? NS - 2 : 0)>();      // (younger stores of the previous epilogue only make this wait longer)
             else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
+            if (!(mode & 16)) __builtin_amdgcn_s_barrier();
             // (ALIAS: the ring must be empty at the tile's end - no stage of the next tile is issued before this tile's epilogue)
             if (iss < S && !(ALIAS && iss >= (ct + 1) * nsteps)) issue_next();
             }
             const char* Sg = ring + (g % NS) * STAGE1;
+            if (!(mode & 2))
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 elem8 af[2], bf[2];
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, cons
         const int q = local + ct * Wx;
         const int n_tile = q % n_tiles, m_tile = xcd * mtx + q / n_tiles;
         const int m0 = m_tile * 64, n0 = n_tile * 64;
-        if (stats) {
+        if (mode & 4) continue;
+        if (stats && !(mode & 8)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float a = 0.f, b = 0.f;
@@ -217,10 +221,11 @@ __global__ void fill_k(elem_t* p, size_t n, unsigned seed, float scale) {
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
 
 struct Prob { const elem_t* x; const elem_t* w; elem_t* y; float* stats; int M, K, Co; };
+static int g_mode = 0;
 template <int NS, bool ALIAS>
 void launch_cfg(const Prob& p, int grid, hipStream_t st) {
     const int tiles = (p.M / 64) * (p.Co / 64);
-    hipLaunchKernelGGL((p1x1_k<NS, ALIAS>), dim3(grid > 0 ? grid : tiles), dim3(256), lds_bytes(NS, ALIAS), st, p.x, p.w, p.y, p.stats, p.M, p.K, p.Co, p.M / 64, p.Co / 64);
+    hipLaunchKernelGGL((p1x1_k<NS, ALIAS>), dim3(grid > 0 ? grid : tiles), dim3(256), lds_bytes(NS, ALIAS), st, p.x, p.w, p.y, p.stats, p.M, p.K, p.Co, p.M / 64, p.Co / 64, g_mode);
 }
 // `reps` launches of every problem, problem k on stream k (concurrent chains, as the step's three branches run), captured once into a graph per
 // stream so that the host's launch rate is out of the picture; returns us per round (one launch of every problem)
@@ -312,6 +317,32 @@ int main() {
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(y2)); CK(hipFree(stats)); CK(hipFree(stats2)); CK(hipFree(yr));
     }
     // ---- three concurrent chains (the step's three branches): which form does the most work per unit of chip time?
+    // ---- where does a work-group's time go?  l3 c3 alone, persistent (256 and 768 work-groups, NS = 2) and one tile per work-group, with parts of the
+    // kernel switched off (results are wrong by design): DMA loads (after the first ring fill), fragment reads + MFMA, the whole epilogue, the statistics
+    {
+        const Shape sh = shapes[0];
+        Prob p{};
+        elem_t *x, *w, *y; float* st;
+        CK(hipMalloc(&x, (size_t)sh.M * sh.K * 2)); CK(hipMalloc(&w, (size_t)sh.Co * sh.K * 2)); CK(hipMalloc(&y, (size_t)sh.M * sh.Co * 2));
+        CK(hipMalloc(&st, (size_t)(sh.M / 64) * 2 * sh.Co * 4));
+        hipLaunchKernelGGL(fill_k, dim3(((size_t)sh.M * sh.K + 255) / 256), dim3(256), 0, 0, x, (size_t)sh.M * sh.K, 1u, 1.0f);
+        hipLaunchKernelGGL(fill_k, dim3(((size_t)sh.Co * sh.K + 255) / 256), dim3(256), 0, 0, w, (size_t)sh.Co * sh.K, 7u, 0.06f);
+        p.x = x; p.w = w; p.y = y; p.stats = st; p.M = sh.M; p.K = sh.K; p.Co = sh.Co;
+        hipStream_t s1[1];
+        CK(hipStreamCreateWithFlags(&s1[0], hipStreamNonBlocking));
+        CK(hipFuncSetAttribute((const void*)(p1x1_k<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2)));
+        const struct { const char* name; int mode; } parts[] = {{"everything", 0}, {"no DMA loads", 1}, {"no reads + MFMA", 2}, {"no epilogue", 4}, {"no statistics", 8},
+                                                                  {"no DMA, no epilogue", 5}, {"no MFMA, no epilogue", 6}, {"only barriers + loop (7)", 7}, {"no barriers", 16}, {"nothing but the loop (23)", 23}};
+        printf("l3 c3 alone, us per launch by what is switched off (grid 256 | 768 | one tile per WG):\n");
+        for (const auto& pt : parts) {
+            g_mode = pt.mode;
+            std::vector<Prob> q{p};
+            printf("  %-28s %6.2f | %6.2f | %6.2f\n", pt.name, time_concurrent<2, false>(q, 256, 40, s1), time_concurrent<2, false>(q, 768, 40, s1), time_concurrent<2, false>(q, 0, 40, s1));
+            fflush(stdout);
+        }
+        g_mode = 0;
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(st));
+    }
     struct Mix { const char* name; Shape s[3]; };
     const Mix mixes[] = {{"3 x l3 c3 (K=256, Co=1024)", {shapes[0], shapes[0], shapes[0]}}, {"l3 c3 | l3 c1 | l3 c3", {shapes[0], shapes[1], shapes[0]}},
                          {"l4 c3 | l4 c1 | l2 c3", {shapes[2], shapes[3], shapes[4]}}, {"l2 c1 | l1 c1 | l3 c1", {shapes[5], shapes[6], shapes[1]}}};
