@@ -81,11 +81,6 @@ typedef struct {
     int wgrad_det;        /* 1 (default, round 6): split weight-gradient reductions of the grouped launches store per-split partial tiles into the pass's
                            * workspace and ONE launch adds them in split order (bit-reproducible gradients; the `loss.backward()` of
                            * train_human.py:436 run twice gives the same bits); 0: fp32 atomics into cleared tensors, arrival order */
-    int bn_bwd_fused_min_k;   /* with bn_bwd_fused: bottleneck data gradients whose reduction (output channels x taps) is shorter than this keep the plain
-                           * epilogue and the BatchNorm consuming their output runs its own reduce + apply launches; 0 (default): every edge fused */
-    int igemm_lean_ns1;   /* lean 1x1 launches (stride-1 single-tap convolutions and data gradients with full tiles) on 64x64 tiles with ONE LDS stage buffer
-                           * (20 KB, 54 registers: up to eight resident work-groups per CU).  bit 0: forward / plain launches; bit 1: data gradients with the
-                           * BatchNorm-backward epilogue; bit 2: single-class non-3x3 launches keep 64x64 tiles where 128x64 would be taken */
     int igemm_ns3_k;      /* 64x64 implicit-GEMM tiles take the 3-stage LDS ring from this reduction length on (K = taps x Ci), the 2-stage ring
                            * below it; 0 = the default, 2048 */
     void* timeline;

@@ -514,31 +514,3 @@ def test_weight_gradient_buffer_load_loader_is_bit_identical(case):
                 assert torch.equal(dw, other), (tile, ks)
             else:
                 assert (dw - other).abs().max().item() <= 1e-4 * scale
-
-
-@pytest.mark.parametrize("bits", [1, 3, 7], ids=["fwd", "fwd_bs", "fwd_bs_64tiles"])
-def test_single_stage_lean_1x1_form_is_bit_identical(dev, bits):
-    """Policy igemm_lean_ns1 (round 6): the lean 1x1 launches on 64x64 tiles with ONE LDS stage buffer and a 54-register budget (eight resident
-    work-groups per CU; igemm.hip, NS == 1) - same tiles, same MFMA order, same statistics rows: outputs, BatchNorm partial statistics, data
-    gradients and the dgrad epilogue's masked gradient + sums are bit for bit the 2-stage ring's (forced to the same 64x64 tiles)."""
-    from uda_poseestimation_amd import ops, _hip
-    for (N, H, Ci, Co) in ((4, 16, 256, 512), (2, 32, 512, 128), (8, 8, 1024, 256)):
-        g = torch.Generator().manual_seed(N * H + Ci)
-        x = (torch.randn(N, H, H, Ci, generator=g)).bfloat16().cuda()
-        w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).bfloat16()
-        dy = torch.randn(N, H, H, Co, generator=g).bfloat16().cuda()
-        d = ops.conv_desc(N, H, H, Ci, Co, 1, 1, 0)
-        wf, wb = ops.pack_weight(w.cuda(), d, "fwd"), ops.pack_weight(w.cuda(), d, "bwd")
-        bn_y = (torch.randn(N, H, H, Ci, generator=g) + 0.2).bfloat16().cuda()
-        mean, invstd, gamma, beta = (torch.rand(Ci, generator=g).cuda() + 0.5 for _ in range(4))
-        out = {}
-        for b in (0, bits):
-            dm = ops.with_policy(d, _hip.policy(igemm_tile=5, igemm_lean_ns1=b) if b != 7 else _hip.policy(igemm_lean_ns1=b))
-            if b == 0 and bits == 7:
-                dm = ops.with_policy(d, _hip.policy(igemm_tile=5))
-            y, stats = ops.conv2d_fwd(x, wf, dm, want_stats=True)
-            dx = ops.conv2d_bwd_data(dy, wb, dm)
-            gq, slab = ops.conv2d_bwd_data_bn(dy, wb, dm, bn_y, mean, invstd, bn_gamma=gamma, bn_beta=beta)
-            out[b] = (y, stats, dx, gq, slab)
-        for a, c in zip(out[0], out[bits]):
-            assert a.shape == c.shape and torch.equal(a, c)

@@ -22,7 +22,7 @@ class Policy(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("igemm_tile", "igemm_h3", "igemm_lean", "igemm_short_lds", "igemm_tap0", "wgrad_tile", "wgrad_ksplit",
                                        "wgrad_fastgeo", "wgrad_group", "wgrad_stages", "wgrad_group_stem", "bn_bwd_fused", "bn_fwd_chunked",
                                        "bn_bwd_chunked", "bn_bwd_pre_legacy", "igemm_wg_min", "wgrad_row3", "bn3_mask", "stem_fused", "debug_sync", "igemm_big_min", "patch_conv",
-                                       "eval_fold", "bn_xcd_rows", "wgrad_det", "bn_bwd_fused_min_k", "igemm_lean_ns1", "igemm_ns3_k")] + [("timeline", C.c_void_p)]
+                                       "eval_fold", "bn_xcd_rows", "wgrad_det", "igemm_ns3_k")] + [("timeline", C.c_void_p)]
 
 
 def policy(**overrides):

@@ -97,7 +97,7 @@ static Policy from_c(const udapose_policy& c) {
     p.igemm_tap0 = c.igemm_tap0; p.wgrad_tile = c.wgrad_tile; p.wgrad_ksplit = c.wgrad_ksplit; p.wgrad_fastgeo = c.wgrad_fastgeo;
     p.wgrad_group = c.wgrad_group; p.wgrad_stages = c.wgrad_stages > 0 ? c.wgrad_stages : 128; p.wgrad_group_stem = c.wgrad_group_stem;
     p.bn_bwd_fused = c.bn_bwd_fused; p.bn_fwd_chunked = c.bn_fwd_chunked; p.bn_bwd_chunked = c.bn_bwd_chunked;
-    p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.igemm_wg_min = c.igemm_wg_min; p.wgrad_row3 = c.wgrad_row3; p.bn3_mask = c.bn3_mask; p.stem_fused = c.stem_fused; p.debug_sync = c.debug_sync; p.igemm_big_min = c.igemm_big_min; p.patch_conv = c.patch_conv; p.eval_fold = c.eval_fold; p.bn_xcd_rows = c.bn_xcd_rows; p.igemm_ns3_k = c.igemm_ns3_k; p.igemm_lean_ns1 = c.igemm_lean_ns1; p.bn_bwd_fused_min_k = c.bn_bwd_fused_min_k; p.wgrad_det = c.wgrad_det; p.timeline = (unsigned long long*)c.timeline;
+    p.bn_bwd_pre_legacy = c.bn_bwd_pre_legacy; p.igemm_wg_min = c.igemm_wg_min; p.wgrad_row3 = c.wgrad_row3; p.bn3_mask = c.bn3_mask; p.stem_fused = c.stem_fused; p.debug_sync = c.debug_sync; p.igemm_big_min = c.igemm_big_min; p.patch_conv = c.patch_conv; p.eval_fold = c.eval_fold; p.bn_xcd_rows = c.bn_xcd_rows; p.igemm_ns3_k = c.igemm_ns3_k; p.wgrad_det = c.wgrad_det; p.timeline = (unsigned long long*)c.timeline;
     return p;
 }
 static void to_c(const Policy& p, udapose_policy* c) {
@@ -105,7 +105,7 @@ static void to_c(const Policy& p, udapose_policy* c) {
     c->igemm_tap0 = p.igemm_tap0; c->wgrad_tile = p.wgrad_tile; c->wgrad_ksplit = p.wgrad_ksplit; c->wgrad_fastgeo = p.wgrad_fastgeo;
     c->wgrad_group = p.wgrad_group; c->wgrad_stages = p.wgrad_stages; c->wgrad_group_stem = p.wgrad_group_stem;
     c->bn_bwd_fused = p.bn_bwd_fused; c->bn_fwd_chunked = p.bn_fwd_chunked; c->bn_bwd_chunked = p.bn_bwd_chunked;
-    c->bn_bwd_pre_legacy = p.bn_bwd_pre_legacy; c->igemm_wg_min = p.igemm_wg_min; c->wgrad_row3 = p.wgrad_row3; c->bn3_mask = p.bn3_mask; c->stem_fused = p.stem_fused; c->debug_sync = p.debug_sync; c->igemm_big_min = p.igemm_big_min; c->patch_conv = p.patch_conv; c->eval_fold = p.eval_fold; c->bn_xcd_rows = p.bn_xcd_rows; c->igemm_ns3_k = p.igemm_ns3_k; c->igemm_lean_ns1 = p.igemm_lean_ns1; c->bn_bwd_fused_min_k = p.bn_bwd_fused_min_k; c->wgrad_det = p.wgrad_det; c->timeline = p.timeline;
+    c->bn_bwd_pre_legacy = p.bn_bwd_pre_legacy; c->igemm_wg_min = p.igemm_wg_min; c->wgrad_row3 = p.wgrad_row3; c->bn3_mask = p.bn3_mask; c->stem_fused = p.stem_fused; c->debug_sync = p.debug_sync; c->igemm_big_min = p.igemm_big_min; c->patch_conv = p.patch_conv; c->eval_fold = p.eval_fold; c->bn_xcd_rows = p.bn_xcd_rows; c->igemm_ns3_k = p.igemm_ns3_k; c->wgrad_det = p.wgrad_det; c->timeline = p.timeline;
 }
 // a convolution descriptor and the policy it names, as the host-side geometry (the policy lives as long as this object)
 struct Geom {

@@ -46,11 +46,6 @@ struct Policy {
                                 // (tools/probe/l2_handoff.hip: 17.9 against 6.7 TB/s); bit-identical results, -0.06..-0.15 ms per step (r4_ab_runs.txt)
     int wgrad_det = 1;          // grouped weight gradients: split pixel reductions store per-split partial tiles that ONE launch adds in split order
                                 // (bit-reproducible gradients; 0: fp32 atomics into cleared tensors, arrival order - rounds 1-5)
-    int bn_bwd_fused_min_k = 0; // bottleneck data gradients that reduce over fewer values (output channels x taps) keep the plain epilogue; their consumer BatchNorm
-                                // runs its own reduce + apply (0: every edge of the chain is fused)
-    int igemm_lean_ns1 = 0;     // lean 1x1 launches on 64x64 tiles with ONE stage buffer (20 KB; 54 registers: eight work-groups per CU).  bit 0: forward / plain
-                                // launches, bit 1: data gradients with the BatchNorm-backward epilogue (95 registers: five per CU), bit 2: single-class non-3x3
-                                // launches keep 64x64 tiles where 128x64 would be taken (so that their 1x1 members qualify)
     int igemm_ns3_k = 0;        // 64x64 igemm tiles: 3-stage ring from this K on, 2-stage below (0 = 2048)
     int debug_sync = 0;         // net calls: synchronise after every stage and report the first failing source line
     unsigned long long* timeline = nullptr;   // device buffer for per-work-group timeline stamps (tuning), normally null

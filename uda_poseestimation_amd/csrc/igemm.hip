@@ -47,9 +47,8 @@ struct IgCfg {
     static constexpr int STAGE1 = (BM + BNL) * 128;
     static constexpr int STAGE_BYTES = NS * STAGE1;
     static constexpr int EPI_BYTES = 4 * ER * ELD * 4;
-    static constexpr int EPI_ALL = EPI_BYTES + WM * 2 * BN * 4;       // + the wave-row exchange of the BN statistics behind the epilogue regions
-    static constexpr int LDS_BYTES = TAP_BYTES + (STAGE_BYTES > EPI_ALL ? STAGE_BYTES : EPI_ALL);
-    static_assert(NS == 1 || EPI_ALL <= STAGE_BYTES, "the wave-row exchange of the BN statistics sits behind the epilogue regions");
+    static constexpr int LDS_BYTES = TAP_BYTES + (STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES);
+    static_assert(EPI_BYTES + WM * 2 * BN * 4 <= STAGE_BYTES, "the wave-row exchange of the BN statistics sits behind the epilogue regions");
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -81,12 +80,7 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, bool BS = false, i
 // SP (with T = float as the 4-byte stride type): the operands are f16x2 split tensors (common.h) - the loaders are the fp32 ones
 // byte for byte, the fragments of a 32-channel stage are the row's chunk pairs (2q, 2q+1) = (h, l) of lane group q, and a stage is
 // three fp16 MFMAs per fragment pair into two accumulator sets (h.h | h.l + l.h, the second scaled by 2^-11 at the end).
-// NS == 1 (round 6, lean 1x1 form only): ONE stage buffer, two barriers per stage, 20 KB of LDS and a 64-register budget - up to EIGHT resident
-// work-groups per CU instead of four.  tools/probe/p1x1.hip, three concurrent chains of layer3 / layer4 / layer2 1x1 shapes: 7-11 % less time
-// per round than the 2-stage ring at 33 KB; a ring that keeps filling across a persistent work-group's tiles (52 KB) is SLOWER than either
-// under concurrency, and one work-group per CU runs at the same speed with 1 or 7 stages in flight (profiles/r6_probe_p1x1_*.txt): these
-// launches are bound by resident waves per CU, not by prefetch depth.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 1 ? (BS ? 5 : 8) : (BM * BN >= 128 * 128 ? 2 : ((BS || H3 == 1 || SP) ? 3 : 4))))) void igemm_kernel(const IgParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN >= 128 * 128 ? 2 : ((BS || H3 == 1 || SP) ? 3 : 4)))) void igemm_kernel(const IgParams p) {
     using C = IgCfg<BM, BN, WM, WN, NS>;
     // T = bf16 (MFMA 16x16x32 bf16) or float (exact fp32 MFMA 16x16x4: the reference's own precision for the teacher and
     // validate(); 1/16 of the bf16 rate, used for strict-parity forward passes).  A stage is 128 bytes of K per row either way.
@@ -506,17 +500,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 1 ? (
                 compute3(tc, Acur, Bq + (t % 3) * (BNL * 128));
             });
         }
-    } else if constexpr (NS == 1) {
-        // single stage buffer: overlap comes from the other resident work-groups of the CU
-        if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
-        for (int st = 0; st < nsteps; ++st) {
-            if (st) __builtin_amdgcn_s_barrier();          // every wave has read the previous stage
-            issue_stage(IC<0>{});
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (dbg && tid == 0 && st == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
-            compute(IC<0>{});
-        }
     } else {
     // prologue: NS-1 stages in flight
     if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
@@ -837,7 +820,7 @@ int launch_cfg_t(IgParams& p, hipStream_t stream, const Policy& pol) {
         constexpr int bke = 128 / (int)sizeof(T);
         int nst = 0;
         for (int c = 0; c < p.nclass; ++c) nst = std::max(nst, p.cls[c].ntaps * p.Ci / bke);
-        constexpr int one = C::TAP_BYTES + (C::STAGE1 > C::EPI_ALL ? C::STAGE1 : C::EPI_ALL);
+        constexpr int one = C::TAP_BYTES + (C::STAGE1 > C::EPI_BYTES + WM * 2 * BN * 4 ? C::STAGE1 : C::EPI_BYTES + WM * 2 * BN * 4);
         if (nst <= 1 && one < lds) lds = one;
     }
     if constexpr (H3 == 1) {
@@ -867,21 +850,10 @@ int launch_cfg(IgParams& p, hipStream_t stream, const Policy& pol) {
     if (p.bs_y) {
         // dgrad with the consumer BatchNorm's backward reduction in the epilogue (bf16 operands; bf16 or fp32 output)
         if ((p.flags & (IG_FLAG_F32 | IG_FLAG_SMALLC | IG_FLAG_RELU)) || p.bias || !p.stats || (p.Co % 8)) return UDAPOSE_ERR_ARG;
-        if (lean) {
-            if constexpr (BM == 64 && BN == 64 && NS != 1) {       // (bit 1: the data gradients with the BatchNorm-backward epilogue too; five per CU)
-                if (pol.igemm_lean_ns1 & 2) return launch_cfg_t<elem_t, 64, 64, 2, 2, 1, true, 3>(p, stream, pol);
-            }
-            return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, true, 3>(p, stream, pol);
-        }
+        if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, true, 3>(p, stream, pol);
         return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, true>(p, stream, pol);
     }
-    if (lean) {
-        // igemm_lean_ns1 bit 0: the 64x64 lean launches take the single-stage, eight-per-CU form (same tiles, same statistics rows)
-        if constexpr (BM == 64 && BN == 64 && NS != 1) {
-            if (pol.igemm_lean_ns1 & 1) return launch_cfg_t<elem_t, 64, 64, 2, 2, 1, false, 3>(p, stream, pol);
-        }
-        return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, 3>(p, stream, pol);
-    }
+    if (lean) return launch_cfg_t<elem_t, BM, BN, WM, WN, NS, false, 3>(p, stream, pol);
     return (p.flags & IG_FLAG_F32) ? launch_cfg_t<float, BM, BN, WM, WN, NS>(p, stream, pol) : launch_cfg_t<elem_t, BM, BN, WM, WN, NS>(p, stream, pol);
 }
 
@@ -910,9 +882,7 @@ int igemm_pick_tile(int M, int Co, int nclass, int K, int h3_ok, const Policy& p
     // single-stream launches with many rounds of work-groups (the style network's 32x32 .. 128x128 maps): 128x128 tiles halve the
     // L2 -> LDS bytes per FLOP of the B operand (655-700 against 555-616 TFLOP/s on its 256-channel layers); Co % 128 != 0 would idle half a tile
     if (pol.igemm_big_min > 0 && nclass == 1 && Co % 128 == 0 && b12864 >= pol.igemm_big_min) return 4;
-    // (igemm_lean_ns1 bit 2: single-class launches outside the 3x3 form keep 64x64 tiles where 128x64 would be taken - the 1x1 ones among them then
-    //  qualify for the single-stage form; the tile id decides the statistics rows, so the choice is made HERE, not at launch)
-    if (b12864 >= pol.igemm_wg_min && !((pol.igemm_lean_ns1 & 4) && nclass == 1 && !h3_ok && M % 64 == 0 && Co % 64 == 0)) return 6;
+    if (b12864 >= pol.igemm_wg_min) return 6;
     // (round 4: the 3-stage ring from K = 2048 on, not 1024 - layer3's c1 and the data gradient of its c3, K = 1024, replayed alone from a graph take 8.6 us
     //  with two stages against 9.8 with three, tools/time_l3_convs.py; whole step -0.03 .. -0.14 ms on two boxes, two stages for every K +0.07: r4_ab_runs.txt)
     return K >= (pol.igemm_ns3_k > 0 ? pol.igemm_ns3_k : 2048) ? 9 : 5;

@@ -991,9 +991,6 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
     const int HWo = n.Hout * n.Wout;
     const int split = split_block(n);
     const bool fused = n.policy.bn_bwd_fused != 0;
-    // (bn_bwd_fused_min_k: a bottleneck convolution whose data gradient reduces over fewer than this many values - output channels x taps - keeps the
-    //  PLAIN dgrad epilogue, and the BatchNorm that consumes its output runs its own reduce + apply: per-edge un-fusing of the chain)
-    auto edge = [&](const ConvL& producer) { return fused && producer.g.Co * producer.g.KH * producer.g.KW >= n.policy.bn_bwd_fused_min_k; };
     DgradBnStat cur, nxt;
     bool have = false;
     elem_t* dz = nullptr;
@@ -1043,7 +1040,7 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         if (fused) {
             cur = bn_stat_of(n, n.blocks[split - 1].c3, n.blocks[split - 1].b3, params, act, ws, 1);
             cur.rows = conv_dgrad_stat_rows(n.blocks[split].c1.g);
-            have = edge(n.blocks[split].c1);
+            have = true;
         }
     }
     // bottlenecks, last to first
@@ -1053,17 +1050,13 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
         // bn3 (+ReLU of the block output): g = masked dz feeds the skip branch (written in place unless the producing dgrad
         // already masked it)
         elem_t *dz2 = nullptr, *dz1 = nullptr, *dxd = nullptr, *dxin = nullptr;
-        const bool e3 = edge(b.c3), e2 = edge(b.c2);
-        if (e3) nxt = bn_stat_of(n, b.c2, b.b2, params, act, ws, 2);
+        if (fused) nxt = bn_stat_of(n, b.c2, b.b2, params, act, ws, 2);
         CK(conv_bn_bwd(s, n, b.c3, b.b3, params, wpack, act, ws, grads, beta, pool, dz, 0, dz, 1, nullptr, &dz2, true, 0, grouped, have ? &cur : nullptr,
-                       e3 ? &nxt : nullptr));
-        if (e3) cur = nxt;
-        have = e3;
-        if (e2) nxt = bn_stat_of(n, b.c1, b.b1, params, act, ws, 2);
+                       fused ? &nxt : nullptr));
+        if (fused) { cur = nxt; nxt = bn_stat_of(n, b.c1, b.b1, params, act, ws, 2); }
         CK(conv_bn_bwd(s, n, b.c2, b.b2, params, wpack, act, ws, grads, beta, pool, dz2, 0, nullptr, 2, nullptr, &dz1, true, 0, grouped,
-                       have ? &cur : nullptr, e2 ? &nxt : nullptr));
-        if (e2) cur = nxt;
-        have = e2;
+                       have ? &cur : nullptr, fused ? &nxt : nullptr));
+        if (fused) cur = nxt;
         pool.put(dz2);
         const elem_t* skip = dz;
         if (b.has_ds) {
@@ -1071,12 +1064,11 @@ int net_backward(void* h, hipStream_t s, const float* dout_nchw, const void* con
             CK(conv_bn_bwd(s, n, b.cd, b.bd, params, wpack, act, ws, grads, beta, pool, dz, 0, nullptr, 0, nullptr, &dxd, true, 0, grouped));
             skip = dxd;
         }
-        const bool chain = bi > 0 && edge(b.c1);      // dxin feeds bn3 of the previous block (block 0: the max-pool backward)
+        const bool chain = fused && bi > 0;      // dxin feeds bn3 of the previous block (block 0: the max-pool backward)
         if (chain) nxt = bn_stat_of(n, n.blocks[bi - 1].c3, n.blocks[bi - 1].b3, params, act, ws, 1);
         CK(conv_bn_bwd(s, n, b.c1, b.b1, params, wpack, act, ws, grads, beta, pool, dz1, 0, nullptr, 2, skip, &dxin, true, 0, grouped,
                        have ? &cur : nullptr, chain ? &nxt : nullptr));
         if (chain) cur = nxt;
-        have = chain;
         pool.put(dz1);
         if (dxd) pool.put(dxd);
         pool.put(dz);
