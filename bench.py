@@ -770,7 +770,7 @@ def main():
                                    "achieved": round(fp_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else None}},
         }
         per_step = measured_traffic_per_step()
-        if per_step and (args.arch, S, K, N) == ("pose_resnet101", 256, 16, 32):
+        if per_step and (args.arch, S, K, N, args.dtype, args.precision) == ("pose_resnet101", 256, 16, 32, "bf16", None) and not args.config2:      # (the PMC passes are the headline's)
             tot = sum(per_step.values())
             res["roofline"]["step_hbm"] = {"bytes_per_step": tot, "by_family": per_step, "achieved_TBps": round(tot / (ms * 1e-3) / 1e12, 3),
                                            "peak_TBps": 8.0, "note": "whole-step HBM traffic of the conv / BN / weight-gradient kernels (PMC passes under "

@@ -164,6 +164,15 @@ def test_eval_mode_and_nograd_teacher_forward():
     with torch.no_grad():
         y2 = net(x.cuda())
     assert not y2.requires_grad and not torch.equal(before, net.backbone.bn1.running_mean)
+    # an eval-mode forward WITH grad enabled (a validation loop that forgot no_grad) keeps no backward state and says so at once: one warning, no grad_fn
+    net.eval()
+    from uda_poseestimation_amd.lib.models.pose_resnet import PoseResNet
+    PoseResNet._warned_eval_grad = False
+    with pytest.warns(UserWarning, match="eval-mode forward with grad enabled"):
+        y3 = net(x.cuda())
+    assert y3.grad_fn is None and not y3.requires_grad
+    with pytest.raises(RuntimeError):
+        y3.sum().backward()
 
 
 def test_full_size_bf16_heatmaps_bounded_by_storage_noise_argmax_identical_on_clear_peaks():

@@ -514,9 +514,23 @@ class PoseResNet(nn.Module):
         fc = getattr(self.backbone, "fc", None)
         return {id(p) for p in fc.parameters()} if fc is not None else set()
 
+    _warned_eval_grad = False
+
     def forward(self, x):
         params = list(self.parameters())
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if need_grad and not self.training:
+            # eval-mode BatchNorm is folded into the convolutions' epilogues (policy eval_fold) and this path has no eval-mode BN backward: such a
+            # forward keeps no backward state.  Say so HERE - the output carries no grad_fn, so a later .backward() fails at once with torch's own
+            # "does not require grad" instead of deep inside the executor (the reference's frozen-BN fine-tuning is not on this path)
+            if not PoseResNet._warned_eval_grad:
+                PoseResNet._warned_eval_grad = True
+                import warnings
+                warnings.warn("PoseResNet: an eval-mode forward with grad enabled is not differentiable on this path (eval-mode BatchNorm is folded into "
+                              "the convolutions; there is no eval-mode BatchNorm backward): the output has no grad_fn.  Wrap evaluation in torch.no_grad(), "
+                              "or call .train() for a differentiable forward.", stacklevel=2)
+            with torch.no_grad():
+                return _PoseNetFn.apply(x, self, False, False, *params)
         return _PoseNetFn.apply(x, self, need_grad, False, *params)
 
     def forward_deferred_bn(self, x):
