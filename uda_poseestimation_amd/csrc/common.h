@@ -127,6 +127,7 @@ int pw_zero(hipStream_t s, void* p, size_t bytes);
 struct ZeroJob { long long off; long long n16; };
 // one layer of the split-sum launch (pw_split_sum): `ks` partial tiles of `n` floats, `stride` floats apart, at byte offset part_off of the pass's
 // workspace, are added in split order into the tensor at byte offset dst_off of the gradient base (dst_ws: of the workspace); beta 1 accumulates
+#define UDAPOSE_SPLIT_SUM_CHUNK 1024u      // floats of a job one work-group of pw_split_sum adds (one 16-byte column per thread)
 struct SumJob { long long part_off; long long dst_off; unsigned n; unsigned stride; int ks; int dst_ws; float beta; int pad; };
 int pw_split_sum(hipStream_t s, const SumJob* d_jobs, const int* d_blk, int nblk, void* ws, void* grad_base, void* ws2 = nullptr, void* grad_base2 = nullptr);
 
