@@ -828,14 +828,14 @@ int build_wg_group(Net& n, Net::WgGroup& G, void* const* grads, float beta, int 
         if (hipMemcpy(G.d_zero, zj.data(), zj.size() * sizeof(ZeroJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         G.n_zero = (int)zj.size();
     }
-    // the split-sum launch's tables: jobs, and one block per 4096-element chunk of a job
+    // the split-sum launch's tables: jobs, and one block per UDAPOSE_SPLIT_SUM_CHUNK elements of a job
     if (G.d_sum) { (void)hipFree(G.d_sum); G.d_sum = nullptr; }
     if (G.d_sum_blk) { (void)hipFree(G.d_sum_blk); G.d_sum_blk = nullptr; }
     G.n_sum_blk = 0;
     if (!sums.empty()) {
         std::vector<int> blk;
         for (size_t j = 0; j < sums.size(); ++j)
-            for (unsigned c = 0; c < (sums[j].n + 4095u) / 4096u; ++c) { blk.push_back((int)j); blk.push_back((int)c); }
+            for (unsigned c = 0; c < (sums[j].n + UDAPOSE_SPLIT_SUM_CHUNK - 1u) / UDAPOSE_SPLIT_SUM_CHUNK; ++c) { blk.push_back((int)j); blk.push_back((int)c); }
         if (hipMalloc((void**)&G.d_sum, sums.size() * sizeof(SumJob)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         if (hipMalloc((void**)&G.d_sum_blk, blk.size() * sizeof(int)) != hipSuccess) return UDAPOSE_ERR_LAUNCH;
         if (hipMemcpy(G.d_sum, sums.data(), sums.size() * sizeof(SumJob), hipMemcpyHostToDevice) != hipSuccess) return UDAPOSE_ERR_LAUNCH;

@@ -1275,22 +1275,22 @@ int pw_zero(hipStream_t s, void* p, size_t bytes) {
     return udapose_check_launch();
 }
 // Deterministic split reductions of the grouped weight-gradient launches (net.hip build_wg_group): split z of a layer stored its partial tile at
-// part + z * stride; dst = beta * dst + ((p0 + p1) + p2) + ... in split order.  One block per 4096-element chunk of a job (blk: (job, chunk) pairs).
+// part + z * stride; dst = beta * dst + ((p0 + p1) + p2) + ... in split order.  One block per UDAPOSE_SPLIT_SUM_CHUNK elements of a job (blk: (job, chunk) pairs).
 // (pair form: blocks [nblk, 2 nblk) run the same jobs on the second pass's workspace and gradient base - the two passes of one plan in ONE launch)
 __global__ __launch_bounds__(TPB) void split_sum_k(const SumJob* __restrict__ jobs, const int* __restrict__ blk, int nblk, char* __restrict__ ws, char* __restrict__ gbase,
                                                    char* __restrict__ ws2, char* __restrict__ gbase2) {
     int bi = blockIdx.x;
     if (bi >= nblk) { bi -= nblk; ws = ws2; gbase = gbase2; }
     const SumJob j = jobs[blk[2 * bi]];
-    const unsigned c0 = (unsigned)blk[2 * bi + 1] * 4096u;
-    const unsigned c1 = c0 + 4096u < j.n ? c0 + 4096u : j.n;
+    const unsigned c0 = (unsigned)blk[2 * bi + 1] * UDAPOSE_SPLIT_SUM_CHUNK;
+    const unsigned c1 = c0 + UDAPOSE_SPLIT_SUM_CHUNK < j.n ? c0 + UDAPOSE_SPLIT_SUM_CHUNK : j.n;
     const float* part = (const float*)(ws + j.part_off);
     float* dst = (float*)((j.dst_ws ? ws : gbase) + j.dst_off);
     if (((((uintptr_t)part) | ((uintptr_t)dst)) & 15) == 0 && (j.stride & 3u) == 0 && (j.n & 3u) == 0) {
         for (unsigned e = c0 + threadIdx.x * 4u; e < c1; e += TPB * 4u) {
             f32x4 a = *(const f32x4*)(part + e);
-#pragma unroll 4
-            for (int z = 1; z < j.ks; ++z) a += *(const f32x4*)(part + (size_t)z * j.stride + e);
+#pragma unroll 8
+            for (int z = 1; z < j.ks; ++z) a += *(const f32x4*)(part + (size_t)z * j.stride + e);        // (loads hoisted in groups of eight, adds in split order)
             if (j.beta != 0.f) a = *(const f32x4*)(dst + e) + a;
             *(f32x4*)(dst + e) = a;
         }
