@@ -1000,7 +1000,8 @@ int wgrad_group_launch(hipStream_t stream, int tile, const WgParams* d_tab, cons
     // 32-pixel stages for the 128x128 tile (32 KB of LDS, 128 VGPRs: four resident work-groups per CU instead of two with
     // 64-pixel stages) and a 2-stage ring of 64-pixel stages for the 64x64 tile (35 KB with the filter-row form's reserve: four per
     // CU; round 1 ran three stages = three per CU, with the buffer-load loader two measure -4.5 % alone and -0.05 ms in the step):
-    // occupancy beats prefetch depth here as in the igemm (a 3-stage ring for the 128x128 tile: +40 % alone)
+    // occupancy beats prefetch depth here as in the igemm (a 3-stage ring for the 128x128 tile at three per CU: +40 % alone in round 2; re-measured in
+    // round 6 inside the step: pair launch 3.28 against 2.60 ms, step +0.7 ms - profiles/r6_ab_runs.txt 4)
     if (tile == 0) return launch_wd_group<128, 128, 2, 2, 2, 32>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
     return launch_wd_group<64, 64, 2, 2, 2, 64>(d_tab, d_blk, per_xcd, x_base, dy_base, dw_base, stream, d_tab2, d_blk2, x_base2, dy_base2, dw_base2);
 }
