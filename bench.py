@@ -376,8 +376,9 @@ def main():
                     "rounding per contribution, all-to-all + fp32 accumulation on the shard's owner + all-gather: half the bytes per xGMI link)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trained-parity", action="store_true", help="skip the parity leg on a network trained in this run (~20 s)")
-    ap.add_argument("--no-capture-comm", action="store_true", help="data parallel: keep the collectives eager between four graphs instead of capturing "
-                    "them into the step's one graph (round 5's default with RCCL)")
+    ap.add_argument("--capture-comm", action="store_true", help="data parallel: capture the RCCL collectives INTO the step's one graph (round 5; +0.4 ms instead of +0.8 ms "
+                    "over the plain step at one rank) instead of keeping them eager between four graphs.  Opt-in (round 6, ADVICE r5): the capture rests on a timed "
+                    "wait for RCCL's watchdog and replayed collectives are invisible to torch.distributed's timeout; if it fails on any rank all ranks fall back together")
     ap.add_argument("--one-bucket", action="store_true", help="data parallel: the whole backward with one merged weight-gradient tail, then ONE "
                     "all-reduce of the flat gradient buffer (no overlap with backward part 2)")
     ap.add_argument("--split-graphs", action="store_true", help="cut the step into three graphs around the collectives even on one rank")
@@ -516,7 +517,7 @@ def main():
         def build_graphed():
             return GraphedTrainStep(trainer, g["x_s"], g["label_s"], g["weight_s"], g["x_t_stu"], g["x_t_tea"], g["aug_param_stu"],
                                     g["aug_param_tea"], split=(True if args.split_graphs else None),
-                                    capture_comm=(not args.no_capture_comm and dist.is_initialized() and dist.get_backend() == "nccl" and not args.split_graphs))
+                                    capture_comm=(args.capture_comm and dist.is_initialized() and dist.get_backend() == "nccl" and not args.split_graphs))
 
         guard.arm(420, "capture / selection of the data-parallel form")
         if dp_auto and dist.is_initialized() and (world > 1 or force_dist):

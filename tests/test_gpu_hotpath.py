@@ -977,10 +977,11 @@ def test_one_rank_rccl_step():
               "--no-cpu-baseline"]
     res = {}
     rccl_env = {"UDAPOSE_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
-    for tag, extra, flags in (("rccl", rccl_env, ["--dp-form", "fixed"]), ("plain", {}, []),
-                              ("rccl_bf16", dict(rccl_env, MASTER_PORT=str(_free_port())), ["--grad-comm", "bf16"]),
-                              ("rccl_auto", dict(rccl_env, MASTER_PORT=str(_free_port())), []),
-                              ("rccl_fail", dict(rccl_env, MASTER_PORT=str(_free_port()), UDAPOSE_TEST_FAIL_CAPTURE="1"), [])):
+    for tag, extra, flags in (("rccl", rccl_env, ["--dp-form", "fixed", "--capture-comm"]), ("plain", {}, []),
+                              ("rccl_bf16", dict(rccl_env, MASTER_PORT=str(_free_port())), ["--grad-comm", "bf16", "--capture-comm"]),
+                              ("rccl_auto", dict(rccl_env, MASTER_PORT=str(_free_port())), ["--capture-comm"]),
+                              ("rccl_eager", dict(rccl_env, MASTER_PORT=str(_free_port())), []),
+                              ("rccl_fail", dict(rccl_env, MASTER_PORT=str(_free_port()), UDAPOSE_TEST_FAIL_CAPTURE="1"), ["--capture-comm"])):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         out = subprocess.run([sys.executable] + common + flags, cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, tag + out.stdout[-2000:] + out.stderr[-4000:]
@@ -994,6 +995,12 @@ def test_one_rank_rccl_step():
     assert dpf["chosen"] in dpf["ms_per_step_5_steps"] and len(dpf["ms_per_step_5_steps"]) == 4 and res["plain"]["dp_form"] is None
     assert res["rccl"]["dp_form"] is None and res["rccl_auto"]["loss"] == res["rccl_auto"]["loss"]
     assert dpf["collectives_captured"] is (not dpf["chosen"] == "two_buckets_bf16") and dpf["capture_fallback"] is None
+    # the DEFAULT data-parallel run (what the driver's `--gpus N` line is): the same four forms timed with EAGER collectives between four graphs
+    dpe = res["rccl_eager"]["dp_form"]
+    assert dpe["collectives_captured"] is False and dpe["capture_fallback"] is None and len(dpe["ms_per_step_5_steps"]) == 4
+    assert "hipGraphs" in res["rccl_eager"]["launch"] and "captured" not in res["rccl_eager"]["launch"]
+    e_ = res["rccl_eager"]["loss"]
+    assert e_ == e_ and abs(e_ - res["rccl_auto"]["loss"]) <= 2e-2 * abs(e_) + 1e-9
     # SCALE-day checklist: the line carries the wall time of communicator creation, of every form's capture and of the selection; an
     # injected capture failure makes every form fall back - collectively, by an all-reduced flag - to eager collectives between four graphs, and the
     # line says so
