@@ -129,7 +129,9 @@ int udapose_conv_bwd_stat_rows(const udapose_conv_desc* d);
 int udapose_conv2d_bwd_data_bn(void* stream, const udapose_conv_desc* d, const void* dy, const void* w_bwd, void* dx, const void* res,
                                int out_f32, const void* bn_y, const void* bn_z, const float* bn_mean, const float* bn_invstd,
                                const float* bn_gamma, const float* bn_beta, float* slab);
-/* dw fp32 [Co][KH*KWp][Ci] (transposed: [Ci][KH*KW][Co]) = (accumulate ? dw : 0) + sum_pixels dy * x */
+/* dw fp32 [Co][KH*KWp][Ci] (transposed: [Ci][KH*KW][Co]) = (accumulate ? dw : 0) + sum_pixels dy * x.  This per-layer call splits long pixel
+ * reductions over work-groups that add with fp32 atomics (arrival order: last-bit differences between runs; policy wgrad_ksplit = 1 forbids the
+ * split); the network plans' grouped launches (udapose_net_backward*, udapose_net_wgrad_pair) are bit-reproducible (udapose_policy.wgrad_det). */
 int udapose_conv2d_bwd_weight(void* stream, const udapose_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate);
 /* weight packing from fp32: cast (n % 8 == 0); per-tap transpose [A][T][B] -> [B][T][A]; strided gather with zero padding */
 int udapose_cast_f32_bf16(void* stream, const float* src, void* dst, size_t n);
