@@ -8,7 +8,7 @@ trap 'cp /tmp/lib_keep.so $L' EXIT
 for i in $(seq 1 $R); do
   for tag in old new; do
     cp tools/_ab/lib$tag.so $L
-    timeout -k 10 200 python bench.py --steps $S --spinup 4 --no-cpu-baseline 2>/dev/null | python -c "
+    timeout -k 10 200 python bench.py --steps $S --spinup 4 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
