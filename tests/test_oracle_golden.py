@@ -152,3 +152,24 @@ def test_state_dict_contract():
     assert sum(p.numel() for p in m50.parameters()) == 36048440 and len(list(m50.parameters())) == 172
     for K, n in ((18, 55041082), (21, 55041853), (14, 55040054)):
         assert sum(p.numel() for p in pose_resnet101_ref(K).parameters()) == n
+
+
+def test_storage_emulation_with_per_stage_switches_reduces_to_its_two_ends():
+    """oracle/bf16_emulation.forward_emulated (round 6: any 16-bit type, rounding switched per stage and tensor kind - the attribution tool's
+    instrument): everything switched on IS forward_bf16_emulated, everything off IS the plain fp32 forward, and one stage's rounding alone moves
+    the heat-maps by less than all of them together."""
+    from oracle.bf16_emulation import STAGES, forward_bf16_emulated, forward_emulated
+    from oracle.pose_resnet_ref import tiny_pose_resnet_ref
+    torch.manual_seed(0)
+    m = tiny_pose_resnet_ref(4).train()
+    x = torch.randn(2, 3, 64, 64)
+    keep = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        full = forward_emulated(m, x, torch.bfloat16, lambda s, k: True)
+        assert torch.equal(full, forward_bf16_emulated(m, x))
+        none = forward_emulated(m, x, torch.bfloat16, lambda s, k: False)
+        m.load_state_dict(keep)
+        assert (none - m(x)).abs().max().item() < 1e-6
+        e_all = (full - none).abs().max().item()
+        e_one = max((forward_emulated(m, x, torch.float16, lambda s, k, st=st: s == st) - none).abs().max().item() for st in STAGES)
+        assert 0 < e_one < e_all
