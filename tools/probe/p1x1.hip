@@ -40,8 +40,8 @@ constexpr int lds_bytes(int ns, bool alias = false) { return alias ? (ns * STAGE
 // before every epilogue, so a persistent work-group gains nothing from it - this is the one-tile-per-work-group baseline at the product's residency.
 // NS = 1 (with ALIAS): a single stage buffer, two barriers per stage, 19.5 KB: up to eight work-groups per CU - overlap comes from residency alone.
 template <int NS, bool ALIAS = false>
-__global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, const elem_t* __restrict__ w, elem_t* __restrict__ y, float* __restrict__ stats,
-                                              int M, int K, int Co, int m_tiles, int n_tiles, int mode = 0) {
+__device__ __forceinline__ void p1x1_body(const elem_t* __restrict__ x, const elem_t* __restrict__ w, elem_t* __restrict__ y, float* __restrict__ stats,
+                                          int M, int K, int Co, int m_tiles, int n_tiles, int mode, const int bx, const int gx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring = smem;
     float* const est_all = (float*)(smem + (ALIAS ? 0 : NS * STAGE1));
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, cons
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     // ---- schedule
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, Wx = gridDim.x >> 3;
+    const int xcd = bx & 7, local = bx >> 3, Wx = gx >> 3;
     const int mtx = m_tiles >> 3, Tx = mtx * n_tiles;
     const int ntile_wg = local < Tx ? (Tx - local + Wx - 1) / Wx : 0;
     const int nsteps = K >> 6;
@@ -201,6 +201,34 @@ __global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+template <int NS, bool ALIAS = false>
+__global__ __launch_bounds__(256) void p1x1_k(const elem_t* __restrict__ x, const elem_t* __restrict__ w, elem_t* __restrict__ y, float* __restrict__ stats,
+                                              int M, int K, int Co, int m_tiles, int n_tiles, int mode = 0) {
+    p1x1_body<NS, ALIAS>(x, w, y, stats, M, K, Co, m_tiles, n_tiles, mode, blockIdx.x, gridDim.x);
+}
+// PAIR (tools/probe/p1x1.hip -DPAIR_PROBE): two problems of one shape in ONE launch, blockIdx.y picks the problem - the student's source and target passes walk
+// the same layer list; would one launch for both (half the launches, each twice as large) beat the two concurrent streams the step uses?
+struct PairArgs { const elem_t* x[2]; const elem_t* w[2]; elem_t* y[2]; float* stats[2]; int M, K, Co; };
+template <int NS, bool ALIAS = false>
+__global__ __launch_bounds__(256) void p1x1_pair_k(const PairArgs a) {
+    const int z = blockIdx.y;
+    p1x1_body<NS, ALIAS>(a.x[z], a.w[z], a.y[z], a.stats[z], a.M, a.K, a.Co, a.M / 64, a.Co / 64, 0, blockIdx.x, gridDim.x);
+}
+// the BatchNorm apply between two convolutions, as a stand-in of the right size: per-channel scale / shift from the tile-row statistics' first rows + ReLU
+__device__ __forceinline__ void apply_body(const elem_t* __restrict__ y, const float* __restrict__ stats, elem_t* __restrict__ z, int M, int C, const int bx, const int gx) {
+    const size_t n8 = (size_t)M * C / 8;
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n8; i += (size_t)gx * 256) {
+        const int c0 = (int)((i * 8) % C);
+        const elem8 v = *(const elem8*)(y + i * 8);
+        elem8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float s = 1.0f + 1e-9f * stats[c0 + e]; o[e] = (elem_t)fmaxf((float)v[e] * s + 0.01f, 0.f); }
+        *(elem8*)(z + i * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void apply_k(const elem_t* y, const float* stats, elem_t* z, int M, int C) { apply_body(y, stats, z, M, C, blockIdx.x, gridDim.x); }
+struct ApplyPair { const elem_t* y[2]; const float* stats[2]; elem_t* z[2]; int M, C; };
+__global__ __launch_bounds__(256) void apply_pair_k(const ApplyPair a) { const int q = blockIdx.y; apply_body(a.y[q], a.stats[q], a.z[q], a.M, a.C, blockIdx.x, gridDim.x); }
 
 __global__ void ref_k(const elem_t* x, const elem_t* w, float* yr, int M, int K, int Co) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -259,6 +287,7 @@ float time_concurrent(const std::vector<Prob>& ps, int grid, int reps, hipStream
     return best;
 }
 
+#ifndef PAIR_PROBE
 int main() {
     struct Shape { const char* name; int M, K, Co; };
     const Shape shapes[] = {{"l3 c3 256->1024 (16x16)", 8192, 256, 1024}, {"l3 c1 1024->256", 8192, 1024, 256}, {"l4 c3 512->2048 (8x8)", 2048, 512, 2048},
@@ -381,3 +410,96 @@ int main() {
     }
     return 0;
 }
+#else
+// ---- PAIR_PROBE: a dependent chain conv (1x1) -> apply -> conv -> apply ... over a layer's shapes; the step runs three such chains (student source, student
+// target, teacher) on three streams.  Form A: three streams of single launches.  Form B: the two student chains as ONE chain of paired launches + the teacher
+// chain of single launches on a second stream.  Same work, same kernels' bodies.
+struct Chain { elem_t* act[2]; elem_t* mid[2]; elem_t* w1; elem_t* w2; float* st; int M, C, Cm; };   // act (M x C) -> w1 (C -> Cm) -> mid -> apply -> w2 (Cm -> C) -> act'
+static Chain make_chain(int M, int C, int Cm) {
+    Chain c{}; c.M = M; c.C = C; c.Cm = Cm;
+    for (int i = 0; i < 2; ++i) { CK(hipMalloc(&c.act[i], (size_t)M * C * 2)); CK(hipMalloc(&c.mid[i], (size_t)M * Cm * 2)); }
+    CK(hipMalloc(&c.w1, (size_t)C * Cm * 2)); CK(hipMalloc(&c.w2, (size_t)C * Cm * 2)); CK(hipMalloc(&c.st, (size_t)(M / 64) * 2 * (C > Cm ? C : Cm) * 4));
+    hipLaunchKernelGGL(fill_k, dim3(((size_t)M * C + 255) / 256), dim3(256), 0, 0, c.act[0], (size_t)M * C, 1u, 1.0f);
+    hipLaunchKernelGGL(fill_k, dim3(((size_t)C * Cm + 255) / 256), dim3(256), 0, 0, c.w1, (size_t)C * Cm, 7u, 0.03f);
+    hipLaunchKernelGGL(fill_k, dim3(((size_t)C * Cm + 255) / 256), dim3(256), 0, 0, c.w2, (size_t)C * Cm, 9u, 0.03f);
+    return c;
+}
+static int apply_grid(int M, int C) { const size_t n8 = (size_t)M * C / 8; const size_t g = (n8 + 255) / 256; return (int)(g < 2048 ? g : 2048); }
+static void chain_single(const Chain& c, int blocks, hipStream_t s) {
+    for (int b = 0; b < blocks; ++b) {
+        hipLaunchKernelGGL((p1x1_k<2, true>), dim3((c.M / 64) * (c.Cm / 64)), dim3(256), lds_bytes(2, true), s, c.act[0], c.w1, c.mid[0], c.st, c.M, c.C, c.Cm, c.M / 64, c.Cm / 64, 0);
+        hipLaunchKernelGGL(apply_k, dim3(apply_grid(c.M, c.Cm)), dim3(256), 0, s, c.mid[0], c.st, c.mid[1], c.M, c.Cm);
+        hipLaunchKernelGGL((p1x1_k<2, true>), dim3((c.M / 64) * (c.C / 64)), dim3(256), lds_bytes(2, true), s, c.mid[1], c.w2, c.act[1], c.st, c.M, c.Cm, c.C, c.M / 64, c.C / 64, 0);
+        hipLaunchKernelGGL(apply_k, dim3(apply_grid(c.M, c.C)), dim3(256), 0, s, c.act[1], c.st, c.act[0], c.M, c.C);
+    }
+}
+static void chain_pair(const Chain& a, const Chain& b, int blocks, hipStream_t s) {
+    for (int k = 0; k < blocks; ++k) {
+        PairArgs p1{{a.act[0], b.act[0]}, {a.w1, b.w1}, {a.mid[0], b.mid[0]}, {a.st, b.st}, a.M, a.C, a.Cm};
+        hipLaunchKernelGGL((p1x1_pair_k<2, true>), dim3((a.M / 64) * (a.Cm / 64), 2), dim3(256), lds_bytes(2, true), s, p1);
+        ApplyPair q1{{a.mid[0], b.mid[0]}, {a.st, b.st}, {a.mid[1], b.mid[1]}, a.M, a.Cm};
+        hipLaunchKernelGGL(apply_pair_k, dim3(apply_grid(a.M, a.Cm), 2), dim3(256), 0, s, q1);
+        PairArgs p2{{a.mid[1], b.mid[1]}, {a.w2, b.w2}, {a.act[1], b.act[1]}, {a.st, b.st}, a.M, a.Cm, a.C};
+        hipLaunchKernelGGL((p1x1_pair_k<2, true>), dim3((a.M / 64) * (a.C / 64), 2), dim3(256), lds_bytes(2, true), s, p2);
+        ApplyPair q2{{a.act[1], b.act[1]}, {a.st, b.st}, {a.act[0], b.act[0]}, a.M, a.C};
+        hipLaunchKernelGGL(apply_pair_k, dim3(apply_grid(a.M, a.C), 2), dim3(256), 0, s, q2);
+    }
+}
+template <typename F>
+static float time_graphs(int nstreams, hipStream_t* streams, F&& record) {
+    std::vector<hipGraphExec_t> ex(nstreams);
+    for (int k = 0; k < nstreams; ++k) {
+        hipGraph_t g;
+        CK(hipStreamBeginCapture(streams[k], hipStreamCaptureModeGlobal));
+        record(k, streams[k]);
+        CK(hipStreamEndCapture(streams[k], &g));
+        CK(hipGraphInstantiate(&ex[k], g, nullptr, nullptr, 0));
+        CK(hipGraphDestroy(g));
+    }
+    hipEvent_t a, b, e[4];
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (auto& v : e) CK(hipEventCreate(&v));
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, streams[0]));
+        for (int k = 1; k < nstreams; ++k) CK(hipStreamWaitEvent(streams[k], a, 0));
+        for (int k = 0; k < nstreams; ++k) CK(hipGraphLaunch(ex[k], streams[k]));
+        for (int k = 1; k < nstreams; ++k) { CK(hipEventRecord(e[k], streams[k])); CK(hipStreamWaitEvent(streams[0], e[k], 0)); }
+        CK(hipEventRecord(b, streams[0]));
+        CK(hipEventSynchronize(b));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (rep) best = fminf(best, ms * 1e3f);
+    }
+    for (auto& x : ex) CK(hipGraphExecDestroy(x));
+    return best;
+}
+int main() {
+    CK(hipFuncSetAttribute((const void*)(p1x1_k<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, true)));
+    CK(hipFuncSetAttribute((const void*)(p1x1_pair_k<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, true)));
+    hipStream_t streams[3];
+    for (auto& st : streams) CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct L { const char* name; int M, C, Cm; };
+    const L layers[] = {{"layer4 (8x8, 2048 <-> 512)", 2048, 2048, 512}, {"layer3 (16x16, 1024 <-> 256)", 8192, 1024, 256}, {"layer2 (32x32, 512 <-> 128)", 32768, 512, 128},
+                        {"layer1 (64x64, 256 <-> 64)", 131072, 256, 64}};
+    const int B = 10;
+    for (const L& l : layers) {
+        Chain c[3] = {make_chain(l.M, l.C, l.Cm), make_chain(l.M, l.C, l.Cm), make_chain(l.M, l.C, l.Cm)};
+        CK(hipDeviceSynchronize());
+        // correctness of the pair form: same bits as two single chains (the chains are deterministic functions of their inputs)
+        const float one = time_graphs(1, streams, [&](int, hipStream_t s) { chain_single(c[0], B, s); });
+        const float two_seq = time_graphs(1, streams, [&](int, hipStream_t s) { chain_single(c[0], B, s); chain_single(c[1], B, s); });
+        const float two_conc = time_graphs(2, streams, [&](int k, hipStream_t s) { chain_single(c[k], B, s); });
+        const float pair1 = time_graphs(1, streams, [&](int, hipStream_t s) { chain_pair(c[0], c[1], B, s); });
+        const float three_conc = time_graphs(3, streams, [&](int k, hipStream_t s) { chain_single(c[k], B, s); });
+        const float pair_plus = time_graphs(2, streams, [&](int k, hipStream_t s) { if (k == 0) chain_pair(c[0], c[1], B, s); else chain_single(c[2], B, s); });
+        const float per = 1.0f / (B * 4);
+        printf("%-30s us per launch-slot (conv or apply) | one chain %.2f | two chains: back to back %.2f, two streams %.2f, PAIRED %.2f | three chains: three streams %.2f, PAIR + single on two streams %.2f\n",
+               l.name, one * per, two_seq * per, two_conc * per, pair1 * per, three_conc * per, pair_plus * per);
+        fflush(stdout);
+        for (auto& ch : c) { for (int i = 0; i < 2; ++i) { CK(hipFree(ch.act[i])); CK(hipFree(ch.mid[i])); } CK(hipFree(ch.w1)); CK(hipFree(ch.w2)); CK(hipFree(ch.st)); }
+    }
+    return 0;
+}
+#endif
